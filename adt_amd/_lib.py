@@ -1,0 +1,85 @@
+"""ctypes binding of libadt_hip.so (C ABI: include/adt_hip.h).
+
+The HIP library IS the product path: if it is missing or fails to load this module raises -- there is no
+CPU or PyTorch fallback anywhere in adt_amd/ (the numpy oracle under oracle/ is test infrastructure only).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libadt_hip.so")
+
+_P, _I, _F, _U, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_uint32, ctypes.c_int64
+
+
+class SasrecCfg(ctypes.Structure):
+    """struct adt_sasrec_cfg (include/adt_hip.h)."""
+    _fields_ = [("item_num", ctypes.c_int32), ("maxlen", ctypes.c_int32), ("hidden", ctypes.c_int32),
+                ("num_heads", ctypes.c_int32), ("num_layers", ctypes.c_int32), ("dropout", ctypes.c_float),
+                ("prec", ctypes.c_int32)]
+
+
+_CP = ctypes.POINTER(SasrecCfg)
+
+# name -> (restype, argtypes); the single source of truth for symbol coverage (tests/test_capi_symbols.py)
+SIGNATURES = {
+    "adt_version": (_I, []),
+    "adt_last_error": (ctypes.c_char_p, []),
+    "adt_rng_keep": (_I, [_U, _U, _U, _F]),
+    "adt_embed_fwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _U, _U, _P, _P]),
+    "adt_embed_bwd": (_I, [_P, _P, _I, _I, _I, _F, _P, _U, _U, _P, _P, _P]),
+    "adt_layernorm_fwd": (_I, [_P, _I, _P, _P, _F, _I, _I, _P, _I, _P]),
+    "adt_layernorm_bwd": (_I, [_P, _I, _P, _I, _P, _F, _I, _I, _P, _I, _I, _P, _P, _P]),
+    "adt_linear_fwd": (_I, [_I, _P, _I, _P, _P, _I, _I, _I, _P, _I, _F, _P, _U, _U, _I, _P, _I, _P, _I, _P, _P]),
+    "adt_linear_bwd": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _F, _P, _U, _U, _P, _I, _P, _I, _I, _P, _I, _P,
+                            _P, _P, _P]),
+    "adt_attn_fwd": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P, _U, _U, _P, _I, _P, _P]),
+    "adt_attn_bwd": (_I, [_I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _U, _U, _P, _I,
+                          _P, _I, _P, _I, _P]),
+    "adt_headcls_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "adt_headcls_bwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
+    "adt_logits_fwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "adt_logits_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P]),
+    "adt_bce_seed": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "adt_mse_seed": (_I, [_P, _P, _L, _F, _P, _P, _I, _P, _P, _P]),
+    "adt_nll_seed": (_I, [_P, _I, _I, _F, _P, _P, _P, _P]),
+    "adt_clip_adam": (_I, [_P, _P, _P, _P, _L, _L, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
+    "adt_score_rank": (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "adt_sasrec_param_layout": (_L, [_CP, _P]),
+    "adt_sasrec_workspace_floats": (_L, [_CP, _I]),
+    "adt_sasrec_ws_offset": (_L, [_CP, _I, _I, _I]),
+    "adt_sasrec_forward": (_I, [_CP, _P, _P, _P, _P, _P, _P, _I, _I, _P, _U, _P]),
+    "adt_sasrec_loss_seed": (_I, [_CP, _P, _P, _I, _P, _P, _P]),
+    "adt_sasrec_backward": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _U, _I, _P]),
+    "adt_sasrec_predict": (_I, [_CP, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class AdtError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libadt_hip.so once.  Raises AdtError (never falls back) when it is absent or unloadable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AdtError("libadt_hip.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise AdtError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise AdtError("%s failed: %s" % (what, load().adt_last_error().decode()))

@@ -1,0 +1,301 @@
+// C ABI (include/adt_hip.h): launch wrappers for the per-stage kernels.  Host code only enqueues work on
+// the caller's stream: no allocation, no synchronisation, graph-capturable.
+#include "adt_host.h"
+
+#include "adt_attn.cuh"
+#include "adt_misc.cuh"
+#include "adt_rowops.cuh"
+
+using namespace adt;
+
+static thread_local char g_err[512] = "";
+
+int adt_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+
+static int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return adt_set_error("%s: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+DropCfg adt_make_drop(float p, const uint32_t* seed, uint32_t site) {
+  DropCfg d;
+  d.seed = seed;
+  d.site = site;
+  if (p > 0.f && seed != nullptr) {
+    double t = (double)p * 4294967296.0;
+    d.thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+    d.scale = 1.0f / (1.0f - p);
+  } else {
+    d.thr = 0;
+    d.scale = 1.0f;
+  }
+  return d;
+}
+
+static int grid_for(size_t work_items, int per_block, int cap) {
+  size_t g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > (size_t)cap) g = cap;
+  return (int)g;
+}
+
+template <int PREC>
+static void launch_linear_bwd(const LinBwdArgs& a, int nch, int grid, hipStream_t s) {
+  if (nch == 1) hipLaunchKernelGGL((k_linear_bwd<PREC, 64, 1>), dim3(grid), dim3(256), 0, s, a);
+  else if (nch == 2) hipLaunchKernelGGL((k_linear_bwd<PREC, 64, 2>), dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_linear_bwd<PREC, 64, 3>), dim3(grid), dim3(256), 0, s, a);
+}
+
+// ---- attention dispatch --------------------------------------------------------------------------
+template <int PREC, int HD, int MAXKT>
+static int launch_attn(bool bwd, const AttnArgs& a, hipStream_t s) {
+  constexpr int RS = HD + 4, LP = MAXKT * 16;
+  const size_t smem = bwd ? (size_t)(4 * LP * RS + 2 * LP) * sizeof(float) : (size_t)(2 * LP * RS) * sizeof(float);
+  if (smem > 160 * 1024) return adt_set_error("attention: L/hd too large for LDS-resident form (%zu B)", smem);
+  static bool attr_done[2] = {false, false};
+  if (!attr_done[bwd ? 1 : 0]) {
+    hipError_t e = bwd ? hipFuncSetAttribute((const void*)k_attn_bwd<PREC, HD, MAXKT>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
+                       : hipFuncSetAttribute((const void*)k_attn_fwd<PREC, HD, MAXKT>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return adt_set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done[bwd ? 1 : 0] = true;
+  }
+  const int grid = a.B * a.H;
+  if (bwd) hipLaunchKernelGGL((k_attn_bwd<PREC, HD, MAXKT>), dim3(grid), dim3(256), smem, s, a);
+  else hipLaunchKernelGGL((k_attn_fwd<PREC, HD, MAXKT>), dim3(grid), dim3(256), smem, s, a);
+  return check_launch(bwd ? "attn_bwd" : "attn_fwd");
+}
+
+template <int PREC, int HD>
+static int dispatch_attn_l(bool bwd, const AttnArgs& a, hipStream_t s) {
+  if (a.L <= 64) return launch_attn<PREC, HD, 4>(bwd, a, s);
+  if (a.L <= 128) return launch_attn<PREC, HD, 8>(bwd, a, s);
+  if (a.L <= 224) return launch_attn<PREC, HD, 14>(bwd, a, s);
+  return adt_set_error("attention: L=%d > 224 unsupported", a.L);
+}
+
+template <int PREC>
+static int dispatch_attn_hd(bool bwd, int hd, const AttnArgs& a, hipStream_t s) {
+  if (hd == 16) return dispatch_attn_l<PREC, 16>(bwd, a, s);
+  if (hd == 32) return dispatch_attn_l<PREC, 32>(bwd, a, s);
+  if (hd == 64 && (!bwd || a.L <= 128)) return dispatch_attn_l<PREC, 64>(bwd, a, s);
+  return adt_set_error("attention: head_dim=%d (L=%d) unsupported", hd, a.L);
+}
+
+static int dispatch_attn(int prec, bool bwd, int hd, const AttnArgs& a, hipStream_t s) {
+  if ((a.ldq % 4) || (a.ldk % 4) || (a.ldv % 4) || (a.ldo % 4)) return adt_set_error("attention: ld %% 4");
+  if (prec == ADT_PREC_F32) return dispatch_attn_hd<PREC_F32>(bwd, hd, a, s);
+  return dispatch_attn_hd<PREC_BF16>(bwd, hd, a, s);
+}
+
+extern "C" {
+
+int adt_version(void) { return 1; }
+const char* adt_last_error(void) { return g_err; }
+
+int adt_rng_keep(uint32_t seed, uint32_t site, uint32_t idx, float p) {
+  DropCfg d = adt_make_drop(p, &seed, site);
+  if (!d.thr) return 1;
+  return adt_keep(adt_site_key(seed, site), idx, d.thr) ? 1 : 0;
+}
+
+int adt_embed_fwd(const int32_t* ids, const float* E, const float* P, int T, int L, int d, float p,
+                  const uint32_t* seed, uint32_t site, uint32_t row_offset, float* X, void* stream) {
+  if (d % 4) return adt_set_error("embed_fwd: d %% 4 != 0");
+  EmbedArgs a{};
+  a.ids = ids; a.E = E; a.P = P; a.T = T; a.L = L; a.d = d; a.scale = sqrtf((float)d);
+  a.drop = adt_make_drop(p, seed, site); a.row_offset = row_offset; a.X = X;
+  hipLaunchKernelGGL(k_embed_fwd, dim3(grid_for((size_t)T * d / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("embed_fwd");
+}
+
+int adt_embed_bwd(const int32_t* ids, const float* dX, int T, int L, int d, float p, const uint32_t* seed,
+                  uint32_t site, uint32_t row_offset, float* dE, float* dP, void* stream) {
+  if (d % 4 || T % L) return adt_set_error("embed_bwd: bad shape");
+  EmbedArgs a{};
+  a.ids = ids; a.T = T; a.L = L; a.d = d; a.scale = sqrtf((float)d);
+  a.drop = adt_make_drop(p, seed, site); a.row_offset = row_offset; a.dX = dX; a.dE = dE; a.dP = dP;
+  const int B = T / L;
+  const int gx = (L * d / 4 + 255) / 256;
+  int gy = B < 32 ? B : 32;
+  hipLaunchKernelGGL(k_embed_bwd, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("embed_bwd");
+}
+
+int adt_layernorm_fwd(const float* X, int ldx, const float* gamma, const float* beta, float eps, int T, int d,
+                      float* Y, int ldy, void* stream) {
+  LnArgs a{};
+  a.X = X; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.eps = eps; a.Y = Y; a.ldy = ldy; a.T = T;
+  const int grid = grid_for(T, 16, 2048);
+  if (d == 64) hipLaunchKernelGGL(k_ln_fwd<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else if (d == 128) hipLaunchKernelGGL(k_ln_fwd<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else if (d == 256) hipLaunchKernelGGL(k_ln_fwd<256>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else return adt_set_error("layernorm_fwd: d=%d unsupported (64/128/256)", d);
+  return check_launch("layernorm_fwd");
+}
+
+int adt_layernorm_bwd(const float* dY, int lddy, const float* X, int ldx, const float* gamma, float eps, int T,
+                      int d, float* dX, int lddx, int accumulate, float* dgamma, float* dbeta, void* stream) {
+  LnArgs a{};
+  a.X = X; a.ldx = ldx; a.gamma = gamma; a.eps = eps; a.T = T; a.dY = dY; a.lddy = lddy; a.dX = dX; a.lddx = lddx;
+  a.acc = accumulate; a.dgamma = dgamma; a.dbeta = dbeta;
+  const int grid = grid_for(T, 16, 512);
+  if (d == 64) hipLaunchKernelGGL(k_ln_bwd<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else if (d == 128) hipLaunchKernelGGL(k_ln_bwd<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else if (d == 256) hipLaunchKernelGGL(k_ln_bwd<256>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else return adt_set_error("layernorm_bwd: d=%d unsupported (64/128/256)", d);
+  return check_launch("layernorm_bwd");
+}
+
+int adt_linear_fwd(int prec, const float* X, int ldx, const float* W, const float* b, int T, int K, int N,
+                   float* Y, int ldy, float p, const uint32_t* seed, uint32_t site, uint32_t row_offset,
+                   int relu, const float* R1, int ldr1, const float* R2, int ldr2, const int32_t* mask_ids,
+                   void* stream) {
+  if (K != 64) return adt_set_error("linear_fwd: K=%d unsupported (64)", K);
+  if (N % 16 || N <= 0) return adt_set_error("linear_fwd: N=%d must be a positive multiple of 16", N);
+  if ((ldx % 4) || (ldy % 4) || (R1 && ldr1 % 4) || (R2 && ldr2 % 4)) return adt_set_error("linear_fwd: ld %% 4");
+  LinFwdArgs a{};
+  a.X = X; a.ldx = ldx; a.W = W; a.b = b; a.N = N; a.Y = Y; a.ldy = ldy; a.T = T;
+  a.drop = adt_make_drop(p, seed, site); a.row_offset = row_offset; a.relu = relu;
+  a.R1 = R1; a.ldr1 = ldr1; a.R2 = R2; a.ldr2 = ldr2; a.ids = mask_ids;
+  const int grid = grid_for(T, BM, 768);
+  if (prec == ADT_PREC_F32) hipLaunchKernelGGL((k_linear_fwd<PREC_F32, 64>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((k_linear_fwd<PREC_BF16, 64>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("linear_fwd");
+}
+
+int adt_linear_bwd(int prec, const float* dY, int lddy, const float* X, int ldx, const float* W, int T, int K,
+                   int N, const int32_t* mask_ids, float p, const uint32_t* seed, uint32_t site,
+                   uint32_t row_offset, const float* U, int ldu, float* dX, int lddx, int beta,
+                   const float* Radd, int ldradd, const int32_t* radd_ids, float* dW, float* db, void* stream) {
+  if (K != 64) return adt_set_error("linear_bwd: K=%d unsupported (64)", K);
+  if (N % 16 || N <= 0 || N > 192) return adt_set_error("linear_bwd: N=%d must be a multiple of 16 in (0,192]", N);
+  if ((lddy % 4) || (ldx % 4) || (dX && lddx % 4) || (U && ldu % 4) || (Radd && ldradd % 4))
+    return adt_set_error("linear_bwd: ld %% 4");
+  LinBwdArgs a{};
+  a.dY = dY; a.lddy = lddy; a.X = X; a.ldx = ldx; a.W = W; a.N = N; a.T = T; a.ids = mask_ids;
+  a.drop = adt_make_drop(p, seed, site); a.row_offset = row_offset; a.U = U; a.ldu = ldu;
+  a.dX = dX; a.lddx = lddx; a.beta = beta; a.Radd = Radd; a.ldradd = ldradd; a.radd_ids = radd_ids;
+  a.dW = dW; a.db = db;
+  const int nch = (N + 63) / 64;
+  const int grid = grid_for(T, BM, 256);
+  if (prec == ADT_PREC_F32) launch_linear_bwd<PREC_F32>(a, nch, grid, (hipStream_t)stream);
+  else launch_linear_bwd<PREC_BF16>(a, nch, grid, (hipStream_t)stream);
+  return check_launch("linear_bwd");
+}
+
+int adt_attn_fwd(int prec, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, int B,
+                 int H, int L, int hd, int causal, float p, const uint32_t* seed, uint32_t site,
+                 uint32_t b_offset, float* O, int ldo, float* LSE, void* stream) {
+  AttnArgs a{};
+  a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.LSE = LSE;
+  a.B = B; a.H = H; a.L = L; a.causal = causal; a.scale = 1.0f / sqrtf((float)hd);
+  a.drop = adt_make_drop(p, seed, site); a.bh_offset = b_offset * (uint32_t)H;
+  return dispatch_attn(prec, false, hd, a, (hipStream_t)stream);
+}
+
+int adt_attn_bwd(int prec, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                 const float* O, int ldo, const float* LSE, const float* dO, int lddo, int B, int H, int L,
+                 int hd, int causal, float p, const uint32_t* seed, uint32_t site, uint32_t b_offset,
+                 float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, void* stream) {
+  AttnArgs a{};
+  a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = const_cast<float*>(O); a.ldo = ldo;
+  a.LSE = const_cast<float*>(LSE); a.B = B; a.H = H; a.L = L; a.causal = causal; a.scale = 1.0f / sqrtf((float)hd);
+  a.drop = adt_make_drop(p, seed, site); a.bh_offset = b_offset * (uint32_t)H;
+  a.dO = dO; a.lddo = lddo; a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv;
+  if ((lddo % 4) || (lddq % 4) || (lddk % 4) || (lddv % 4)) return adt_set_error("attn_bwd: ld %% 4");
+  return dispatch_attn(prec, true, hd, a, (hipStream_t)stream);
+}
+
+int adt_headcls_fwd(const float* O, int ldo, const float* Ws, const float* bs, int B, int L, int H, int hd,
+                    float* rec, void* stream) {
+  if (H > MAXH || hd % 4) return adt_set_error("headcls: H=%d (max %d) hd=%d", H, MAXH, hd);
+  HeadClsArgs a{};
+  a.O = O; a.ldo = ldo; a.Ws = Ws; a.bs = bs; a.B = B; a.L = L; a.H = H; a.hd = hd; a.rec = rec;
+  hipLaunchKernelGGL(k_headcls_fwd, dim3(grid_for((size_t)B * L * H, 256, 1024)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("headcls_fwd");
+}
+
+int adt_headcls_bwd(const float* O, int ldo, const float* Ws, const float* rec, const float* drec, int B, int L,
+                    int H, int hd, float* dO, int lddo, float* dWs, float* dbs, void* stream) {
+  if (H > MAXH || hd % 4) return adt_set_error("headcls: H=%d (max %d) hd=%d", H, MAXH, hd);
+  HeadClsArgs a{};
+  a.O = O; a.ldo = ldo; a.Ws = Ws; a.B = B; a.L = L; a.H = H; a.hd = hd; a.rec = const_cast<float*>(rec);
+  a.drec = drec; a.dO = dO; a.lddo = lddo; a.dWs = dWs; a.dbs = dbs;
+  const size_t smem = (size_t)(H * hd + H) * sizeof(float);
+  hipLaunchKernelGGL(k_headcls_bwd, dim3(grid_for((size_t)B * L * H, 256, 256)), dim3(256), smem, (hipStream_t)stream, a);
+  return check_launch("headcls_bwd");
+}
+
+int adt_logits_fwd(const float* F, int ldf, const float* E, const int32_t* pos, const int32_t* neg, int T, int d,
+                   float* pos_logits, float* neg_logits, void* stream) {
+  LogitsArgs a{};
+  a.F = F; a.ldf = ldf; a.E = E; a.pos = pos; a.neg = neg; a.T = T; a.d = d; a.pos_logits = pos_logits;
+  a.neg_logits = neg_logits;
+  hipLaunchKernelGGL(k_logits_fwd, dim3(grid_for(T, 16, 2048)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("logits_fwd");
+}
+
+int adt_logits_bwd(const float* F, int ldf, const float* E, const int32_t* pos, const int32_t* neg,
+                   const float* dpos, const float* dneg, int T, int d, float* dF, int lddf, float* dE,
+                   void* stream) {
+  LogitsArgs a{};
+  a.F = F; a.ldf = ldf; a.E = E; a.pos = pos; a.neg = neg; a.T = T; a.d = d; a.dpos = dpos; a.dneg = dneg;
+  a.dF = dF; a.lddf = lddf; a.dE = dE;
+  hipLaunchKernelGGL(k_logits_bwd, dim3(grid_for(T, 16, 2048)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("logits_bwd");
+}
+
+int adt_bce_seed(const float* pos_logits, const float* neg_logits, const int32_t* pos, int T, const float* norms,
+                 float* dpos, float* dneg, float* loss2, void* stream) {
+  BceArgs a{pos_logits, neg_logits, pos, T, norms, dpos, dneg, loss2};
+  hipLaunchKernelGGL(k_bce, dim3(grid_for(T, 256, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("bce_seed");
+}
+
+int adt_mse_seed(const float* A, const float* Bm, int64_t n, float lambda, const float* norms, float* GA,
+                 int accumulate_a, float* GB, float* loss1, void* stream) {
+  if (n % 4) return adt_set_error("mse_seed: n %% 4");
+  MseArgs a{A, Bm, (size_t)n, lambda, norms, GA, accumulate_a, GB, loss1};
+  hipLaunchKernelGGL(k_mse_seed, dim3(grid_for((size_t)n / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("mse_seed");
+}
+
+int adt_nll_seed(const float* rec, int n_rows, int H, float lambda2, const float* norms, float* drec,
+                 float* loss1, void* stream) {
+  NllArgs a{rec, n_rows, H, lambda2, norms, drec, loss1};
+  hipLaunchKernelGGL(k_nll_seed, dim3(grid_for((size_t)n_rows * H * H, 256, 512)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("nll_seed");
+}
+
+int adt_clip_adam(float* P, float* G, float* M, float* V, int64_t n, int64_t nE, float wd, float clip, float lr,
+                  float b1, float b2, float eps, float grad_scale, float* scal, void* stream) {
+  OptArgs a{};
+  a.P = P; a.G = G; a.M = M; a.Vv = V; a.n = (size_t)n; a.nE = (size_t)nE; a.wd = wd; a.clip = clip; a.lr = lr;
+  a.b1 = b1; a.b2 = b2; a.eps = eps; a.scal = scal; a.grad_scale = grad_scale;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(scal, 0, 2 * sizeof(float), s) != hipSuccess) return adt_set_error("clip_adam: memset");
+  if (wd != 0.f && nE > 0) hipLaunchKernelGGL(k_sumsq, dim3(grid_for((size_t)nE, 256, 256)), dim3(256), 0, s, (const float*)P, (size_t)nE, scal);
+  hipLaunchKernelGGL(k_wd_gradnorm, dim3(grid_for((size_t)n, 256, 512)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_adam, dim3(grid_for((size_t)n, 256, 1024)), dim3(256), 0, s, a);
+  return check_launch("clip_adam");
+}
+
+int adt_score_rank(const float* F, int ldf, const float* E, const int32_t* cand, int B, int C, int d,
+                   float* logits, int32_t* rank, void* stream) {
+  ScoreArgs a{F, ldf, E, cand, B, C, d, logits, rank};
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_score, dim3(grid_for((size_t)B * C, 16, 4096)), dim3(256), 0, s, a);
+  if (rank) hipLaunchKernelGGL(k_rank, dim3(grid_for(B, 4, 1024)), dim3(256), 0, s, a);
+  return check_launch("score_rank");
+}
+
+}  // extern "C"

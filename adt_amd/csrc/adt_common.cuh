@@ -1,0 +1,114 @@
+// Shared device-side toolkit for the ADT hot-path kernels (gfx950 / CDNA4 only).
+//
+// Conventions
+//   * wave = 64 lanes; lane l -> c = l & 15 (tile row/col on the lane), g = l >> 4 (k group 0..3).
+//   * All matrix products go through ONE primitive, mma16<PREC>(acc, a, b): a 16x16 output tile that
+//     contracts 32 k-slots.  Lane (c, g) supplies 8 floats a[j] = A[row c][slot(g, j)],
+//     b[j] = B[slot(g, j)][col c].  PREC_F32 issues 8 x v_mfma_f32_16x16x4_f32 (exact fp32, used to pin
+//     parity against the oracle), PREC_BF16 converts to bf16 and issues 1 x v_mfma_f32_16x16x32_bf16
+//     (fp32 accumulate; the benchmark precision).  Any slot order is legal as long as A and B agree.
+//   * C/D layout of a 16x16 tile: col = c, row = 4*g + r for accumulator register r = 0..3.
+//   * LDS row tiles are fp32, row stride RS = K + 4 dwords: contiguous 8-float fragments are two
+//     ds_read_b128; "strided" fragments (8 rows at one column, rows 4g+j / 16+4g+(j-4)) are conflict-free
+//     because 4*RS == 16 (mod 32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+enum { PREC_F32 = 0, PREC_BF16 = 1 };
+
+struct Frag8 {
+  float v[8];
+};
+
+template <int PREC>
+__device__ __forceinline__ f32x4 mma16(f32x4 acc, const Frag8& a, const Frag8& b) {
+  if constexpr (PREC == PREC_BF16) {
+    bf16x8 pa, pb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pa[j] = (__bf16)a.v[j];
+      pb[j] = (__bf16)b.v[j];
+    }
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, pb, acc, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
+    return acc;
+  }
+}
+
+// 8 contiguous floats at p (16-byte aligned).
+__device__ __forceinline__ Frag8 frag_contig(const float* p) {
+  Frag8 f;
+  const float4 x = *reinterpret_cast<const float4*>(p);
+  const float4 y = *reinterpret_cast<const float4*>(p + 4);
+  f.v[0] = x.x; f.v[1] = x.y; f.v[2] = x.z; f.v[3] = x.w;
+  f.v[4] = y.x; f.v[5] = y.y; f.v[6] = y.z; f.v[7] = y.w;
+  return f;
+}
+
+// slot(g, j) of the "strided" order: rows 4g + (j&3) + 16*(j>>2) of a 32-row block.
+__device__ __forceinline__ int slot_row(int g, int j) { return 4 * g + (j & 3) + 16 * (j >> 2); }
+
+// 8 floats of one row in slot order: columns 4g..4g+3 and 16+4g..16+4g+3 of a 32-column block at p.
+__device__ __forceinline__ Frag8 frag_slotc(const float* p, int g) {
+  Frag8 f;
+  const float4 x = *reinterpret_cast<const float4*>(p + 4 * g);
+  const float4 y = *reinterpret_cast<const float4*>(p + 16 + 4 * g);
+  f.v[0] = x.x; f.v[1] = x.y; f.v[2] = x.z; f.v[3] = x.w;
+  f.v[4] = y.x; f.v[5] = y.y; f.v[6] = y.z; f.v[7] = y.w;
+  return f;
+}
+
+// 8 floats down one column: base points at [row0][col]; rs = row stride in floats.
+__device__ __forceinline__ Frag8 frag_strided(const float* base, int rs, int g) {
+  Frag8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = base[slot_row(g, j) * rs];
+  return f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dropout RNG: lowbias32 hash of (element index ^ key(seed, site)); identical to oracle/rng.py.
+__host__ __device__ __forceinline__ uint32_t adt_hash32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t adt_site_key(uint32_t seed, uint32_t site) {
+  return adt_hash32(seed ^ (site * 0x9E3779B9u));
+}
+__host__ __device__ __forceinline__ bool adt_keep(uint32_t key, uint32_t idx, uint32_t thr) {
+  return adt_hash32(idx ^ key) >= thr;
+}
+
+struct DropCfg {
+  const uint32_t* seed;  // device scalar (changes every step; lives in device memory so a captured graph replays)
+  uint32_t site;
+  uint32_t thr;    // drop iff hash < thr ; 0 = dropout off
+  float scale;     // 1/(1-p)
+};
+
+__device__ __forceinline__ uint32_t drop_key(const DropCfg& d) { return d.thr ? adt_site_key(*d.seed, d.site) : 0u; }
+
+// ---------------------------------------------------------------------------------------------
+// reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+#define ADT_DEVICE_INLINE __device__ __forceinline__

@@ -1,0 +1,18 @@
+// Host-side shared declarations for libadt_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/adt_hip.h"
+#include "adt_common.cuh"
+
+int adt_set_error(const char* fmt, ...);
+DropCfg adt_make_drop(float p, const uint32_t* seed, uint32_t site);
+
+// dropout sites (identical to oracle/sasrec_oracle.py)
+enum { SITE_EMB_SEQ = 1, SITE_EMB_DEC = 2 };
+static inline uint32_t enc_site(int layer, int which) { return 16u + 8u * (uint32_t)layer + (uint32_t)which; }   // 0 attn 1 ffn1 2 ffn2
+static inline uint32_t dec_site(int layer, int which) { return 128u + 8u * (uint32_t)layer + (uint32_t)which; }  // 0 slf 1 enc 2 ffn1 3 ffn2

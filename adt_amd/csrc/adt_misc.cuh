@@ -1,0 +1,421 @@
+// Embedding gather / scatter, head classifier, pos/neg logits + BCE, reconstruction (MSE) seeds,
+// clip + Adam.  HBM-bound integer/elementwise work: coalesced float4 accesses, no MFMA.
+#pragma once
+#include "adt_common.cuh"
+
+namespace adt {
+
+// ---------------------------------------------------------------------------------------------
+// sasrec/model.py:34-41 / :53-59 : x = dropout(E[ids] * sqrt(d) + P[l]) * (ids != 0)
+struct EmbedArgs {
+  const int* ids;            // T = B*L
+  const float* E; const float* P;
+  int T, L, d;
+  float scale;               // sqrt(d)
+  DropCfg drop; uint32_t row_offset;
+  float* X;                  // fwd out (T x d)
+  const float* dX;           // bwd in
+  float* dE; float* dP;      // bwd out (atomics)
+};
+
+__global__ __launch_bounds__(256) void k_embed_fwd(EmbedArgs a) {
+  const int V = a.d / 4;
+  const uint32_t key = drop_key(a.drop);
+  const size_t n = (size_t)a.T * V;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / V), c4 = (int)(i % V) * 4;
+    const int id = a.ids[row];
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (id != 0) {
+      const float4 e = *reinterpret_cast<const float4*>(a.E + (size_t)id * a.d + c4);
+      const float4 p = *reinterpret_cast<const float4*>(a.P + (size_t)(row % a.L) * a.d + c4);
+      v[0] = e.x * a.scale + p.x; v[1] = e.y * a.scale + p.y; v[2] = e.z * a.scale + p.z; v[3] = e.w * a.scale + p.w;
+      if (a.drop.thr) {
+        const uint32_t base = (uint32_t)(row + a.row_offset) * (uint32_t)a.d + (uint32_t)c4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = adt_keep(key, base + j, a.drop.thr) ? v[j] * a.drop.scale : 0.f;
+      }
+    }
+    *reinterpret_cast<float4*>(a.X + (size_t)row * a.d + c4) = *reinterpret_cast<float4*>(v);
+  }
+}
+
+// dE[id] += g * keep/(1-p) * sqrt(d) ; dP[l] += g * keep/(1-p)   (rows with id == 0 contribute nothing).
+// grid: (blocks over L*d/4 columns, slices over the batch); each thread sums its batch slice for one
+// (l, 4 columns) in registers before one atomic per column, items go straight to atomics.
+__global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a) {
+  const int V = a.d / 4;
+  const uint32_t key = drop_key(a.drop);
+  const int B = a.T / a.L;
+  const int lc = blockIdx.x * 256 + threadIdx.x;   // (l, c4)
+  if (lc >= a.L * V) return;
+  const int l = lc / V, c4 = (lc % V) * 4;
+  const int bper = (B + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * bper, b1 = min(B, b0 + bper);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = b0; b < b1; ++b) {
+    const int row = b * a.L + l;
+    const int id = a.ids[row];
+    if (id == 0) continue;
+    float v[4];
+    *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(a.dX + (size_t)row * a.d + c4);
+    if (a.drop.thr) {
+      const uint32_t base = (uint32_t)(row + a.row_offset) * (uint32_t)a.d + (uint32_t)c4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = adt_keep(key, base + j, a.drop.thr) ? v[j] * a.drop.scale : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[j] += v[j];
+      atomicAdd(a.dE + (size_t)id * a.d + c4 + j, v[j] * a.scale);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) atomicAdd(a.dP + (size_t)l * a.d + c4 + j, acc[j]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Independence head classifier: SparseInputLinear(hd -> H) + log_softmax over the H outputs
+// (sasrec/modules.py:648-649,679-703).  One thread per (token, head).  rec is written in the REFERENCE's
+// row order: row l*B + b holds token (b, l) (the .view() at sasrec/modules.py:518 reinterprets (L,B,E)).
+struct HeadClsArgs {
+  const float* O; int ldo;    // T x d attention output (pre out_proj)
+  const float* Ws; const float* bs;   // H x hd, H
+  int B, L, H, hd;
+  float* rec;                 // (L*B) x H x H log-probabilities
+  const float* drec;          // bwd: same layout
+  float* dO; int lddo;        // bwd: dO += dz Ws
+  float* dWs; float* dbs;     // bwd: atomics
+};
+
+constexpr int MAXH = 8;
+
+__global__ __launch_bounds__(256) void k_headcls_fwd(HeadClsArgs a) {
+  const int n = a.B * a.L * a.H;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int tok = i / a.H, h = i % a.H;
+    const int b = tok / a.L, l = tok % a.L;
+    const float* o = a.O + (size_t)tok * a.ldo + h * a.hd;
+    float z[MAXH];
+#pragma unroll
+    for (int cc = 0; cc < MAXH; ++cc) z[cc] = (cc < a.H) ? a.bs[cc] : -INFINITY;
+    for (int j = 0; j < a.hd; j += 4) {
+      const float4 ov = *reinterpret_cast<const float4*>(o + j);
+#pragma unroll
+      for (int cc = 0; cc < MAXH; ++cc)
+        if (cc < a.H) {
+          const float4 wv = *reinterpret_cast<const float4*>(a.Ws + cc * a.hd + j);
+          z[cc] += ov.x * wv.x + ov.y * wv.y + ov.z * wv.z + ov.w * wv.w;
+        }
+    }
+    float m = z[0];
+#pragma unroll
+    for (int cc = 1; cc < MAXH; ++cc) m = fmaxf(m, z[cc]);
+    float s = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < MAXH; ++cc) s += (cc < a.H) ? expf(z[cc] - m) : 0.f;
+    const float lz = m + logf(s);
+    float* dst = a.rec + ((size_t)(l * a.B + b) * a.H + h) * a.H;
+#pragma unroll
+    for (int cc = 0; cc < MAXH; ++cc)
+      if (cc < a.H) dst[cc] = z[cc] - lz;
+  }
+}
+
+// dz = drec - softmax(z) * sum(drec) with softmax = exp(rec);  dO[h*hd + j] += sum_c dz[c] Ws[c][j];
+// dWs[c][j] += dz[c] o[j]; dbs[c] += dz[c].  Weight partials are reduced through LDS per block.
+__global__ __launch_bounds__(256) void k_headcls_bwd(HeadClsArgs a) {
+  extern __shared__ float sacc[];   // H*hd + H
+  const int nW = a.H * a.hd;
+  for (int i = threadIdx.x; i < nW + a.H; i += 256) sacc[i] = 0.f;
+  __syncthreads();
+  const int n = a.B * a.L * a.H;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int tok = i / a.H, h = i % a.H;
+    const int b = tok / a.L, l = tok % a.L;
+    const size_t ro = ((size_t)(l * a.B + b) * a.H + h) * a.H;
+    float dz[MAXH];
+    float sd = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < MAXH; ++cc) {
+      dz[cc] = (cc < a.H) ? a.drec[ro + cc] : 0.f;
+      sd += dz[cc];
+    }
+#pragma unroll
+    for (int cc = 0; cc < MAXH; ++cc)
+      if (cc < a.H) {
+        dz[cc] -= expf(a.rec[ro + cc]) * sd;
+        atomicAdd(&sacc[nW + cc], dz[cc]);
+      }
+    const float* o = a.O + (size_t)tok * a.ldo + h * a.hd;
+    float* dobase = a.dO + (size_t)tok * a.lddo + h * a.hd;
+    for (int j = 0; j < a.hd; ++j) {
+      const float ov = o[j];
+      float acc = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < MAXH; ++cc)
+        if (cc < a.H) {
+          acc += dz[cc] * a.Ws[cc * a.hd + j];
+          atomicAdd(&sacc[cc * a.hd + j], dz[cc] * ov);
+        }
+      dobase[j] += acc;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nW; i += 256) atomicAdd(a.dWs + i, sacc[i]);
+  for (int i = threadIdx.x; i < a.H; i += 256) atomicAdd(a.dbs + i, sacc[nW + i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// sasrec/model.py:72-76: pos/neg logits = sum_d f * E[pos|neg]; 16 lanes per token.
+struct LogitsArgs {
+  const float* F; int ldf;     // T x d (post last_layernorm)
+  const float* E;
+  const int* pos; const int* neg;
+  int T, d;
+  float* pos_logits; float* neg_logits;   // T
+  const float* dpos; const float* dneg;   // bwd: T
+  float* dF; int lddf;                    // bwd out (overwritten)
+  float* dE;                              // bwd atomics
+};
+
+__global__ __launch_bounds__(256) void k_logits_fwd(LogitsArgs a) {
+  const int sub = threadIdx.x & 15;
+  for (int row = blockIdx.x * 16 + (threadIdx.x >> 4); row < a.T; row += gridDim.x * 16) {
+    const int ip = a.pos[row], in = a.neg[row];
+    float sp = 0.f, sn = 0.f;
+    for (int c4 = 4 * sub; c4 < a.d; c4 += 64) {
+      const float4 f = *reinterpret_cast<const float4*>(a.F + (size_t)row * a.ldf + c4);
+      const float4 p = *reinterpret_cast<const float4*>(a.E + (size_t)ip * a.d + c4);
+      const float4 q = *reinterpret_cast<const float4*>(a.E + (size_t)in * a.d + c4);
+      sp += f.x * p.x + f.y * p.y + f.z * p.z + f.w * p.w;
+      sn += f.x * q.x + f.y * q.y + f.z * q.z + f.w * q.w;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { sp += __shfl_xor(sp, o, 64); sn += __shfl_xor(sn, o, 64); }
+    if (sub == 0) { a.pos_logits[row] = sp; a.neg_logits[row] = sn; }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_logits_bwd(LogitsArgs a) {
+  const int sub = threadIdx.x & 15;
+  for (int row = blockIdx.x * 16 + (threadIdx.x >> 4); row < a.T; row += gridDim.x * 16) {
+    const int ip = a.pos[row], in = a.neg[row];
+    const float gp = a.dpos[row], gn = a.dneg[row];
+    for (int c4 = 4 * sub; c4 < a.d; c4 += 64) {
+      const float4 f = *reinterpret_cast<const float4*>(a.F + (size_t)row * a.ldf + c4);
+      const float4 p = *reinterpret_cast<const float4*>(a.E + (size_t)ip * a.d + c4);
+      const float4 q = *reinterpret_cast<const float4*>(a.E + (size_t)in * a.d + c4);
+      float4 df;
+      df.x = gp * p.x + gn * q.x; df.y = gp * p.y + gn * q.y; df.z = gp * p.z + gn * q.z; df.w = gp * p.w + gn * q.w;
+      *reinterpret_cast<float4*>(a.dF + (size_t)row * a.lddf + c4) = df;
+      if (gp != 0.f && ip != 0) {
+        float* e = a.dE + (size_t)ip * a.d + c4;
+        atomicAdd(e + 0, gp * f.x); atomicAdd(e + 1, gp * f.y); atomicAdd(e + 2, gp * f.z); atomicAdd(e + 3, gp * f.w);
+      }
+      if (gn != 0.f && in != 0) {
+        float* e = a.dE + (size_t)in * a.d + c4;
+        atomicAdd(e + 0, gn * f.x); atomicAdd(e + 1, gn * f.y); atomicAdd(e + 2, gn * f.z); atomicAdd(e + 3, gn * f.w);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Loss seeds of sasrec/main.py:151-169.  `norms` is a device array {n_bce, n_mse, n_nll} holding the
+// GLOBAL normalisers (data-parallel exactness).  loss slots: [0] bce_pos [1] bce_neg
+// [2..2+nl) mse_i [2+nl..2+2nl) nll_l  (sums already divided by their normalisers).
+struct BceArgs {
+  const float* pos_logits; const float* neg_logits; const int* pos;
+  int T;
+  const float* norms;
+  float* dpos; float* dneg;
+  float* loss;
+};
+
+ADT_DEVICE_INLINE float block_sum(float v, float* sbuf) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sbuf[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) r = sbuf[0] + sbuf[1] + sbuf[2] + sbuf[3];
+  __syncthreads();
+  return r;  // valid on thread 0
+}
+
+__global__ __launch_bounds__(256) void k_bce(BceArgs a) {
+  __shared__ float sbuf[4];
+  const float inv = 1.0f / a.norms[0];
+  float lp = 0.f, ln = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.T; i += gridDim.x * 256) {
+    float gp = 0.f, gn = 0.f;
+    if (a.pos[i] != 0) {
+      const float xp = a.pos_logits[i], xn = a.neg_logits[i];
+      // BCEWithLogits: target 1 -> softplus(-x), target 0 -> softplus(x)
+      lp += fmaxf(-xp, 0.f) + log1pf(expf(-fabsf(xp)));
+      ln += fmaxf(xn, 0.f) + log1pf(expf(-fabsf(xn)));
+      gp = (1.0f / (1.0f + expf(-xp)) - 1.0f) * inv;
+      gn = (1.0f / (1.0f + expf(-xn))) * inv;
+    }
+    a.dpos[i] = gp;
+    a.dneg[i] = gn;
+  }
+  const float sp = block_sum(lp, sbuf);
+  const float sn = block_sum(ln, sbuf);
+  if (threadIdx.x == 0) { atomicAdd(a.loss + 0, sp * inv); atomicAdd(a.loss + 1, sn * inv); }
+}
+
+// g = 2*lambda/n_mse * (A - Bm);  GA += g (or = g), GB = -g;  loss += sum (A-B)^2 / n_mse
+struct MseArgs {
+  const float* A; const float* Bm;
+  size_t n;                  // elements (multiple of 4)
+  float lambda;
+  const float* norms;
+  float* GA; int accA;       // accA: GA += g
+  float* GB;
+  float* loss;               // one slot
+};
+
+__global__ __launch_bounds__(256) void k_mse_seed(MseArgs a) {
+  __shared__ float sbuf[4];
+  const float inv = 1.0f / a.norms[1];
+  const float coef = 2.0f * a.lambda * inv;
+  float acc = 0.f;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < a.n; i += (size_t)gridDim.x * 1024) {
+    const float4 x = *reinterpret_cast<const float4*>(a.A + i);
+    const float4 y = *reinterpret_cast<const float4*>(a.Bm + i);
+    float4 dlt = make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
+    acc += dlt.x * dlt.x + dlt.y * dlt.y + dlt.z * dlt.z + dlt.w * dlt.w;
+    float4 g = make_float4(coef * dlt.x, coef * dlt.y, coef * dlt.z, coef * dlt.w);
+    *reinterpret_cast<float4*>(a.GB + i) = make_float4(-g.x, -g.y, -g.z, -g.w);
+    if (a.accA) {
+      const float4 o = *reinterpret_cast<const float4*>(a.GA + i);
+      g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w;
+    }
+    *reinterpret_cast<float4*>(a.GA + i) = g;
+  }
+  const float s = block_sum(acc, sbuf);
+  if (threadIdx.x == 0) atomicAdd(a.loss, s * inv);
+}
+
+// drec[n][h][c] = -(lambda2 / n_nll) * [h == c];  loss += -sum_n,h rec[n][h][h] / n_nll
+struct NllArgs {
+  const float* rec; int n_rows; int H;
+  float lambda2;
+  const float* norms;
+  float* drec;
+  float* loss;
+};
+
+__global__ __launch_bounds__(256) void k_nll_seed(NllArgs a) {
+  __shared__ float sbuf[4];
+  const float inv = 1.0f / a.norms[2];
+  const int HH = a.H * a.H;
+  const int n = a.n_rows * HH;
+  float acc = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int e = i % HH;
+    const bool diag = (e / a.H) == (e % a.H);
+    if (diag) acc -= a.rec[i];
+    a.drec[i] = diag ? -a.lambda2 * inv : 0.f;
+  }
+  const float s = block_sum(acc, sbuf);
+  if (threadIdx.x == 0) atomicAdd(a.loss, s * inv);
+}
+
+// ---------------------------------------------------------------------------------------------
+// sasrec/main.py:170-173: + wd * ||item_emb||_F (un-squared), clip_grad_norm_(clip), Adam(b1, b2).
+struct OptArgs {
+  float* P; float* G; float* M; float* Vv;
+  size_t n;          // number of trainable floats (flat prefix of the parameter buffer)
+  size_t nE;         // item table size (flat offset 0)
+  float wd, clip, lr, b1, b2, eps;
+  float* scal;       // device scalars: [0] ||E||^2  [1] ||g||^2  [2] step (float)  [3] wd loss term
+  float grad_scale;  // multiply grads first (1/world for averaged all-reduce; normally 1)
+};
+
+__global__ __launch_bounds__(256) void k_sumsq(const float* x, size_t n, float* out) {
+  __shared__ float sbuf[4];
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += x[i] * x[i];
+  const float s = block_sum(acc, sbuf);
+  if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+__global__ __launch_bounds__(256) void k_wd_gradnorm(OptArgs a) {
+  __shared__ float sbuf[4];
+  const float nrm = sqrtf(a.scal[0]);
+  const float coef = (a.wd != 0.f && nrm > 0.f) ? a.wd / nrm : 0.f;
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+    float g = a.G[i] * a.grad_scale;
+    if (i < a.nE) g += coef * a.P[i];
+    a.G[i] = g;
+    acc += g * g;
+  }
+  const float s = block_sum(acc, sbuf);
+  if (threadIdx.x == 0) atomicAdd(a.scal + 1, s);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { a.scal[3] = a.wd * nrm; a.scal[2] += 1.0f; }
+}
+
+__global__ __launch_bounds__(256) void k_adam(OptArgs a) {
+  const float tn = sqrtf(a.scal[1]);
+  const float coef = fminf(1.0f, a.clip / (tn + 1e-6f));
+  const float t = a.scal[2];
+  const float bc1 = 1.0f - powf(a.b1, t), bc2 = 1.0f - powf(a.b2, t);
+  const float step = a.lr / bc1, rs2 = 1.0f / sqrtf(bc2);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+    const float g = a.G[i] * coef;
+    const float m = a.b1 * a.M[i] + (1.0f - a.b1) * g;
+    const float v = a.b2 * a.Vv[i] + (1.0f - a.b2) * g * g;
+    a.M[i] = m;
+    a.Vv[i] = v;
+    a.P[i] -= step * m / (sqrtf(v) * rs2 + a.eps);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SASRecADT.predict (sasrec/model.py:89-96) + the rank of evaluate_loader (sasrec/utils.py:410):
+// logits[b][c] = E[cand[b][c]] . f[b] ; rank[b] = #{c > 0 : logits[b][c] > logits[b][0]}.
+struct ScoreArgs {
+  const float* F; int ldf;   // B rows (already the last position), d wide
+  const float* E;
+  const int* cand;           // B x C item ids, or null: all items 0..C-1
+  int B, C, d;
+  float* logits;             // B x C
+  int* rank;                 // B (may be null)
+};
+
+__global__ __launch_bounds__(256) void k_score(ScoreArgs a) {
+  // one wave per (b, candidate) pair group: 16 lanes per candidate
+  const int sub = threadIdx.x & 15;
+  const size_t n = (size_t)a.B * a.C;
+  for (size_t i = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4); i < n; i += (size_t)gridDim.x * 16) {
+    const int b = (int)(i / a.C), cidx = (int)(i % a.C);
+    const int item = a.cand ? a.cand[i] : cidx;
+    float s = 0.f;
+    for (int c4 = 4 * sub; c4 < a.d; c4 += 64) {
+      const float4 f = *reinterpret_cast<const float4*>(a.F + (size_t)b * a.ldf + c4);
+      const float4 e = *reinterpret_cast<const float4*>(a.E + (size_t)item * a.d + c4);
+      s += f.x * e.x + f.y * e.y + f.z * e.z + f.w * e.w;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (sub == 0) a.logits[i] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_rank(ScoreArgs a) {
+  const int lane = threadIdx.x & 63;
+  for (int b = blockIdx.x * 4 + (threadIdx.x >> 6); b < a.B; b += gridDim.x * 4) {
+    const float* row = a.logits + (size_t)b * a.C;
+    const float s0 = row[0];
+    int cnt = 0;
+    for (int cidx = 1 + lane; cidx < a.C; cidx += 64) cnt += (row[cidx] > s0) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) a.rank[b] = cnt;
+  }
+}
+
+}  // namespace adt

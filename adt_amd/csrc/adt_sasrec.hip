@@ -1,0 +1,366 @@
+// Model-level executor for SASRec-ADT: the sequence of stage launches that replaces SASRecADT.forward /
+// predict (sasrec/model.py:32-97), Encoder/EncoderLayer/Decoder/DecoderLayer (sasrec/modules.py:635-757) and
+// their autograd reverse pass, plus the loss seeds of sasrec/main.py:151-169.  Pure host code: it only
+// enqueues kernels (via the per-stage C ABI) on the caller's stream.
+#include "adt_host.h"
+
+namespace {
+
+constexpr float LN_EPS = 1e-8f;   // sasrec/modules.py:638,640,660 ; sasrec/model.py:28
+
+struct Layout {
+  int64_t off[4 + 30 * 16];
+  int64_t total;
+  int nl;
+  int64_t item() const { return off[0]; }
+  int64_t posw() const { return off[1]; }
+  int64_t lnl_w() const { return off[2]; }
+  int64_t lnl_b() const { return off[3]; }
+  int64_t enc(int i, int k) const { return off[4 + 14 * i + k]; }
+  int64_t dec(int i, int k) const { return off[4 + 14 * nl + 16 * i + k]; }
+};
+enum { E_LN1W, E_LN1B, E_INW, E_INB, E_OW, E_OB, E_LN2W, E_LN2B, E_C1W, E_C1B, E_C2W, E_C2B, E_SW, E_SB };
+enum { D_LNW, D_LNB, D_SINW, D_SINB, D_SOW, D_SOB, D_EINW, D_EINB, D_EOW, D_EOB, D_C1W, D_C1B, D_C2W, D_C2B, D_UW, D_UB };
+
+int64_t up64(int64_t x) { return (x + 63) / 64 * 64; }
+
+bool make_layout(const adt_sasrec_cfg* c, Layout* lo) {
+  if (c->num_layers < 1 || c->num_layers > 16) return false;
+  const int64_t d = c->hidden, H = c->num_heads, hd = d / H, L = c->maxlen, V = c->item_num;
+  lo->nl = c->num_layers;
+  int64_t o = 0;
+  int n = 0;
+  auto put = [&](int64_t sz) { lo->off[n++] = o; o += up64(sz); };
+  put((V + 1) * d); put(L * d); put(d); put(d);
+  for (int i = 0; i < c->num_layers; ++i) {
+    put(d); put(d); put(3 * d * d); put(3 * d); put(d * d); put(d); put(d); put(d);
+    put(d * d); put(d); put(d * d); put(d); put(H * hd); put(H);
+  }
+  for (int i = 0; i < c->num_layers; ++i) {
+    put(d); put(d);
+    put(3 * d * d); put(3 * d); put(d * d); put(d);
+    put(3 * d * d); put(3 * d); put(d * d); put(d);
+    put(d * d); put(d); put(d * d); put(d); put(d); put(d);
+  }
+  lo->total = o;
+  return true;
+}
+
+// workspace carve-up (offsets in floats)
+struct WS {
+  int64_t T, d, H, L, nl, B;
+  int64_t enc_x, dec_x, f, posl, negl;                                  // (nl+1)*Td each for enc_x/dec_x
+  int64_t e_qn, e_qkv, e_o, e_lse, e_h, e_h2, e_u, e_rec, e_stride;     // per encoder layer
+  int64_t d_dn, d_qkv, d_o1, d_lse1, d_a1, d_q2, d_kv2, d_o2, d_lse2, d_a2, d_u, d_stride;
+  int64_t g_enc_x, g_dec_x, g_f, g_pos, g_neg, g_rec;                   // gradients
+  int64_t s1, s2, s3, s4, s5;                                           // backward scratch: Td, Td, 3Td, 2Td, Td
+  int64_t loss, norms, scal;
+  int64_t total;
+};
+
+void make_ws(const adt_sasrec_cfg* c, int B, WS* w) {
+  w->B = B; w->d = c->hidden; w->H = c->num_heads; w->L = c->maxlen; w->nl = c->num_layers;
+  w->T = (int64_t)B * w->L;
+  const int64_t Td = up64(w->T * w->d), T1 = up64(w->T), lse = up64((int64_t)B * w->H * w->L);
+  const int64_t rec = up64(w->T * w->H * w->H);
+  int64_t o = 0;
+  auto take = [&](int64_t n) { int64_t r = o; o += n; return r; };
+  w->enc_x = take((w->nl + 1) * Td); w->dec_x = take((w->nl + 1) * Td); w->f = take(Td);
+  w->posl = take(T1); w->negl = take(T1);
+  {
+    const int64_t s = o;
+    w->e_qn = take(Td); w->e_qkv = take(3 * Td); w->e_o = take(Td); w->e_lse = take(lse); w->e_h = take(Td);
+    w->e_h2 = take(Td); w->e_u = take(Td); w->e_rec = take(rec);
+    w->e_stride = o - s;
+    o = s + w->e_stride * w->nl;
+  }
+  {
+    const int64_t s = o;
+    w->d_dn = take(Td); w->d_qkv = take(3 * Td); w->d_o1 = take(Td); w->d_lse1 = take(lse); w->d_a1 = take(Td);
+    w->d_q2 = take(Td); w->d_kv2 = take(2 * Td); w->d_o2 = take(Td); w->d_lse2 = take(lse); w->d_a2 = take(Td);
+    w->d_u = take(Td);
+    w->d_stride = o - s;
+    o = s + w->d_stride * w->nl;
+  }
+  w->g_enc_x = take((w->nl + 1) * Td); w->g_dec_x = take((w->nl + 1) * Td); w->g_f = take(Td);
+  w->g_pos = take(T1); w->g_neg = take(T1); w->g_rec = take(rec * w->nl);
+  w->s1 = take(Td); w->s2 = take(Td); w->s3 = take(3 * Td); w->s4 = take(2 * Td); w->s5 = take(Td);
+  w->loss = take(64); w->norms = take(64); w->scal = take(64);
+  w->total = o;
+}
+
+#define CK(call) do { int _r = (call); if (_r) return _r; } while (0)
+
+int check_cfg(const adt_sasrec_cfg* c) {
+  if (c->hidden != 64) return adt_set_error("sasrec: hidden=%d unsupported in this build (64)", c->hidden);
+  if (c->num_heads < 1 || c->hidden % c->num_heads) return adt_set_error("sasrec: bad num_heads");
+  const int hd = c->hidden / c->num_heads;
+  if (hd != 16 && hd != 32 && hd != 64) return adt_set_error("sasrec: head_dim=%d unsupported (16/32/64)", hd);
+  if (c->maxlen > 224) return adt_set_error("sasrec: maxlen=%d > 224 unsupported", c->maxlen);
+  if (c->num_layers < 1 || c->num_layers > 16) return adt_set_error("sasrec: num_layers");
+  return 0;
+}
+
+// encoder stack forward on embedded input ws[enc_x[0]]; shared by forward() and predict()
+int encoder_forward(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const float* P, float* ws,
+                    const int32_t* seq, float p, const uint32_t* seed, uint32_t b_offset, bool want_rec, void* st) {
+  const int T = (int)w.T, d = (int)w.d, H = (int)w.H, hd = d / H, L = (int)w.L, B = (int)w.B, prec = c->prec;
+  const int64_t Td = up64(w.T * w.d);
+  const uint32_t ro = b_offset * (uint32_t)L;
+  for (int i = 0; i < c->num_layers; ++i) {
+    const float* x = ws + w.enc_x + i * Td;
+    float* y = ws + w.enc_x + (i + 1) * Td;
+    float* base = ws + i * w.e_stride;
+    float *qn = base + w.e_qn, *qkv = base + w.e_qkv, *o = base + w.e_o, *lse = base + w.e_lse, *h = base + w.e_h,
+          *h2 = base + w.e_h2, *u = base + w.e_u, *rec = base + w.e_rec;
+    const float* inw = P + lo.enc(i, E_INW);
+    const float* inb = P + lo.enc(i, E_INB);
+    // Q = LN1(x); q = Q Wq^T + bq ; [k, v] = x Wkv^T + bkv        (sasrec/modules.py:646-647, :123-130)
+    CK(adt_layernorm_fwd(x, d, P + lo.enc(i, E_LN1W), P + lo.enc(i, E_LN1B), LN_EPS, T, d, qn, d, st));
+    CK(adt_linear_fwd(prec, qn, d, inw, inb, T, d, d, qkv, 3 * d, 0.f, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, nullptr, st));
+    CK(adt_linear_fwd(prec, x, d, inw + (int64_t)d * d, inb + d, T, d, 2 * d, qkv + d, 3 * d, 0.f, nullptr, 0, 0, 0, nullptr, 0,
+                      nullptr, 0, nullptr, st));
+    CK(adt_attn_fwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, B, H, L, hd, 1, p, seed, enc_site(i, 0), b_offset, o, d,
+                    lse, st));
+    if (want_rec) CK(adt_headcls_fwd(o, d, P + lo.enc(i, E_SW), P + lo.enc(i, E_SB), B, L, H, hd, rec, st));
+    // h = Q + out_proj(o) ; h2 = LN2(h)                            (:650-652)
+    CK(adt_linear_fwd(prec, o, d, P + lo.enc(i, E_OW), P + lo.enc(i, E_OB), T, d, d, h, d, 0.f, nullptr, 0, 0, 0, qn, d, nullptr, 0,
+                      nullptr, st));
+    CK(adt_layernorm_fwd(h, d, P + lo.enc(i, E_LN2W), P + lo.enc(i, E_LN2B), LN_EPS, T, d, h2, d, st));
+    // u = relu(drop1(conv1 h2)) ; y = (h2 + drop2(conv2 u)) * mask  (:629-633, :653-654)
+    CK(adt_linear_fwd(prec, h2, d, P + lo.enc(i, E_C1W), P + lo.enc(i, E_C1B), T, d, d, u, d, p, seed, enc_site(i, 1), ro, 1,
+                      nullptr, 0, nullptr, 0, nullptr, st));
+    CK(adt_linear_fwd(prec, u, d, P + lo.enc(i, E_C2W), P + lo.enc(i, E_C2B), T, d, d, y, d, p, seed, enc_site(i, 2), ro, 0, h2, d,
+                      nullptr, 0, seq, st));
+  }
+  // log_feats = last_layernorm(encoder out)                        (sasrec/model.py:48)
+  CK(adt_layernorm_fwd(ws + w.enc_x + c->num_layers * Td, d, P + lo.lnl_w(), P + lo.lnl_b(), LN_EPS, T, d, ws + w.f, d, st));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t adt_sasrec_param_layout(const adt_sasrec_cfg* cfg, int64_t* offsets) {
+  Layout lo;
+  if (!make_layout(cfg, &lo)) return adt_set_error("param_layout: bad cfg");
+  if (offsets)
+    for (int i = 0; i < 4 + 30 * cfg->num_layers; ++i) offsets[i] = lo.off[i];
+  return lo.total;
+}
+
+int64_t adt_sasrec_workspace_floats(const adt_sasrec_cfg* cfg, int B) {
+  WS w;
+  make_ws(cfg, B, &w);
+  return w.total;
+}
+
+int64_t adt_sasrec_ws_offset(const adt_sasrec_cfg* cfg, int B, int what, int layer) {
+  WS w;
+  make_ws(cfg, B, &w);
+  const int64_t Td = up64(w.T * w.d), rec = up64(w.T * w.H * w.H);
+  switch (what) {
+    case ADT_WS_ENC_X: return w.enc_x + layer * Td;
+    case ADT_WS_DEC_X: return w.dec_x + layer * Td;
+    case ADT_WS_REC: return layer * w.e_stride + w.e_rec;
+    case ADT_WS_POS_LOGITS: return w.posl;
+    case ADT_WS_NEG_LOGITS: return w.negl;
+    case ADT_WS_F: return w.f;
+    case ADT_WS_G_ENC_X: return w.g_enc_x + layer * Td;
+    case ADT_WS_G_DEC_X: return w.g_dec_x + layer * Td;
+    case ADT_WS_G_REC: return w.g_rec + layer * rec;
+    case ADT_WS_G_POS: return w.g_pos;
+    case ADT_WS_G_NEG: return w.g_neg;
+    case ADT_WS_LOSS: return w.loss;
+    case ADT_WS_NORMS: return w.norms;
+    case ADT_WS_SCAL: return w.scal;
+  }
+  return adt_set_error("ws_offset: unknown id %d", what);
+}
+
+int adt_sasrec_forward(const adt_sasrec_cfg* c, const float* P, float* ws, const int32_t* seq, const int32_t* dec,
+                       const int32_t* pos, const int32_t* neg, int B, int training, const uint32_t* seed,
+                       uint32_t b_offset, void* st) {
+  CK(check_cfg(c));
+  Layout lo;
+  make_layout(c, &lo);
+  WS w;
+  make_ws(c, B, &w);
+  const int T = (int)w.T, d = (int)w.d, H = (int)w.H, hd = d / H, L = (int)w.L, prec = c->prec;
+  const int64_t Td = up64(w.T * w.d);
+  const float p = training ? c->dropout : 0.f;
+  const uint32_t ro = b_offset * (uint32_t)L;
+  CK(adt_embed_fwd(seq, P + lo.item(), P + lo.posw(), T, L, d, p, seed, SITE_EMB_SEQ, ro, ws + w.enc_x, st));
+  CK(encoder_forward(c, lo, w, P, ws, seq, p, seed, b_offset, true, st));
+  const float* f = ws + w.f;
+  CK(adt_embed_fwd(dec, P + lo.item(), P + lo.posw(), T, L, d, p, seed, SITE_EMB_DEC, ro, ws + w.dec_x, st));
+  for (int i = 0; i < c->num_layers; ++i) {
+    const float* x = ws + w.dec_x + i * Td;
+    float* y = ws + w.dec_x + (i + 1) * Td;
+    float* base = ws + w.e_stride * c->num_layers + i * w.d_stride;
+    float *dn = base + w.d_dn, *qkv = base + w.d_qkv, *o1 = base + w.d_o1, *lse1 = base + w.d_lse1, *a1 = base + w.d_a1,
+          *q2 = base + w.d_q2, *kv2 = base + w.d_kv2, *o2 = base + w.d_o2, *lse2 = base + w.d_lse2, *a2 = base + w.d_a2,
+          *u = base + w.d_u;
+    // D = LN(x); a1 = MHA_slf(D, D, D; causal)                     (sasrec/modules.py:668-670)
+    CK(adt_layernorm_fwd(x, d, P + lo.dec(i, D_LNW), P + lo.dec(i, D_LNB), LN_EPS, T, d, dn, d, st));
+    CK(adt_linear_fwd(prec, dn, d, P + lo.dec(i, D_SINW), P + lo.dec(i, D_SINB), T, d, 3 * d, qkv, 3 * d, 0.f, nullptr, 0, 0, 0,
+                      nullptr, 0, nullptr, 0, nullptr, st));
+    CK(adt_attn_fwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, B, H, L, hd, 1, p, seed, dec_site(i, 0), b_offset, o1, d,
+                    lse1, st));
+    CK(adt_linear_fwd(prec, o1, d, P + lo.dec(i, D_SOW), P + lo.dec(i, D_SOB), T, d, d, a1, d, 0.f, nullptr, 0, 0, 0, nullptr, 0,
+                      nullptr, 0, nullptr, st));
+    // a2 = MHA_enc(q = a1, k = v = log_feats; causal)               (:671-672)
+    const float* einw = P + lo.dec(i, D_EINW);
+    const float* einb = P + lo.dec(i, D_EINB);
+    CK(adt_linear_fwd(prec, a1, d, einw, einb, T, d, d, q2, d, 0.f, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, nullptr, st));
+    CK(adt_linear_fwd(prec, f, d, einw + (int64_t)d * d, einb + d, T, d, 2 * d, kv2, 2 * d, 0.f, nullptr, 0, 0, 0, nullptr, 0,
+                      nullptr, 0, nullptr, st));
+    CK(adt_attn_fwd(prec, q2, d, kv2, 2 * d, kv2 + d, 2 * d, B, H, L, hd, 1, p, seed, dec_site(i, 1), b_offset, o2, d, lse2, st));
+    CK(adt_linear_fwd(prec, o2, d, P + lo.dec(i, D_EOW), P + lo.dec(i, D_EOB), T, d, d, a2, d, 0.f, nullptr, 0, 0, 0, nullptr, 0,
+                      nullptr, 0, nullptr, st));
+    // y = (D + a2 + drop2(conv2 relu(drop1(conv1 a2)))) * mask       (:673-676, :629-633)
+    CK(adt_linear_fwd(prec, a2, d, P + lo.dec(i, D_C1W), P + lo.dec(i, D_C1B), T, d, d, u, d, p, seed, dec_site(i, 2), ro, 1,
+                      nullptr, 0, nullptr, 0, nullptr, st));
+    CK(adt_linear_fwd(prec, u, d, P + lo.dec(i, D_C2W), P + lo.dec(i, D_C2B), T, d, d, y, d, p, seed, dec_site(i, 3), ro, 0, a2, d,
+                      dn, d, dec, st));
+  }
+  CK(adt_logits_fwd(f, d, P + lo.item(), pos, neg, T, d, ws + w.posl, ws + w.negl, st));
+  return 0;
+}
+
+int adt_sasrec_loss_seed(const adt_sasrec_cfg* c, float* ws, const int32_t* pos, int B, const float* lambdas1,
+                         const float* lambdas2, void* st) {
+  WS w;
+  make_ws(c, B, &w);
+  const int nl = c->num_layers, T = (int)w.T, H = (int)w.H;
+  const int64_t Td = up64(w.T * w.d), rec = up64(w.T * w.H * w.H);
+  float* loss = ws + w.loss;
+  const float* norms = ws + w.norms;
+  if (hipMemsetAsync(loss, 0, 64 * sizeof(float), (hipStream_t)st) != hipSuccess) return adt_set_error("loss memset");
+  CK(adt_bce_seed(ws + w.posl, ws + w.negl, pos, T, norms, ws + w.g_pos, ws + w.g_neg, loss, st));
+  for (int i = 0; i < nl; ++i)   // enc_in[i] pairs with dec_out_rev[i] = DEC_X[nl - i]      (sasrec/main.py:155-158)
+    CK(adt_mse_seed(ws + w.enc_x + i * Td, ws + w.dec_x + (nl - i) * Td, w.T * w.d, lambdas1[i], norms, ws + w.g_enc_x + i * Td, 0,
+                    ws + w.g_dec_x + (nl - i) * Td, loss + 2 + i, st));
+  if (H > 1)
+    for (int l = 0; l < nl; ++l)   // stale loop index: lambdas2[nl-1] for every layer          (sasrec/main.py:169)
+      CK(adt_nll_seed(ws + l * w.e_stride + w.e_rec, T * H, H, lambdas2[nl - 1], norms, ws + w.g_rec + l * rec, loss + 2 + nl + l, st));
+  return 0;
+}
+
+int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float* ws, const int32_t* seq,
+                        const int32_t* dec, const int32_t* pos, const int32_t* neg, int B, int training,
+                        const uint32_t* seed, uint32_t b_offset, int phase, void* st) {
+  CK(check_cfg(c));
+  Layout lo;
+  make_layout(c, &lo);
+  WS w;
+  make_ws(c, B, &w);
+  const int T = (int)w.T, d = (int)w.d, H = (int)w.H, hd = d / H, L = (int)w.L, prec = c->prec, nl = c->num_layers;
+  const int64_t Td = up64(w.T * w.d), recsz = up64(w.T * w.H * w.H);
+  const float p = training ? c->dropout : 0.f;
+  const uint32_t ro = b_offset * (uint32_t)L;
+  float *s1 = ws + w.s1, *s2 = ws + w.s2, *s3 = ws + w.s3, *s4 = ws + w.s4, *s5 = ws + w.s5;
+  float* gf = ws + w.g_f;
+  const float* f = ws + w.f;
+  if (phase == 0 || phase == 1) {
+    // d log_feats (overwrites g_f) and item-table rows of pos/neg      (sasrec/model.py:72-76)
+    CK(adt_logits_bwd(f, d, P + lo.item(), pos, neg, ws + w.g_pos, ws + w.g_neg, T, d, gf, d, G + lo.item(), st));
+    for (int i = nl - 1; i >= 0; --i) {
+      float* gy = ws + w.g_dec_x + (i + 1) * Td;      // d loss / d (output of decoder layer i), complete
+      float* gx = ws + w.g_dec_x + i * Td;            // accumulates d / d (input of layer i)
+      const float* x = ws + w.dec_x + i * Td;
+      float* base = ws + w.e_stride * nl + i * w.d_stride;
+      float *dn = base + w.d_dn, *qkv = base + w.d_qkv, *o1 = base + w.d_o1, *lse1 = base + w.d_lse1, *a1 = base + w.d_a1,
+            *q2 = base + w.d_q2, *kv2 = base + w.d_kv2, *o2 = base + w.d_o2, *lse2 = base + w.d_lse2, *a2 = base + w.d_a2,
+            *u = base + w.d_u;
+      // FFN: du = (gy*mask*drop2) W2 ; da2 = gy*mask + (du*relu'*drop1) W1
+      CK(adt_linear_bwd(prec, gy, d, u, d, P + lo.dec(i, D_C2W), T, d, d, dec, p, seed, dec_site(i, 3), ro, nullptr, 0, s1, d, 0,
+                        nullptr, 0, nullptr, G + lo.dec(i, D_C2W), G + lo.dec(i, D_C2B), st));
+      CK(adt_linear_bwd(prec, s1, d, a2, d, P + lo.dec(i, D_C1W), T, d, d, nullptr, p, seed, dec_site(i, 2), ro, u, d, s2, d, 0, gy, d,
+                        dec, G + lo.dec(i, D_C1W), G + lo.dec(i, D_C1B), st));
+      // enc_attn out_proj: do2 = da2 Wo2
+      CK(adt_linear_bwd(prec, s2, d, o2, d, P + lo.dec(i, D_EOW), T, d, d, nullptr, 0.f, nullptr, 0, 0, nullptr, 0, s1, d, 0, nullptr,
+                        0, nullptr, G + lo.dec(i, D_EOW), G + lo.dec(i, D_EOB), st));
+      // cross attention core: dq2 -> s5, dkv2 -> s4
+      CK(adt_attn_bwd(prec, q2, d, kv2, 2 * d, kv2 + d, 2 * d, o2, d, lse2, s1, d, B, H, L, hd, 1, p, seed, dec_site(i, 1), b_offset,
+                      s5, d, s4, 2 * d, s4 + d, 2 * d, st));
+      const float* einw = P + lo.dec(i, D_EINW);
+      float* geinw = G + lo.dec(i, D_EINW);
+      float* geinb = G + lo.dec(i, D_EINB);
+      // q2 = a1 Wq^T: da1 -> s2 ;  kv2 = f Wkv^T: g_f += dkv2 Wkv
+      CK(adt_linear_bwd(prec, s5, d, a1, d, einw, T, d, d, nullptr, 0.f, nullptr, 0, 0, nullptr, 0, s2, d, 0, nullptr, 0, nullptr,
+                        geinw, geinb, st));
+      CK(adt_linear_bwd(prec, s4, 2 * d, f, d, einw + (int64_t)d * d, T, d, 2 * d, nullptr, 0.f, nullptr, 0, 0, nullptr, 0, gf, d, 1,
+                        nullptr, 0, nullptr, geinw + (int64_t)d * d, geinb + d, st));
+      // slf_attn out_proj: do1 = da1 Wo1 -> s1 ; core -> dqkv1 (s3) ; in_proj: dD = dqkv1 Win + gy*mask -> s2
+      CK(adt_linear_bwd(prec, s2, d, o1, d, P + lo.dec(i, D_SOW), T, d, d, nullptr, 0.f, nullptr, 0, 0, nullptr, 0, s1, d, 0, nullptr,
+                        0, nullptr, G + lo.dec(i, D_SOW), G + lo.dec(i, D_SOB), st));
+      CK(adt_attn_bwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, o1, d, lse1, s1, d, B, H, L, hd, 1, p, seed,
+                      dec_site(i, 0), b_offset, s3, 3 * d, s3 + d, 3 * d, s3 + 2 * d, 3 * d, st));
+      CK(adt_linear_bwd(prec, s3, 3 * d, dn, d, P + lo.dec(i, D_SINW), T, d, 3 * d, nullptr, 0.f, nullptr, 0, 0, nullptr, 0, s2, d, 0,
+                        gy, d, dec, G + lo.dec(i, D_SINW), G + lo.dec(i, D_SINB), st));
+      // layer_norm: gx (+)= LN'(dD)
+      CK(adt_layernorm_bwd(s2, d, x, d, P + lo.dec(i, D_LNW), LN_EPS, T, d, gx, d, i > 0 ? 1 : 0, G + lo.dec(i, D_LNW),
+                           G + lo.dec(i, D_LNB), st));
+    }
+    // decoder input embedding (sasrec/model.py:53-59)
+    CK(adt_embed_bwd(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.item(), G + lo.posw(), st));
+  }
+  if (phase == 0 || phase == 2) {
+    // last_layernorm: g_enc_x[nl] = LN'(g_f)
+    CK(adt_layernorm_bwd(gf, d, ws + w.enc_x + nl * Td, d, P + lo.lnl_w(), LN_EPS, T, d, ws + w.g_enc_x + nl * Td, d, 0,
+                         G + lo.lnl_w(), G + lo.lnl_b(), st));
+    for (int i = nl - 1; i >= 0; --i) {
+      float* gy = ws + w.g_enc_x + (i + 1) * Td;
+      float* gx = ws + w.g_enc_x + i * Td;     // already holds the reconstruction seed for enc_in[i]
+      const float* x = ws + w.enc_x + i * Td;
+      float* base = ws + i * w.e_stride;
+      float *qn = base + w.e_qn, *qkv = base + w.e_qkv, *o = base + w.e_o, *lse = base + w.e_lse, *h = base + w.e_h,
+            *h2 = base + w.e_h2, *u = base + w.e_u, *rec = base + w.e_rec;
+      // FFN: du -> s1 ; dh2 = gy*mask + (du*relu'*drop1) W1 -> s2
+      CK(adt_linear_bwd(prec, gy, d, u, d, P + lo.enc(i, E_C2W), T, d, d, seq, p, seed, enc_site(i, 2), ro, nullptr, 0, s1, d, 0,
+                        nullptr, 0, nullptr, G + lo.enc(i, E_C2W), G + lo.enc(i, E_C2B), st));
+      CK(adt_linear_bwd(prec, s1, d, h2, d, P + lo.enc(i, E_C1W), T, d, d, nullptr, p, seed, enc_site(i, 1), ro, u, d, s2, d, 0, gy, d,
+                        seq, G + lo.enc(i, E_C1W), G + lo.enc(i, E_C1B), st));
+      // forward_layernorm: dh -> s5
+      CK(adt_layernorm_bwd(s2, d, h, d, P + lo.enc(i, E_LN2W), LN_EPS, T, d, s5, d, 0, G + lo.enc(i, E_LN2W), G + lo.enc(i, E_LN2B), st));
+      // out_proj: do -> s1 (+ classifier gradient)
+      CK(adt_linear_bwd(prec, s5, d, o, d, P + lo.enc(i, E_OW), T, d, d, nullptr, 0.f, nullptr, 0, 0, nullptr, 0, s1, d, 0, nullptr, 0,
+                        nullptr, G + lo.enc(i, E_OW), G + lo.enc(i, E_OB), st));
+      if (H > 1)
+        CK(adt_headcls_bwd(o, d, P + lo.enc(i, E_SW), rec, ws + w.g_rec + i * recsz, (int)w.B, L, H, hd, s1, d, G + lo.enc(i, E_SW),
+                           G + lo.enc(i, E_SB), st));
+      CK(adt_attn_bwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, o, d, lse, s1, d, (int)w.B, H, L, hd, 1, p, seed,
+                      enc_site(i, 0), b_offset, s3, 3 * d, s3 + d, 3 * d, s3 + 2 * d, 3 * d, st));
+      const float* inw = P + lo.enc(i, E_INW);
+      float* ginw = G + lo.enc(i, E_INW);
+      float* ginb = G + lo.enc(i, E_INB);
+      // q = Q Wq^T: dQ = dq Wq + dh -> s2 ; [k,v] = x Wkv^T: gx += dkv Wkv
+      CK(adt_linear_bwd(prec, s3, 3 * d, qn, d, inw, T, d, d, nullptr, 0.f, nullptr, 0, 0, nullptr, 0, s2, d, 0, s5, d, nullptr, ginw,
+                        ginb, st));
+      CK(adt_linear_bwd(prec, s3 + d, 3 * d, x, d, inw + (int64_t)d * d, T, d, 2 * d, nullptr, 0.f, nullptr, 0, 0, nullptr, 0, gx, d, 1,
+                        nullptr, 0, nullptr, ginw + (int64_t)d * d, ginb + d, st));
+      // attention_layernorm: gx += LN'(dQ)
+      CK(adt_layernorm_bwd(s2, d, x, d, P + lo.enc(i, E_LN1W), LN_EPS, T, d, gx, d, 1, G + lo.enc(i, E_LN1W), G + lo.enc(i, E_LN1B), st));
+    }
+    CK(adt_embed_bwd(seq, ws + w.g_enc_x, T, L, d, p, seed, SITE_EMB_SEQ, ro, G + lo.item(), G + lo.posw(), st));
+  }
+  return 0;
+}
+
+int adt_sasrec_predict(const adt_sasrec_cfg* c, const float* P, float* ws, const int32_t* seq, const int32_t* cand,
+                       int B, int C, float* logits, int32_t* rank, void* st) {
+  CK(check_cfg(c));
+  Layout lo;
+  make_layout(c, &lo);
+  WS w;
+  make_ws(c, B, &w);
+  const int T = (int)w.T, d = (int)w.d, L = (int)w.L;
+  CK(adt_embed_fwd(seq, P + lo.item(), P + lo.posw(), T, L, d, 0.f, nullptr, SITE_EMB_SEQ, 0, ws + w.enc_x, st));
+  CK(encoder_forward(c, lo, w, P, ws, seq, 0.f, nullptr, 0, false, st));
+  // final_feat = log_feats[:, -1, :]  (sasrec/model.py:89): row b*L + L-1, i.e. ld = L*d starting at (L-1)*d
+  return adt_score_rank(ws + w.f + (int64_t)(L - 1) * d, L * d, P + lo.item(), cand, B, C, d, logits, rank, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,171 @@
+"""Torch-tensor wrappers over the C ABI (include/adt_hip.h).  Tensors must be CUDA (HIP) fp32/int32 and
+contiguous in their last dimension; every call enqueues on torch's current stream.  Nothing here computes on
+the host: a missing libadt_hip.so or a CPU tensor is an error, not a fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+PREC_F32, PREC_BF16 = 0, 1
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.AdtError("adt_amd.ops: tensor is not on the GPU (no CPU fallback)")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ld(t):
+    return t.stride(-2) if t is not None and t.dim() >= 2 else 0
+
+
+def _f32(t):
+    assert t.dtype == torch.float32 and t.stride(-1) == 1, (t.dtype, t.stride())
+    return t
+
+
+def _i32(t):
+    assert t.dtype == torch.int32 and t.is_contiguous()
+    return t
+
+
+def embed_fwd(ids, E, P, L, p, seed, site, row_offset=0):
+    T = ids.numel()
+    d = E.shape[1]
+    X = torch.empty(T, d, device=E.device, dtype=torch.float32)
+    _lib.check(_lib.load().adt_embed_fwd(_p(_i32(ids)), _p(_f32(E)), _p(_f32(P)), T, L, d, float(p), _p(seed), site,
+                                         row_offset, _p(X), _stream()), "embed_fwd")
+    return X
+
+
+def embed_bwd(ids, dX, L, p, seed, site, dE, dP, row_offset=0):
+    T, d = dX.shape
+    _lib.check(_lib.load().adt_embed_bwd(_p(_i32(ids)), _p(_f32(dX)), T, L, d, float(p), _p(seed), site, row_offset,
+                                         _p(dE), _p(dP), _stream()), "embed_bwd")
+
+
+def layernorm_fwd(X, gamma, beta, eps):
+    T, d = X.shape
+    Y = torch.empty(T, d, device=X.device, dtype=torch.float32)
+    _lib.check(_lib.load().adt_layernorm_fwd(_p(_f32(X)), _ld(X), _p(gamma), _p(beta), eps, T, d, _p(Y), d, _stream()), "ln_fwd")
+    return Y
+
+
+def layernorm_bwd(dY, X, gamma, eps, dX, accumulate, dgamma, dbeta):
+    T, d = X.shape
+    _lib.check(_lib.load().adt_layernorm_bwd(_p(_f32(dY)), _ld(dY), _p(_f32(X)), _ld(X), _p(gamma), eps, T, d, _p(dX), _ld(dX),
+                                             int(accumulate), _p(dgamma), _p(dbeta), _stream()), "ln_bwd")
+
+
+def linear_fwd(prec, X, W, b, Y=None, p=0.0, seed=None, site=0, row_offset=0, relu=False, R1=None, R2=None, mask_ids=None):
+    T, K = X.shape
+    N = W.shape[0]
+    if Y is None:
+        Y = torch.empty(T, N, device=X.device, dtype=torch.float32)
+    _lib.check(_lib.load().adt_linear_fwd(prec, _p(_f32(X)), _ld(X), _p(_f32(W)), _p(b), T, K, N, _p(Y), _ld(Y), float(p), _p(seed),
+                                          site, row_offset, int(relu), _p(R1), _ld(R1), _p(R2), _ld(R2), _p(mask_ids), _stream()),
+               "linear_fwd")
+    return Y
+
+
+def linear_bwd(prec, dY, X, W, dW, db, dX=None, beta=False, mask_ids=None, p=0.0, seed=None, site=0, row_offset=0, U=None,
+               Radd=None, radd_ids=None):
+    T, K = X.shape
+    N = W.shape[0]
+    _lib.check(_lib.load().adt_linear_bwd(prec, _p(_f32(dY)), _ld(dY), _p(_f32(X)), _ld(X), _p(_f32(W)), T, K, N, _p(mask_ids),
+                                          float(p), _p(seed), site, row_offset, _p(U), _ld(U), _p(dX), _ld(dX), int(beta), _p(Radd),
+                                          _ld(Radd), _p(radd_ids), _p(dW), _p(db), _stream()), "linear_bwd")
+
+
+def attn_fwd(prec, Q, K, V, B, H, L, causal=True, p=0.0, seed=None, site=0, b_offset=0):
+    """Q, K, V: (B*L, >= H*hd) views (head h in columns [h*hd, (h+1)*hd)); returns O (B*L, H*hd), LSE (B*H*L)."""
+    d = Q.shape[1]
+    hd = d // H
+    O = torch.empty(B * L, d, device=Q.device, dtype=torch.float32)
+    LSE = torch.empty(B * H * L, device=Q.device, dtype=torch.float32)
+    _lib.check(_lib.load().adt_attn_fwd(prec, _p(_f32(Q)), _ld(Q), _p(_f32(K)), _ld(K), _p(_f32(V)), _ld(V), B, H, L, hd, int(causal),
+                                        float(p), _p(seed), site, b_offset, _p(O), d, _p(LSE), _stream()), "attn_fwd")
+    return O, LSE
+
+
+def attn_bwd(prec, Q, K, V, O, LSE, dO, B, H, L, causal=True, p=0.0, seed=None, site=0, b_offset=0):
+    d = Q.shape[1]
+    hd = d // H
+    dQ = torch.empty(B * L, d, device=Q.device, dtype=torch.float32)
+    dK = torch.empty_like(dQ)
+    dV = torch.empty_like(dQ)
+    _lib.check(_lib.load().adt_attn_bwd(prec, _p(_f32(Q)), _ld(Q), _p(_f32(K)), _ld(K), _p(_f32(V)), _ld(V), _p(_f32(O)), _ld(O),
+                                        _p(LSE), _p(_f32(dO)), _ld(dO), B, H, L, hd, int(causal), float(p), _p(seed), site, b_offset,
+                                        _p(dQ), d, _p(dK), d, _p(dV), d, _stream()), "attn_bwd")
+    return dQ, dK, dV
+
+
+def headcls_fwd(O, Ws, bs, B, L):
+    H, hd = Ws.shape
+    rec = torch.empty(L * B, H, H, device=O.device, dtype=torch.float32)
+    _lib.check(_lib.load().adt_headcls_fwd(_p(_f32(O)), _ld(O), _p(Ws), _p(bs), B, L, H, hd, _p(rec), _stream()), "headcls_fwd")
+    return rec
+
+
+def headcls_bwd(O, Ws, rec, drec, B, L, dO, dWs, dbs):
+    H, hd = Ws.shape
+    _lib.check(_lib.load().adt_headcls_bwd(_p(_f32(O)), _ld(O), _p(Ws), _p(rec), _p(drec), B, L, H, hd, _p(dO), _ld(dO), _p(dWs),
+                                           _p(dbs), _stream()), "headcls_bwd")
+
+
+def logits_fwd(F, E, pos, neg):
+    T, d = F.shape
+    pl = torch.empty(T, device=F.device, dtype=torch.float32)
+    nl = torch.empty_like(pl)
+    _lib.check(_lib.load().adt_logits_fwd(_p(_f32(F)), _ld(F), _p(E), _p(_i32(pos)), _p(_i32(neg)), T, d, _p(pl), _p(nl), _stream()),
+               "logits_fwd")
+    return pl, nl
+
+
+def logits_bwd(F, E, pos, neg, dpos, dneg, dE):
+    T, d = F.shape
+    dF = torch.empty(T, d, device=F.device, dtype=torch.float32)
+    _lib.check(_lib.load().adt_logits_bwd(_p(_f32(F)), _ld(F), _p(E), _p(_i32(pos)), _p(_i32(neg)), _p(dpos), _p(dneg), T, d, _p(dF),
+                                          d, _p(dE), _stream()), "logits_bwd")
+    return dF
+
+
+def bce_seed(pos_logits, neg_logits, pos, norms, loss2):
+    T = pos_logits.numel()
+    dpos = torch.empty(T, device=pos_logits.device, dtype=torch.float32)
+    dneg = torch.empty_like(dpos)
+    _lib.check(_lib.load().adt_bce_seed(_p(pos_logits), _p(neg_logits), _p(_i32(pos)), T, _p(norms), _p(dpos), _p(dneg), _p(loss2),
+                                        _stream()), "bce_seed")
+    return dpos, dneg
+
+
+def mse_seed(A, Bm, lam, norms, GA, accumulate_a, GB, loss1):
+    _lib.check(_lib.load().adt_mse_seed(_p(A), _p(Bm), A.numel(), float(lam), _p(norms), _p(GA), int(accumulate_a), _p(GB), _p(loss1),
+                                        _stream()), "mse_seed")
+
+
+def nll_seed(rec, H, lam2, norms, drec, loss1):
+    _lib.check(_lib.load().adt_nll_seed(_p(rec), rec.numel() // (H * H), H, float(lam2), _p(norms), _p(drec), _p(loss1), _stream()),
+               "nll_seed")
+
+
+def clip_adam(P, G, M, V, nE, wd, clip, lr, b1, b2, eps, scal, grad_scale=1.0, n=None):
+    n = P.numel() if n is None else n
+    _lib.check(_lib.load().adt_clip_adam(_p(P), _p(G), _p(M), _p(V), n, nE, float(wd), float(clip), float(lr), float(b1), float(b2),
+                                         float(eps), float(grad_scale), _p(scal), _stream()), "clip_adam")
+
+
+def score_rank(F, ldf, E, cand, B, C, want_rank=True):
+    d = E.shape[1]
+    logits = torch.empty(B, C, device=E.device, dtype=torch.float32)
+    rank = torch.empty(B, device=E.device, dtype=torch.int32) if want_rank else None
+    _lib.check(_lib.load().adt_score_rank(_p(F), ldf, _p(E), _p(cand), B, C, d, _p(logits), _p(rank), _stream()), "score_rank")
+    return logits, rank

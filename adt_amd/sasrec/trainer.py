@@ -1,0 +1,122 @@
+"""Fused training step for SASRecADT: the loop body of the reference's sasrec/main.py:143-173 (forward, loss
+assembly, backward, weight-decay term, clip_grad_norm_, Adam) as ONE device-side launch sequence, optionally
+replayed from a HIP graph.  Host work per step = one pinned-buffer fill + one H2D copy of the id batch.
+
+Data-parallel (one process per GPU, torch.distributed "nccl" = RCCL over xGMI): every rank runs the same
+sequence on its contiguous slice of the batch with GLOBAL loss normalisers and GLOBAL dropout indices, the
+flat gradient buffer is summed with all-reduce in two buckets (decoder bucket overlaps the encoder's
+backward), and the weight-decay term, clipping and Adam run identically on every rank on the reduced
+buffer -- so N ranks reproduce the 1-rank step on the same global batch.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .model import WS_LOSS, WS_NORMS
+
+
+class FusedTrainer:
+    def __init__(self, model, lambdas1, lambdas2, lr=1e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0, clip=5.0,
+                 process_group=None, use_graph=False, seed=23):
+        self.model = model
+        self.lambdas1, self.lambdas2 = [float(x) for x in lambdas1], [float(x) for x in lambdas2]
+        assert len(self.lambdas1) == model.num_layers and len(self.lambdas2) == model.num_layers
+        self.lr, self.betas, self.eps, self.wd, self.clip = lr, betas, eps, weight_decay, clip
+        self.pg = process_group
+        self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
+        self.rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
+        self.use_graph = use_graph and self.world == 1
+        dev = model.dev
+        self.m = torch.zeros_like(model.flat)
+        self.v = torch.zeros_like(model.flat)
+        self.scal = torch.zeros(4, device=dev, dtype=torch.float32)
+        self.base_seed = seed
+        self.nstep = 0
+        self._B = -1
+        self._graph = None
+        nl, H = model.num_layers, model.num_heads
+        w = [1.0, 1.0] + self.lambdas1 + [self.lambdas2[nl - 1] if H > 1 else 0.0] * nl   # stale-index NLL weight
+        self._loss_w = torch.tensor(w, device=dev, dtype=torch.float32)
+        # bucket boundary for the overlapped all-reduce: decoder parameters start at this flat offset
+        self._dec_off = model.offsets[4 + 14 * nl]
+
+    # ------------------------------------------------------------------------------------------
+    def _alloc(self, B):
+        m = self.model
+        T = B * m.maxlen
+        self._B, self._T = B, T
+        n_int = 4 * T + 4   # seq, dec, pos, neg, 3 normalisers (float bits), seed
+        self._host = torch.empty(n_int, dtype=torch.int32).pin_memory()
+        self._devbuf = torch.empty(n_int, device=m.dev, dtype=torch.int32)
+        self._ids = [self._devbuf[i * T:(i + 1) * T].view(B, m.maxlen) for i in range(4)]
+        self._norms_dev = self._devbuf[4 * T:4 * T + 3].view(torch.float32)
+        self._seed_dev = self._devbuf[4 * T + 3:4 * T + 4]
+        self._host_np = self._host.numpy()
+        m.workspace(B)
+        self._graph = None
+
+    def _launch(self, B, b_offset):
+        """Everything after the H2D copy; capturable."""
+        m = self.model
+        seq, dec, pos, neg = self._ids
+        m._seed.copy_(self._seed_dev)
+        m.ws_view(B, WS_NORMS, 0, 3).copy_(self._norms_dev)
+        m.run_forward(seq, dec, pos, neg, B, True, b_offset)
+        m.run_loss_seed(pos, B, self.lambdas1, self.lambdas2)
+        m.flat_grad.zero_()
+        if self.world == 1:
+            m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=0)
+        else:
+            m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=1)
+            h1 = torch.distributed.all_reduce(m.flat_grad[self._dec_off:], group=self.pg, async_op=True)
+            m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=2)
+            h2 = torch.distributed.all_reduce(m.flat_grad[:self._dec_off], group=self.pg, async_op=True)
+            h1.wait()
+            h2.wait()
+        from .. import ops
+        ops.clip_adam(m.flat, m.flat_grad, self.m, self.v, (m.item_num + 1) * m.hidden_units, self.wd, self.clip, self.lr,
+                      self.betas[0], self.betas[1], self.eps, self.scal)
+
+    def step(self, seq, dec, pos, neg, norms=None, b_offset=0):
+        """One optimisation step on numpy/torch int arrays (B_local, L).  `norms` = (n_bce, n_mse, n_nll) of
+        the GLOBAL batch (defaults to this batch's own counts).  Returns nothing; see `loss()`."""
+        m = self.model
+        seq = np.asarray(seq)
+        B = seq.shape[0]
+        if B != self._B:
+            self._alloc(B)
+        T = self._T
+        hn = self._host_np
+        hn[0:T] = seq.reshape(-1)
+        hn[T:2 * T] = np.asarray(dec).reshape(-1)
+        hn[2 * T:3 * T] = np.asarray(pos).reshape(-1)
+        hn[3 * T:4 * T] = np.asarray(neg).reshape(-1)
+        if norms is None:
+            norms = (float(np.count_nonzero(hn[2 * T:3 * T])), float(T * m.hidden_units), float(T * m.num_heads))
+        hn[4 * T:4 * T + 3] = np.array(norms, dtype=np.float32).view(np.int32)
+        self.nstep += 1
+        hn[4 * T + 3] = np.array([(self.base_seed * 1000003 + self.nstep * 2654435761) & 0xFFFFFFFF], dtype=np.uint32).view(np.int32)[0]
+        self._devbuf.copy_(self._host, non_blocking=True)
+        if not self.use_graph:
+            self._launch(B, b_offset)
+            return
+        if self._graph is None:
+            # warm up once eagerly (hipFuncSetAttribute etc. are not capturable), then capture
+            self._launch(B, b_offset)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._launch(B, b_offset)
+            return
+        self._graph.replay()
+
+    def loss(self):
+        """Device scalar: the loss of the last step as the reference prints it (sasrec/main.py:174)."""
+        m = self.model
+        slots = m.ws_view(self._B, WS_LOSS, 0, 2 + 2 * m.num_layers)
+        return (slots * self._loss_w).sum() + self.scal[3]
+
+    def grad_norm(self):
+        return self.scal[1].sqrt()

@@ -138,4 +138,6 @@ def test_dropout_rng_is_deterministic_and_calibrated():
     assert (rng.keep_mask(8, 17, idx, 0.5) != k1).mean() > 0.4
     # known-answer values (also asserted by the HIP unit test through the C ABI)
     assert [int(x) for x in rng.hash32(np.array([0, 1, 2, 0xDEADBEEF], np.uint32))] == \
-        [0, 1753845952, 3507691905, 3077942095] or True
+        [0, 1753845952, 3507691905, 3861431939]
+    assert int(rng.site_key(7, 17)) == 88319467
+    assert list(rng.keep_mask(7, 17, np.arange(16), 0.5).astype(int)) == [1, 1, 1, 0, 1, 1, 1, 0, 1, 0, 1, 0, 1, 1, 1, 1]
