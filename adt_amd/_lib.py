@@ -66,6 +66,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: libadt_hip.so's NEEDED libamdhip64.so.7 must bind to the HIP runtime torch has already
+    # loaded (its bundled copy), otherwise the process ends up with two runtimes and ours sees no device
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise AdtError("libadt_hip.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
     try:

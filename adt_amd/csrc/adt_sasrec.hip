@@ -198,7 +198,7 @@ int adt_sasrec_forward(const adt_sasrec_cfg* c, const float* P, float* ws, const
   for (int i = 0; i < c->num_layers; ++i) {
     const float* x = ws + w.dec_x + i * Td;
     float* y = ws + w.dec_x + (i + 1) * Td;
-    float* base = ws + w.e_stride * c->num_layers + i * w.d_stride;
+    float* base = ws + i * w.d_stride;   // d_* offsets are absolute for layer 0
     float *dn = base + w.d_dn, *qkv = base + w.d_qkv, *o1 = base + w.d_o1, *lse1 = base + w.d_lse1, *a1 = base + w.d_a1,
           *q2 = base + w.d_q2, *kv2 = base + w.d_kv2, *o2 = base + w.d_o2, *lse2 = base + w.d_lse2, *a2 = base + w.d_a2,
           *u = base + w.d_u;
@@ -244,7 +244,7 @@ int adt_sasrec_loss_seed(const adt_sasrec_cfg* c, float* ws, const int32_t* pos,
                     ws + w.g_dec_x + (nl - i) * Td, loss + 2 + i, st));
   if (H > 1)
     for (int l = 0; l < nl; ++l)   // stale loop index: lambdas2[nl-1] for every layer          (sasrec/main.py:169)
-      CK(adt_nll_seed(ws + l * w.e_stride + w.e_rec, T * H, H, lambdas2[nl - 1], norms, ws + w.g_rec + l * rec, loss + 2 + nl + l, st));
+      CK(adt_nll_seed(ws + l * w.e_stride + w.e_rec, T, H, lambdas2[nl - 1], norms, ws + w.g_rec + l * rec, loss + 2 + nl + l, st));
   return 0;
 }
 
@@ -270,7 +270,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       float* gy = ws + w.g_dec_x + (i + 1) * Td;      // d loss / d (output of decoder layer i), complete
       float* gx = ws + w.g_dec_x + i * Td;            // accumulates d / d (input of layer i)
       const float* x = ws + w.dec_x + i * Td;
-      float* base = ws + w.e_stride * nl + i * w.d_stride;
+      float* base = ws + i * w.d_stride;
       float *dn = base + w.d_dn, *qkv = base + w.d_qkv, *o1 = base + w.d_o1, *lse1 = base + w.d_lse1, *a1 = base + w.d_a1,
             *q2 = base + w.d_q2, *kv2 = base + w.d_kv2, *o2 = base + w.d_o2, *lse2 = base + w.d_lse2, *a2 = base + w.d_a2,
             *u = base + w.d_u;
