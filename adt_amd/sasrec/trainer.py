@@ -47,12 +47,11 @@ class FusedTrainer:
         m = self.model
         T = B * m.maxlen
         self._B, self._T = B, T
-        n_int = 4 * T + 4   # seq, dec, pos, neg, 3 normalisers (float bits), seed
+        n_int = 4 * T + 4   # seq, dec, pos, neg, 3 normalisers (float bits), pad
         self._host = torch.empty(n_int, dtype=torch.int32).pin_memory()
         self._devbuf = torch.empty(n_int, device=m.dev, dtype=torch.int32)
         self._ids = [self._devbuf[i * T:(i + 1) * T].view(B, m.maxlen) for i in range(4)]
         self._norms_dev = self._devbuf[4 * T:4 * T + 3].view(torch.float32)
-        self._seed_dev = self._devbuf[4 * T + 3:4 * T + 4]
         self._host_np = self._host.numpy()
         m.workspace(B)
         self._graph = None
@@ -61,7 +60,7 @@ class FusedTrainer:
         """Everything after the H2D copy; capturable."""
         m = self.model
         seq, dec, pos, neg = self._ids
-        m._seed.copy_(self._seed_dev)
+        m._seed.add_(-1640531535)   # += 0x9E3779B1 (mod 2^32): a fresh dropout stream every step, on the device
         m.ws_view(B, WS_NORMS, 0, 3).copy_(self._norms_dev)
         m.run_forward(seq, dec, pos, neg, B, True, b_offset)
         m.run_loss_seed(pos, B, self.lambdas1, self.lambdas2)
@@ -79,14 +78,14 @@ class FusedTrainer:
         ops.clip_adam(m.flat, m.flat_grad, self.m, self.v, (m.item_num + 1) * m.hidden_units, self.wd, self.clip, self.lr,
                       self.betas[0], self.betas[1], self.eps, self.scal)
 
-    def step(self, seq, dec, pos, neg, norms=None, b_offset=0):
-        """One optimisation step on numpy/torch int arrays (B_local, L).  `norms` = (n_bce, n_mse, n_nll) of
-        the GLOBAL batch (defaults to this batch's own counts).  Returns nothing; see `loss()`."""
+    def _fill_host(self, seq, dec, pos, neg, norms):
         m = self.model
         seq = np.asarray(seq)
         B = seq.shape[0]
         if B != self._B:
             self._alloc(B)
+            if self.nstep == 0:
+                m.set_seed(self.base_seed * 1000003 + 12345)
         T = self._T
         hn = self._host_np
         hn[0:T] = seq.reshape(-1)
@@ -94,11 +93,39 @@ class FusedTrainer:
         hn[2 * T:3 * T] = np.asarray(pos).reshape(-1)
         hn[3 * T:4 * T] = np.asarray(neg).reshape(-1)
         if norms is None:
-            norms = (float(np.count_nonzero(hn[2 * T:3 * T])), float(T * m.hidden_units), float(T * m.num_heads))
+            n_bce = float(np.count_nonzero(hn[2 * T:3 * T]))
+            if self.world > 1:   # global normalisers: sum of the per-rank counts
+                t = torch.tensor([n_bce], device=m.dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, group=self.pg)
+                n_bce = float(t)
+            norms = (n_bce, float(self.world * T * m.hidden_units), float(self.world * T * m.num_heads))
         hn[4 * T:4 * T + 3] = np.array(norms, dtype=np.float32).view(np.int32)
-        self.nstep += 1
-        hn[4 * T + 3] = np.array([(self.base_seed * 1000003 + self.nstep * 2654435761) & 0xFFFFFFFF], dtype=np.uint32).view(np.int32)[0]
+        hn[4 * T + 3] = 0
+        return B
+
+    def stage(self, batch, norms=None, **_):
+        """Upload one id batch (+ normalisers) to HBM ahead of time; returns the device buffer for step_staged."""
+        self._fill_host(*batch, norms)
+        buf = torch.empty_like(self._devbuf)
+        buf.copy_(self._host)
+        torch.cuda.synchronize()
+        return buf
+
+    def step_staged(self, buf, b_offset=0):
+        """One optimisation step on an id batch already resident in HBM (see stage())."""
+        self._devbuf.copy_(buf, non_blocking=True)
+        self._run(self._B, b_offset)
+
+    def step(self, seq, dec, pos, neg, norms=None, b_offset=0):
+        """One optimisation step on numpy/torch int arrays (B_local, L).  `norms` = (n_bce, n_mse, n_nll) of
+        the GLOBAL batch (defaults to this batch's own counts, all-reduced over the process group).  Returns
+        nothing; see `loss()`."""
+        B = self._fill_host(seq, dec, pos, neg, norms)
         self._devbuf.copy_(self._host, non_blocking=True)
+        self._run(B, b_offset)
+
+    def _run(self, B, b_offset):
+        self.nstep += 1
         if not self.use_graph:
             self._launch(B, b_offset)
             return

@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- train sequences/sec of SASRec-ADT (ml-1m shape: seq_len 200, d=64, 2 heads, 2 blocks, batch 256 per
+GPU, dropout 0.5, bf16 MFMA operands / fp32 accumulate) on N MI355X.
+
+A "step" is the whole loop body of the reference's sasrec/main.py:143-173 on one batch of 256 sequences per GPU:
+forward (encoder + reconstruction decoder + head classifiers), loss assembly, backward, weight-decay term,
+gradient all-reduce (N > 1), clip_grad_norm_ and Adam -- nothing skipped, dropout on.  Inputs (synthetic,
+ml-1m-shaped id batches) are resident in HBM before the timed region.  One JSON line on stdout (rank 0).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+CFG = dict(item_num=3416, maxlen=200, hidden_units=64, num_heads=2, num_layers=2, dropout=0.5, batch=256,
+           lambdas1=[0.104292, 0.065892], lambdas2=[0.100833, 0.000607], weight_decay=1e-3, lr=1e-3, clip=5.0)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+class Args:
+    pass
+
+
+def synth_batches(n, B, L, V, seed):
+    """ml-1m-shaped id batches: history length ~ lognormal clipped to [20, 2314] (mean ~165) so most
+    rows are full, items Zipf(1.0)-popular; layout of WarpDataset.sample_data (sasrec/utils.py:288-307)."""
+    r = np.random.RandomState(seed)
+    pop = 1.0 / np.arange(1, V + 1)
+    pop = pop[r.permutation(V)]
+    pop /= pop.sum()
+    out = []
+    for _ in range(n):
+        seq = np.zeros((B, L), np.int32)
+        dec = np.zeros((B, L), np.int32)
+        pos = np.zeros((B, L), np.int32)
+        neg = np.zeros((B, L), np.int32)
+        lens = np.clip(np.exp(r.normal(4.6, 0.95, size=B)), 20, 2314).astype(int)
+        for b in range(B):
+            n_hist = min(int(lens[b]) - 3, L)   # train part minus the item used as last target
+            items = r.choice(V, size=n_hist + 1, p=pop) + 1
+            seq[b, L - n_hist:] = items[:-1]
+            pos[b, L - n_hist:] = items[1:]
+            neg[b, L - n_hist:] = r.randint(1, V + 1, size=n_hist)
+            dec[b, 1:] = seq[b, :-1]
+        out.append((seq, dec, pos, neg))
+    return out
+
+
+def build_model(device, prec):
+    import torch
+    from adt_amd.sasrec.model import SASRecADT
+    a = Args()
+    a.device, a.num_heads, a.maxlen, a.num_layers = device, CFG["num_heads"], CFG["maxlen"], CFG["num_layers"]
+    a.hidden_units, a.dropout, a.precision = CFG["hidden_units"], CFG["dropout"], prec
+    torch.manual_seed(23)
+    m = SASRecADT(6040, CFG["item_num"], a)
+    for _, p in m.named_parameters():   # sasrec/main.py:95-99
+        try:
+            torch.nn.init.xavier_normal_(p.data)
+        except Exception:
+            pass
+    m.train()
+    return m
+
+
+def cpu_baseline():
+    """The numpy oracle (a port of the reference's step, oracle/sasrec_oracle.py) timed on this host's cores on a
+    bounded sample of the same workload: batch 64 of the same shape, 1 warm-up + 2 timed steps."""
+    from oracle import sasrec_oracle as so
+    cfg = so.Cfg(CFG["item_num"], CFG["maxlen"], CFG["hidden_units"], CFG["num_heads"], CFG["num_layers"], CFG["dropout"])
+    P = so.init_params(cfg, 0)
+    B = 64
+    batch = synth_batches(1, B, CFG["maxlen"], CFG["item_num"], 5)[0]
+    st = {}
+    so.train_step(P, cfg, st, batch, CFG["lambdas1"], CFG["lambdas2"], CFG["weight_decay"], seed=1)
+    t0 = time.time()
+    nst = 2
+    for i in range(nst):
+        so.train_step(P, cfg, st, batch, CFG["lambdas1"], CFG["lambdas2"], CFG["weight_decay"], seed=2 + i)
+    dt = time.time() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count()
+    return {"value": round(B * nst / dt, 2), "unit": "sequences/s", "cores": int(cores), "kind": "port",
+            "sample": "numpy oracle, %d full train steps at batch %d (same L=200, d=64, 2 blocks, dropout 0.5) after 1 warm-up" % (nst, B)}
+
+
+def roofline_probe(model, trainer, B):
+    """Average launch duration of the dominant kernel (attention backward, causal, hd=32: see profiles/) measured
+    live with HIP events on the launch stream, on the buffers of the last step; algorithmic bytes per launch =
+    B*H (b,h) units x 8 tensors (q, k, v, o, dO in; dQ, dK, dV out) x L*hd*4 B (fp32 activations) -- DESIGN.md."""
+    import torch
+    from adt_amd import ops
+    L, d, H = CFG["maxlen"], CFG["hidden_units"], CFG["num_heads"]
+    T = B * L
+    dev = model.dev
+    qkv = torch.randn(T, 3 * d, device=dev)
+    O, LSE = ops.attn_fwd(model.cfg.prec, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, L, True, CFG["dropout"], model._seed, 16, 0)
+    dO = torch.randn(T, d, device=dev)
+    for _ in range(3):
+        ops.attn_bwd(model.cfg.prec, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], O, LSE, dO, B, H, L, True, CFG["dropout"], model._seed, 16, 0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    R = 20
+    e0.record()
+    for _ in range(R):
+        ops.attn_bwd(model.cfg.prec, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], O, LSE, dO, B, H, L, True, CFG["dropout"], model._seed, 16, 0)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / R
+    alg_bytes = B * H * 8 * L * (d // H) * 4
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "k_attn_bwd", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(ms * 1e3, 2),
+            "algorithmic_bytes_per_launch": alg_bytes}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    device = "cuda:%d" % local
+    torch.cuda.set_device(local)
+    from adt_amd.sasrec.trainer import FusedTrainer
+    B = CFG["batch"]
+    model = build_model(device, args.precision)
+    tr = FusedTrainer(model, CFG["lambdas1"], CFG["lambdas2"], lr=CFG["lr"], weight_decay=CFG["weight_decay"], clip=CFG["clip"],
+                      process_group=dist.group.WORLD if world > 1 else None, use_graph=not args.no_graph, seed=23)
+    # weak scaling: every rank gets its own 256-sequence shard of a global batch of 256*N
+    nb = 4
+    batches = synth_batches(nb, B, CFG["maxlen"], CFG["item_num"], seed=100 + rank)
+    staged = [tr.stage(b, norms_scale=world, b_offset=rank * B) for b in batches]
+    torch.cuda.synchronize()
+
+    def run(k0, k):
+        for i in range(k0, k0 + k):
+            tr.step_staged(staged[i % nb], b_offset=rank * B)
+
+    run(0, args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.warmup, args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss = float(tr.loss())
+    if rank == 0:
+        res = {"metric": "train sequences/sec, SASRec-ADT ml-1m (seq_len=200, d=64, 2 blocks)", "value": round(world * B * args.steps / dt, 1),
+               "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+               "config": {"workload": "SASRec-ADT ml-1m shape, 2 blocks d=64 H=2 seq_len=200, batch 256/GPU, dropout 0.5, "
+                                      "full train step (fwd+loss+bwd+clip+Adam), ids resident in HBM",
+                          "global_batch": world * B, "seq_len": CFG["maxlen"], "parallelism": "dp%d" % world,
+                          "hip_graph": not args.no_graph and world == 1},
+               "loss_last_step": round(loss, 5)}
+        res["roofline"] = roofline_probe(model, tr, B)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
