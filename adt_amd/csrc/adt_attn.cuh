@@ -43,10 +43,10 @@ ADT_DEVICE_INLINE Frag8 frag_contig_hd(const float* row, int kb, int g) {
   return z;
 }
 
-template <int HD, int RS>
+template <int HD, int RS, int NTH>
 ADT_DEVICE_INLINE void stage_head(float* s, const float* g, int ld, int L, int LP, float mul) {
   constexpr int V = HD / 4;
-  for (int i = threadIdx.x; i < LP * V; i += 256) {
+  for (int i = threadIdx.x; i < LP * V; i += NTH) {
     const int r = i / V, c4 = i % V;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < L) {
@@ -57,8 +57,8 @@ ADT_DEVICE_INLINE void stage_head(float* s, const float* g, int ld, int L, int L
   }
 }
 
-template <int PREC, int HD, int MAXKT>
-__global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
+template <int PREC, int HD, int MAXKT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_attn_fwd(AttnArgs a) {
   constexpr int RS = HD + 4, LP = MAXKT * 16, NT = HD / 16, KB = (HD + 31) / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sK = smem;
@@ -67,12 +67,16 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int L = a.L;
   const size_t row_b = (size_t)b * L;
-  stage_head<HD, RS>(sK, a.K + row_b * a.ldk + h * HD, a.ldk, L, LP, 1.0f);
-  stage_head<HD, RS>(sV, a.V + row_b * a.ldv + h * HD, a.ldv, L, LP, 1.0f);
+  stage_head<HD, RS, NW * 64>(sK, a.K + row_b * a.ldk + h * HD, a.ldk, L, LP, 1.0f);
+  stage_head<HD, RS, NW * 64>(sV, a.V + row_b * a.ldv + h * HD, a.ldv, L, LP, 1.0f);
   __syncthreads();
   const uint32_t key_rng = drop_key(a.drop);
   const int nqt = (L + 15) / 16;
-  for (int qt = w; qt < nqt; qt += 4) {
+  for (int rnd = 0; rnd * NW < nqt; ++rnd) {
+    // snake assignment, heaviest causal tile (largest qt) first: balances the triangular work over waves
+    const int tix = rnd * NW + ((rnd & 1) ? NW - 1 - w : w);
+    if (tix >= nqt) continue;
+    const int qt = nqt - 1 - tix;
     const int q = qt * 16 + c;
     Frag8 fq[KB];
 #pragma unroll
@@ -171,8 +175,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
 // Backward: recompute P from Q, K and the saved LSE.  Pass A (wave owns a query tile) produces dQ; pass B
 // (wave owns a key tile) produces dK and dV, so no gradient is summed across waves or workgroups and the
 // result is bitwise reproducible.
-template <int PREC, int HD, int MAXKT>
-__global__ __launch_bounds__(256) void k_attn_bwd(AttnArgs a) {
+template <int PREC, int HD, int MAXKT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_attn_bwd(AttnArgs a) {
   constexpr int RS = HD + 4, LP = MAXKT * 16, NT = HD / 16, KB = (HD + 31) / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sQ = smem;               // pre-scaled by 1/sqrt(HD)
@@ -185,12 +189,12 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnArgs a) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int L = a.L;
   const size_t row_b = (size_t)b * L;
-  stage_head<HD, RS>(sQ, a.Q + row_b * a.ldq + h * HD, a.ldq, L, LP, a.scale);
-  stage_head<HD, RS>(sK, a.K + row_b * a.ldk + h * HD, a.ldk, L, LP, 1.0f);
-  stage_head<HD, RS>(sV, a.V + row_b * a.ldv + h * HD, a.ldv, L, LP, 1.0f);
+  stage_head<HD, RS, NW * 64>(sQ, a.Q + row_b * a.ldq + h * HD, a.ldq, L, LP, a.scale);
+  stage_head<HD, RS, NW * 64>(sK, a.K + row_b * a.ldk + h * HD, a.ldk, L, LP, 1.0f);
+  stage_head<HD, RS, NW * 64>(sV, a.V + row_b * a.ldv + h * HD, a.ldv, L, LP, 1.0f);
   {
     constexpr int V4 = HD / 4;  // threads per row (4, 8 or 16): a row's threads are adjacent lanes
-    for (int i = threadIdx.x; i < LP * V4; i += 256) {
+    for (int i = threadIdx.x; i < LP * V4; i += NW * 64) {
       const int r = i / V4, c4 = i % V4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       float part = 0.f;
@@ -214,7 +218,10 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnArgs a) {
   const int nqt = (L + 15) / 16;
 
   // ---- pass A: dQ -------------------------------------------------------------------------
-  for (int qt = w; qt < nqt; qt += 4) {
+  for (int rnd = 0; rnd * NW < nqt; ++rnd) {
+    const int tix = rnd * NW + ((rnd & 1) ? NW - 1 - w : w);
+    if (tix >= nqt) continue;
+    const int qt = nqt - 1 - tix;   // heaviest first (snake order)
     const int q = qt * 16 + c;
     const float lse_q = sLse[q], delta_q = sDelta[q];
     Frag8 fq[KB], fdo[KB];
@@ -272,7 +279,9 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnArgs a) {
   }
 
   // ---- pass B: dK, dV ---------------------------------------------------------------------
-  for (int kt = w; kt < nqt; kt += 4) {
+  for (int rnd = 0; rnd * NW < nqt; ++rnd) {
+    const int kt = rnd * NW + ((rnd & 1) ? NW - 1 - w : w);   // key tile 0 is the heaviest under the causal mask
+    if (kt >= nqt) continue;
     const int key = kt * 16 + c;
     Frag8 fk[KB], fv[KB];
 #pragma unroll

@@ -1,6 +1,7 @@
 // C ABI (include/adt_hip.h): launch wrappers for the per-stage kernels.  Host code only enqueues work on
 // the caller's stream: no allocation, no synchronisation, graph-capturable.
 #include "adt_host.h"
+#include <stdlib.h>
 
 #include "adt_attn.cuh"
 #include "adt_misc.cuh"
@@ -54,24 +55,42 @@ static void launch_linear_bwd(const LinBwdArgs& a, int nch, int grid, hipStream_
 }
 
 // ---- attention dispatch --------------------------------------------------------------------------
-template <int PREC, int HD, int MAXKT>
-static int launch_attn(bool bwd, const AttnArgs& a, hipStream_t s) {
+static int attn_waves(bool bwd) {
+  // waves per workgroup: tunable for experiments (ADT_ATTN_FWD_NW / ADT_ATTN_BWD_NW = 4 or 8)
+  static int nw[2] = {0, 0};
+  if (!nw[0]) {
+    const char* f = getenv("ADT_ATTN_FWD_NW");
+    const char* b = getenv("ADT_ATTN_BWD_NW");
+    nw[0] = (f && atoi(f) == 4) ? 4 : 8;
+    nw[1] = (b && atoi(b) == 4) ? 4 : 8;
+  }
+  return nw[bwd ? 1 : 0];
+}
+
+template <int PREC, int HD, int MAXKT, int NW>
+static int launch_attn_nw(bool bwd, const AttnArgs& a, hipStream_t s) {
   constexpr int RS = HD + 4, LP = MAXKT * 16;
   const size_t smem = bwd ? (size_t)(4 * LP * RS + 2 * LP) * sizeof(float) : (size_t)(2 * LP * RS) * sizeof(float);
   if (smem > 160 * 1024) return adt_set_error("attention: L/hd too large for LDS-resident form (%zu B)", smem);
   static bool attr_done[2] = {false, false};
   if (!attr_done[bwd ? 1 : 0]) {
-    hipError_t e = bwd ? hipFuncSetAttribute((const void*)k_attn_bwd<PREC, HD, MAXKT>,
+    hipError_t e = bwd ? hipFuncSetAttribute((const void*)k_attn_bwd<PREC, HD, MAXKT, NW>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
-                       : hipFuncSetAttribute((const void*)k_attn_fwd<PREC, HD, MAXKT>,
+                       : hipFuncSetAttribute((const void*)k_attn_fwd<PREC, HD, MAXKT, NW>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return adt_set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done[bwd ? 1 : 0] = true;
   }
   const int grid = a.B * a.H;
-  if (bwd) hipLaunchKernelGGL((k_attn_bwd<PREC, HD, MAXKT>), dim3(grid), dim3(256), smem, s, a);
-  else hipLaunchKernelGGL((k_attn_fwd<PREC, HD, MAXKT>), dim3(grid), dim3(256), smem, s, a);
+  if (bwd) hipLaunchKernelGGL((k_attn_bwd<PREC, HD, MAXKT, NW>), dim3(grid), dim3(NW * 64), smem, s, a);
+  else hipLaunchKernelGGL((k_attn_fwd<PREC, HD, MAXKT, NW>), dim3(grid), dim3(NW * 64), smem, s, a);
   return check_launch(bwd ? "attn_bwd" : "attn_fwd");
+}
+
+template <int PREC, int HD, int MAXKT>
+static int launch_attn(bool bwd, const AttnArgs& a, hipStream_t s) {
+  if (attn_waves(bwd) == 4) return launch_attn_nw<PREC, HD, MAXKT, 4>(bwd, a, s);
+  return launch_attn_nw<PREC, HD, MAXKT, 8>(bwd, a, s);
 }
 
 template <int PREC, int HD>
@@ -126,7 +145,11 @@ int adt_embed_bwd(const int32_t* ids, const float* dX, int T, int L, int d, floa
   const int B = T / L;
   const int gx = (L * d / 4 + 255) / 256;
   int gy = B < 32 ? B : 32;
-  hipLaunchKernelGGL(k_embed_bwd, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_posemb_bwd, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, a);
+  ScatterArgs sc{};
+  sc.ids = ids; sc.G = dX; sc.ldg = d; sc.rowscale = nullptr; sc.T = T; sc.d = d; sc.scale = a.scale; sc.drop = a.drop;
+  sc.row_offset = row_offset; sc.dE = dE;
+  hipLaunchKernelGGL(k_item_scatter, dim3(grid_for(T, 4, 2048)), dim3(256), 0, (hipStream_t)stream, sc);
   return check_launch("embed_bwd");
 }
 
@@ -231,7 +254,7 @@ int adt_headcls_bwd(const float* O, int ldo, const float* Ws, const float* rec, 
   a.O = O; a.ldo = ldo; a.Ws = Ws; a.B = B; a.L = L; a.H = H; a.hd = hd; a.rec = const_cast<float*>(rec);
   a.drec = drec; a.dO = dO; a.lddo = lddo; a.dWs = dWs; a.dbs = dbs;
   const size_t smem = (size_t)(H * hd + H) * sizeof(float);
-  hipLaunchKernelGGL(k_headcls_bwd, dim3(grid_for((size_t)B * L * H, 256, 256)), dim3(256), smem, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_headcls_bwd, dim3(grid_for((size_t)B * L, 4, 512)), dim3(256), smem, (hipStream_t)stream, a);
   return check_launch("headcls_bwd");
 }
 
@@ -251,6 +274,12 @@ int adt_logits_bwd(const float* F, int ldf, const float* E, const int32_t* pos, 
   a.F = F; a.ldf = ldf; a.E = E; a.pos = pos; a.neg = neg; a.T = T; a.d = d; a.dpos = dpos; a.dneg = dneg;
   a.dF = dF; a.lddf = lddf; a.dE = dE;
   hipLaunchKernelGGL(k_logits_bwd, dim3(grid_for(T, 16, 2048)), dim3(256), 0, (hipStream_t)stream, a);
+  ScatterArgs sc{};
+  sc.G = F; sc.ldg = ldf; sc.T = T; sc.d = d; sc.scale = 1.0f; sc.drop = adt_make_drop(0.f, nullptr, 0); sc.dE = dE;
+  sc.ids = pos; sc.rowscale = dpos;
+  hipLaunchKernelGGL(k_item_scatter, dim3(grid_for(T, 4, 2048)), dim3(256), 0, (hipStream_t)stream, sc);
+  sc.ids = neg; sc.rowscale = dneg;
+  hipLaunchKernelGGL(k_item_scatter, dim3(grid_for(T, 4, 2048)), dim3(256), 0, (hipStream_t)stream, sc);
   return check_launch("logits_bwd");
 }
 

@@ -40,10 +40,37 @@ __global__ __launch_bounds__(256) void k_embed_fwd(EmbedArgs a) {
   }
 }
 
-// dE[id] += g * keep/(1-p) * sqrt(d) ; dP[l] += g * keep/(1-p)   (rows with id == 0 contribute nothing).
-// grid: (blocks over L*d/4 columns, slices over the batch); each thread sums its batch slice for one
-// (l, 4 columns) in registers before one atomic per column, items go straight to atomics.
-__global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a) {
+// Row scatter-add into the item table: dE[ids[row]] += G[row] * rowscale[row] * keep/(1-p) * scale.
+// One wave per row so that every atomic wave-instruction covers 256 contiguous bytes of one table row (the
+// shape that runs at the full float-atomic rate, MI355X_MICROARCH.md "Global float atomics"); rows with
+// id == 0 (padding_idx, sasrec/model.py:18) contribute nothing.
+struct ScatterArgs {
+  const int* ids; const float* G; int ldg; const float* rowscale;
+  int T, d; float scale;
+  DropCfg drop; uint32_t row_offset;
+  float* dE;
+};
+
+__global__ __launch_bounds__(256) void k_item_scatter(ScatterArgs a) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t key = drop_key(a.drop);
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  for (int row = wave; row < a.T; row += nwaves) {
+    const int id = a.ids[row];
+    if (id == 0) continue;
+    const float rs = (a.rowscale ? a.rowscale[row] : 1.0f) * a.scale;
+    if (rs == 0.f) continue;
+    for (int c = lane; c < a.d; c += 64) {
+      float v = a.G[(size_t)row * a.ldg + c] * rs;
+      if (a.drop.thr) v = adt_keep(key, (uint32_t)(row + a.row_offset) * (uint32_t)a.d + (uint32_t)c, a.drop.thr) ? v * a.drop.scale : 0.f;
+      atomicAdd(a.dE + (size_t)id * a.d + c, v);
+    }
+  }
+}
+
+// dP[l] += sum_b dX[b, l] * keep/(1-p) * (ids != 0).  grid: (blocks over L*d/4 columns, slices over the
+// batch); each thread sums its batch slice for one (l, 4 columns) in registers, then one atomic per column.
+__global__ __launch_bounds__(256) void k_posemb_bwd(EmbedArgs a) {
   const int V = a.d / 4;
   const uint32_t key = drop_key(a.drop);
   const int B = a.T / a.L;
@@ -55,8 +82,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a) {
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int b = b0; b < b1; ++b) {
     const int row = b * a.L + l;
-    const int id = a.ids[row];
-    if (id == 0) continue;
+    if (a.ids[row] == 0) continue;
     float v[4];
     *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(a.dX + (size_t)row * a.d + c4);
     if (a.drop.thr) {
@@ -65,10 +91,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a) {
       for (int j = 0; j < 4; ++j) v[j] = adt_keep(key, base + j, a.drop.thr) ? v[j] * a.drop.scale : 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      acc[j] += v[j];
-      atomicAdd(a.dE + (size_t)id * a.d + c4 + j, v[j] * a.scale);
-    }
+    for (int j = 0; j < 4; ++j) acc[j] += v[j];
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) atomicAdd(a.dP + (size_t)l * a.d + c4 + j, acc[j]);
@@ -123,42 +146,56 @@ __global__ __launch_bounds__(256) void k_headcls_fwd(HeadClsArgs a) {
 }
 
 // dz = drec - softmax(z) * sum(drec) with softmax = exp(rec);  dO[h*hd + j] += sum_c dz[c] Ws[c][j];
-// dWs[c][j] += dz[c] o[j]; dbs[c] += dz[c].  Weight partials are reduced through LDS per block.
+// dWs[c][j] += dz[c] o[j]; dbs[c] += dz[c].  One wave per token, lane = column of o (coalesced 256-B rows);
+// each lane keeps its H partial sums of dWs[:, j] in registers across tokens, reduced through LDS at the end.
 __global__ __launch_bounds__(256) void k_headcls_bwd(HeadClsArgs a) {
   extern __shared__ float sacc[];   // H*hd + H
-  const int nW = a.H * a.hd;
+  const int nW = a.H * a.hd, d = a.H * a.hd;
   for (int i = threadIdx.x; i < nW + a.H; i += 256) sacc[i] = 0.f;
   __syncthreads();
-  const int n = a.B * a.L * a.H;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const int tok = i / a.H, h = i % a.H;
-    const int b = tok / a.L, l = tok % a.L;
-    const size_t ro = ((size_t)(l * a.B + b) * a.H + h) * a.H;
-    float dz[MAXH];
-    float sd = 0.f;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int T = a.B * a.L;
+  for (int c0 = 0; c0 < d; c0 += 64) {     // column chunk (d = 64: one pass)
+    const int col = c0 + lane;
+    const bool live = col < d;
+    const int h = live ? col / a.hd : 0, j = live ? col % a.hd : 0;
+    float wreg[MAXH], acc[MAXH], accb[MAXH];
 #pragma unroll
     for (int cc = 0; cc < MAXH; ++cc) {
-      dz[cc] = (cc < a.H) ? a.drec[ro + cc] : 0.f;
-      sd += dz[cc];
+      wreg[cc] = (live && cc < a.H) ? a.Ws[cc * a.hd + j] : 0.f;
+      acc[cc] = 0.f;
+      accb[cc] = 0.f;
     }
+    for (int tok = wave; tok < T; tok += nwaves) {
+      const int b = tok / a.L, l = tok % a.L;
+      const size_t ro = ((size_t)(l * a.B + b) * a.H + h) * a.H;
+      float dz[MAXH];
+      float sd = 0.f;
 #pragma unroll
-    for (int cc = 0; cc < MAXH; ++cc)
-      if (cc < a.H) {
-        dz[cc] -= expf(a.rec[ro + cc]) * sd;
-        atomicAdd(&sacc[nW + cc], dz[cc]);
+      for (int cc = 0; cc < MAXH; ++cc) {
+        dz[cc] = (live && cc < a.H) ? a.drec[ro + cc] : 0.f;
+        sd += dz[cc];
       }
-    const float* o = a.O + (size_t)tok * a.ldo + h * a.hd;
-    float* dobase = a.dO + (size_t)tok * a.lddo + h * a.hd;
-    for (int j = 0; j < a.hd; ++j) {
-      const float ov = o[j];
-      float acc = 0.f;
+      const float ov = live ? a.O[(size_t)tok * a.ldo + col] : 0.f;
+      float dov = 0.f;
 #pragma unroll
       for (int cc = 0; cc < MAXH; ++cc)
         if (cc < a.H) {
-          acc += dz[cc] * a.Ws[cc * a.hd + j];
-          atomicAdd(&sacc[cc * a.hd + j], dz[cc] * ov);
+          dz[cc] -= (live ? expf(a.rec[ro + cc]) : 0.f) * sd;
+          dov += dz[cc] * wreg[cc];
+          acc[cc] += dz[cc] * ov;
+          if (j == 0) accb[cc] += dz[cc];
         }
-      dobase[j] += acc;
+      if (live) a.dO[(size_t)tok * a.lddo + col] += dov;
+    }
+    if (live) {
+#pragma unroll
+      for (int cc = 0; cc < MAXH; ++cc)
+        if (cc < a.H) {
+          atomicAdd(&sacc[cc * a.hd + j], acc[cc]);
+          if (j == 0) atomicAdd(&sacc[nW + cc], accb[cc]);
+        }
     }
   }
   __syncthreads();
@@ -198,25 +235,17 @@ __global__ __launch_bounds__(256) void k_logits_fwd(LogitsArgs a) {
 }
 
 __global__ __launch_bounds__(256) void k_logits_bwd(LogitsArgs a) {
+  // dF = dpos * E[pos] + dneg * E[neg]; the item-table side goes through k_item_scatter
   const int sub = threadIdx.x & 15;
   for (int row = blockIdx.x * 16 + (threadIdx.x >> 4); row < a.T; row += gridDim.x * 16) {
     const int ip = a.pos[row], in = a.neg[row];
     const float gp = a.dpos[row], gn = a.dneg[row];
     for (int c4 = 4 * sub; c4 < a.d; c4 += 64) {
-      const float4 f = *reinterpret_cast<const float4*>(a.F + (size_t)row * a.ldf + c4);
       const float4 p = *reinterpret_cast<const float4*>(a.E + (size_t)ip * a.d + c4);
       const float4 q = *reinterpret_cast<const float4*>(a.E + (size_t)in * a.d + c4);
       float4 df;
       df.x = gp * p.x + gn * q.x; df.y = gp * p.y + gn * q.y; df.z = gp * p.z + gn * q.z; df.w = gp * p.w + gn * q.w;
       *reinterpret_cast<float4*>(a.dF + (size_t)row * a.lddf + c4) = df;
-      if (gp != 0.f && ip != 0) {
-        float* e = a.dE + (size_t)ip * a.d + c4;
-        atomicAdd(e + 0, gp * f.x); atomicAdd(e + 1, gp * f.y); atomicAdd(e + 2, gp * f.z); atomicAdd(e + 3, gp * f.w);
-      }
-      if (gn != 0.f && in != 0) {
-        float* e = a.dE + (size_t)in * a.d + c4;
-        atomicAdd(e + 0, gn * f.x); atomicAdd(e + 1, gn * f.y); atomicAdd(e + 2, gn * f.z); atomicAdd(e + 3, gn * f.w);
-      }
     }
   }
 }
