@@ -16,3 +16,7 @@ DropCfg adt_make_drop(float p, const uint32_t* seed, uint32_t site);
 enum { SITE_EMB_SEQ = 1, SITE_EMB_DEC = 2 };
 static inline uint32_t enc_site(int layer, int which) { return 16u + 8u * (uint32_t)layer + (uint32_t)which; }   // 0 attn 1 ffn1 2 ffn2
 static inline uint32_t dec_site(int layer, int which) { return 128u + 8u * (uint32_t)layer + (uint32_t)which; }  // 0 slf 1 enc 2 ffn1 3 ffn2
+
+// fused forward chain (adt_chain.cuh); defined in adt_capi.hip
+namespace adt { struct ChainArgs; }
+int adt_launch_rowchain_fwd(int prec, const adt::ChainArgs& a, void* stream);

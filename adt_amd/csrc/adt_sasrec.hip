@@ -3,6 +3,8 @@
 // their autograd reverse pass, plus the loss seeds of sasrec/main.py:151-169.  Pure host code: it only
 // enqueues kernels (via the per-stage C ABI) on the caller's stream.
 #include "adt_host.h"
+#include <string.h>
+#include "adt_chain_args.h"
 
 namespace {
 
@@ -101,40 +103,91 @@ int check_cfg(const adt_sasrec_cfg* c) {
   return 0;
 }
 
-// encoder stack forward on embedded input ws[enc_x[0]]; shared by forward() and predict()
+using adt::ChainArgs;
+using adt::ChainStep;
+
+// ---- fused-chain program builders (adt_chain.cuh) ------------------------------------------------
+struct Prog {
+  ChainArgs a;
+  int n = 0;
+  Prog(int T, int L, int B, const int32_t* ids, float p, const uint32_t* seed, uint32_t row_offset) {
+    memset(&a, 0, sizeof(a));
+    a.T = T; a.L = L; a.B = B; a.ids = ids; a.drop = adt_make_drop(p, seed, 0); a.row_offset = row_offset; a.ln_eps = LN_EPS;
+  }
+  ChainStep& add(int op, int src, int dst) {
+    ChainStep& s = a.steps[n++];
+    s.op = op; s.src = src; s.dst = dst; s.add_buf = -1;
+    return s;
+  }
+  void load(int dst, const float* g, int ld) { ChainStep& s = add(adt::ST_LOAD, 0, dst); s.in_g = g; s.ld_in = ld; }
+  void gather(int dst, const float* E, const float* P, float scale, uint32_t site, float* out, int ld) {
+    ChainStep& s = add(adt::ST_GATHER, 0, dst); s.site = site; s.out_g = out; s.ld_out = ld;
+    a.E = E; a.P = P; a.emb_scale = scale;
+  }
+  void ln(int src, int dst, const float* gm, const float* bt, float* out, int ld) {
+    ChainStep& s = add(adt::ST_LN, src, dst); s.W = gm; s.b = bt; s.out_g = out; s.ld_out = ld;
+  }
+  ChainStep& gemm(int src, int dst, const float* W, const float* b, float* out, int ld, int flags = 0, uint32_t site = 0) {
+    ChainStep& s = add(adt::ST_GEMM, src, dst); s.W = W; s.b = b; s.out_g = out; s.ld_out = ld; s.flags = flags; s.site = site;
+    return s;
+  }
+  int run(int prec, void* st) { return adt_launch_rowchain_fwd(prec, a, st); }
+};
+
+// encoder stack forward; `embed` = gather the input embedding inside the first chain (else enc_x[0] is given)
 int encoder_forward(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const float* P, float* ws,
-                    const int32_t* seq, float p, const uint32_t* seed, uint32_t b_offset, bool want_rec, void* st) {
+                    const int32_t* seq, const int32_t* pos, const int32_t* neg, float p, const uint32_t* seed,
+                    uint32_t b_offset, bool training_outputs, void* st) {
   const int T = (int)w.T, d = (int)w.d, H = (int)w.H, hd = d / H, L = (int)w.L, B = (int)w.B, prec = c->prec;
   const int64_t Td = up64(w.T * w.d);
   const uint32_t ro = b_offset * (uint32_t)L;
+  const int dd = d * d;
   for (int i = 0; i < c->num_layers; ++i) {
-    const float* x = ws + w.enc_x + i * Td;
+    float* x = ws + w.enc_x + i * Td;
     float* y = ws + w.enc_x + (i + 1) * Td;
     float* base = ws + i * w.e_stride;
     float *qn = base + w.e_qn, *qkv = base + w.e_qkv, *o = base + w.e_o, *lse = base + w.e_lse, *h = base + w.e_h,
           *h2 = base + w.e_h2, *u = base + w.e_u, *rec = base + w.e_rec;
     const float* inw = P + lo.enc(i, E_INW);
     const float* inb = P + lo.enc(i, E_INB);
-    // Q = LN1(x); q = Q Wq^T + bq ; [k, v] = x Wkv^T + bkv        (sasrec/modules.py:646-647, :123-130)
-    CK(adt_layernorm_fwd(x, d, P + lo.enc(i, E_LN1W), P + lo.enc(i, E_LN1B), LN_EPS, T, d, qn, d, st));
-    CK(adt_linear_fwd(prec, qn, d, inw, inb, T, d, d, qkv, 3 * d, 0.f, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, nullptr, st));
-    CK(adt_linear_fwd(prec, x, d, inw + (int64_t)d * d, inb + d, T, d, 2 * d, qkv + d, 3 * d, 0.f, nullptr, 0, 0, 0, nullptr, 0,
-                      nullptr, 0, nullptr, st));
+    {  // Q = LN1(x); q = Q Wq^T + bq ; k, v = x Wk^T, x Wv^T      (sasrec/modules.py:646-647, :123-130)
+      Prog g(T, L, B, seq, p, seed, ro);
+      if (i == 0) g.gather(0, P + lo.item(), P + lo.posw(), sqrtf((float)d), SITE_EMB_SEQ, x, d);   // model.py:34-41
+      else g.load(0, x, d);
+      g.ln(0, 1, P + lo.enc(i, E_LN1W), P + lo.enc(i, E_LN1B), qn, d);
+      g.gemm(1, 2, inw, inb, qkv, 3 * d);
+      g.gemm(0, 2, inw + dd, inb + d, qkv + d, 3 * d);
+      g.gemm(0, 2, inw + 2 * dd, inb + 2 * d, qkv + 2 * d, 3 * d);
+      CK(g.run(prec, st));
+    }
     CK(adt_attn_fwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, B, H, L, hd, 1, p, seed, enc_site(i, 0), b_offset, o, d,
                     lse, st));
-    if (want_rec) CK(adt_headcls_fwd(o, d, P + lo.enc(i, E_SW), P + lo.enc(i, E_SB), B, L, H, hd, rec, st));
-    // h = Q + out_proj(o) ; h2 = LN2(h)                            (:650-652)
-    CK(adt_linear_fwd(prec, o, d, P + lo.enc(i, E_OW), P + lo.enc(i, E_OB), T, d, d, h, d, 0.f, nullptr, 0, 0, 0, qn, d, nullptr, 0,
-                      nullptr, st));
-    CK(adt_layernorm_fwd(h, d, P + lo.enc(i, E_LN2W), P + lo.enc(i, E_LN2B), LN_EPS, T, d, h2, d, st));
-    // u = relu(drop1(conv1 h2)) ; y = (h2 + drop2(conv2 u)) * mask  (:629-633, :653-654)
-    CK(adt_linear_fwd(prec, h2, d, P + lo.enc(i, E_C1W), P + lo.enc(i, E_C1B), T, d, d, u, d, p, seed, enc_site(i, 1), ro, 1,
-                      nullptr, 0, nullptr, 0, nullptr, st));
-    CK(adt_linear_fwd(prec, u, d, P + lo.enc(i, E_C2W), P + lo.enc(i, E_C2B), T, d, d, y, d, p, seed, enc_site(i, 2), ro, 0, h2, d,
-                      nullptr, 0, seq, st));
+    {  // h = Q + out_proj(o); h2 = LN2(h); u = relu(drop1(conv1 h2)); y = (h2 + drop2(conv2 u)) * mask   (:648-654)
+      Prog g(T, L, B, seq, p, seed, ro);
+      g.load(0, o, d);
+      if (training_outputs) {
+        g.add(adt::ST_CLS, 0, 0);
+        g.a.Ws = P + lo.enc(i, E_SW); g.a.bs = P + lo.enc(i, E_SB); g.a.H = H; g.a.rec = rec;
+      }
+      ChainStep& s1 = g.gemm(0, 1, P + lo.enc(i, E_OW), P + lo.enc(i, E_OB), h, d);
+      s1.in_g = qn; s1.ld_in = d;
+      g.ln(1, 2, P + lo.enc(i, E_LN2W), P + lo.enc(i, E_LN2B), h2, d);
+      g.gemm(2, 0, P + lo.enc(i, E_C1W), P + lo.enc(i, E_C1B), u, d, adt::F_DROP | adt::F_RELU, enc_site(i, 1));
+      ChainStep& s2 = g.gemm(0, 1, P + lo.enc(i, E_C2W), P + lo.enc(i, E_C2B), y, d, adt::F_DROP | adt::F_MASK, enc_site(i, 2));
+      s2.add_buf = 2;
+      CK(g.run(prec, st));
+    }
   }
-  // log_feats = last_layernorm(encoder out)                        (sasrec/model.py:48)
-  CK(adt_layernorm_fwd(ws + w.enc_x + c->num_layers * Td, d, P + lo.lnl_w(), P + lo.lnl_b(), LN_EPS, T, d, ws + w.f, d, st));
+  {  // log_feats = last_layernorm(encoder out); pos/neg logits          (sasrec/model.py:48, :72-76)
+    Prog g(T, L, B, seq, 0.f, nullptr, ro);
+    g.load(0, ws + w.enc_x + c->num_layers * Td, d);
+    g.ln(0, 1, P + lo.lnl_w(), P + lo.lnl_b(), ws + w.f, d);
+    if (training_outputs) {
+      g.add(adt::ST_LOGITS, 1, 1);
+      g.a.E = P + lo.item(); g.a.pos = pos; g.a.neg = neg; g.a.pos_logits = ws + w.posl; g.a.neg_logits = ws + w.negl;
+    }
+    CK(g.run(prec, st));
+  }
   return 0;
 }
 
@@ -191,41 +244,54 @@ int adt_sasrec_forward(const adt_sasrec_cfg* c, const float* P, float* ws, const
   const int64_t Td = up64(w.T * w.d);
   const float p = training ? c->dropout : 0.f;
   const uint32_t ro = b_offset * (uint32_t)L;
-  CK(adt_embed_fwd(seq, P + lo.item(), P + lo.posw(), T, L, d, p, seed, SITE_EMB_SEQ, ro, ws + w.enc_x, st));
-  CK(encoder_forward(c, lo, w, P, ws, seq, p, seed, b_offset, true, st));
+  CK(encoder_forward(c, lo, w, P, ws, seq, pos, neg, p, seed, b_offset, true, st));
   const float* f = ws + w.f;
-  CK(adt_embed_fwd(dec, P + lo.item(), P + lo.posw(), T, L, d, p, seed, SITE_EMB_DEC, ro, ws + w.dec_x, st));
+  const int dd = d * d;
+  const int B_ = (int)w.B;
   for (int i = 0; i < c->num_layers; ++i) {
-    const float* x = ws + w.dec_x + i * Td;
+    float* x = ws + w.dec_x + i * Td;
     float* y = ws + w.dec_x + (i + 1) * Td;
     float* base = ws + i * w.d_stride;   // d_* offsets are absolute for layer 0
     float *dn = base + w.d_dn, *qkv = base + w.d_qkv, *o1 = base + w.d_o1, *lse1 = base + w.d_lse1, *a1 = base + w.d_a1,
           *q2 = base + w.d_q2, *kv2 = base + w.d_kv2, *o2 = base + w.d_o2, *lse2 = base + w.d_lse2, *a2 = base + w.d_a2,
           *u = base + w.d_u;
-    // D = LN(x); a1 = MHA_slf(D, D, D; causal)                     (sasrec/modules.py:668-670)
-    CK(adt_layernorm_fwd(x, d, P + lo.dec(i, D_LNW), P + lo.dec(i, D_LNB), LN_EPS, T, d, dn, d, st));
-    CK(adt_linear_fwd(prec, dn, d, P + lo.dec(i, D_SINW), P + lo.dec(i, D_SINB), T, d, 3 * d, qkv, 3 * d, 0.f, nullptr, 0, 0, 0,
-                      nullptr, 0, nullptr, 0, nullptr, st));
-    CK(adt_attn_fwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, B, H, L, hd, 1, p, seed, dec_site(i, 0), b_offset, o1, d,
-                    lse1, st));
-    CK(adt_linear_fwd(prec, o1, d, P + lo.dec(i, D_SOW), P + lo.dec(i, D_SOB), T, d, d, a1, d, 0.f, nullptr, 0, 0, 0, nullptr, 0,
-                      nullptr, 0, nullptr, st));
-    // a2 = MHA_enc(q = a1, k = v = log_feats; causal)               (:671-672)
+    const float* sinw = P + lo.dec(i, D_SINW);
+    const float* sinb = P + lo.dec(i, D_SINB);
     const float* einw = P + lo.dec(i, D_EINW);
     const float* einb = P + lo.dec(i, D_EINB);
-    CK(adt_linear_fwd(prec, a1, d, einw, einb, T, d, d, q2, d, 0.f, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, nullptr, st));
-    CK(adt_linear_fwd(prec, f, d, einw + (int64_t)d * d, einb + d, T, d, 2 * d, kv2, 2 * d, 0.f, nullptr, 0, 0, 0, nullptr, 0,
-                      nullptr, 0, nullptr, st));
-    CK(adt_attn_fwd(prec, q2, d, kv2, 2 * d, kv2 + d, 2 * d, B, H, L, hd, 1, p, seed, dec_site(i, 1), b_offset, o2, d, lse2, st));
-    CK(adt_linear_fwd(prec, o2, d, P + lo.dec(i, D_EOW), P + lo.dec(i, D_EOB), T, d, d, a2, d, 0.f, nullptr, 0, 0, 0, nullptr, 0,
-                      nullptr, 0, nullptr, st));
-    // y = (D + a2 + drop2(conv2 relu(drop1(conv1 a2)))) * mask       (:673-676, :629-633)
-    CK(adt_linear_fwd(prec, a2, d, P + lo.dec(i, D_C1W), P + lo.dec(i, D_C1B), T, d, d, u, d, p, seed, dec_site(i, 2), ro, 1,
-                      nullptr, 0, nullptr, 0, nullptr, st));
-    CK(adt_linear_fwd(prec, u, d, P + lo.dec(i, D_C2W), P + lo.dec(i, D_C2B), T, d, d, y, d, p, seed, dec_site(i, 3), ro, 0, a2, d,
-                      dn, d, dec, st));
+    {  // D = LN(x); qkv = D Win^T + b ; kv2 = log_feats Wkv^T + b        (sasrec/modules.py:668-672)
+      Prog g(T, L, B_, dec, p, seed, ro);
+      if (i == 0) g.gather(0, P + lo.item(), P + lo.posw(), sqrtf((float)d), SITE_EMB_DEC, x, d);   // model.py:53-59
+      else g.load(0, x, d);
+      g.ln(0, 1, P + lo.dec(i, D_LNW), P + lo.dec(i, D_LNB), dn, d);
+      g.gemm(1, 2, sinw, sinb, qkv, 3 * d);
+      g.gemm(1, 2, sinw + dd, sinb + d, qkv + d, 3 * d);
+      g.gemm(1, 2, sinw + 2 * dd, sinb + 2 * d, qkv + 2 * d, 3 * d);
+      g.load(0, f, d);
+      g.gemm(0, 2, einw + dd, einb + d, kv2, 2 * d);
+      g.gemm(0, 2, einw + 2 * dd, einb + 2 * d, kv2 + d, 2 * d);
+      CK(g.run(prec, st));
+    }
+    CK(adt_attn_fwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, B_, H, L, hd, 1, p, seed, dec_site(i, 0), b_offset, o1, d,
+                    lse1, st));
+    {  // a1 = out_proj(o1); q2 = a1 Wq^T + bq
+      Prog g(T, L, B_, dec, 0.f, nullptr, ro);
+      g.load(0, o1, d);
+      g.gemm(0, 1, P + lo.dec(i, D_SOW), P + lo.dec(i, D_SOB), a1, d);
+      g.gemm(1, 2, einw, einb, q2, d);
+      CK(g.run(prec, st));
+    }
+    CK(adt_attn_fwd(prec, q2, d, kv2, 2 * d, kv2 + d, 2 * d, B_, H, L, hd, 1, p, seed, dec_site(i, 1), b_offset, o2, d, lse2, st));
+    {  // a2 = out_proj(o2); y = (D + a2 + drop2(conv2 relu(drop1(conv1 a2)))) * mask       (:673-676, :629-633)
+      Prog g(T, L, B_, dec, p, seed, ro);
+      g.load(0, o2, d);
+      g.gemm(0, 1, P + lo.dec(i, D_EOW), P + lo.dec(i, D_EOB), a2, d);
+      g.gemm(1, 0, P + lo.dec(i, D_C1W), P + lo.dec(i, D_C1B), u, d, adt::F_DROP | adt::F_RELU, dec_site(i, 2));
+      ChainStep& s2 = g.gemm(0, 2, P + lo.dec(i, D_C2W), P + lo.dec(i, D_C2B), y, d, adt::F_DROP | adt::F_MASK, dec_site(i, 3));
+      s2.add_buf = 1; s2.in_g = dn; s2.ld_in = d;
+      CK(g.run(prec, st));
+    }
   }
-  CK(adt_logits_fwd(f, d, P + lo.item(), pos, neg, T, d, ws + w.posl, ws + w.negl, st));
   return 0;
 }
 
@@ -357,8 +423,7 @@ int adt_sasrec_predict(const adt_sasrec_cfg* c, const float* P, float* ws, const
   WS w;
   make_ws(c, B, &w);
   const int T = (int)w.T, d = (int)w.d, L = (int)w.L;
-  CK(adt_embed_fwd(seq, P + lo.item(), P + lo.posw(), T, L, d, 0.f, nullptr, SITE_EMB_SEQ, 0, ws + w.enc_x, st));
-  CK(encoder_forward(c, lo, w, P, ws, seq, 0.f, nullptr, 0, false, st));
+  CK(encoder_forward(c, lo, w, P, ws, seq, nullptr, nullptr, 0.f, nullptr, 0, false, st));
   // final_feat = log_feats[:, -1, :]  (sasrec/model.py:89): row b*L + L-1, i.e. ld = L*d starting at (L-1)*d
   return adt_score_rank(ws + w.f + (int64_t)(L - 1) * d, L * d, P + lo.item(), cand, B, C, d, logits, rank, st);
 }
