@@ -1,0 +1,33 @@
+// Argument block of the fused backward row-chain kernels (adt_bwdchain.cuh); shared with the host executor.
+#pragma once
+#include "adt_common.cuh"
+
+namespace adt {
+
+struct BwdChainArgs {
+  int T, L, B;
+  const int* ids;
+  DropCfg drop; uint32_t site1, site2; uint32_t row_offset;   // site1 = ffn1 (after conv1), site2 = ffn2
+  float ln_eps;
+  // activations (T x 64 unless noted)
+  const float* gy;            // upstream gradient of the layer output (pre-mask)
+  const float* u;             // relu(drop1(conv1 .))
+  const float* xin;           // enc_post: h (LN2 input); dec_post: a2; *_pre: layer input x; dec_mid: a1
+  const float* o;             // attention core output feeding the out_proj of this chain (o / o2 / o1)
+  const float* dqkv; int lddqkv;   // *_pre: packed (T x 192) gradient of q,k,v ; dec_mid: dq2 (ld 64)
+  const float* dkv2;          // dec_mid: (T x 128) gradient of cross k,v
+  const float* dh;            // enc_pre: gradient wrt LN1 output from the residual path
+  const float* f;             // dec_mid: log_feats
+  // weights (64 x 64 blocks, row-major)
+  const float* W0; const float* W1; const float* W2; const float* W3;
+  const float* gamma; const float* beta;
+  // outputs
+  float* out0; int acc0;      // enc_post: dh ; enc_pre/dec_pre: gx (acc0: +=) ; dec_post: do2 ; dec_mid: do1
+  float* out1; int acc1;      // enc_post: dO ; dec_mid: gf (+=)
+  // gradient accumulators (global, atomics)
+  float* dW0; float* dW1; float* dW2; float* dW3;
+  float* db0; float* db1; float* db2; float* db3;
+  float* dgamma; float* dbeta;
+};
+
+}  // namespace adt

@@ -5,6 +5,7 @@
 
 #include "adt_attn.cuh"
 #include "adt_chain.cuh"
+#include "adt_bwdchain.cuh"
 #include "adt_misc.cuh"
 #include "adt_rowops.cuh"
 
@@ -131,6 +132,40 @@ int adt_launch_rowchain_fwd(int prec, const ChainArgs& a, void* stream) {
   return check_launch("rowchain_fwd");
 }
 
+template <int PREC, int NW>
+static int launch_bwdchain_t(int which, const BwdChainArgs& a, hipStream_t s) {
+  const int ntiles = (a.T + 15) / 16;
+  int grid = (ntiles + NW - 1) / NW;
+  if (grid > 256) grid = 256;
+  const void* fn = nullptr;
+  size_t smem = 0;
+  switch (which) {
+    case 0: fn = (const void*)k_enc_post_bwd<PREC, NW>; smem = BwdLds<PREC, NW, 3>::bytes; break;
+    case 1: fn = (const void*)k_dec_post_bwd<PREC, NW>; smem = BwdLds<PREC, NW, 3>::bytes; break;
+    case 2: fn = (const void*)k_pre_bwd<PREC, NW, true>; smem = BwdLds<PREC, NW, 3>::bytes; break;
+    case 3: fn = (const void*)k_pre_bwd<PREC, NW, false>; smem = BwdLds<PREC, NW, 3>::bytes; break;
+    case 4: fn = (const void*)k_dec_mid_bwd<PREC, NW>; smem = BwdLds<PREC, NW, 4>::bytes; break;
+    default: return adt_set_error("bwdchain: bad kernel id %d", which);
+  }
+  if (smem > 160 * 1024) return adt_set_error("bwdchain %d: %zu B of LDS", which, smem);
+  static bool done[5] = {false, false, false, false, false};
+  if (!done[which]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return adt_set_error("bwdchain: hipFuncSetAttribute");
+    done[which] = true;
+  }
+  BwdChainArgs args = a;
+  void* kargs[] = {&args};
+  if (hipLaunchKernel(fn, dim3(grid), dim3(NW * 64), kargs, smem, s) != hipSuccess) return adt_set_error("bwdchain %d: launch failed", which);
+  return check_launch("bwdchain");
+}
+
+int adt_launch_bwdchain(int prec, int which, const BwdChainArgs& a, void* stream) {
+  // fp32 weight images are twice as large: 4 waves per workgroup keep the 4-weight chain inside 160 KB of LDS
+  if (prec == ADT_PREC_F32) return launch_bwdchain_t<PREC_F32, 4>(which, a, (hipStream_t)stream);
+  return launch_bwdchain_t<PREC_BF16, 8>(which, a, (hipStream_t)stream);
+}
+
 extern "C" {
 
 int adt_version(void) { return 1; }
@@ -225,7 +260,9 @@ int adt_linear_bwd(int prec, const float* dY, int lddy, const float* X, int ldx,
   a.dX = dX; a.lddx = lddx; a.beta = beta; a.Radd = Radd; a.ldradd = ldradd; a.radd_ids = radd_ids;
   a.dW = dW; a.db = db;
   const int nch = (N + 63) / 64;
-  const int grid = grid_for(T, BM, 256);
+  static int cap = 0;
+  if (!cap) { const char* e = getenv("ADT_LINBWD_GRID"); cap = e ? atoi(e) : 256; if (cap < 1) cap = 256; }
+  const int grid = grid_for(T, BM, cap);
   if (prec == ADT_PREC_F32) launch_linear_bwd<PREC_F32>(a, nch, grid, (hipStream_t)stream);
   else launch_linear_bwd<PREC_BF16>(a, nch, grid, (hipStream_t)stream);
   return check_launch("linear_bwd");

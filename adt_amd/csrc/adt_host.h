@@ -20,3 +20,7 @@ static inline uint32_t dec_site(int layer, int which) { return 128u + 8u * (uint
 // fused forward chain (adt_chain.cuh); defined in adt_capi.hip
 namespace adt { struct ChainArgs; }
 int adt_launch_rowchain_fwd(int prec, const adt::ChainArgs& a, void* stream);
+
+// fused backward chains (adt_bwdchain.cuh); defined in adt_capi.hip.  which: 0 enc_post, 1 dec_post, 2 enc_pre, 3 dec_pre, 4 dec_mid
+namespace adt { struct BwdChainArgs; }
+int adt_launch_bwdchain(int prec, int which, const adt::BwdChainArgs& a, void* stream);

@@ -5,6 +5,7 @@
 #include "adt_host.h"
 #include <string.h>
 #include "adt_chain_args.h"
+#include "adt_bwdchain_args.h"
 
 namespace {
 
@@ -105,6 +106,13 @@ int check_cfg(const adt_sasrec_cfg* c) {
 
 using adt::ChainArgs;
 using adt::ChainStep;
+
+adt::BwdChainArgs bwd_args(int T, int L, int B, const int32_t* ids, float p, const uint32_t* seed, uint32_t row_offset) {
+  adt::BwdChainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.T = T; a.L = L; a.B = B; a.ids = ids; a.drop = adt_make_drop(p, seed, 0); a.row_offset = row_offset; a.ln_eps = LN_EPS;
+  return a;
+}
 
 // ---- fused-chain program builders (adt_chain.cuh) ------------------------------------------------
 struct Prog {
@@ -326,7 +334,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   const int64_t Td = up64(w.T * w.d), recsz = up64(w.T * w.H * w.H);
   const float p = training ? c->dropout : 0.f;
   const uint32_t ro = b_offset * (uint32_t)L;
-  float *s1 = ws + w.s1, *s2 = ws + w.s2, *s3 = ws + w.s3, *s4 = ws + w.s4, *s5 = ws + w.s5;
+  float *s1 = ws + w.s1, *s3 = ws + w.s3, *s4 = ws + w.s4, *s5 = ws + w.s5;
   float* gf = ws + w.g_f;
   const float* f = ws + w.f;
   if (phase == 0 || phase == 1) {
@@ -337,38 +345,49 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       float* gx = ws + w.g_dec_x + i * Td;            // accumulates d / d (input of layer i)
       const float* x = ws + w.dec_x + i * Td;
       float* base = ws + i * w.d_stride;
-      float *dn = base + w.d_dn, *qkv = base + w.d_qkv, *o1 = base + w.d_o1, *lse1 = base + w.d_lse1, *a1 = base + w.d_a1,
+      float *qkv = base + w.d_qkv, *o1 = base + w.d_o1, *lse1 = base + w.d_lse1, *a1 = base + w.d_a1,
             *q2 = base + w.d_q2, *kv2 = base + w.d_kv2, *o2 = base + w.d_o2, *lse2 = base + w.d_lse2, *a2 = base + w.d_a2,
             *u = base + w.d_u;
-      // FFN: du = (gy*mask*drop2) W2 ; da2 = gy*mask + (du*relu'*drop1) W1
-      CK(adt_linear_bwd(prec, gy, d, u, d, P + lo.dec(i, D_C2W), T, d, d, dec, p, seed, dec_site(i, 3), ro, nullptr, 0, s1, d, 0,
-                        nullptr, 0, nullptr, G + lo.dec(i, D_C2W), G + lo.dec(i, D_C2B), st));
-      CK(adt_linear_bwd(prec, s1, d, a2, d, P + lo.dec(i, D_C1W), T, d, d, nullptr, p, seed, dec_site(i, 2), ro, u, d, s2, d, 0, gy, d,
-                        dec, G + lo.dec(i, D_C1W), G + lo.dec(i, D_C1B), st));
-      // enc_attn out_proj: do2 = da2 Wo2
-      CK(adt_linear_bwd(prec, s2, d, o2, d, P + lo.dec(i, D_EOW), T, d, d, nullptr, 0.f, nullptr, 0, 0, nullptr, 0, s1, d, 0, nullptr,
-                        0, nullptr, G + lo.dec(i, D_EOW), G + lo.dec(i, D_EOB), st));
-      // cross attention core: dq2 -> s5, dkv2 -> s4
-      CK(adt_attn_bwd(prec, q2, d, kv2, 2 * d, kv2 + d, 2 * d, o2, d, lse2, s1, d, B, H, L, hd, 1, p, seed, dec_site(i, 1), b_offset,
-                      s5, d, s4, 2 * d, s4 + d, 2 * d, st));
       const float* einw = P + lo.dec(i, D_EINW);
       float* geinw = G + lo.dec(i, D_EINW);
       float* geinb = G + lo.dec(i, D_EINB);
-      // q2 = a1 Wq^T: da1 -> s2 ;  kv2 = f Wkv^T: g_f += dkv2 Wkv
-      CK(adt_linear_bwd(prec, s5, d, a1, d, einw, T, d, d, nullptr, 0.f, nullptr, 0, 0, nullptr, 0, s2, d, 0, nullptr, 0, nullptr,
-                        geinw, geinb, st));
-      CK(adt_linear_bwd(prec, s4, 2 * d, f, d, einw + (int64_t)d * d, T, d, 2 * d, nullptr, 0.f, nullptr, 0, 0, nullptr, 0, gf, d, 1,
-                        nullptr, 0, nullptr, geinw + (int64_t)d * d, geinb + d, st));
-      // slf_attn out_proj: do1 = da1 Wo1 -> s1 ; core -> dqkv1 (s3) ; in_proj: dD = dqkv1 Win + gy*mask -> s2
-      CK(adt_linear_bwd(prec, s2, d, o1, d, P + lo.dec(i, D_SOW), T, d, d, nullptr, 0.f, nullptr, 0, 0, nullptr, 0, s1, d, 0, nullptr,
-                        0, nullptr, G + lo.dec(i, D_SOW), G + lo.dec(i, D_SOB), st));
+      const float* sinw = P + lo.dec(i, D_SINW);
+      float* gsinw = G + lo.dec(i, D_SINW);
+      float* gsinb = G + lo.dec(i, D_SINB);
+      const int dd = d * d;
+      {  // FFN + mask + enc_attn.out_proj reverse -> dO2 (s1)
+        adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, dec, p, seed, ro);
+        a.site1 = dec_site(i, 2); a.site2 = dec_site(i, 3);
+        a.gy = gy; a.u = u; a.xin = a2; a.o = o2;
+        a.W0 = P + lo.dec(i, D_C2W); a.W1 = P + lo.dec(i, D_C1W); a.W2 = P + lo.dec(i, D_EOW);
+        a.dW0 = G + lo.dec(i, D_C2W); a.dW1 = G + lo.dec(i, D_C1W); a.dW2 = G + lo.dec(i, D_EOW);
+        a.db0 = G + lo.dec(i, D_C2B); a.db1 = G + lo.dec(i, D_C1B); a.db2 = G + lo.dec(i, D_EOB);
+        a.out0 = s1;
+        CK(adt_launch_bwdchain(prec, 1, a, st));
+      }
+      // cross attention core: dq2 -> s5, dkv2 -> s4
+      CK(adt_attn_bwd(prec, q2, d, kv2, 2 * d, kv2 + d, 2 * d, o2, d, lse2, s1, d, B, H, L, hd, 1, p, seed, dec_site(i, 1), b_offset,
+                      s5, d, s4, 2 * d, s4 + d, 2 * d, st));
+      {  // q2 = a1 Wq^T, a1 = o1 Wo1^T, [k2, v2] = f Wkv^T  -> dO1 (s1), g_f +=
+        adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, dec, 0.f, nullptr, ro);
+        a.dqkv = s5; a.lddqkv = d; a.dkv2 = s4; a.xin = a1; a.o = o1; a.f = f;
+        a.W0 = einw; a.W1 = P + lo.dec(i, D_SOW); a.W2 = einw + dd; a.W3 = einw + 2 * dd;
+        a.dW0 = geinw; a.dW1 = G + lo.dec(i, D_SOW); a.dW2 = geinw + dd; a.dW3 = geinw + 2 * dd;
+        a.db0 = geinb; a.db1 = G + lo.dec(i, D_SOB); a.db2 = geinb + d; a.db3 = geinb + 2 * d;
+        a.out0 = s1; a.out1 = gf; a.acc1 = 1;
+        CK(adt_launch_bwdchain(prec, 4, a, st));
+      }
       CK(adt_attn_bwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, o1, d, lse1, s1, d, B, H, L, hd, 1, p, seed,
                       dec_site(i, 0), b_offset, s3, 3 * d, s3 + d, 3 * d, s3 + 2 * d, 3 * d, st));
-      CK(adt_linear_bwd(prec, s3, 3 * d, dn, d, P + lo.dec(i, D_SINW), T, d, 3 * d, nullptr, 0.f, nullptr, 0, 0, nullptr, 0, s2, d, 0,
-                        gy, d, dec, G + lo.dec(i, D_SINW), G + lo.dec(i, D_SINB), st));
-      // layer_norm: gx (+)= LN'(dD)
-      CK(adt_layernorm_bwd(s2, d, x, d, P + lo.dec(i, D_LNW), LN_EPS, T, d, gx, d, i > 0 ? 1 : 0, G + lo.dec(i, D_LNW),
-                           G + lo.dec(i, D_LNB), st));
+      {  // layer_norm + packed in_proj reverse: gx (+)= LN'(dqkv Win + gy*mask)
+        adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, dec, 0.f, nullptr, ro);
+        a.dqkv = s3; a.lddqkv = 3 * d; a.gy = gy; a.xin = x;
+        a.W0 = sinw; a.W1 = sinw + dd; a.W2 = sinw + 2 * dd; a.gamma = P + lo.dec(i, D_LNW); a.beta = P + lo.dec(i, D_LNB);
+        a.dW0 = gsinw; a.dW1 = gsinw + dd; a.dW2 = gsinw + 2 * dd; a.db0 = gsinb; a.db1 = gsinb + d; a.db2 = gsinb + 2 * d;
+        a.dgamma = G + lo.dec(i, D_LNW); a.dbeta = G + lo.dec(i, D_LNB);
+        a.out0 = gx; a.acc0 = i > 0 ? 1 : 0;
+        CK(adt_launch_bwdchain(prec, 3, a, st));
+      }
     }
     // decoder input embedding (sasrec/model.py:53-59)
     CK(adt_embed_bwd(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.item(), G + lo.posw(), st));
@@ -382,33 +401,38 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       float* gx = ws + w.g_enc_x + i * Td;     // already holds the reconstruction seed for enc_in[i]
       const float* x = ws + w.enc_x + i * Td;
       float* base = ws + i * w.e_stride;
-      float *qn = base + w.e_qn, *qkv = base + w.e_qkv, *o = base + w.e_o, *lse = base + w.e_lse, *h = base + w.e_h,
-            *h2 = base + w.e_h2, *u = base + w.e_u, *rec = base + w.e_rec;
-      // FFN: du -> s1 ; dh2 = gy*mask + (du*relu'*drop1) W1 -> s2
-      CK(adt_linear_bwd(prec, gy, d, u, d, P + lo.enc(i, E_C2W), T, d, d, seq, p, seed, enc_site(i, 2), ro, nullptr, 0, s1, d, 0,
-                        nullptr, 0, nullptr, G + lo.enc(i, E_C2W), G + lo.enc(i, E_C2B), st));
-      CK(adt_linear_bwd(prec, s1, d, h2, d, P + lo.enc(i, E_C1W), T, d, d, nullptr, p, seed, enc_site(i, 1), ro, u, d, s2, d, 0, gy, d,
-                        seq, G + lo.enc(i, E_C1W), G + lo.enc(i, E_C1B), st));
-      // forward_layernorm: dh -> s5
-      CK(adt_layernorm_bwd(s2, d, h, d, P + lo.enc(i, E_LN2W), LN_EPS, T, d, s5, d, 0, G + lo.enc(i, E_LN2W), G + lo.enc(i, E_LN2B), st));
-      // out_proj: do -> s1 (+ classifier gradient)
-      CK(adt_linear_bwd(prec, s5, d, o, d, P + lo.enc(i, E_OW), T, d, d, nullptr, 0.f, nullptr, 0, 0, nullptr, 0, s1, d, 0, nullptr, 0,
-                        nullptr, G + lo.enc(i, E_OW), G + lo.enc(i, E_OB), st));
+      float *qkv = base + w.e_qkv, *o = base + w.e_o, *lse = base + w.e_lse, *h = base + w.e_h, *u = base + w.e_u,
+            *rec = base + w.e_rec;
+      const float* inw = P + lo.enc(i, E_INW);
+      float* ginw = G + lo.enc(i, E_INW);
+      float* ginb = G + lo.enc(i, E_INB);
+      const int dd = d * d;
+      {  // FFN + mask + forward_layernorm + out_proj reverse -> dh (s5), dO (s1)
+        adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, seq, p, seed, ro);
+        a.site1 = enc_site(i, 1); a.site2 = enc_site(i, 2);
+        a.gy = gy; a.u = u; a.xin = h; a.o = o;
+        a.W0 = P + lo.enc(i, E_C2W); a.W1 = P + lo.enc(i, E_C1W); a.W2 = P + lo.enc(i, E_OW);
+        a.gamma = P + lo.enc(i, E_LN2W); a.beta = P + lo.enc(i, E_LN2B);
+        a.dW0 = G + lo.enc(i, E_C2W); a.dW1 = G + lo.enc(i, E_C1W); a.dW2 = G + lo.enc(i, E_OW);
+        a.db0 = G + lo.enc(i, E_C2B); a.db1 = G + lo.enc(i, E_C1B); a.db2 = G + lo.enc(i, E_OB);
+        a.dgamma = G + lo.enc(i, E_LN2W); a.dbeta = G + lo.enc(i, E_LN2B);
+        a.out0 = s5; a.out1 = s1;
+        CK(adt_launch_bwdchain(prec, 0, a, st));
+      }
       if (H > 1)
         CK(adt_headcls_bwd(o, d, P + lo.enc(i, E_SW), rec, ws + w.g_rec + i * recsz, (int)w.B, L, H, hd, s1, d, G + lo.enc(i, E_SW),
                            G + lo.enc(i, E_SB), st));
       CK(adt_attn_bwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, o, d, lse, s1, d, (int)w.B, H, L, hd, 1, p, seed,
                       enc_site(i, 0), b_offset, s3, 3 * d, s3 + d, 3 * d, s3 + 2 * d, 3 * d, st));
-      const float* inw = P + lo.enc(i, E_INW);
-      float* ginw = G + lo.enc(i, E_INW);
-      float* ginb = G + lo.enc(i, E_INB);
-      // q = Q Wq^T: dQ = dq Wq + dh -> s2 ; [k,v] = x Wkv^T: gx += dkv Wkv
-      CK(adt_linear_bwd(prec, s3, 3 * d, qn, d, inw, T, d, d, nullptr, 0.f, nullptr, 0, 0, nullptr, 0, s2, d, 0, s5, d, nullptr, ginw,
-                        ginb, st));
-      CK(adt_linear_bwd(prec, s3 + d, 3 * d, x, d, inw + (int64_t)d * d, T, d, 2 * d, nullptr, 0.f, nullptr, 0, 0, nullptr, 0, gx, d, 1,
-                        nullptr, 0, nullptr, ginw + (int64_t)d * d, ginb + d, st));
-      // attention_layernorm: gx += LN'(dQ)
-      CK(adt_layernorm_bwd(s2, d, x, d, P + lo.enc(i, E_LN1W), LN_EPS, T, d, gx, d, 1, G + lo.enc(i, E_LN1W), G + lo.enc(i, E_LN1B), st));
+      {  // attention_layernorm + in_proj reverse: gx += LN'(dq Wq + dh) + dk Wk + dv Wv
+        adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, seq, 0.f, nullptr, ro);
+        a.dqkv = s3; a.lddqkv = 3 * d; a.dh = s5; a.xin = x;
+        a.W0 = inw; a.W1 = inw + dd; a.W2 = inw + 2 * dd; a.gamma = P + lo.enc(i, E_LN1W); a.beta = P + lo.enc(i, E_LN1B);
+        a.dW0 = ginw; a.dW1 = ginw + dd; a.dW2 = ginw + 2 * dd; a.db0 = ginb; a.db1 = ginb + d; a.db2 = ginb + 2 * d;
+        a.dgamma = G + lo.enc(i, E_LN1W); a.dbeta = G + lo.enc(i, E_LN1B);
+        a.out0 = gx; a.acc0 = 1;
+        CK(adt_launch_bwdchain(prec, 2, a, st));
+      }
     }
     CK(adt_embed_bwd(seq, ws + w.g_enc_x, T, L, d, p, seed, SITE_EMB_SEQ, ro, G + lo.item(), G + lo.posw(), st));
   }

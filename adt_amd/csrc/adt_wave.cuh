@@ -1,0 +1,339 @@
+// Wave-local row-chain toolkit (d == 64).
+//
+// One wave owns a 16-token tile end to end: every activation of the tile lives in registers in the MFMA C
+// layout ("CT": lane (c, g) holds rows 4g+r, columns 16nt+c), every product is a 16x64x64 MFMA chain whose
+// B operand comes from a weight image that the workgroup staged into LDS once, and LDS is otherwise used only
+// as a per-wave 16x64 scratch to change layout (C layout -> A fragments, or <-> full 256-byte rows so that all
+// global traffic is float4-coalesced).  There is NO workgroup barrier inside a chain: waves only share the
+// read-only weight images and the ds_add_f32-accumulated weight-gradient images, so a CU hides latency by
+// running 8-16 independent waves.
+//
+// Weight-gradient products dW = dY^T X contract over the 16 tile rows; both operands are taken straight from
+// CT registers (accumulator-as-operand identity: slot (g, j<4) of the k-step is row 4g+j), the upper 16 slots
+// are zero.
+#pragma once
+#include "adt_common.cuh"
+
+namespace adt {
+
+struct CT {            // 16 x 64 fp32 tile in C layout
+  f32x4 v[4];          // v[nt][r] = element (row 4g + r, col 16 nt + c)
+};
+
+constexpr int WV_RS = 68;              // per-wave scratch row stride (floats)
+constexpr int WV_SCR = 16 * WV_RS;     // floats per wave scratch
+constexpr int DW_RS = 68;              // fp32 weight-gradient image row stride
+constexpr int DW_IMG = 64 * DW_RS;
+
+template <int PREC> struct WImg;       // weight image element type / row stride
+template <> struct WImg<PREC_F32> { typedef float T; static constexpr int RS = 68; };
+template <> struct WImg<PREC_BF16> { typedef __bf16 T; static constexpr int RS = 72; };
+
+template <int PREC> struct OpFrag;     // MFMA operand fragment (8 k-slots)
+template <> struct OpFrag<PREC_F32> { Frag8 f; };
+template <> struct OpFrag<PREC_BF16> { bf16x8 f; };
+
+ADT_DEVICE_INLINE void wave_fence() {
+  // LDS operations of one wave execute in program order; this only stops the compiler from reordering them
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int PREC>
+ADT_DEVICE_INLINE OpFrag<PREC> to_op(const Frag8& a) {
+  OpFrag<PREC> o;
+  if constexpr (PREC == PREC_BF16) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.f[j] = (__bf16)a.v[j];
+  } else {
+    o.f = a;
+  }
+  return o;
+}
+
+template <int PREC>
+ADT_DEVICE_INLINE f32x4 mma_op(f32x4 acc, const OpFrag<PREC>& a, const OpFrag<PREC>& b) {
+  if constexpr (PREC == PREC_BF16) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.f, b.f, acc, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f.v[j], b.f.v[j], acc, 0, 0, 0);
+    return acc;
+  }
+}
+
+// ---- weight images ---------------------------------------------------------------------------------
+// plain image: img[n][k] = W[n][k]  (forward products y = x W^T: rows = output column n, contraction k)
+// transposed : img[k][n] = W[n][k]  (backward products dx = dy W: rows = output column k, contraction n)
+template <int PREC, int NTHREADS>
+ADT_DEVICE_INLINE void stage_wimg(typename WImg<PREC>::T* img, const float* W, bool transposed) {
+  constexpr int RS = WImg<PREC>::RS;
+  typedef typename WImg<PREC>::T T;
+  for (int i = threadIdx.x; i < 64 * 16; i += NTHREADS) {
+    const int n = i >> 4, k4 = (i & 15) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(W + n * 64 + k4);
+    if (!transposed) {
+      img[n * RS + k4 + 0] = (T)v.x; img[n * RS + k4 + 1] = (T)v.y; img[n * RS + k4 + 2] = (T)v.z; img[n * RS + k4 + 3] = (T)v.w;
+    } else {
+      img[(k4 + 0) * RS + n] = (T)v.x; img[(k4 + 1) * RS + n] = (T)v.y; img[(k4 + 2) * RS + n] = (T)v.z; img[(k4 + 3) * RS + n] = (T)v.w;
+    }
+  }
+}
+
+template <int PREC>
+ADT_DEVICE_INLINE OpFrag<PREC> wfrag(const typename WImg<PREC>::T* img, int nt, int kb, int c, int g) {
+  constexpr int RS = WImg<PREC>::RS;
+  OpFrag<PREC> o;
+  const typename WImg<PREC>::T* p = img + (16 * nt + c) * RS + kb * 32 + 8 * g;
+  if constexpr (PREC == PREC_BF16) {
+    o.f = *reinterpret_cast<const bf16x8*>(p);
+  } else {
+    o.f = frag_contig(p);
+  }
+  return o;
+}
+
+// ---- layout changes through the per-wave scratch ------------------------------------------------------
+// global rows -> scratch (4 float4 per lane; one instruction covers 4 full 256-byte rows)
+ADT_DEVICE_INLINE void rows_to_scr(float* scr, const float* g, int ld, int row0, int T, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = q * 64 + lane, r = i >> 4, c4 = (i & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + r < T) v = *reinterpret_cast<const float4*>(g + (size_t)(row0 + r) * ld + c4);
+    *reinterpret_cast<float4*>(scr + r * WV_RS + c4) = v;
+  }
+}
+
+struct RowRegs { float4 v[4]; };   // a tile as 4 full-row float4 pieces per lane (prefetch form)
+
+ADT_DEVICE_INLINE RowRegs rows_load(const float* g, int ld, int row0, int T, int lane) {
+  RowRegs x;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = q * 64 + lane, r = i >> 4, c4 = (i & 15) * 4;
+    x.v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + r < T) x.v[q] = *reinterpret_cast<const float4*>(g + (size_t)(row0 + r) * ld + c4);
+  }
+  return x;
+}
+
+ADT_DEVICE_INLINE void rows_put(float* scr, const RowRegs& x, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = q * 64 + lane, r = i >> 4, c4 = (i & 15) * 4;
+    *reinterpret_cast<float4*>(scr + r * WV_RS + c4) = x.v[q];
+  }
+}
+
+ADT_DEVICE_INLINE void scr_to_rows(float* g, int ld, const float* scr, int row0, int T, int lane, bool accumulate = false) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = q * 64 + lane, r = i >> 4, c4 = (i & 15) * 4;
+    if (row0 + r < T) {
+      float4 v = *reinterpret_cast<const float4*>(scr + r * WV_RS + c4);
+      float* dst = g + (size_t)(row0 + r) * ld + c4;
+      if (accumulate) {
+        const float4 o = *reinterpret_cast<const float4*>(dst);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      *reinterpret_cast<float4*>(dst) = v;
+    }
+  }
+}
+
+ADT_DEVICE_INLINE CT scr_to_ct(const float* scr, int c, int g) {
+  CT t;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t.v[nt][r] = scr[(4 * g + r) * WV_RS + 16 * nt + c];
+  return t;
+}
+
+ADT_DEVICE_INLINE void ct_to_scr(float* scr, const CT& t, int c, int g) {
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) scr[(4 * g + r) * WV_RS + 16 * nt + c] = t.v[nt][r];
+}
+
+template <int PREC>
+struct AFrags { OpFrag<PREC> kb[2]; };
+
+template <int PREC>
+ADT_DEVICE_INLINE AFrags<PREC> scr_to_a(const float* scr, int c, int g) {
+  AFrags<PREC> a;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) a.kb[kb] = to_op<PREC>(frag_contig(scr + c * WV_RS + kb * 32 + 8 * g));
+  return a;
+}
+
+// convenience: global tile -> CT (through scratch)
+ADT_DEVICE_INLINE CT load_ct(float* scr, const float* gptr, int ld, int row0, int T, int lane, int c, int g) {
+  wave_fence();
+  rows_to_scr(scr, gptr, ld, row0, T, lane);
+  wave_fence();
+  return scr_to_ct(scr, c, g);
+}
+
+ADT_DEVICE_INLINE void store_ct(float* scr, float* gptr, int ld, const CT& t, int row0, int T, int lane, int c, int g,
+                                bool accumulate = false) {
+  wave_fence();
+  ct_to_scr(scr, t, c, g);
+  wave_fence();
+  scr_to_rows(gptr, ld, scr, row0, T, lane, accumulate);
+}
+
+// CT -> A fragments (through scratch)
+template <int PREC>
+ADT_DEVICE_INLINE AFrags<PREC> ct_to_a(float* scr, const CT& t, int c, int g) {
+  wave_fence();
+  ct_to_scr(scr, t, c, g);
+  wave_fence();
+  return scr_to_a<PREC>(scr, c, g);
+}
+
+// out[16 x 64] = A[16 x 64] * img^T  (img rows = output columns)
+template <int PREC>
+ADT_DEVICE_INLINE CT gemm_w(const AFrags<PREC>& a, const typename WImg<PREC>::T* img, int c, int g) {
+  CT o;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    o.v[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) o.v[nt] = mma_op<PREC>(o.v[nt], a.kb[kb], wfrag<PREC>(img, nt, kb, c, g));
+  }
+  return o;
+}
+
+// dW image (LDS, fp32, [n][k] stride DW_RS) += dY^T X over the 16 tile rows; db image += column sums of dY
+template <int PREC>
+ADT_DEVICE_INLINE void dw_accum(float* dwimg, float* dbimg, const CT& dy, const CT& x, int c, int g) {
+  OpFrag<PREC> fb[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    Frag8 b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { b.v[j] = x.v[kt][j]; b.v[4 + j] = 0.f; }
+    fb[kt] = to_op<PREC>(b);
+  }
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    Frag8 a;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a.v[j] = dy.v[nt][j]; a.v[4 + j] = 0.f; }
+    const OpFrag<PREC> fa = to_op<PREC>(a);
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = mma_op<PREC>(acc, fa, fb[kt]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&dwimg[(16 * nt + 4 * g + r) * DW_RS + 16 * kt + c], acc[r]);
+    }
+    if (dbimg) {
+      float s = dy.v[nt][0] + dy.v[nt][1] + dy.v[nt][2] + dy.v[nt][3];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (g == 0) atomicAdd(&dbimg[16 * nt + c], s);
+    }
+  }
+}
+
+// column sums of a CT over the 16 rows -> LDS image (used for LayerNorm dgamma / dbeta)
+ADT_DEVICE_INLINE void colsum_accum(float* img, const CT& t, int c, int g) {
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    float s = t.v[nt][0] + t.v[nt][1] + t.v[nt][2] + t.v[nt][3];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (g == 0) atomicAdd(&img[16 * nt + c], s);
+  }
+}
+
+// ---- LayerNorm in C layout ---------------------------------------------------------------------------
+// row r of the tile lives on the 16 lanes with the same g (one value per nt per lane)
+ADT_DEVICE_INLINE float row_sum16(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+struct LnStat { float rstd[4]; };   // per row r of this lane's group
+
+// xhat (normalised, before gamma/beta) and rstd of a CT
+ADT_DEVICE_INLINE CT ln_xhat(const CT& x, float eps, LnStat& st) {
+  CT h;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float s = x.v[0][r] + x.v[1][r] + x.v[2][r] + x.v[3][r];
+    s = row_sum16(s);
+    const float mu = s * (1.0f / 64);
+    float q = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { const float d = x.v[nt][r] - mu; h.v[nt][r] = d; q += d * d; }
+    q = row_sum16(q);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / 64) + eps);
+    st.rstd[r] = rstd;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) h.v[nt][r] *= rstd;
+  }
+  return h;
+}
+
+ADT_DEVICE_INLINE CT ln_apply(const CT& xhat, const float* gamma, const float* beta, int c) {
+  CT y;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const float gm = gamma[16 * nt + c], bt = beta[16 * nt + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y.v[nt][r] = xhat.v[nt][r] * gm + bt;
+  }
+  return y;
+}
+
+// dx = rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat)), dxh = dy * gamma; also accumulates dgamma/dbeta
+ADT_DEVICE_INLINE CT ln_bwd_ct(const CT& dy, const CT& xhat, const LnStat& st, const float* gamma, float* dg_img, float* db_img,
+                               int c, int g) {
+  CT t;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t.v[nt][r] = dy.v[nt][r] * xhat.v[nt][r];
+  colsum_accum(dg_img, t, c, g);
+  colsum_accum(db_img, dy, c, g);
+  CT dx;
+  float gm[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) gm[nt] = gamma[16 * nt + c];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const float dxh = dy.v[nt][r] * gm[nt];
+      dx.v[nt][r] = dxh;
+      m1 += dxh;
+      m2 += dxh * xhat.v[nt][r];
+    }
+    m1 = row_sum16(m1) * (1.0f / 64);
+    m2 = row_sum16(m2) * (1.0f / 64);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) dx.v[nt][r] = st.rstd[r] * (dx.v[nt][r] - m1 - xhat.v[nt][r] * m2);
+  }
+  return dx;
+}
+
+// flush an LDS fp32 image [64][DW_RS] (or a 64-vector) into global with atomics; call after __syncthreads()
+template <int NTHREADS>
+ADT_DEVICE_INLINE void flush_dw(float* gW, const float* img) {
+  for (int i = threadIdx.x; i < 64 * 64; i += NTHREADS) atomicAdd(gW + i, img[(i >> 6) * DW_RS + (i & 63)]);
+}
+template <int NTHREADS>
+ADT_DEVICE_INLINE void flush_vec(float* gv, const float* img) {
+  for (int i = threadIdx.x; i < 64; i += NTHREADS) atomicAdd(gv + i, img[i]);
+}
+
+}  // namespace adt
