@@ -144,11 +144,12 @@ static int launch_bwdchain_t(int which, const BwdChainArgs& a, hipStream_t s) {
     case 1: fn = (const void*)k_dec_post_bwd<PREC, NW>; smem = BwdLds<PREC, NW, 3>::bytes; break;
     case 2: fn = (const void*)k_pre_bwd<PREC, NW, true>; smem = BwdLds<PREC, NW, 3>::bytes; break;
     case 3: fn = (const void*)k_pre_bwd<PREC, NW, false>; smem = BwdLds<PREC, NW, 3>::bytes; break;
-    case 4: fn = (const void*)k_dec_mid_bwd<PREC, NW>; smem = BwdLds<PREC, NW, 4>::bytes; break;
+    case 4: fn = (const void*)k_dec_mid_bwd<PREC, NW>; smem = BwdLds<PREC, NW, 2>::bytes; break;
+    case 5: fn = (const void*)k_kv_bwd<PREC, NW>; smem = BwdLds<PREC, NW, 2>::bytes; break;
     default: return adt_set_error("bwdchain: bad kernel id %d", which);
   }
   if (smem > 160 * 1024) return adt_set_error("bwdchain %d: %zu B of LDS", which, smem);
-  static bool done[5] = {false, false, false, false, false};
+  static bool done[6] = {false, false, false, false, false, false};
   if (!done[which]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return adt_set_error("bwdchain: hipFuncSetAttribute");
@@ -161,9 +162,10 @@ static int launch_bwdchain_t(int which, const BwdChainArgs& a, hipStream_t s) {
 }
 
 int adt_launch_bwdchain(int prec, int which, const BwdChainArgs& a, void* stream) {
-  // fp32 weight images are twice as large: 4 waves per workgroup keep the 4-weight chain inside 160 KB of LDS
+  // one wave per SIMD (4 waves per workgroup, one workgroup per CU): each wave may use the whole 512-entry
+  // register file, which is what keeps three 64x64 weight-gradient accumulators resident
   if (prec == ADT_PREC_F32) return launch_bwdchain_t<PREC_F32, 4>(which, a, (hipStream_t)stream);
-  return launch_bwdchain_t<PREC_BF16, 8>(which, a, (hipStream_t)stream);
+  return launch_bwdchain_t<PREC_BF16, 4>(which, a, (hipStream_t)stream);
 }
 
 extern "C" {

@@ -368,14 +368,21 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       // cross attention core: dq2 -> s5, dkv2 -> s4
       CK(adt_attn_bwd(prec, q2, d, kv2, 2 * d, kv2 + d, 2 * d, o2, d, lse2, s1, d, B, H, L, hd, 1, p, seed, dec_site(i, 1), b_offset,
                       s5, d, s4, 2 * d, s4 + d, 2 * d, st));
-      {  // q2 = a1 Wq^T, a1 = o1 Wo1^T, [k2, v2] = f Wkv^T  -> dO1 (s1), g_f +=
+      {  // q2 = a1 Wq^T, a1 = o1 Wo1^T  -> dO1 (s1)
         adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, dec, 0.f, nullptr, ro);
-        a.dqkv = s5; a.lddqkv = d; a.dkv2 = s4; a.xin = a1; a.o = o1; a.f = f;
-        a.W0 = einw; a.W1 = P + lo.dec(i, D_SOW); a.W2 = einw + dd; a.W3 = einw + 2 * dd;
-        a.dW0 = geinw; a.dW1 = G + lo.dec(i, D_SOW); a.dW2 = geinw + dd; a.dW3 = geinw + 2 * dd;
-        a.db0 = geinb; a.db1 = G + lo.dec(i, D_SOB); a.db2 = geinb + d; a.db3 = geinb + 2 * d;
-        a.out0 = s1; a.out1 = gf; a.acc1 = 1;
+        a.dqkv = s5; a.lddqkv = d; a.xin = a1; a.o = o1;
+        a.W0 = einw; a.W1 = P + lo.dec(i, D_SOW);
+        a.dW0 = geinw; a.dW1 = G + lo.dec(i, D_SOW); a.db0 = geinb; a.db1 = G + lo.dec(i, D_SOB);
+        a.out0 = s1;
         CK(adt_launch_bwdchain(prec, 4, a, st));
+      }
+      {  // [k2, v2] = f Wkv^T  -> g_f +=
+        adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, dec, 0.f, nullptr, ro);
+        a.dkv2 = s4; a.f = f;
+        a.W0 = einw + dd; a.W1 = einw + 2 * dd;
+        a.dW0 = geinw + dd; a.dW1 = geinw + 2 * dd; a.db0 = geinb + d; a.db1 = geinb + 2 * d;
+        a.out0 = gf; a.acc0 = 1;
+        CK(adt_launch_bwdchain(prec, 5, a, st));
       }
       CK(adt_attn_bwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, o1, d, lse1, s1, d, B, H, L, hd, 1, p, seed,
                       dec_site(i, 0), b_offset, s3, 3 * d, s3 + d, 3 * d, s3 + 2 * d, 3 * d, st));

@@ -207,9 +207,24 @@ ADT_DEVICE_INLINE CT gemm_w(const AFrags<PREC>& a, const typename WImg<PREC>::T*
   return o;
 }
 
-// dW image (LDS, fp32, [n][k] stride DW_RS) += dY^T X over the 16 tile rows; db image += column sums of dY
+// Weight-gradient accumulator of one 64x64 weight, resident in registers (AGPR-able) for the whole kernel:
+// t[nt*4 + kt] is the 16x16 tile (rows n = 16nt + 4g + r, cols k = 16kt + c); bias[nt] = this lane's partial
+// column sums of dY (rows 4g..4g+3 of every tile it has seen).
+struct WAcc {
+  f32x4 t[16];
+  float bias[4];
+};
+
+ADT_DEVICE_INLINE void wacc_zero(WAcc& a) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a.t[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a.bias[i] = 0.f;
+}
+
+// acc += dY^T X over the 16 tile rows (accumulator-as-operand: both operands straight from CT registers)
 template <int PREC>
-ADT_DEVICE_INLINE void dw_accum(float* dwimg, float* dbimg, const CT& dy, const CT& x, int c, int g) {
+ADT_DEVICE_INLINE void dw_accum(WAcc& acc, const CT& dy, const CT& x) {
   OpFrag<PREC> fb[4];
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
@@ -225,29 +240,59 @@ ADT_DEVICE_INLINE void dw_accum(float* dwimg, float* dbimg, const CT& dy, const 
     for (int j = 0; j < 4; ++j) { a.v[j] = dy.v[nt][j]; a.v[4 + j] = 0.f; }
     const OpFrag<PREC> fa = to_op<PREC>(a);
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      acc = mma_op<PREC>(acc, fa, fb[kt]);
+    for (int kt = 0; kt < 4; ++kt) acc.t[nt * 4 + kt] = mma_op<PREC>(acc.t[nt * 4 + kt], fa, fb[kt]);
+    acc.bias[nt] += dy.v[nt][0] + dy.v[nt][1] + dy.v[nt][2] + dy.v[nt][3];
+  }
+}
+
+// per-lane partial column sums (LayerNorm dgamma / dbeta)
+struct VAcc { float v[4]; };
+ADT_DEVICE_INLINE void vacc_zero(VAcc& a) { a.v[0] = a.v[1] = a.v[2] = a.v[3] = 0.f; }
+ADT_DEVICE_INLINE void colsum_accum(VAcc& a, const CT& t) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&dwimg[(16 * nt + 4 * g + r) * DW_RS + 16 * kt + c], acc[r]);
-    }
-    if (dbimg) {
-      float s = dy.v[nt][0] + dy.v[nt][1] + dy.v[nt][2] + dy.v[nt][3];
+  for (int nt = 0; nt < 4; ++nt) a.v[nt] += t.v[nt][0] + t.v[nt][1] + t.v[nt][2] + t.v[nt][3];
+}
+
+// End-of-kernel reduction of one weight accumulator over the NW waves of the workgroup: every wave parks its
+// tiles in a private LDS image, then all threads sum the NW images and add the result to global memory with
+// one float atomic per element (coalesced 256-byte rows).  red: NW * DW_IMG floats.  Must be called by all
+// threads (contains workgroup barriers).
+template <int NW>
+ADT_DEVICE_INLINE void wacc_flush(const WAcc& acc, float* red, float* gW, float* gb, int w, int c, int g) {
+  __syncthreads();
+  float* mine = red + w * DW_IMG;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[(16 * nt + 4 * g + r) * DW_RS + 16 * kt + c] = acc.t[nt * 4 + kt][r];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += NW * 64) {
+    const int o = (i >> 6) * DW_RS + (i & 63);
+    float s = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) s += red[ww * DW_IMG + o];
+    atomicAdd(gW + i, s);
+  }
+  if (gb) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      float s = acc.bias[nt];
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
-      if (g == 0) atomicAdd(&dbimg[16 * nt + c], s);
+      if (g == 0) atomicAdd(gb + 16 * nt + c, s);
     }
   }
 }
 
-// column sums of a CT over the 16 rows -> LDS image (used for LayerNorm dgamma / dbeta)
-ADT_DEVICE_INLINE void colsum_accum(float* img, const CT& t, int c, int g) {
+ADT_DEVICE_INLINE void vacc_flush(const VAcc& a, float* gv, int c, int g) {
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
-    float s = t.v[nt][0] + t.v[nt][1] + t.v[nt][2] + t.v[nt][3];
+    float s = a.v[nt];
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
-    if (g == 0) atomicAdd(&img[16 * nt + c], s);
+    if (g == 0) atomicAdd(gv + 16 * nt + c, s);
   }
 }
 
@@ -295,15 +340,15 @@ ADT_DEVICE_INLINE CT ln_apply(const CT& xhat, const float* gamma, const float* b
 }
 
 // dx = rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat)), dxh = dy * gamma; also accumulates dgamma/dbeta
-ADT_DEVICE_INLINE CT ln_bwd_ct(const CT& dy, const CT& xhat, const LnStat& st, const float* gamma, float* dg_img, float* db_img,
+ADT_DEVICE_INLINE CT ln_bwd_ct(const CT& dy, const CT& xhat, const LnStat& st, const float* gamma, VAcc& dg_acc, VAcc& db_acc,
                                int c, int g) {
   CT t;
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) t.v[nt][r] = dy.v[nt][r] * xhat.v[nt][r];
-  colsum_accum(dg_img, t, c, g);
-  colsum_accum(db_img, dy, c, g);
+  colsum_accum(dg_acc, t);
+  colsum_accum(db_acc, dy);
   CT dx;
   float gm[4];
 #pragma unroll
@@ -324,16 +369,6 @@ ADT_DEVICE_INLINE CT ln_bwd_ct(const CT& dy, const CT& xhat, const LnStat& st, c
     for (int nt = 0; nt < 4; ++nt) dx.v[nt][r] = st.rstd[r] * (dx.v[nt][r] - m1 - xhat.v[nt][r] * m2);
   }
   return dx;
-}
-
-// flush an LDS fp32 image [64][DW_RS] (or a 64-vector) into global with atomics; call after __syncthreads()
-template <int NTHREADS>
-ADT_DEVICE_INLINE void flush_dw(float* gW, const float* img) {
-  for (int i = threadIdx.x; i < 64 * 64; i += NTHREADS) atomicAdd(gW + i, img[(i >> 6) * DW_RS + (i & 63)]);
-}
-template <int NTHREADS>
-ADT_DEVICE_INLINE void flush_vec(float* gv, const float* img) {
-  for (int i = threadIdx.x; i < 64; i += NTHREADS) atomicAdd(gv + i, img[i]);
 }
 
 }  // namespace adt
