@@ -68,6 +68,9 @@ class FusedTrainer:
         if self.world == 1:
             m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=0)
         else:
+            # two buckets: the decoder bucket's all-reduce (RCCL, its own stream) overlaps the encoder's backward.
+            # NOTE: phase 1 also scatters the decoder-input embedding rows, which live in the encoder bucket
+            # (item/pos tables at flat offset 0) -- that bucket is reduced after phase 2, so nothing is lost.
             m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=1)
             h1 = torch.distributed.all_reduce(m.flat_grad[self._dec_off:], group=self.pg, async_op=True)
             m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=2)
