@@ -6,6 +6,7 @@
 #include "adt_attn.cuh"
 #include "adt_chain.cuh"
 #include "adt_bwdchain.cuh"
+#include "adt_fwdchain.cuh"
 #include "adt_misc.cuh"
 #include "adt_rowops.cuh"
 
@@ -159,6 +160,39 @@ static int launch_bwdchain_t(int which, const BwdChainArgs& a, hipStream_t s) {
   void* kargs[] = {&args};
   if (hipLaunchKernel(fn, dim3(grid), dim3(NW * 64), kargs, smem, s) != hipSuccess) return adt_set_error("bwdchain %d: launch failed", which);
   return check_launch("bwdchain");
+}
+
+template <int PREC, int NW>
+static int launch_fwdchain_t(int which, const FwdChainArgs& a, hipStream_t s) {
+  const int ntiles = (a.T + 15) / 16;
+  int grid = (ntiles + NW - 1) / NW;
+  if (grid > 512) grid = 512;
+  const void* fn = nullptr;
+  size_t smem = 0;
+  switch (which) {
+    case 0: fn = (const void*)k_pre_fwd<PREC, NW, true>; smem = FwdLds<PREC, NW, 3>::bytes; break;
+    case 1: fn = (const void*)k_pre_fwd<PREC, NW, false>; smem = FwdLds<PREC, NW, 3>::bytes; break;
+    case 2: fn = (const void*)k_enc_post_fwd<PREC, NW>; smem = FwdLds<PREC, NW, 3>::bytes; break;
+    case 3: fn = (const void*)k_dec_mid_fwd<PREC, NW>; smem = FwdLds<PREC, NW, 2>::bytes; break;
+    case 4: fn = (const void*)k_dec_post_fwd<PREC, NW>; smem = FwdLds<PREC, NW, 3>::bytes; break;
+    case 5: fn = (const void*)k_final_fwd<PREC, NW>; smem = FwdLds<PREC, NW, 4>::bytes; break;
+    default: return adt_set_error("fwdchain: bad kernel id %d", which);
+  }
+  static bool done[6] = {false, false, false, false, false, false};
+  if (!done[which]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return adt_set_error("fwdchain: hipFuncSetAttribute");
+    done[which] = true;
+  }
+  FwdChainArgs args = a;
+  void* kargs[] = {&args};
+  if (hipLaunchKernel(fn, dim3(grid), dim3(NW * 64), kargs, smem, s) != hipSuccess) return adt_set_error("fwdchain %d: launch failed", which);
+  return check_launch("fwdchain");
+}
+
+int adt_launch_fwdchain(int prec, int which, const FwdChainArgs& a, void* stream) {
+  if (prec == ADT_PREC_F32) return launch_fwdchain_t<PREC_F32, 8>(which, a, (hipStream_t)stream);
+  return launch_fwdchain_t<PREC_BF16, 8>(which, a, (hipStream_t)stream);
 }
 
 int adt_launch_bwdchain(int prec, int which, const BwdChainArgs& a, void* stream) {

@@ -24,3 +24,7 @@ int adt_launch_rowchain_fwd(int prec, const adt::ChainArgs& a, void* stream);
 // fused backward chains (adt_bwdchain.cuh); defined in adt_capi.hip.  which: 0 enc_post, 1 dec_post, 2 enc_pre, 3 dec_pre, 4 dec_mid
 namespace adt { struct BwdChainArgs; }
 int adt_launch_bwdchain(int prec, int which, const adt::BwdChainArgs& a, void* stream);
+
+// wave-local forward chains (adt_fwdchain.cuh); which: 0 enc_pre, 1 dec_pre, 2 enc_post, 3 dec_mid, 4 dec_post, 5 final
+namespace adt { struct FwdChainArgs; }
+int adt_launch_fwdchain(int prec, int which, const adt::FwdChainArgs& a, void* stream);

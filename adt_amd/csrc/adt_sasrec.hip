@@ -6,6 +6,7 @@
 #include <string.h>
 #include "adt_chain_args.h"
 #include "adt_bwdchain_args.h"
+#include "adt_fwdchain_args.h"
 
 namespace {
 
@@ -107,6 +108,13 @@ int check_cfg(const adt_sasrec_cfg* c) {
 using adt::ChainArgs;
 using adt::ChainStep;
 
+adt::FwdChainArgs fwd_args(int T, int L, int B, int H, const int32_t* ids, float p, const uint32_t* seed, uint32_t row_offset) {
+  adt::FwdChainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.T = T; a.L = L; a.B = B; a.H = H; a.ids = ids; a.drop = adt_make_drop(p, seed, 0); a.row_offset = row_offset; a.ln_eps = LN_EPS;
+  return a;
+}
+
 adt::BwdChainArgs bwd_args(int T, int L, int B, const int32_t* ids, float p, const uint32_t* seed, uint32_t row_offset) {
   adt::BwdChainArgs a;
   memset(&a, 0, sizeof(a));
@@ -142,59 +150,62 @@ struct Prog {
   int run(int prec, void* st) { return adt_launch_rowchain_fwd(prec, a, st); }
 };
 
-// encoder stack forward; `embed` = gather the input embedding inside the first chain (else enc_x[0] is given)
+// encoder stack forward (gathers the input embedding inside the first chain) + last LayerNorm (+ logits and the
+// cross-attention k/v projections of every decoder layer when training_outputs)
 int encoder_forward(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const float* P, float* ws,
                     const int32_t* seq, const int32_t* pos, const int32_t* neg, float p, const uint32_t* seed,
                     uint32_t b_offset, bool training_outputs, void* st) {
-  const int T = (int)w.T, d = (int)w.d, H = (int)w.H, hd = d / H, L = (int)w.L, B = (int)w.B, prec = c->prec;
+  const int T = (int)w.T, d = (int)w.d, H = (int)w.H, hd = d / H, L = (int)w.L, B = (int)w.B, prec = c->prec, nl = c->num_layers;
   const int64_t Td = up64(w.T * w.d);
   const uint32_t ro = b_offset * (uint32_t)L;
   const int dd = d * d;
-  for (int i = 0; i < c->num_layers; ++i) {
+  for (int i = 0; i < nl; ++i) {
     float* x = ws + w.enc_x + i * Td;
     float* y = ws + w.enc_x + (i + 1) * Td;
     float* base = ws + i * w.e_stride;
     float *qn = base + w.e_qn, *qkv = base + w.e_qkv, *o = base + w.e_o, *lse = base + w.e_lse, *h = base + w.e_h,
-          *h2 = base + w.e_h2, *u = base + w.e_u, *rec = base + w.e_rec;
+          *u = base + w.e_u, *rec = base + w.e_rec;
     const float* inw = P + lo.enc(i, E_INW);
     const float* inb = P + lo.enc(i, E_INB);
-    {  // Q = LN1(x); q = Q Wq^T + bq ; k, v = x Wk^T, x Wv^T      (sasrec/modules.py:646-647, :123-130)
-      Prog g(T, L, B, seq, p, seed, ro);
-      if (i == 0) g.gather(0, P + lo.item(), P + lo.posw(), sqrtf((float)d), SITE_EMB_SEQ, x, d);   // model.py:34-41
-      else g.load(0, x, d);
-      g.ln(0, 1, P + lo.enc(i, E_LN1W), P + lo.enc(i, E_LN1B), qn, d);
-      g.gemm(1, 2, inw, inb, qkv, 3 * d);
-      g.gemm(0, 2, inw + dd, inb + d, qkv + d, 3 * d);
-      g.gemm(0, 2, inw + 2 * dd, inb + 2 * d, qkv + 2 * d, 3 * d);
-      CK(g.run(prec, st));
+    {  // [gather] ; Q = LN1(x) ; q = Q Wq^T + bq ; k, v = x Wk^T, x Wv^T     (sasrec/model.py:34-41, modules.py:646-647)
+      adt::FwdChainArgs a = fwd_args(T, L, B, H, seq, p, seed, ro);
+      a.x = i == 0 ? nullptr : x; a.E = P + lo.item(); a.P = P + lo.posw(); a.emb_scale = sqrtf((float)d); a.site0 = SITE_EMB_SEQ;
+      a.gamma = P + lo.enc(i, E_LN1W); a.beta = P + lo.enc(i, E_LN1B);
+      for (int j = 0; j < 3; ++j) { a.W[j] = inw + j * dd; a.b[j] = inb + j * d; }
+      a.o0 = x; a.ld0 = d; a.o1 = qn; a.ld1 = d; a.o2 = qkv; a.ld2 = 3 * d;
+      CK(adt_launch_fwdchain(prec, 0, a, st));
     }
     CK(adt_attn_fwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, B, H, L, hd, 1, p, seed, enc_site(i, 0), b_offset, o, d,
                     lse, st));
     {  // h = Q + out_proj(o); h2 = LN2(h); u = relu(drop1(conv1 h2)); y = (h2 + drop2(conv2 u)) * mask   (:648-654)
-      Prog g(T, L, B, seq, p, seed, ro);
-      g.load(0, o, d);
-      if (training_outputs) {
-        g.add(adt::ST_CLS, 0, 0);
-        g.a.Ws = P + lo.enc(i, E_SW); g.a.bs = P + lo.enc(i, E_SB); g.a.H = H; g.a.rec = rec;
-      }
-      ChainStep& s1 = g.gemm(0, 1, P + lo.enc(i, E_OW), P + lo.enc(i, E_OB), h, d);
-      s1.in_g = qn; s1.ld_in = d;
-      g.ln(1, 2, P + lo.enc(i, E_LN2W), P + lo.enc(i, E_LN2B), h2, d);
-      g.gemm(2, 0, P + lo.enc(i, E_C1W), P + lo.enc(i, E_C1B), u, d, adt::F_DROP | adt::F_RELU, enc_site(i, 1));
-      ChainStep& s2 = g.gemm(0, 1, P + lo.enc(i, E_C2W), P + lo.enc(i, E_C2B), y, d, adt::F_DROP | adt::F_MASK, enc_site(i, 2));
-      s2.add_buf = 2;
-      CK(g.run(prec, st));
+      adt::FwdChainArgs a = fwd_args(T, L, B, H, seq, p, seed, ro);
+      a.x = o; a.r0 = qn; a.site1 = enc_site(i, 1); a.site2 = enc_site(i, 2);
+      a.W[0] = P + lo.enc(i, E_OW); a.b[0] = P + lo.enc(i, E_OB);
+      a.W[1] = P + lo.enc(i, E_C1W); a.b[1] = P + lo.enc(i, E_C1B);
+      a.W[2] = P + lo.enc(i, E_C2W); a.b[2] = P + lo.enc(i, E_C2B);
+      a.gamma = P + lo.enc(i, E_LN2W); a.beta = P + lo.enc(i, E_LN2B);
+      a.o0 = h; a.ld0 = d; a.o1 = u; a.ld1 = d; a.o2 = y; a.ld2 = d;
+      if (training_outputs) { a.rec = rec; a.Ws = P + lo.enc(i, E_SW); a.bs = P + lo.enc(i, E_SB); }
+      CK(adt_launch_fwdchain(prec, 2, a, st));
     }
   }
-  {  // log_feats = last_layernorm(encoder out); pos/neg logits          (sasrec/model.py:48, :72-76)
-    Prog g(T, L, B, seq, 0.f, nullptr, ro);
-    g.load(0, ws + w.enc_x + c->num_layers * Td, d);
-    g.ln(0, 1, P + lo.lnl_w(), P + lo.lnl_b(), ws + w.f, d);
+  // log_feats = last_layernorm(encoder out); pos/neg logits; [k2, v2] of every decoder layer   (model.py:48, :72-76)
+  for (int j0 = 0; j0 == 0 || (training_outputs && j0 < nl); j0 += 2) {
+    adt::FwdChainArgs a = fwd_args(T, L, B, H, seq, 0.f, nullptr, ro);
+    a.x = ws + w.enc_x + nl * Td; a.gamma = P + lo.lnl_w(); a.beta = P + lo.lnl_b();
+    if (j0 == 0) { a.o0 = ws + w.f; a.ld0 = d; }
     if (training_outputs) {
-      g.add(adt::ST_LOGITS, 1, 1);
-      g.a.E = P + lo.item(); g.a.pos = pos; g.a.neg = neg; g.a.pos_logits = ws + w.posl; g.a.neg_logits = ws + w.negl;
+      if (j0 == 0) { a.E = P + lo.item(); a.pos = pos; a.neg = neg; a.pos_logits = ws + w.posl; a.neg_logits = ws + w.negl; }
+      a.nkv = nl - j0 >= 2 ? 2 : 1;
+      for (int k = 0; k < a.nkv; ++k) {
+        const float* einw = P + lo.dec(j0 + k, D_EINW);
+        const float* einb = P + lo.dec(j0 + k, D_EINB);
+        a.W[2 * k] = einw + dd; a.W[2 * k + 1] = einw + 2 * dd; a.b[2 * k] = einb + d; a.b[2 * k + 1] = einb + 2 * d;
+        float* kv2 = ws + (j0 + k) * w.d_stride + w.d_kv2;
+        if (k == 0) { a.o2 = kv2; a.ld2 = 2 * d; } else { a.o3 = kv2; a.ld3 = 2 * d; }
+      }
     }
-    CK(g.run(prec, st));
+    CK(adt_launch_fwdchain(prec, 5, a, st));
   }
   return 0;
 }
@@ -267,37 +278,31 @@ int adt_sasrec_forward(const adt_sasrec_cfg* c, const float* P, float* ws, const
     const float* sinb = P + lo.dec(i, D_SINB);
     const float* einw = P + lo.dec(i, D_EINW);
     const float* einb = P + lo.dec(i, D_EINB);
-    {  // D = LN(x); qkv = D Win^T + b ; kv2 = log_feats Wkv^T + b        (sasrec/modules.py:668-672)
-      Prog g(T, L, B_, dec, p, seed, ro);
-      if (i == 0) g.gather(0, P + lo.item(), P + lo.posw(), sqrtf((float)d), SITE_EMB_DEC, x, d);   // model.py:53-59
-      else g.load(0, x, d);
-      g.ln(0, 1, P + lo.dec(i, D_LNW), P + lo.dec(i, D_LNB), dn, d);
-      g.gemm(1, 2, sinw, sinb, qkv, 3 * d);
-      g.gemm(1, 2, sinw + dd, sinb + d, qkv + d, 3 * d);
-      g.gemm(1, 2, sinw + 2 * dd, sinb + 2 * d, qkv + 2 * d, 3 * d);
-      g.load(0, f, d);
-      g.gemm(0, 2, einw + dd, einb + d, kv2, 2 * d);
-      g.gemm(0, 2, einw + 2 * dd, einb + 2 * d, kv2 + d, 2 * d);
-      CK(g.run(prec, st));
+    {  // [gather] ; D = LN(x) ; qkv = D Win^T + b                          (sasrec/model.py:53-59, modules.py:668-670)
+      adt::FwdChainArgs a = fwd_args(T, L, B_, H, dec, p, seed, ro);
+      a.x = i == 0 ? nullptr : x; a.E = P + lo.item(); a.P = P + lo.posw(); a.emb_scale = sqrtf((float)d); a.site0 = SITE_EMB_DEC;
+      a.gamma = P + lo.dec(i, D_LNW); a.beta = P + lo.dec(i, D_LNB);
+      for (int j = 0; j < 3; ++j) { a.W[j] = sinw + j * dd; a.b[j] = sinb + j * d; }
+      a.o0 = x; a.ld0 = d; a.o1 = dn; a.ld1 = d; a.o2 = qkv; a.ld2 = 3 * d;
+      CK(adt_launch_fwdchain(prec, 1, a, st));
     }
     CK(adt_attn_fwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, B_, H, L, hd, 1, p, seed, dec_site(i, 0), b_offset, o1, d,
                     lse1, st));
     {  // a1 = out_proj(o1); q2 = a1 Wq^T + bq
-      Prog g(T, L, B_, dec, 0.f, nullptr, ro);
-      g.load(0, o1, d);
-      g.gemm(0, 1, P + lo.dec(i, D_SOW), P + lo.dec(i, D_SOB), a1, d);
-      g.gemm(1, 2, einw, einb, q2, d);
-      CK(g.run(prec, st));
+      adt::FwdChainArgs a = fwd_args(T, L, B_, H, dec, 0.f, nullptr, ro);
+      a.x = o1; a.W[0] = P + lo.dec(i, D_SOW); a.b[0] = P + lo.dec(i, D_SOB); a.W[1] = einw; a.b[1] = einb;
+      a.o0 = a1; a.ld0 = d; a.o2 = q2; a.ld2 = d;
+      CK(adt_launch_fwdchain(prec, 3, a, st));
     }
     CK(adt_attn_fwd(prec, q2, d, kv2, 2 * d, kv2 + d, 2 * d, B_, H, L, hd, 1, p, seed, dec_site(i, 1), b_offset, o2, d, lse2, st));
     {  // a2 = out_proj(o2); y = (D + a2 + drop2(conv2 relu(drop1(conv1 a2)))) * mask       (:673-676, :629-633)
-      Prog g(T, L, B_, dec, p, seed, ro);
-      g.load(0, o2, d);
-      g.gemm(0, 1, P + lo.dec(i, D_EOW), P + lo.dec(i, D_EOB), a2, d);
-      g.gemm(1, 0, P + lo.dec(i, D_C1W), P + lo.dec(i, D_C1B), u, d, adt::F_DROP | adt::F_RELU, dec_site(i, 2));
-      ChainStep& s2 = g.gemm(0, 2, P + lo.dec(i, D_C2W), P + lo.dec(i, D_C2B), y, d, adt::F_DROP | adt::F_MASK, dec_site(i, 3));
-      s2.add_buf = 1; s2.in_g = dn; s2.ld_in = d;
-      CK(g.run(prec, st));
+      adt::FwdChainArgs a = fwd_args(T, L, B_, H, dec, p, seed, ro);
+      a.x = o2; a.r0 = dn; a.site1 = dec_site(i, 2); a.site2 = dec_site(i, 3);
+      a.W[0] = P + lo.dec(i, D_EOW); a.b[0] = P + lo.dec(i, D_EOB);
+      a.W[1] = P + lo.dec(i, D_C1W); a.b[1] = P + lo.dec(i, D_C1B);
+      a.W[2] = P + lo.dec(i, D_C2W); a.b[2] = P + lo.dec(i, D_C2B);
+      a.o0 = a2; a.ld0 = d; a.o1 = u; a.ld1 = d; a.o2 = y; a.ld2 = d;
+      CK(adt_launch_fwdchain(prec, 4, a, st));
     }
   }
   return 0;

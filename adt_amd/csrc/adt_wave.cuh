@@ -371,4 +371,40 @@ ADT_DEVICE_INLINE CT ln_bwd_ct(const CT& dy, const CT& xhat, const LnStat& st, c
   return dx;
 }
 
+ADT_DEVICE_INLINE void ct_mask_rows(CT& t, const int* ids, int row0, int T, int g) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + 4 * g + r;
+    const bool dead = row >= T || ids[row] == 0;
+    if (dead) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) t.v[nt][r] = 0.f;
+    }
+  }
+}
+
+ADT_DEVICE_INLINE void ct_dropmask(CT& t, uint32_t key, const DropCfg& d, uint32_t row_base, int c, int g) {
+  if (!d.thr) return;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t idx = (row_base + (uint32_t)(4 * g + r)) * 64u + (uint32_t)(16 * nt + c);
+      t.v[nt][r] = adt_keep(key, idx, d.thr) ? t.v[nt][r] * d.scale : 0.f;
+    }
+}
+
+ADT_DEVICE_INLINE void ct_add(CT& a, const CT& b) {
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) a.v[nt] += b.v[nt];
+}
+
+ADT_DEVICE_INLINE CT rows_to_ct(float* scr, const RowRegs& x, int lane, int c, int g) {
+  wave_fence();
+  rows_put(scr, x, lane);
+  wave_fence();
+  return scr_to_ct(scr, c, g);
+}
+
+
 }  // namespace adt
