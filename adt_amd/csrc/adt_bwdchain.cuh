@@ -9,35 +9,54 @@
 
 namespace adt {
 
-// LDS carve-up: NWT weight images, then a region shared by the per-wave layout scratch (during the tile loop)
-// and the NW per-wave reduction images (after it).
+// LDS carve-up: NWT weight images | two cooperative exchange areas (Coop) | per-wave layout scratch.
 template <int PREC, int NW, int NWT>
 struct BwdLds {
   typedef typename WImg<PREC>::T WT;
   static constexpr int WIMG = 64 * WImg<PREC>::RS;           // elements per weight image
-  static constexpr size_t bytes = NWT * WIMG * sizeof(WT) + (size_t)NW * DW_IMG * sizeof(float);
-  WT* w[4]; float* red; float* scr;
+  static constexpr size_t wbytes = NWT * WIMG * sizeof(WT);
+  static constexpr size_t bytes = wbytes + Coop<PREC, NW>::bytes + (size_t)NW * WV_SCR * sizeof(float);
+  WT* w[4]; void* coop; float* scr;
   __device__ BwdLds(unsigned char* base, int wave) {
     WT* pw = reinterpret_cast<WT*>(base);
     for (int i = 0; i < NWT; ++i) w[i] = pw + i * WIMG;
-    red = reinterpret_cast<float*>(base + NWT * WIMG * sizeof(WT));
-    scr = red + wave * DW_IMG;      // a wave's scratch lives at the head of its own reduction image
+    coop = base + wbytes;
+    scr = reinterpret_cast<float*>(base + wbytes + Coop<PREC, NW>::bytes) + wave * WV_SCR;
   }
 };
 
+template <int N>
+ADT_DEVICE_INLINE void acc_zero(f32x4 (&a)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) a[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+#define BWD_PROLOGUE(NWT_)                                                                         \
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];                         \
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;           \
+  BwdLds<PREC, NW, NWT_> lds(smem_raw, w);                                                         \
+  Coop<PREC, NW> coop(lds.coop, w, lane, a.ablate);                                                        \
+  constexpr int NOWN = Coop<PREC, NW>::NOWN;                                                       \
+  const int ntiles = (a.T + 15) / 16;                                                              \
+  const int tstride = gridDim.x * NW;                                                              \
+  const int nrounds = (ntiles + tstride - 1) / tstride;   /* identical for every wave: barriers inside */ \
+  int tile = blockIdx.x * NW + w;
+
 // FFN reverse shared by encoder and decoder:  y = mask(R + drop2(conv2 relu(drop1(conv1 xin)))).
 // Returns g = masked upstream gradient and dxin = gradient reaching xin through the FFN.
-template <int PREC>
-ADT_DEVICE_INLINE void ffn_bwd_tile(const BwdChainArgs& a, float* scr, const typename WImg<PREC>::T* W2t,
-                                    const typename WImg<PREC>::T* W1t, WAcc& dW2, WAcc& dW1, const CT& xin,
-                                    const RowRegs& gy_rows, const RowRegs& u_rows, uint32_t key1, uint32_t key2, int row0,
-                                    int lane, int c, int g, CT& gout, CT& dxin) {
+template <int PREC, int NW>
+ADT_DEVICE_INLINE void ffn_bwd_tile(const BwdChainArgs& a, float* scr, Coop<PREC, NW>& coop,
+                                    const typename WImg<PREC>::T* W2t, const typename WImg<PREC>::T* W1t,
+                                    f32x4 (&dW2)[Coop<PREC, NW>::NOWN], f32x4 (&dW1)[Coop<PREC, NW>::NOWN], VAcc& db2, VAcc& db1,
+                                    const CT& xin, const RowRegs& gy_rows, const RowRegs& u_rows, uint32_t key1, uint32_t key2,
+                                    int row0, int lane, int c, int g, CT& gout, CT& dxin) {
   gout = rows_to_ct(scr, gy_rows, lane, c, g);
   ct_mask_rows(gout, a.ids, row0, a.T, g);
   CT df = gout;
   ct_dropmask(df, key2, a.drop, (uint32_t)row0 + a.row_offset, c, g);
   const CT u = rows_to_ct(scr, u_rows, lane, c, g);
-  dw_accum<PREC>(dW2, df, u);
+  coop.product(dW2, df, u);
+  colsum_accum(db2, df);
   CT dt = gemm_w<PREC>(ct_to_a<PREC>(scr, df, c, g), W2t, c, g);
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
@@ -45,17 +64,10 @@ ADT_DEVICE_INLINE void ffn_bwd_tile(const BwdChainArgs& a, float* scr, const typ
     for (int r = 0; r < 4; ++r)
       if (!(u.v[nt][r] > 0.f)) dt.v[nt][r] = 0.f;
   ct_dropmask(dt, key1, a.drop, (uint32_t)row0 + a.row_offset, c, g);
-  dw_accum<PREC>(dW1, dt, xin);
+  coop.product(dW1, dt, xin);
+  colsum_accum(db1, dt);
   dxin = gemm_w<PREC>(ct_to_a<PREC>(scr, dt, c, g), W1t, c, g);
 }
-
-#define BWD_PROLOGUE(NWT_)                                                                         \
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];                         \
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;           \
-  BwdLds<PREC, NW, NWT_> lds(smem_raw, w);                                                         \
-  const int ntiles = (a.T + 15) / 16;                                                              \
-  const int tstride = gridDim.x * NW;                                                              \
-  int tile = blockIdx.x * NW + w;
 
 // ---- encoder: y = mask(h2 + FFN(h2)), h2 = LN2(h), h = Qn + o Wo^T + bo ------------------------------------
 // W0 = conv2, W1 = conv1, W2 = out_proj ; out0 = dh (gradient wrt h == wrt Qn residual), out1 = dO
@@ -68,40 +80,43 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_bwd(BwdChainArgs a) {
   __syncthreads();
   const uint32_t seedv = a.drop.thr ? *a.drop.seed : 0u;
   const uint32_t key1 = adt_site_key(seedv, a.site1), key2 = adt_site_key(seedv, a.site2);
-  WAcc dW2, dW1, dWo;
-  VAcc dgm, dbt;
-  wacc_zero(dW2); wacc_zero(dW1); wacc_zero(dWo); vacc_zero(dgm); vacc_zero(dbt);
+  f32x4 dW2[NOWN], dW1[NOWN], dWo[NOWN];
+  VAcc db2, db1, dbo, dgm, dbt;
+  acc_zero(dW2); acc_zero(dW1); acc_zero(dWo);
+  vacc_zero(db2); vacc_zero(db1); vacc_zero(dbo); vacc_zero(dgm); vacc_zero(dbt);
   RowRegs gy_rows = rows_load(a.gy, 64, tile * 16, a.T, lane);
-  RowRegs u_rows = rows_load(a.u, 64, tile * 16, a.T, lane);
   RowRegs h_rows = rows_load(a.xin, 64, tile * 16, a.T, lane);
-  RowRegs o_rows = rows_load(a.o, 64, tile * 16, a.T, lane);
-  for (; tile < ntiles; tile += tstride) {
-    const int row0 = tile * 16;
+  for (int rnd = 0; rnd < nrounds; ++rnd, tile += tstride) {
+    const int row0 = tile * 16;    // may lie beyond T: a phantom tile of zeros that only takes part in the barriers
+    const RowRegs u_cur = rows_load(a.u, 64, row0, a.T, lane);    // requested now, consumed later in the round
+    const RowRegs o_rows = rows_load(a.o, 64, row0, a.T, lane);
     const CT h = rows_to_ct(lds.scr, h_rows, lane, c, g);
+    const RowRegs gy_cur = gy_rows;
+    // the next round's first inputs are requested now and consumed one round later
+    const int nrow0 = (tile + tstride) * 16;
+    gy_rows = rows_load(a.gy, 64, nrow0, a.T, lane);
+    h_rows = rows_load(a.xin, 64, nrow0, a.T, lane);
     LnStat st;
     const CT xhat = ln_xhat(h, a.ln_eps, st);
     const CT h2 = ln_apply(xhat, a.gamma, a.beta, c);
     CT gm, dh2;
-    ffn_bwd_tile<PREC>(a, lds.scr, lds.w[0], lds.w[1], dW2, dW1, h2, gy_rows, u_rows, key1, key2, row0, lane, c, g, gm, dh2);
-    const CT o = rows_to_ct(lds.scr, o_rows, lane, c, g);
-    // the next tile's inputs are requested now and consumed one iteration later
-    const int nrow0 = (tile + tstride) * 16;
-    gy_rows = rows_load(a.gy, 64, nrow0, a.T, lane);
-    u_rows = rows_load(a.u, 64, nrow0, a.T, lane);
-    h_rows = rows_load(a.xin, 64, nrow0, a.T, lane);
-    o_rows = rows_load(a.o, 64, nrow0, a.T, lane);
+    ffn_bwd_tile<PREC, NW>(a, lds.scr, coop, lds.w[0], lds.w[1], dW2, dW1, db2, db1, h2, gy_cur, u_cur, key1, key2, row0, lane, c, g,
+                           gm, dh2);
     ct_add(dh2, gm);
     const CT dh = ln_bwd_ct(dh2, xhat, st, a.gamma, dgm, dbt, c, g);
     store_ct(lds.scr, a.out0, 64, dh, row0, a.T, lane, c, g);
-    dw_accum<PREC>(dWo, dh, o);
+    const CT o = rows_to_ct(lds.scr, o_rows, lane, c, g);
+    coop.product(dWo, dh, o);
+    colsum_accum(dbo, dh);
     const CT dO = gemm_w<PREC>(ct_to_a<PREC>(lds.scr, dh, c, g), lds.w[2], c, g);
     store_ct(lds.scr, a.out1, 64, dO, row0, a.T, lane, c, g);
   }
-  wacc_flush<NW>(dW2, lds.red, a.dW0, a.db0, w, c, g);
-  wacc_flush<NW>(dW1, lds.red, a.dW1, a.db1, w, c, g);
-  wacc_flush<NW>(dWo, lds.red, a.dW2, a.db2, w, c, g);
-  vacc_flush(dgm, a.dgamma, c, g);
-  vacc_flush(dbt, a.dbeta, c, g);
+  coop.flush(dW2, a.dW0, c, g); coop.flush(dW1, a.dW1, c, g); coop.flush(dWo, a.dW2, c, g);
+  {
+    const VAcc* const accs[5] = {&db2, &db1, &dbo, &dgm, &dbt};
+    float* const dst[5] = {a.db0, a.db1, a.db2, a.dgamma, a.dbeta};
+    vacc_flush_wg<NW, 5>(accs, dst, reinterpret_cast<float*>(lds.coop), w, c, g);
+  }
 }
 
 // ---- decoder: y = mask(Dn + a2 + FFN(a2)), a2 = o2 Wo2^T + b --------------------------------------------------
@@ -115,31 +130,39 @@ __global__ __launch_bounds__(NW * 64) void k_dec_post_bwd(BwdChainArgs a) {
   __syncthreads();
   const uint32_t seedv = a.drop.thr ? *a.drop.seed : 0u;
   const uint32_t key1 = adt_site_key(seedv, a.site1), key2 = adt_site_key(seedv, a.site2);
-  WAcc dW2, dW1, dWo;
-  wacc_zero(dW2); wacc_zero(dW1); wacc_zero(dWo);
+  f32x4 dW2[NOWN], dW1[NOWN], dWo[NOWN];
+  VAcc db2, db1, dbo;
+  acc_zero(dW2); acc_zero(dW1); acc_zero(dWo);
+  vacc_zero(db2); vacc_zero(db1); vacc_zero(dbo);
   RowRegs gy_rows = rows_load(a.gy, 64, tile * 16, a.T, lane);
   RowRegs u_rows = rows_load(a.u, 64, tile * 16, a.T, lane);
   RowRegs a2_rows = rows_load(a.xin, 64, tile * 16, a.T, lane);
   RowRegs o_rows = rows_load(a.o, 64, tile * 16, a.T, lane);
-  for (; tile < ntiles; tile += tstride) {
+  for (int rnd = 0; rnd < nrounds; ++rnd, tile += tstride) {
     const int row0 = tile * 16;
     const CT a2 = rows_to_ct(lds.scr, a2_rows, lane, c, g);
-    CT gm, da2;
-    ffn_bwd_tile<PREC>(a, lds.scr, lds.w[0], lds.w[1], dW2, dW1, a2, gy_rows, u_rows, key1, key2, row0, lane, c, g, gm, da2);
     const CT o = rows_to_ct(lds.scr, o_rows, lane, c, g);
+    const RowRegs gy_cur = gy_rows, u_cur = u_rows;
     const int nrow0 = (tile + tstride) * 16;
     gy_rows = rows_load(a.gy, 64, nrow0, a.T, lane);
     u_rows = rows_load(a.u, 64, nrow0, a.T, lane);
     a2_rows = rows_load(a.xin, 64, nrow0, a.T, lane);
     o_rows = rows_load(a.o, 64, nrow0, a.T, lane);
+    CT gm, da2;
+    ffn_bwd_tile<PREC, NW>(a, lds.scr, coop, lds.w[0], lds.w[1], dW2, dW1, db2, db1, a2, gy_cur, u_cur, key1, key2, row0, lane, c, g,
+                           gm, da2);
     ct_add(da2, gm);
-    dw_accum<PREC>(dWo, da2, o);
+    coop.product(dWo, da2, o);
+    colsum_accum(dbo, da2);
     const CT dO = gemm_w<PREC>(ct_to_a<PREC>(lds.scr, da2, c, g), lds.w[2], c, g);
     store_ct(lds.scr, a.out0, 64, dO, row0, a.T, lane, c, g);
   }
-  wacc_flush<NW>(dW2, lds.red, a.dW0, a.db0, w, c, g);
-  wacc_flush<NW>(dW1, lds.red, a.dW1, a.db1, w, c, g);
-  wacc_flush<NW>(dWo, lds.red, a.dW2, a.db2, w, c, g);
+  coop.flush(dW2, a.dW0, c, g); coop.flush(dW1, a.dW1, c, g); coop.flush(dWo, a.dW2, c, g);
+  {
+    const VAcc* const accs[3] = {&db2, &db1, &dbo};
+    float* const dst[3] = {a.db0, a.db1, a.db2};
+    vacc_flush_wg<NW, 3>(accs, dst, reinterpret_cast<float*>(lds.coop), w, c, g);
+  }
 }
 
 // ---- LayerNorm + packed in-projection reverse (encoder: q from LN(x), k/v from x; decoder: all from LN(x)) ----
@@ -152,40 +175,52 @@ __global__ __launch_bounds__(NW * 64) void k_pre_bwd(BwdChainArgs a) {
   stage_wimg<PREC, NW * 64>(lds.w[1], a.W1, true);
   stage_wimg<PREC, NW * 64>(lds.w[2], a.W2, true);
   __syncthreads();
-  WAcc dWq, dWk, dWv;
-  VAcc dgm, dbt;
-  wacc_zero(dWq); wacc_zero(dWk); wacc_zero(dWv); vacc_zero(dgm); vacc_zero(dbt);
+  f32x4 dWq[NOWN], dWk[NOWN], dWv[NOWN];
+  VAcc dbq, dbk, dbv, dgm, dbt;
+  acc_zero(dWq); acc_zero(dWk); acc_zero(dWv);
+  vacc_zero(dbq); vacc_zero(dbk); vacc_zero(dbv); vacc_zero(dgm); vacc_zero(dbt);
   const float* rsrc = ENC ? a.dh : a.gy;
   RowRegs dq_rows = rows_load(a.dqkv, a.lddqkv, tile * 16, a.T, lane);
-  RowRegs dk_rows = rows_load(a.dqkv + 64, a.lddqkv, tile * 16, a.T, lane);
-  RowRegs dv_rows = rows_load(a.dqkv + 128, a.lddqkv, tile * 16, a.T, lane);
   RowRegs x_rows = rows_load(a.xin, 64, tile * 16, a.T, lane);
-  for (; tile < ntiles; tile += tstride) {
+  for (int rnd = 0; rnd < nrounds; ++rnd, tile += tstride) {
     const int row0 = tile * 16;
-    // requested at the top of the iteration, consumed at its end (not carried across iterations: registers)
+    // requested at the top of the round, consumed later in it (not carried across rounds: register budget)
+    const RowRegs dk_rows = rows_load(a.dqkv + 64, a.lddqkv, row0, a.T, lane);
+    const RowRegs dv_rows = rows_load(a.dqkv + 128, a.lddqkv, row0, a.T, lane);
     const RowRegs r_rows = rows_load(rsrc, 64, row0, a.T, lane);
     const CT x = rows_to_ct(lds.scr, x_rows, lane, c, g);
     LnStat st;
     const CT xhat = ln_xhat(x, a.ln_eps, st);
     const CT xn = ln_apply(xhat, a.gamma, a.beta, c);
-    const CT dq = rows_to_ct(lds.scr, dq_rows, lane, c, g);
-    const AFrags<PREC> aq = scr_to_a<PREC>(lds.scr, c, g);
-    dw_accum<PREC>(dWq, dq, xn);
-    CT dn = gemm_w<PREC>(aq, lds.w[0], c, g);          // gradient wrt the LN output
-    const CT dk = rows_to_ct(lds.scr, dk_rows, lane, c, g);
-    const AFrags<PREC> ak = scr_to_a<PREC>(lds.scr, c, g);
-    dw_accum<PREC>(dWk, dk, ENC ? x : xn);
-    CT dkv = gemm_w<PREC>(ak, lds.w[1], c, g);
-    const CT dv = rows_to_ct(lds.scr, dv_rows, lane, c, g);
-    const AFrags<PREC> av = scr_to_a<PREC>(lds.scr, c, g);
-    dw_accum<PREC>(dWv, dv, ENC ? x : xn);
-    ct_add(dkv, gemm_w<PREC>(av, lds.w[2], c, g));
+    CT dn;
+    {
+      const CT dq = rows_to_ct(lds.scr, dq_rows, lane, c, g);
+      const AFrags<PREC> aq = scr_to_a<PREC>(lds.scr, c, g);
+      const int nrow0 = (tile + tstride) * 16;
+      dq_rows = rows_load(a.dqkv, a.lddqkv, nrow0, a.T, lane);
+      x_rows = rows_load(a.xin, 64, nrow0, a.T, lane);
+      coop.product(dWq, dq, xn);
+      colsum_accum(dbq, dq);
+      dn = gemm_w<PREC>(aq, lds.w[0], c, g);          // gradient wrt the LN output
+    }
+    CT dkv;
+    {
+      const CT dk = rows_to_ct(lds.scr, dk_rows, lane, c, g);
+      const AFrags<PREC> ak = scr_to_a<PREC>(lds.scr, c, g);
+      coop.product(dWk, dk, ENC ? x : xn);
+      colsum_accum(dbk, dk);
+      dkv = gemm_w<PREC>(ak, lds.w[1], c, g);
+    }
+    {
+      const CT dv = rows_to_ct(lds.scr, dv_rows, lane, c, g);
+      const AFrags<PREC> av = scr_to_a<PREC>(lds.scr, c, g);
+      coop.product(dWv, dv, ENC ? x : xn);
+      colsum_accum(dbv, dv);
+      ct_add(dkv, gemm_w<PREC>(av, lds.w[2], c, g));
+    }
+    RowRegs acc_rows;
+    if (a.acc0) acc_rows = rows_load(a.out0, 64, row0, a.T, lane);
     CT res = rows_to_ct(lds.scr, r_rows, lane, c, g);
-    const int nrow0 = (tile + tstride) * 16;
-    dq_rows = rows_load(a.dqkv, a.lddqkv, nrow0, a.T, lane);
-    dk_rows = rows_load(a.dqkv + 64, a.lddqkv, nrow0, a.T, lane);
-    dv_rows = rows_load(a.dqkv + 128, a.lddqkv, nrow0, a.T, lane);
-    x_rows = rows_load(a.xin, 64, nrow0, a.T, lane);
     if (!ENC) ct_mask_rows(res, a.ids, row0, a.T, g);
     ct_add(dn, res);
     CT dx;
@@ -196,13 +231,15 @@ __global__ __launch_bounds__(NW * 64) void k_pre_bwd(BwdChainArgs a) {
       ct_add(dn, dkv);
       dx = ln_bwd_ct(dn, xhat, st, a.gamma, dgm, dbt, c, g);
     }
-    store_ct(lds.scr, a.out0, 64, dx, row0, a.T, lane, c, g, a.acc0 != 0);
+    if (a.acc0) ct_add(dx, rows_to_ct(lds.scr, acc_rows, lane, c, g));
+    store_ct(lds.scr, a.out0, 64, dx, row0, a.T, lane, c, g);
   }
-  wacc_flush<NW>(dWq, lds.red, a.dW0, a.db0, w, c, g);
-  wacc_flush<NW>(dWk, lds.red, a.dW1, a.db1, w, c, g);
-  wacc_flush<NW>(dWv, lds.red, a.dW2, a.db2, w, c, g);
-  vacc_flush(dgm, a.dgamma, c, g);
-  vacc_flush(dbt, a.dbeta, c, g);
+  coop.flush(dWq, a.dW0, c, g); coop.flush(dWk, a.dW1, c, g); coop.flush(dWv, a.dW2, c, g);
+  {
+    const VAcc* const accs[5] = {&dbq, &dbk, &dbv, &dgm, &dbt};
+    float* const dst[5] = {a.db0, a.db1, a.db2, a.dgamma, a.dbeta};
+    vacc_flush_wg<NW, 5>(accs, dst, reinterpret_cast<float*>(lds.coop), w, c, g);
+  }
 }
 
 // ---- decoder middle, part 1: q2 = a1 Wq^T + b, a1 = o1 Wo1^T + b --------------------------------------------------
@@ -213,12 +250,13 @@ __global__ __launch_bounds__(NW * 64) void k_dec_mid_bwd(BwdChainArgs a) {
   stage_wimg<PREC, NW * 64>(lds.w[0], a.W0, true);
   stage_wimg<PREC, NW * 64>(lds.w[1], a.W1, true);
   __syncthreads();
-  WAcc dWq, dWo;
-  wacc_zero(dWq); wacc_zero(dWo);
+  f32x4 dWq[NOWN], dWo[NOWN];
+  VAcc dbq, dbo;
+  acc_zero(dWq); acc_zero(dWo); vacc_zero(dbq); vacc_zero(dbo);
   RowRegs dq_rows = rows_load(a.dqkv, a.lddqkv, tile * 16, a.T, lane);
   RowRegs a1_rows = rows_load(a.xin, 64, tile * 16, a.T, lane);
   RowRegs o1_rows = rows_load(a.o, 64, tile * 16, a.T, lane);
-  for (; tile < ntiles; tile += tstride) {
+  for (int rnd = 0; rnd < nrounds; ++rnd, tile += tstride) {
     const int row0 = tile * 16;
     const CT a1 = rows_to_ct(lds.scr, a1_rows, lane, c, g);
     const CT dq = rows_to_ct(lds.scr, dq_rows, lane, c, g);
@@ -228,14 +266,20 @@ __global__ __launch_bounds__(NW * 64) void k_dec_mid_bwd(BwdChainArgs a) {
     dq_rows = rows_load(a.dqkv, a.lddqkv, nrow0, a.T, lane);
     a1_rows = rows_load(a.xin, 64, nrow0, a.T, lane);
     o1_rows = rows_load(a.o, 64, nrow0, a.T, lane);
-    dw_accum<PREC>(dWq, dq, a1);
+    coop.product(dWq, dq, a1);
+    colsum_accum(dbq, dq);
     const CT da1 = gemm_w<PREC>(aq, lds.w[0], c, g);
-    dw_accum<PREC>(dWo, da1, o1);
+    coop.product(dWo, da1, o1);
+    colsum_accum(dbo, da1);
     const CT dO1 = gemm_w<PREC>(ct_to_a<PREC>(lds.scr, da1, c, g), lds.w[1], c, g);
     store_ct(lds.scr, a.out0, 64, dO1, row0, a.T, lane, c, g);
   }
-  wacc_flush<NW>(dWq, lds.red, a.dW0, a.db0, w, c, g);
-  wacc_flush<NW>(dWo, lds.red, a.dW1, a.db1, w, c, g);
+  coop.flush(dWq, a.dW0, c, g); coop.flush(dWo, a.dW1, c, g);
+  {
+    const VAcc* const accs[2] = {&dbq, &dbo};
+    float* const dst[2] = {a.db0, a.db1};
+    vacc_flush_wg<NW, 2>(accs, dst, reinterpret_cast<float*>(lds.coop), w, c, g);
+  }
 }
 
 // ---- decoder middle, part 2: [k2, v2] = f Wkv^T + b --------------------------------------------------------------
@@ -246,30 +290,40 @@ __global__ __launch_bounds__(NW * 64) void k_kv_bwd(BwdChainArgs a) {
   stage_wimg<PREC, NW * 64>(lds.w[0], a.W0, true);
   stage_wimg<PREC, NW * 64>(lds.w[1], a.W1, true);
   __syncthreads();
-  WAcc dWk, dWv;
-  wacc_zero(dWk); wacc_zero(dWv);
+  f32x4 dWk[NOWN], dWv[NOWN];
+  VAcc dbk, dbv;
+  acc_zero(dWk); acc_zero(dWv); vacc_zero(dbk); vacc_zero(dbv);
   RowRegs dk_rows = rows_load(a.dkv2, 128, tile * 16, a.T, lane);
   RowRegs dv_rows = rows_load(a.dkv2 + 64, 128, tile * 16, a.T, lane);
   RowRegs f_rows = rows_load(a.f, 64, tile * 16, a.T, lane);
-  for (; tile < ntiles; tile += tstride) {
+  RowRegs acc_rows = rows_load(a.out0, 64, tile * 16, a.T, lane);
+  for (int rnd = 0; rnd < nrounds; ++rnd, tile += tstride) {
     const int row0 = tile * 16;
     const CT f = rows_to_ct(lds.scr, f_rows, lane, c, g);
     const CT dk = rows_to_ct(lds.scr, dk_rows, lane, c, g);
     const AFrags<PREC> ak = scr_to_a<PREC>(lds.scr, c, g);
     const CT dv = rows_to_ct(lds.scr, dv_rows, lane, c, g);
     const AFrags<PREC> av = scr_to_a<PREC>(lds.scr, c, g);
+    CT df = rows_to_ct(lds.scr, acc_rows, lane, c, g);
     const int nrow0 = (tile + tstride) * 16;
     dk_rows = rows_load(a.dkv2, 128, nrow0, a.T, lane);
     dv_rows = rows_load(a.dkv2 + 64, 128, nrow0, a.T, lane);
     f_rows = rows_load(a.f, 64, nrow0, a.T, lane);
-    dw_accum<PREC>(dWk, dk, f);
-    dw_accum<PREC>(dWv, dv, f);
-    CT df = gemm_w<PREC>(ak, lds.w[0], c, g);
+    acc_rows = rows_load(a.out0, 64, nrow0, a.T, lane);
+    coop.product(dWk, dk, f);
+    colsum_accum(dbk, dk);
+    coop.product(dWv, dv, f);
+    colsum_accum(dbv, dv);
+    ct_add(df, gemm_w<PREC>(ak, lds.w[0], c, g));
     ct_add(df, gemm_w<PREC>(av, lds.w[1], c, g));
-    store_ct(lds.scr, a.out0, 64, df, row0, a.T, lane, c, g, true);
+    store_ct(lds.scr, a.out0, 64, df, row0, a.T, lane, c, g);
   }
-  wacc_flush<NW>(dWk, lds.red, a.dW0, a.db0, w, c, g);
-  wacc_flush<NW>(dWv, lds.red, a.dW1, a.db1, w, c, g);
+  coop.flush(dWk, a.dW0, c, g); coop.flush(dWv, a.dW1, c, g);
+  {
+    const VAcc* const accs[2] = {&dbk, &dbv};
+    float* const dst[2] = {a.db0, a.db1};
+    vacc_flush_wg<NW, 2>(accs, dst, reinterpret_cast<float*>(lds.coop), w, c, g);
+  }
 }
 
 }  // namespace adt

@@ -28,6 +28,7 @@ struct BwdChainArgs {
   float* dW0; float* dW1; float* dW2; float* dW3;
   float* db0; float* db1; float* db2; float* db3;
   float* dgamma; float* dbeta;
+  int ablate;                 // timing experiments only (ADT_BWD_ABLATE): 1 skip weight-gradient products, 2 skip flush
 };
 
 }  // namespace adt

@@ -138,6 +138,12 @@ static int launch_bwdchain_t(int which, const BwdChainArgs& a, hipStream_t s) {
   const int ntiles = (a.T + 15) / 16;
   int grid = (ntiles + NW - 1) / NW;
   if (grid > 256) grid = 256;
+  // whole rounds: every workgroup runs the same number of cooperative rounds; fewer, fuller rounds waste less
+  {
+    const int per = grid * NW;
+    const int rounds = (ntiles + per - 1) / per;
+    grid = (ntiles + rounds * NW - 1) / (rounds * NW);
+  }
   const void* fn = nullptr;
   size_t smem = 0;
   switch (which) {
@@ -157,6 +163,9 @@ static int launch_bwdchain_t(int which, const BwdChainArgs& a, hipStream_t s) {
     done[which] = true;
   }
   BwdChainArgs args = a;
+  static int ablate = -1;
+  if (ablate < 0) { const char* e = getenv("ADT_BWD_ABLATE"); ablate = e ? atoi(e) : 0; }
+  args.ablate = ablate;
   void* kargs[] = {&args};
   if (hipLaunchKernel(fn, dim3(grid), dim3(NW * 64), kargs, smem, s) != hipSuccess) return adt_set_error("bwdchain %d: launch failed", which);
   return check_launch("bwdchain");
@@ -166,7 +175,9 @@ template <int PREC, int NW>
 static int launch_fwdchain_t(int which, const FwdChainArgs& a, hipStream_t s) {
   const int ntiles = (a.T + 15) / 16;
   int grid = (ntiles + NW - 1) / NW;
-  if (grid > 512) grid = 512;
+  static int cap = 0;
+  if (!cap) { const char* e = getenv("ADT_FWD_GRID"); cap = e ? atoi(e) : 512; if (cap < 1) cap = 512; }
+  if (grid > cap) grid = cap;
   const void* fn = nullptr;
   size_t smem = 0;
   switch (which) {
@@ -196,10 +207,10 @@ int adt_launch_fwdchain(int prec, int which, const FwdChainArgs& a, void* stream
 }
 
 int adt_launch_bwdchain(int prec, int which, const BwdChainArgs& a, void* stream) {
-  // one wave per SIMD (4 waves per workgroup, one workgroup per CU): each wave may use the whole 512-entry
-  // register file, which is what keeps three 64x64 weight-gradient accumulators resident
+  // cooperative weight gradients (adt_wave.cuh: Coop): 8 waves per workgroup in bf16 mode; the fp32-exact mode
+  // publishes fp32 register images (twice the LDS) and runs 4 waves per workgroup
   if (prec == ADT_PREC_F32) return launch_bwdchain_t<PREC_F32, 4>(which, a, (hipStream_t)stream);
-  return launch_bwdchain_t<PREC_BF16, 4>(which, a, (hipStream_t)stream);
+  return launch_bwdchain_t<PREC_BF16, 8>(which, a, (hipStream_t)stream);
 }
 
 extern "C" {
@@ -257,7 +268,7 @@ int adt_layernorm_bwd(const float* dY, int lddy, const float* X, int ldx, const 
   LnArgs a{};
   a.X = X; a.ldx = ldx; a.gamma = gamma; a.eps = eps; a.T = T; a.dY = dY; a.lddy = lddy; a.dX = dX; a.lddx = lddx;
   a.acc = accumulate; a.dgamma = dgamma; a.dbeta = dbeta;
-  const int grid = grid_for(T, 16, 512);
+  const int grid = grid_for(T, 16, 256);
   if (d == 64) hipLaunchKernelGGL(k_ln_bwd<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   else if (d == 128) hipLaunchKernelGGL(k_ln_bwd<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   else if (d == 256) hipLaunchKernelGGL(k_ln_bwd<256>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
@@ -343,7 +354,7 @@ int adt_headcls_bwd(const float* O, int ldo, const float* Ws, const float* rec, 
   a.O = O; a.ldo = ldo; a.Ws = Ws; a.B = B; a.L = L; a.H = H; a.hd = hd; a.rec = const_cast<float*>(rec);
   a.drec = drec; a.dO = dO; a.lddo = lddo; a.dWs = dWs; a.dbs = dbs;
   const size_t smem = (size_t)(H * hd + H) * sizeof(float);
-  hipLaunchKernelGGL(k_headcls_bwd, dim3(grid_for((size_t)B * L, 4, 512)), dim3(256), smem, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_headcls_bwd, dim3(grid_for((size_t)B * L, 4, 256)), dim3(256), smem, (hipStream_t)stream, a);
   return check_launch("headcls_bwd");
 }
 
@@ -400,8 +411,8 @@ int adt_clip_adam(float* P, float* G, float* M, float* V, int64_t n, int64_t nE,
   a.P = P; a.G = G; a.M = M; a.Vv = V; a.n = (size_t)n; a.nE = (size_t)nE; a.wd = wd; a.clip = clip; a.lr = lr;
   a.b1 = b1; a.b2 = b2; a.eps = eps; a.scal = scal; a.grad_scale = grad_scale;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(scal, 0, 2 * sizeof(float), s) != hipSuccess) return adt_set_error("clip_adam: memset");
-  if (wd != 0.f && nE > 0) hipLaunchKernelGGL(k_sumsq, dim3(grid_for((size_t)nE, 256, 256)), dim3(256), 0, s, (const float*)P, (size_t)nE, scal);
+  if (hipMemsetAsync(scal + 64, 0, 128 * sizeof(float), s) != hipSuccess) return adt_set_error("clip_adam: memset");
+  if (wd != 0.f && nE > 0) hipLaunchKernelGGL(k_sumsq, dim3(grid_for((size_t)nE, 256, 256)), dim3(256), 0, s, (const float*)P, (size_t)nE, scal + 64);
   hipLaunchKernelGGL(k_wd_gradnorm, dim3(grid_for((size_t)n, 256, 512)), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_adam, dim3(grid_for((size_t)n, 256, 1024)), dim3(256), 0, s, a);
   return check_launch("clip_adam");

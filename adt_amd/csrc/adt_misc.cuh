@@ -291,7 +291,9 @@ __global__ __launch_bounds__(256) void k_bce(BceArgs a) {
   }
   const float sp = block_sum(lp, sbuf);
   const float sn = block_sum(ln, sbuf);
-  if (threadIdx.x == 0) { atomicAdd(a.loss + 0, sp * inv); atomicAdd(a.loss + 1, sn * inv); }
+  // 64 sub-slots per loss term: same-address float atomics serialise (~10 ns each), thousands of blocks would cost
+  // tens of microseconds on one address
+  if (threadIdx.x == 0) { atomicAdd(a.loss + (blockIdx.x & 63), sp * inv); atomicAdd(a.loss + 64 + (blockIdx.x & 63), sn * inv); }
 }
 
 // g = 2*lambda/n_mse * (A - Bm);  GA += g (or = g), GB = -g;  loss += sum (A-B)^2 / n_mse
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(256) void k_mse_seed(MseArgs a) {
     *reinterpret_cast<float4*>(a.GA + i) = g;
   }
   const float s = block_sum(acc, sbuf);
-  if (threadIdx.x == 0) atomicAdd(a.loss, s * inv);
+  if (threadIdx.x == 0) atomicAdd(a.loss + (blockIdx.x & 63), s * inv);
 }
 
 // drec[n][h][c] = -(lambda2 / n_nll) * [h == c];  loss += -sum_n,h rec[n][h][h] / n_nll
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(256) void k_nll_seed(NllArgs a) {
     a.drec[i] = diag ? -a.lambda2 * inv : 0.f;
   }
   const float s = block_sum(acc, sbuf);
-  if (threadIdx.x == 0) atomicAdd(a.loss, s * inv);
+  if (threadIdx.x == 0) atomicAdd(a.loss + (blockIdx.x & 63), s * inv);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -359,7 +361,8 @@ struct OptArgs {
   size_t n;          // number of trainable floats (flat prefix of the parameter buffer)
   size_t nE;         // item table size (flat offset 0)
   float wd, clip, lr, b1, b2, eps;
-  float* scal;       // device scalars: [0] ||E||^2  [1] ||g||^2  [2] step (float)  [3] wd loss term
+  float* scal;       // device scalars: [0] ||E||^2  [1] ||g||^2  [2] step (float)  [3] wd loss term ; [64..128) partial
+                     // sums of ||E||^2, [128..192) partial sums of ||g||^2 (64 sub-slots each: no same-address contention)
   float grad_scale;  // multiply grads first (1/world for averaged all-reduce; normally 1)
 };
 
@@ -368,12 +371,23 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* x, size_t n, float* 
   float acc = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += x[i] * x[i];
   const float s = block_sum(acc, sbuf);
-  if (threadIdx.x == 0) atomicAdd(out, s);
+  if (threadIdx.x == 0) atomicAdd(out + (blockIdx.x & 63), s);
+}
+
+ADT_DEVICE_INLINE float sum64(const float* part, float* sbuf) {
+  // every thread returns the sum of 64 partial slots
+  float v = threadIdx.x < 64 ? part[threadIdx.x] : 0.f;
+  v = wave_sum(v);
+  if (threadIdx.x == 0) sbuf[0] = v;
+  __syncthreads();
+  const float r = sbuf[0];
+  __syncthreads();
+  return r;
 }
 
 __global__ __launch_bounds__(256) void k_wd_gradnorm(OptArgs a) {
   __shared__ float sbuf[4];
-  const float nrm = sqrtf(a.scal[0]);
+  const float nrm = sqrtf(sum64(a.scal + 64, sbuf));
   const float coef = (a.wd != 0.f && nrm > 0.f) ? a.wd / nrm : 0.f;
   float acc = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
@@ -383,12 +397,15 @@ __global__ __launch_bounds__(256) void k_wd_gradnorm(OptArgs a) {
     acc += g * g;
   }
   const float s = block_sum(acc, sbuf);
-  if (threadIdx.x == 0) atomicAdd(a.scal + 1, s);
-  if (blockIdx.x == 0 && threadIdx.x == 0) { a.scal[3] = a.wd * nrm; a.scal[2] += 1.0f; }
+  if (threadIdx.x == 0) atomicAdd(a.scal + 128 + (blockIdx.x & 63), s);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { a.scal[0] = nrm * nrm; a.scal[3] = a.wd * nrm; a.scal[2] += 1.0f; }
 }
 
 __global__ __launch_bounds__(256) void k_adam(OptArgs a) {
-  const float tn = sqrtf(a.scal[1]);
+  __shared__ float sbuf[4];
+  const float gn2 = sum64(a.scal + 128, sbuf);
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.scal[1] = gn2;
+  const float tn = sqrtf(gn2);
   const float coef = fminf(1.0f, a.clip / (tn + 1e-6f));
   const float t = a.scal[2];
   const float bc1 = 1.0f - powf(a.b1, t), bc2 = 1.0f - powf(a.b2, t);

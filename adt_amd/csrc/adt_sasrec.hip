@@ -89,7 +89,7 @@ void make_ws(const adt_sasrec_cfg* c, int B, WS* w) {
   w->g_enc_x = take((w->nl + 1) * Td); w->g_dec_x = take((w->nl + 1) * Td); w->g_f = take(Td);
   w->g_pos = take(T1); w->g_neg = take(T1); w->g_rec = take(rec * w->nl);
   w->s1 = take(Td); w->s2 = take(Td); w->s3 = take(3 * Td); w->s4 = take(2 * Td); w->s5 = take(Td);
-  w->loss = take(64); w->norms = take(64); w->scal = take(64);
+  w->loss = take(64 * (2 + 2 * 16)); w->norms = take(64); w->scal = take(192);
   w->total = o;
 }
 
@@ -316,14 +316,14 @@ int adt_sasrec_loss_seed(const adt_sasrec_cfg* c, float* ws, const int32_t* pos,
   const int64_t Td = up64(w.T * w.d), rec = up64(w.T * w.H * w.H);
   float* loss = ws + w.loss;
   const float* norms = ws + w.norms;
-  if (hipMemsetAsync(loss, 0, 64 * sizeof(float), (hipStream_t)st) != hipSuccess) return adt_set_error("loss memset");
+  if (hipMemsetAsync(loss, 0, 64 * (2 + 2 * nl) * sizeof(float), (hipStream_t)st) != hipSuccess) return adt_set_error("loss memset");
   CK(adt_bce_seed(ws + w.posl, ws + w.negl, pos, T, norms, ws + w.g_pos, ws + w.g_neg, loss, st));
   for (int i = 0; i < nl; ++i)   // enc_in[i] pairs with dec_out_rev[i] = DEC_X[nl - i]      (sasrec/main.py:155-158)
     CK(adt_mse_seed(ws + w.enc_x + i * Td, ws + w.dec_x + (nl - i) * Td, w.T * w.d, lambdas1[i], norms, ws + w.g_enc_x + i * Td, 0,
-                    ws + w.g_dec_x + (nl - i) * Td, loss + 2 + i, st));
+                    ws + w.g_dec_x + (nl - i) * Td, loss + 64 * (2 + i), st));
   if (H > 1)
     for (int l = 0; l < nl; ++l)   // stale loop index: lambdas2[nl-1] for every layer          (sasrec/main.py:169)
-      CK(adt_nll_seed(ws + l * w.e_stride + w.e_rec, T, H, lambdas2[nl - 1], norms, ws + w.g_rec + l * rec, loss + 2 + nl + l, st));
+      CK(adt_nll_seed(ws + l * w.e_stride + w.e_rec, T, H, lambdas2[nl - 1], norms, ws + w.g_rec + l * rec, loss + 64 * (2 + nl + l), st));
   return 0;
 }
 

@@ -197,6 +197,13 @@ ADT_DEVICE_INLINE AFrags<PREC> ct_to_a(float* scr, const CT& t, int c, int g) {
 // out[16 x 64] = A[16 x 64] * img^T  (img rows = output columns)
 template <int PREC>
 ADT_DEVICE_INLINE CT gemm_w(const AFrags<PREC>& a, const typename WImg<PREC>::T* img, int c, int g) {
+  // The image is loop-invariant, so the compiler would hoist all 8 fragments per weight (32 VGPRs each) out of the
+  // tile loop and spill; re-reading them from LDS per tile is far cheaper than the lost occupancy.  Only the OFFSET
+  // is made opaque: an opaque pointer loses its LDS address space and turns the reads into flat loads, whose
+  // vmcnt(0) waits would also drain every prefetch in flight.
+  int opaque_zero = 0;
+  asm volatile("" : "+v"(opaque_zero));
+  img += opaque_zero;
   CT o;
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
@@ -245,7 +252,99 @@ ADT_DEVICE_INLINE void dw_accum(WAcc& acc, const CT& dy, const CT& x) {
   }
 }
 
-// per-lane partial column sums (LayerNorm dgamma / dbeta)
+
+// ---- cooperative weight gradients -------------------------------------------------------------------------
+// dW = dY^T X contracts over ALL rows.  Each wave publishes the C-layout registers of its 16-row dY and X tiles
+// to an LDS exchange area ("register image": [nt][lane][r], so the consumer lane reads the SAME lane index with
+// one 8/16-byte load), the workgroup synchronises once, and every wave then accumulates only ITS output tiles
+// (16 tiles of 16x16 per 64x64 weight, dealt round-robin over the NW waves) over the NW published row tiles with
+// full K=32 MFMAs: slots j<4 of a k-step are rows 4g+j of tile 2s, slots j>=4 rows 4g+j-4 of tile 2s+1
+// (accumulator-as-operand identity).  Accumulators are 4 registers per owned tile instead of 64 per weight, so the
+// chain keeps a high wave count.  Two exchange areas alternate => ONE barrier per product.
+template <int PREC, int NW>
+struct Coop {
+  typedef typename WImg<PREC>::T XT;
+  static constexpr int TILE = 4 * 64 * 4;                 // elements per published CT
+  static constexpr int AREA = NW * 2 * TILE;              // elements per exchange area (dY and X of every wave)
+  static constexpr int NOWN = (16 + NW - 1) / NW;         // output tiles owned by a wave
+  static constexpr size_t bytes = 2 * (size_t)AREA * sizeof(XT);
+  XT* base;
+  int w, lane;
+  int parity;
+  int skip;
+  __device__ Coop(void* p, int wave, int lane_, int skip_ = 0) : base(reinterpret_cast<XT*>(p)), w(wave), lane(lane_), parity(0), skip(skip_) {}
+
+  ADT_DEVICE_INLINE void put(XT* dst, const CT& t) const {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      XT* q = dst + (nt * 64 + lane) * 4;
+      if constexpr (PREC == PREC_BF16) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (__bf16)t.v[nt][r];
+        *reinterpret_cast<bf16x4*>(q) = v;
+      } else {
+        *reinterpret_cast<f32x4*>(q) = t.v[nt];
+      }
+    }
+  }
+
+  ADT_DEVICE_INLINE OpFrag<PREC> frag(const XT* area, int which, int s, int tile_idx) const {
+    // k-step s: tiles 2s and 2s+1 of the published set, sub-tile (nt or kt) = tile_idx
+    const XT* p0 = area + ((2 * s) * 2 + which) * TILE + (tile_idx * 64 + lane) * 4;
+    const XT* p1 = area + ((2 * s + 1) * 2 + which) * TILE + (tile_idx * 64 + lane) * 4;
+    OpFrag<PREC> o;
+    if constexpr (PREC == PREC_BF16) {
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      const bf16x4 a = *reinterpret_cast<const bf16x4*>(p0);
+      const bf16x4 b = *reinterpret_cast<const bf16x4*>(p1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o.f[j] = a[j]; o.f[4 + j] = b[j]; }
+    } else {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p0);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(p1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o.f.v[j] = a[j]; o.f.v[4 + j] = b[j]; }
+    }
+    return o;
+  }
+
+  // acc[i] (i < NOWN) accumulates output tile id = w + i*NW  (nt = id >> 2, kt = id & 3).  ALL waves must call.
+  ADT_DEVICE_INLINE void product(f32x4 (&acc)[NOWN], const CT& dy, const CT& x) {
+    if (skip & 1) return;
+    XT* area = base + parity * AREA;
+    parity ^= 1;
+    put(area + (w * 2 + 0) * TILE, dy);
+    put(area + (w * 2 + 1) * TILE, x);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i) {
+      const int id = w + i * NW;
+      if (id < 16) {
+        const int nt = id >> 2, kt = id & 3;
+#pragma unroll
+        for (int s = 0; s < NW / 2; ++s) acc[i] = mma_op<PREC>(acc[i], frag(area, 0, s, nt), frag(area, 1, s, kt));
+      }
+    }
+  }
+
+  // add the owned tiles of one finished weight gradient to global memory (row-major 64 x 64)
+  ADT_DEVICE_INLINE void flush(const f32x4 (&acc)[NOWN], float* gW, int c, int g) const {
+    if (skip & 2) return;
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i) {
+      const int id = w + i * NW;
+      if (id < 16) {
+        const int nt = id >> 2, kt = id & 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(gW + (16 * nt + 4 * g + r) * 64 + 16 * kt + c, acc[i][r]);
+      }
+    }
+  }
+};
+
+// per-lane partial column sums (bias / LayerNorm dgamma / dbeta gradients); reduced at kernel end
 struct VAcc { float v[4]; };
 ADT_DEVICE_INLINE void vacc_zero(VAcc& a) { a.v[0] = a.v[1] = a.v[2] = a.v[3] = 0.f; }
 ADT_DEVICE_INLINE void colsum_accum(VAcc& a, const CT& t) {
@@ -286,13 +385,29 @@ ADT_DEVICE_INLINE void wacc_flush(const WAcc& acc, float* red, float* gW, float*
   }
 }
 
-ADT_DEVICE_INLINE void vacc_flush(const VAcc& a, float* gv, int c, int g) {
+// Reduce up to NV per-lane column-sum accumulators over the whole workgroup and add them to global memory with ONE
+// float atomic per column per workgroup.  (Every wave flushing on its own means thousands of serialised atomics on
+// the same 64 addresses -- tens of microseconds.)  red: LDS, NV * NW * 64 floats, free at this point; all threads call.
+template <int NW, int NV>
+ADT_DEVICE_INLINE void vacc_flush_wg(const VAcc* const (&accs)[NV], float* const (&dst)[NV], float* red, int w, int c, int g) {
+  __syncthreads();
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    float s = a.v[nt];
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    if (g == 0) atomicAdd(gv + 16 * nt + c, s);
+  for (int v = 0; v < NV; ++v) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      float s = accs[v]->v[nt];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (g == 0) red[(v * NW + w) * 64 + 16 * nt + c] = s;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NV * 64; i += NW * 64) {
+    const int v = i >> 6, col = i & 63;
+    float s = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) s += red[(v * NW + ww) * 64 + col];
+    if (dst[v]) atomicAdd(dst[v] + col, s);
   }
 }
 

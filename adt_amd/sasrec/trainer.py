@@ -31,7 +31,7 @@ class FusedTrainer:
         dev = model.dev
         self.m = torch.zeros_like(model.flat)
         self.v = torch.zeros_like(model.flat)
-        self.scal = torch.zeros(4, device=dev, dtype=torch.float32)
+        self.scal = torch.zeros(192, device=dev, dtype=torch.float32)   # adt_clip_adam scalars + partial-sum slots
         self.base_seed = seed
         self.nstep = 0
         self._B = -1
@@ -145,7 +145,8 @@ class FusedTrainer:
     def loss(self):
         """Device scalar: the loss of the last step as the reference prints it (sasrec/main.py:174)."""
         m = self.model
-        slots = m.ws_view(self._B, WS_LOSS, 0, 2 + 2 * m.num_layers)
+        n = 2 + 2 * m.num_layers
+        slots = m.ws_view(self._B, WS_LOSS, 0, 64 * n).view(n, 64).sum(1)   # 64 sub-slots per loss term
         return (slots * self._loss_w).sum() + self.scal[3]
 
     def grad_norm(self):

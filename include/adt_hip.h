@@ -88,7 +88,8 @@ int adt_logits_bwd(const float* F, int ldf, const float* E, const int32_t* pos, 
                    void* stream);
 
 /* ---- loss seeds: sasrec/main.py:151-153 (BCE), :155-158 (MSE), :160-169 (NLL).  norms = device
- * {n_bce, n_mse, n_nll} (global normalisers); loss slots are accumulated. */
+ * {n_bce, n_mse, n_nll} (global normalisers).  Every loss term is accumulated over 64 consecutive floats (sub-slots,
+ * to avoid same-address atomic contention): bce: loss2[0..64) = pos term, [64..128) = neg term; the reader sums. */
 int adt_bce_seed(const float* pos_logits, const float* neg_logits, const int32_t* pos, int T, const float* norms,
                  float* dpos, float* dneg, float* loss2, void* stream);
 int adt_mse_seed(const float* A, const float* Bm, int64_t n, float lambda, const float* norms, float* GA,
@@ -97,8 +98,8 @@ int adt_nll_seed(const float* rec, int n_rows, int H, float lambda2, const float
                  float* loss1, void* stream);
 
 /* ---- sasrec/main.py:170-173: grad += wd * E/||E||_F on the item table (flat offset 0, nE floats),
- * clip_grad_norm_(clip), Adam(lr, (b1, b2), eps).  scal = 4 device floats {||E||^2, ||g||^2, step, wd*||E||};
- * [0],[1] are zeroed inside, [2] is incremented. */
+ * clip_grad_norm_(clip), Adam(lr, (b1, b2), eps).  scal = 192 device floats: [0] ||E||^2, [1] ||g||^2, [2] step
+ * (incremented), [3] wd*||E||, [64..192) partial-sum slots zeroed inside. */
 int adt_clip_adam(float* P, float* G, float* M, float* V, int64_t n, int64_t nE, float wd, float clip, float lr,
                   float b1, float b2, float eps, float grad_scale, float* scal, void* stream);
 
@@ -137,9 +138,9 @@ int64_t adt_sasrec_workspace_floats(const adt_sasrec_cfg* cfg, int B);
 #define ADT_WS_G_REC 8
 #define ADT_WS_G_POS 9
 #define ADT_WS_G_NEG 10
-#define ADT_WS_LOSS 11      /* 2 + 2*num_layers floats: bce_pos, bce_neg, mse_i.., nll_l..                    */
+#define ADT_WS_LOSS 11      /* (2 + 2*num_layers) x 64 floats: bce_pos, bce_neg, mse_i.., nll_l.. (64 sub-slots each) */
 #define ADT_WS_NORMS 12     /* 3 floats: n_bce, n_mse, n_nll                                                   */
-#define ADT_WS_SCAL 13      /* 4 floats for adt_clip_adam                                                      */
+#define ADT_WS_SCAL 13      /* 192 floats for adt_clip_adam                                                    */
 int64_t adt_sasrec_ws_offset(const adt_sasrec_cfg* cfg, int B, int what, int layer);
 
 /* SASRecADT.forward (sasrec/model.py:67-81).  ids are device int32 (B*L). training != 0 enables dropout. */

@@ -263,14 +263,14 @@ def test_logits_and_loss_seeds(ops):
     check(pl, wp, 1e-5, "pos logits")
     check(nl, wn, 1e-5, "neg logits")
     norms = np.array([float((pos != 0).sum()), float(T * d), float(T * H)], np.float32)
-    loss = torch.zeros(8, device=dev())
+    loss = torch.zeros(4 * 64, device=dev())   # 64 sub-slots per loss term
     dpos, dneg = ops.bce_seed(pl, nl, T_(pos), T_(norms), loss)
     mk = pos != 0
     sig = lambda t: 1 / (1 + np.exp(-t))
     check(dpos, (sig(wp) - 1) * mk / norms[0], 1e-5, "dpos")
     check(dneg, sig(wn) * mk / norms[0], 1e-5, "dneg")
     want_loss = [(so.softplus(-wp) * mk).sum() / norms[0], (so.softplus(wn) * mk).sum() / norms[0]]
-    check(loss[:2], np.array(want_loss, np.float32), 1e-5, "bce loss")
+    check(loss[:128].view(2, 64).sum(1), np.array(want_loss, np.float32), 1e-5, "bce loss")
     dE = torch.zeros(V + 1, d, device=dev())
     dF = ops.logits_bwd(T_(f), T_(E), T_(pos), T_(neg), dpos, dneg, dE)
     gp, gn = dpos.cpu().numpy(), dneg.cpu().numpy()
@@ -283,16 +283,16 @@ def test_logits_and_loss_seeds(ops):
     # mse / nll seeds
     a, b = r.randn(T, d).astype(np.float32), r.randn(T, d).astype(np.float32)
     GA, GB = T_(np.ones((T, d), np.float32)), torch.empty(T, d, device=dev())
-    ops.mse_seed(T_(a), T_(b), 0.3, T_(norms), GA, 1, GB, loss[2:3])
+    ops.mse_seed(T_(a), T_(b), 0.3, T_(norms), GA, 1, GB, loss[128:192])
     g = 2 * 0.3 / norms[1] * (a - b)
     check(GA, 1 + g, 1e-5, "mse GA")
     check(GB, -g, 1e-5, "mse GB")
-    check(loss[2:3], np.array([((a - b) ** 2).sum() / norms[1]], np.float32), 1e-5, "mse loss")
+    check(loss[128:192].sum().view(1), np.array([((a - b) ** 2).sum() / norms[1]], np.float32), 1e-5, "mse loss")
     rec = np.log(np.random.RandomState(9).dirichlet(np.ones(H), size=(T, H))).astype(np.float32)
     drec = torch.empty(T, H, H, device=dev())
-    ops.nll_seed(T_(rec), H, 0.7, T_(norms), drec, loss[3:4])
+    ops.nll_seed(T_(rec), H, 0.7, T_(norms), drec, loss[192:256])
     check(drec, np.broadcast_to(-0.7 / norms[2] * np.eye(H, dtype=np.float32), (T, H, H)), 1e-6, "nll drec")
-    check(loss[3:4], np.array([-(rec * np.eye(H)).sum() / norms[2]], np.float32), 1e-5, "nll loss")
+    check(loss[192:256].sum().view(1), np.array([-(rec * np.eye(H)).sum() / norms[2]], np.float32), 1e-5, "nll loss")
 
 
 def test_clip_adam_three_steps(ops):
@@ -303,7 +303,7 @@ def test_clip_adam_three_steps(ops):
     state = {}
     Pt = T_(P0.copy())
     M, V = torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
-    scal = torch.zeros(4, device=dev())
+    scal = torch.zeros(192, device=dev())
     wd = 1e-2
     for step in range(3):
         g = (r.randn(n) * (3.0 if step == 1 else 0.02)).astype(np.float32)   # step 1 clips, others do not
