@@ -251,6 +251,42 @@ int adt_embed_bwd(const int32_t* ids, const float* dX, int T, int L, int d, floa
   return check_launch("embed_bwd");
 }
 
+int adt_item_scatter(const int32_t* ids, const float* G, int ldg, const float* rowscale, int T, int d, float scale, float p,
+                     const uint32_t* seed, uint32_t site, uint32_t row_offset, float* rep, int nrep, int64_t rep_stride,
+                     void* stream) {
+  ScatterArgs sc{};
+  sc.ids = ids; sc.G = G; sc.ldg = ldg; sc.rowscale = rowscale; sc.T = T; sc.d = d; sc.scale = scale;
+  sc.drop = adt_make_drop(p, seed, site); sc.row_offset = row_offset; sc.dE = rep; sc.nrep = nrep; sc.rep_stride = (size_t)rep_stride;
+  hipLaunchKernelGGL(k_item_scatter, dim3(grid_for(T, 4, 2048)), dim3(256), 0, (hipStream_t)stream, sc);
+  return check_launch("item_scatter");
+}
+
+int adt_replica_reduce(float* dE, const float* rep, int64_t n, int nrep, int64_t rep_stride, void* stream) {
+  if (n % 4 || rep_stride % 4) return adt_set_error("replica_reduce: n, stride %% 4");
+  hipLaunchKernelGGL(k_replica_reduce, dim3(grid_for((size_t)n / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream, dE, rep, (size_t)n, nrep,
+                     (size_t)rep_stride);
+  return check_launch("replica_reduce");
+}
+
+int adt_posemb_bwd(const int32_t* ids, const float* dX, int T, int L, int d, float p, const uint32_t* seed,
+                   uint32_t site, uint32_t row_offset, float* dP, void* stream) {
+  if (d % 4 || T % L) return adt_set_error("posemb_bwd: bad shape");
+  EmbedArgs a{};
+  a.ids = ids; a.T = T; a.L = L; a.d = d; a.scale = sqrtf((float)d);
+  a.drop = adt_make_drop(p, seed, site); a.row_offset = row_offset; a.dX = dX; a.dP = dP;
+  const int B = T / L;
+  hipLaunchKernelGGL(k_posemb_bwd, dim3((L * d / 4 + 255) / 256, B < 32 ? B : 32), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("posemb_bwd");
+}
+
+int adt_logits_bwd_df(const float* E, const int32_t* pos, const int32_t* neg, const float* dpos, const float* dneg, int T,
+                      int d, float* dF, int lddf, void* stream) {
+  LogitsArgs a{};
+  a.E = E; a.pos = pos; a.neg = neg; a.T = T; a.d = d; a.dpos = dpos; a.dneg = dneg; a.dF = dF; a.lddf = lddf;
+  hipLaunchKernelGGL(k_logits_bwd, dim3(grid_for(T, 16, 2048)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("logits_bwd_df");
+}
+
 int adt_layernorm_fwd(const float* X, int ldx, const float* gamma, const float* beta, float eps, int T, int d,
                       float* Y, int ldy, void* stream) {
   LnArgs a{};

@@ -49,12 +49,16 @@ struct ScatterArgs {
   int T, d; float scale;
   DropCfg drop; uint32_t row_offset;
   float* dE;
+  int nrep; size_t rep_stride;   // nrep > 1: dE is a set of replicas (rep_stride floats apart); wave -> replica wave % nrep.
+                                 // Popular items receive thousands of adds per step; same-address float atomics
+                                 // serialise, replicas divide that chain by nrep (k_replica_reduce sums them afterwards)
 };
 
 __global__ __launch_bounds__(256) void k_item_scatter(ScatterArgs a) {
   const int lane = threadIdx.x & 63;
   const uint32_t key = drop_key(a.drop);
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  float* dE = a.dE + (a.nrep > 1 ? (size_t)(wave % a.nrep) * a.rep_stride : 0);
   for (int row = wave; row < a.T; row += nwaves) {
     const int id = a.ids[row];
     if (id == 0) continue;
@@ -63,8 +67,20 @@ __global__ __launch_bounds__(256) void k_item_scatter(ScatterArgs a) {
     for (int c = lane; c < a.d; c += 64) {
       float v = a.G[(size_t)row * a.ldg + c] * rs;
       if (a.drop.thr) v = adt_keep(key, (uint32_t)(row + a.row_offset) * (uint32_t)a.d + (uint32_t)c, a.drop.thr) ? v * a.drop.scale : 0.f;
-      atomicAdd(a.dE + (size_t)id * a.d + c, v);
+      atomicAdd(dE + (size_t)id * a.d + c, v);
     }
+  }
+}
+
+// dst[i] += sum_r rep[r * stride + i]  (float4 granularity; n multiple of 4)
+__global__ __launch_bounds__(256) void k_replica_reduce(float* dst, const float* rep, size_t n, int nrep, size_t stride) {
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+    float4 s = *reinterpret_cast<const float4*>(dst + i);
+    for (int r = 0; r < nrep; ++r) {
+      const float4 v = *reinterpret_cast<const float4*>(rep + (size_t)r * stride + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dst + i) = s;
   }
 }
 

@@ -10,7 +10,8 @@
 
 namespace {
 
-constexpr float LN_EPS = 1e-8f;   // sasrec/modules.py:638,640,660 ; sasrec/model.py:28
+constexpr float LN_EPS = 1e-8f;
+constexpr int NREP = 16;          // replicas of the item-table gradient (contention relief for popular items)   // sasrec/modules.py:638,640,660 ; sasrec/model.py:28
 
 struct Layout {
   int64_t off[4 + 30 * 16];
@@ -59,6 +60,7 @@ struct WS {
   int64_t g_enc_x, g_dec_x, g_f, g_pos, g_neg, g_rec;                   // gradients
   int64_t s1, s2, s3, s4, s5;                                           // backward scratch: Td, Td, 3Td, 2Td, Td
   int64_t loss, norms, scal;
+  int64_t rep, rep_stride;                                              // item-table gradient replicas
   int64_t total;
 };
 
@@ -90,6 +92,8 @@ void make_ws(const adt_sasrec_cfg* c, int B, WS* w) {
   w->g_pos = take(T1); w->g_neg = take(T1); w->g_rec = take(rec * w->nl);
   w->s1 = take(Td); w->s2 = take(Td); w->s3 = take(3 * Td); w->s4 = take(2 * Td); w->s5 = take(Td);
   w->loss = take(64 * (2 + 2 * 16)); w->norms = take(64); w->scal = take(192);
+  w->rep_stride = up64((int64_t)(c->item_num + 1) * w->d);
+  w->rep = take(NREP * w->rep_stride);
   w->total = o;
 }
 
@@ -344,7 +348,11 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   const float* f = ws + w.f;
   if (phase == 0 || phase == 1) {
     // d log_feats (overwrites g_f) and item-table rows of pos/neg      (sasrec/model.py:72-76)
-    CK(adt_logits_bwd(f, d, P + lo.item(), pos, neg, ws + w.g_pos, ws + w.g_neg, T, d, gf, d, G + lo.item(), st));
+    if (hipMemsetAsync(ws + w.rep, 0, (size_t)NREP * w.rep_stride * sizeof(float), (hipStream_t)st) != hipSuccess)
+      return adt_set_error("replica memset");
+    CK(adt_logits_bwd_df(P + lo.item(), pos, neg, ws + w.g_pos, ws + w.g_neg, T, d, gf, d, st));
+    CK(adt_item_scatter(pos, f, d, ws + w.g_pos, T, d, 1.0f, 0.f, nullptr, 0, 0, ws + w.rep, NREP, w.rep_stride, st));
+    CK(adt_item_scatter(neg, f, d, ws + w.g_neg, T, d, 1.0f, 0.f, nullptr, 0, 0, ws + w.rep, NREP, w.rep_stride, st));
     for (int i = nl - 1; i >= 0; --i) {
       float* gy = ws + w.g_dec_x + (i + 1) * Td;      // d loss / d (output of decoder layer i), complete
       float* gx = ws + w.g_dec_x + i * Td;            // accumulates d / d (input of layer i)
@@ -402,7 +410,10 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       }
     }
     // decoder input embedding (sasrec/model.py:53-59)
-    CK(adt_embed_bwd(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.item(), G + lo.posw(), st));
+    CK(adt_posemb_bwd(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), st));
+    CK(adt_item_scatter(dec, ws + w.g_dec_x, d, nullptr, T, d, sqrtf((float)d), p, seed, SITE_EMB_DEC, ro, ws + w.rep, NREP, w.rep_stride, st));
+    if (phase == 1)   // two-phase (data-parallel) use: fold what has been scattered so far, the replicas restart at zero
+      CK(adt_replica_reduce(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, NREP, w.rep_stride, st));
   }
   if (phase == 0 || phase == 2) {
     // last_layernorm: g_enc_x[nl] = LN'(g_f)
@@ -446,7 +457,11 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         CK(adt_launch_bwdchain(prec, 2, a, st));
       }
     }
-    CK(adt_embed_bwd(seq, ws + w.g_enc_x, T, L, d, p, seed, SITE_EMB_SEQ, ro, G + lo.item(), G + lo.posw(), st));
+    if (phase == 2 && hipMemsetAsync(ws + w.rep, 0, (size_t)NREP * w.rep_stride * sizeof(float), (hipStream_t)st) != hipSuccess)
+      return adt_set_error("replica memset");
+    CK(adt_posemb_bwd(seq, ws + w.g_enc_x, T, L, d, p, seed, SITE_EMB_SEQ, ro, G + lo.posw(), st));
+    CK(adt_item_scatter(seq, ws + w.g_enc_x, d, nullptr, T, d, sqrtf((float)d), p, seed, SITE_EMB_SEQ, ro, ws + w.rep, NREP, w.rep_stride, st));
+    CK(adt_replica_reduce(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, NREP, w.rep_stride, st));
   }
   return 0;
 }

@@ -87,6 +87,20 @@ int adt_logits_bwd(const float* F, int ldf, const float* E, const int32_t* pos, 
                    const float* dpos, const float* dneg, int T, int d, float* dF, int lddf, float* dE,
                    void* stream);
 
+/* Contention-relieved form of the item-table scatter-add used by the executor: `rep` holds nrep zeroed replicas of
+ * the (V+1) x d table (rep_stride floats apart); rows are spread over the replicas.  adt_item_scatter adds
+ * rowscale[row] * scale * dropmask * G[row] into rep[wave % nrep][ids[row]]; adt_replica_reduce adds all replicas to dE. */
+int adt_item_scatter(const int32_t* ids, const float* G, int ldg, const float* rowscale, int T, int d, float scale, float p,
+                     const uint32_t* seed, uint32_t site, uint32_t row_offset, float* rep, int nrep, int64_t rep_stride,
+                     void* stream);
+int adt_replica_reduce(float* dE, const float* rep, int64_t n, int nrep, int64_t rep_stride, void* stream);
+/* position-table half of adt_embed_bwd alone: dP[l] += sum_b dX[b, l] * dropmask * (ids != 0) */
+int adt_posemb_bwd(const int32_t* ids, const float* dX, int T, int L, int d, float p, const uint32_t* seed,
+                   uint32_t site, uint32_t row_offset, float* dP, void* stream);
+/* dF = dpos * E[pos] + dneg * E[neg] alone (no item-table scatter) */
+int adt_logits_bwd_df(const float* E, const int32_t* pos, const int32_t* neg, const float* dpos, const float* dneg, int T,
+                      int d, float* dF, int lddf, void* stream);
+
 /* ---- loss seeds: sasrec/main.py:151-153 (BCE), :155-158 (MSE), :160-169 (NLL).  norms = device
  * {n_bce, n_mse, n_nll} (global normalisers).  Every loss term is accumulated over 64 consecutive floats (sub-slots,
  * to avoid same-address atomic contention): bce: loss2[0..64) = pos term, [64..128) = neg term; the reader sums. */
