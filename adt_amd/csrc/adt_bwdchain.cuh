@@ -5,6 +5,7 @@
 // LDS images per workgroup (ds_add_f32) and flushed once with global atomics.
 #pragma once
 #include "adt_bwdchain_args.h"
+#include "adt_misc.cuh"
 #include "adt_wave.cuh"
 
 namespace adt {
@@ -84,6 +85,22 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_bwd(BwdChainArgs a) {
   VAcc db2, db1, dbo, dgm, dbt;
   acc_zero(dW2); acc_zero(dW1); acc_zero(dWo);
   vacc_zero(db2); vacc_zero(db1); vacc_zero(dbo); vacc_zero(dgm); vacc_zero(dbt);
+  // head classifier: column 16nt+c of this lane is element jcol of head hcol[nt]
+  const bool cls = a.drec != nullptr;
+  const int hd = 64 / (a.H > 0 ? a.H : 1);
+  int hcol[4];
+  float wcls[4][MAXH];
+  VAcc dws[MAXH];          // dws[cc].v[nt]: partial of dWs[cc][jcol(nt)] over this lane's rows
+  float dbs_acc[MAXH];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    hcol[nt] = (16 * nt + c) / hd;
+    const int j = 16 * nt + c - hcol[nt] * hd;
+#pragma unroll
+    for (int cc = 0; cc < MAXH; ++cc) wcls[nt][cc] = (cls && cc < a.H) ? a.Ws[cc * hd + j] : 0.f;
+  }
+#pragma unroll
+  for (int cc = 0; cc < MAXH; ++cc) { vacc_zero(dws[cc]); dbs_acc[cc] = 0.f; }
   RowRegs gy_rows = rows_load(a.gy, 64, tile * 16, a.T, lane);
   RowRegs h_rows = rows_load(a.xin, 64, tile * 16, a.T, lane);
   for (int rnd = 0; rnd < nrounds; ++rnd, tile += tstride) {
@@ -108,8 +125,70 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_bwd(BwdChainArgs a) {
     const CT o = rows_to_ct(lds.scr, o_rows, lane, c, g);
     coop.product(dWo, dh, o);
     colsum_accum(dbo, dh);
-    const CT dO = gemm_w<PREC>(ct_to_a<PREC>(lds.scr, dh, c, g), lds.w[2], c, g);
+    CT dO = gemm_w<PREC>(ct_to_a<PREC>(lds.scr, dh, c, g), lds.w[2], c, g);
+    if (cls) {
+      // dz = drec - softmax(z) * sum(drec), softmax = exp(rec); dO += dz Ws; dWs += dz^T o_head; dbs += dz
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + 4 * g + r;
+        if (row < a.T) {
+          const int b = row / a.L, l = row - b * a.L;
+          const size_t rb = (size_t)(l * a.B + b) * a.H * a.H;
+#pragma unroll 1
+          for (int h = 0; h < a.H; ++h) {
+            float dz[MAXH];
+            float sd = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < MAXH; ++cc) {
+              dz[cc] = (cc < a.H) ? a.drec[rb + h * a.H + cc] : 0.f;
+              sd += dz[cc];
+            }
+#pragma unroll
+            for (int cc = 0; cc < MAXH; ++cc)
+              if (cc < a.H) {
+                dz[cc] -= __expf(a.rec[rb + h * a.H + cc]) * sd;
+                if (c == 0) dbs_acc[cc] += dz[cc];
+              }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+              if (hcol[nt] == h) {
+                float add = 0.f;
+#pragma unroll
+                for (int cc = 0; cc < MAXH; ++cc)
+                  if (cc < a.H) {
+                    add += dz[cc] * wcls[nt][cc];
+                    dws[cc].v[nt] += dz[cc] * o.v[nt][r];
+                  }
+                dO.v[nt][r] += add;
+              }
+          }
+        }
+      }
+    }
     store_ct(lds.scr, a.out1, 64, dO, row0, a.T, lane, c, g);
+  }
+  if (cls) {
+    // classifier weight gradient: H column-sum vectors folded modulo hd; bias: one value per (wave, g) through LDS
+    float* red = reinterpret_cast<float*>(lds.coop);
+#pragma unroll
+    for (int cc = 0; cc < MAXH; ++cc) {
+      if (cc < a.H) {
+        const VAcc* const accs[1] = {&dws[cc]};
+        float* const dst[1] = {a.dWs + cc * hd};
+        vacc_flush_wg<NW, 1>(accs, dst, red, w, c, g, hd);
+      }
+    }
+    __syncthreads();
+    if (c == 0) {
+#pragma unroll
+      for (int cc = 0; cc < MAXH; ++cc) red[(w * 4 + g) * MAXH + cc] = dbs_acc[cc];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < a.H) {
+      float sb = 0.f;
+      for (int i = 0; i < NW * 4; ++i) sb += red[i * MAXH + threadIdx.x];
+      atomicAdd(a.dbs + threadIdx.x, sb);
+    }
   }
   coop.flush(dW2, a.dW0, c, g); coop.flush(dW1, a.dW1, c, g); coop.flush(dWo, a.dW2, c, g);
   {

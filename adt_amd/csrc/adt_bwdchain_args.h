@@ -28,6 +28,8 @@ struct BwdChainArgs {
   float* dW0; float* dW1; float* dW2; float* dW3;
   float* db0; float* db1; float* db2; float* db3;
   float* dgamma; float* dbeta;
+  // head classifier reverse fused into enc_post (sasrec/modules.py:648-649): rec/drec in reference row order (l*B+b)
+  const float* rec; const float* drec; const float* Ws; float* dWs; float* dbs; int H;
   int ablate;                 // timing experiments only (ADT_BWD_ABLATE): 1 skip weight-gradient products, 2 skip flush
 };
 

@@ -106,6 +106,15 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_fwd(FwdChainArgs a) {
   __syncthreads();
   const uint32_t key1 = adt_site_key(seedv, a.site1), key2 = adt_site_key(seedv, a.site2);
   const int hd = 64 / a.H;
+  int hcol[4];
+  float wcls[4][MAXH];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    hcol[nt] = (16 * nt + c) / hd;
+    const int j = 16 * nt + c - hcol[nt] * hd;
+#pragma unroll
+    for (int cc = 0; cc < MAXH; ++cc) wcls[nt][cc] = (a.rec && cc < a.H) ? a.Ws[cc * hd + j] : 0.f;
+  }
   for (int tile = blockIdx.x * NW + w; tile < ntiles; tile += tstride) {
     const int row0 = tile * 16;
     const RowRegs qn_rows = rows_load(a.r0, 64, row0, a.T, lane);
@@ -114,35 +123,34 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_fwd(FwdChainArgs a) {
     wave_fence();
     const AFrags<PREC> ao = scr_to_a<PREC>(lds.scr, c, g);
     if (a.rec) {
-      // head classifier (sasrec/modules.py:648-649): z[h][cc] = sum_j o[h*hd + j] Ws[cc][j] + bs[cc]; log-softmax over cc
+      // head classifier (sasrec/modules.py:648-649): z[h][cc] = sum_j o[h*hd + j] Ws[cc][j] + bs[cc]; log-softmax over cc.
+      // Column 16nt+c of this lane belongs to head hcol[nt]; one 16-lane row reduction per (row, head, class).
       const CT o = scr_to_ct(lds.scr, c, g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = row0 + 4 * g + r;
+#pragma unroll 1
         for (int h = 0; h < a.H; ++h) {
           float z[MAXH];
 #pragma unroll
           for (int cc = 0; cc < MAXH; ++cc) {
-            float s = 0.f;
+            z[cc] = -INFINITY;
             if (cc < a.H) {
+              float s = 0.f;
 #pragma unroll
-              for (int nt = 0; nt < 4; ++nt) {
-                const int col = 16 * nt + c;
-                if (col / hd == h) s += o.v[nt][r] * a.Ws[cc * hd + (col - h * hd)];
-              }
-              s = row_sum16(s) + a.bs[cc];
+              for (int nt = 0; nt < 4; ++nt) s += (hcol[nt] == h) ? o.v[nt][r] * wcls[nt][cc] : 0.f;
+              z[cc] = row_sum16(s) + a.bs[cc];
             }
-            z[cc] = (cc < a.H) ? s : -INFINITY;
           }
           float m = z[0];
 #pragma unroll
           for (int cc = 1; cc < MAXH; ++cc) m = fmaxf(m, z[cc]);
           float se = 0.f;
 #pragma unroll
-          for (int cc = 0; cc < MAXH; ++cc) se += (cc < a.H) ? expf(z[cc] - m) : 0.f;
-          const float lz = m + logf(se);
+          for (int cc = 0; cc < MAXH; ++cc) se += (cc < a.H) ? __expf(z[cc] - m) : 0.f;
+          const float lz = m + __logf(se);
           if (c == 0 && row < a.T) {
-            const int b = row / a.L, l = row % a.L;
+            const int b = row / a.L, l = row - b * a.L;
             float* dst = a.rec + ((size_t)(l * a.B + b) * a.H + h) * a.H;
 #pragma unroll
             for (int cc = 0; cc < MAXH; ++cc)

@@ -389,7 +389,8 @@ ADT_DEVICE_INLINE void wacc_flush(const WAcc& acc, float* red, float* gW, float*
 // float atomic per column per workgroup.  (Every wave flushing on its own means thousands of serialised atomics on
 // the same 64 addresses -- tens of microseconds.)  red: LDS, NV * NW * 64 floats, free at this point; all threads call.
 template <int NW, int NV>
-ADT_DEVICE_INLINE void vacc_flush_wg(const VAcc* const (&accs)[NV], float* const (&dst)[NV], float* red, int w, int c, int g) {
+ADT_DEVICE_INLINE void vacc_flush_wg(const VAcc* const (&accs)[NV], float* const (&dst)[NV], float* red, int w, int c, int g,
+                                     int fold = 64) {
   __syncthreads();
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
@@ -407,7 +408,7 @@ ADT_DEVICE_INLINE void vacc_flush_wg(const VAcc* const (&accs)[NV], float* const
     float s = 0.f;
 #pragma unroll
     for (int ww = 0; ww < NW; ++ww) s += red[(v * NW + ww) * 64 + col];
-    if (dst[v]) atomicAdd(dst[v] + col, s);
+    if (dst[v]) atomicAdd(dst[v] + (col % fold), s);   // fold < 64: columns with equal col % fold share a destination
   }
 }
 
