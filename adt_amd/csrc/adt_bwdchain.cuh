@@ -16,13 +16,15 @@ struct BwdLds {
   typedef typename WImg<PREC>::T WT;
   static constexpr int WIMG = 64 * WImg<PREC>::RS;           // elements per weight image
   static constexpr size_t wbytes = NWT * WIMG * sizeof(WT);
-  static constexpr size_t bytes = wbytes + Coop<PREC, NW>::bytes + (size_t)NW * WV_SCR * sizeof(float);
-  WT* w[4]; void* coop; float* scr;
+  static constexpr int CLS = 2 * 16 * 16;                     // per wave: rec + drec rows of a tile (H <= 4)
+  static constexpr size_t bytes = wbytes + Coop<PREC, NW>::bytes + (size_t)NW * (WV_SCR + CLS) * sizeof(float);
+  WT* w[4]; void* coop; float* scr; float* cls;
   __device__ BwdLds(unsigned char* base, int wave) {
     WT* pw = reinterpret_cast<WT*>(base);
     for (int i = 0; i < NWT; ++i) w[i] = pw + i * WIMG;
     coop = base + wbytes;
     scr = reinterpret_cast<float*>(base + wbytes + Coop<PREC, NW>::bytes) + wave * WV_SCR;
+    cls = reinterpret_cast<float*>(base + wbytes + Coop<PREC, NW>::bytes) + NW * WV_SCR + wave * CLS;
   }
 };
 
@@ -107,6 +109,23 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_bwd(BwdChainArgs a) {
     const int row0 = tile * 16;    // may lie beyond T: a phantom tile of zeros that only takes part in the barriers
     const RowRegs u_cur = rows_load(a.u, 64, row0, a.T, lane);    // requested now, consumed later in the round
     const RowRegs o_rows = rows_load(a.o, 64, row0, a.T, lane);
+    // classifier log-probs and their upstream gradient for the 16 tile rows (H*H floats per row, reference row order
+    // l*B + b): requested now as one element per lane and step, parked in LDS when needed
+    float cls_rec[4], cls_drec[4];
+    const int HH = a.H * a.H;
+    if (cls) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = q * 64 + lane, rr = e / HH, row = row0 + rr;
+        cls_rec[q] = 0.f; cls_drec[q] = 0.f;
+        if (e < 16 * HH && row < a.T) {
+          const int b = row / a.L, l = row - b * a.L;
+          const size_t off = (size_t)(l * a.B + b) * HH + (e - rr * HH);
+          cls_rec[q] = a.rec[off];
+          cls_drec[q] = a.drec[off];
+        }
+      }
+    }
     const CT h = rows_to_ct(lds.scr, h_rows, lane, c, g);
     const RowRegs gy_cur = gy_rows;
     // the next round's first inputs are requested now and consumed one round later
@@ -128,25 +147,30 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_bwd(BwdChainArgs a) {
     CT dO = gemm_w<PREC>(ct_to_a<PREC>(lds.scr, dh, c, g), lds.w[2], c, g);
     if (cls) {
       // dz = drec - softmax(z) * sum(drec), softmax = exp(rec); dO += dz Ws; dWs += dz^T o_head; dbs += dz
+      wave_fence();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = q * 64 + lane;
+        if (e < 16 * HH) { lds.cls[e] = cls_rec[q]; lds.cls[256 + e] = cls_drec[q]; }
+      }
+      wave_fence();
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = row0 + 4 * g + r;
-        if (row < a.T) {
-          const int b = row / a.L, l = row - b * a.L;
-          const size_t rb = (size_t)(l * a.B + b) * a.H * a.H;
+        const int rl = 4 * g + r;
+        if (row0 + rl < a.T) {
 #pragma unroll 1
           for (int h = 0; h < a.H; ++h) {
             float dz[MAXH];
             float sd = 0.f;
 #pragma unroll
             for (int cc = 0; cc < MAXH; ++cc) {
-              dz[cc] = (cc < a.H) ? a.drec[rb + h * a.H + cc] : 0.f;
+              dz[cc] = (cc < a.H) ? lds.cls[256 + rl * HH + h * a.H + cc] : 0.f;
               sd += dz[cc];
             }
 #pragma unroll
             for (int cc = 0; cc < MAXH; ++cc)
               if (cc < a.H) {
-                dz[cc] -= __expf(a.rec[rb + h * a.H + cc]) * sd;
+                dz[cc] -= __expf(lds.cls[rl * HH + h * a.H + cc]) * sd;
                 if (c == 0) dbs_acc[cc] += dz[cc];
               }
 #pragma unroll

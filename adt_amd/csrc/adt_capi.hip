@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include "adt_attn.cuh"
+#include "adt_attn_bf16.cuh"
 #include "adt_chain.cuh"
 #include "adt_bwdchain.cuh"
 #include "adt_fwdchain.cuh"
@@ -70,8 +71,31 @@ static int attn_waves(bool bwd) {
   return nw[bwd ? 1 : 0];
 }
 
+// bf16-image kernels (adt_attn_bf16.cuh) for the bf16-operand precision
+template <int HD, int MAXKT, int NW>
+static int launch_attn_bf16(bool bwd, const AttnArgs& a, hipStream_t s) {
+  const size_t smem = bwd ? AttnBf16Lds<HD, MAXKT>::bwd_bytes : AttnBf16Lds<HD, MAXKT>::fwd_bytes;
+  if (smem > 160 * 1024) return adt_set_error("attention(bf16): L/hd too large for LDS-resident form (%zu B)", smem);
+  static bool attr_done[2] = {false, false};
+  if (!attr_done[bwd ? 1 : 0]) {
+    hipError_t e = bwd ? hipFuncSetAttribute((const void*)k_attn_bwd_bf16<HD, MAXKT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
+                       : hipFuncSetAttribute((const void*)k_attn_fwd_bf16<HD, MAXKT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return adt_set_error("attention(bf16): hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done[bwd ? 1 : 0] = true;
+  }
+  const int grid = a.B * a.H;
+  if (bwd) hipLaunchKernelGGL((k_attn_bwd_bf16<HD, MAXKT, NW>), dim3(grid), dim3(NW * 64), smem, s, a);
+  else hipLaunchKernelGGL((k_attn_fwd_bf16<HD, MAXKT, NW>), dim3(grid), dim3(NW * 64), smem, s, a);
+  return check_launch(bwd ? "attn_bwd_bf16" : "attn_fwd_bf16");
+}
+
 template <int PREC, int HD, int MAXKT, int NW>
 static int launch_attn_nw(bool bwd, const AttnArgs& a, hipStream_t s) {
+  if constexpr (PREC == PREC_BF16) {
+    static int use_img = -1;
+    if (use_img < 0) { const char* e = getenv("ADT_ATTN_BF16_IMG"); use_img = (e && atoi(e) == 0) ? 0 : 1; }
+    if (use_img) return launch_attn_bf16<HD, MAXKT, NW>(bwd, a, s);
+  }
   constexpr int RS = HD + 4, LP = MAXKT * 16;
   const size_t smem = bwd ? (size_t)(4 * LP * RS + 2 * LP) * sizeof(float) : (size_t)(2 * LP * RS) * sizeof(float);
   if (smem > 160 * 1024) return adt_set_error("attention: L/hd too large for LDS-resident form (%zu B)", smem);

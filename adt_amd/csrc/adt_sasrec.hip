@@ -440,12 +440,15 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.db0 = G + lo.enc(i, E_C2B); a.db1 = G + lo.enc(i, E_C1B); a.db2 = G + lo.enc(i, E_OB);
         a.dgamma = G + lo.enc(i, E_LN2W); a.dbeta = G + lo.enc(i, E_LN2B);
         a.out0 = s5; a.out1 = s1;
-        if (H > 1) {   // independence-head classifier reverse, fused (sasrec/modules.py:648-649; main.py:160-169)
+        if (H > 1 && H <= 4) {   // independence-head classifier reverse, fused (sasrec/modules.py:648-649; main.py:160-169)
           a.rec = rec; a.drec = ws + w.g_rec + i * recsz; a.Ws = P + lo.enc(i, E_SW); a.dWs = G + lo.enc(i, E_SW);
           a.dbs = G + lo.enc(i, E_SB); a.H = H;
         }
         CK(adt_launch_bwdchain(prec, 0, a, st));
       }
+      if (H > 4)   // wider classifiers: separate kernel
+        CK(adt_headcls_bwd(o, d, P + lo.enc(i, E_SW), rec, ws + w.g_rec + i * recsz, (int)w.B, L, H, hd, s1, d, G + lo.enc(i, E_SW),
+                           G + lo.enc(i, E_SB), st));
       CK(adt_attn_bwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, o, d, lse, s1, d, (int)w.B, H, L, hd, 1, p, seed,
                       enc_site(i, 0), b_offset, s3, 3 * d, s3 + d, 3 * d, s3 + 2 * d, 3 * d, st));
       {  // attention_layernorm + in_proj reverse: gx += LN'(dq Wq + dh) + dk Wk + dv Wv
