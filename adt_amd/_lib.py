@@ -33,9 +33,9 @@ SIGNATURES = {
     "adt_linear_fwd": (_I, [_I, _P, _I, _P, _P, _I, _I, _I, _P, _I, _F, _P, _U, _U, _I, _P, _I, _P, _I, _P, _P]),
     "adt_linear_bwd": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _F, _P, _U, _U, _P, _I, _P, _I, _I, _P, _I, _P,
                             _P, _P, _P]),
-    "adt_attn_fwd": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P, _U, _U, _P, _I, _P, _P]),
+    "adt_attn_fwd": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P, _U, _U, _P, _I, _P, _P, _P]),
     "adt_attn_bwd": (_I, [_I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _U, _U, _P, _I,
-                          _P, _I, _P, _I, _P]),
+                          _P, _I, _P, _I, _P, _P]),
     "adt_headcls_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
     "adt_headcls_bwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
     "adt_logits_fwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),

@@ -31,6 +31,7 @@ struct AttnArgs {
   float* dQ; int lddq;
   float* dK; int lddk;
   float* dV; int lddv;
+  uint32_t* mask;             // optional (B*H*L x 8 words): dropout keep bits written by the bf16 forward, read by its backward
 };
 
 template <int HD>

@@ -72,7 +72,7 @@ template <int HD, int MAXKT>
 struct AttnBf16Lds {
   static constexpr int LP = MAXKT * 16, LPT = LP + 8, RS = BImg<HD>::RS;
   static constexpr size_t fwd_bytes = (size_t)(LP * RS + HD * LPT) * 2;
-  static constexpr size_t bwd_bytes = (size_t)(4 * LP * RS + 3 * HD * LPT) * 2 + 2 * LP * sizeof(float);
+  static constexpr size_t bwd_bytes = (size_t)(4 * LP * RS + 3 * HD * LPT) * 2 + 2 * LP * sizeof(float) + (size_t)LP * 8 * sizeof(uint32_t);
 };
 
 template <int HD, int MAXKT, int NW>
@@ -146,6 +146,9 @@ __global__ __launch_bounds__(NW * 64) void k_attn_fwd_bf16(AttnArgs a) {
     if (g == 0 && q < L) a.LSE[(size_t)bh * L + q] = m + __logf(sum);
     const uint32_t idx_q = ((uint32_t)(bh + a.bh_offset) * (uint32_t)L + (uint32_t)q) * (uint32_t)L;
     const float keep_scale = inv * a.drop.scale;
+    uint32_t mw[MAXKT / 2];      // keep bits of this lane's keys: word kp, bit 16*(kt&1) + 4g + r
+#pragma unroll
+    for (int i = 0; i < MAXKT / 2; ++i) mw[i] = 0u;
     f32x4 o[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -162,7 +165,9 @@ __global__ __launch_bounds__(NW * 64) void k_attn_fwd_bf16(AttnArgs a) {
             if (kt < nkt) {
               if (a.drop.thr) {
                 const uint32_t key = kt * 16 + 4 * g + r;
-                p = adt_keep(key_rng, idx_q + key, a.drop.thr) ? s[kt][r] * keep_scale : 0.f;
+                const bool keep = adt_keep(key_rng, idx_q + key, a.drop.thr);
+                p = keep ? s[kt][r] * keep_scale : 0.f;
+                mw[kp] |= (keep ? 1u : 0u) << (16 * t + 4 * g + r);
               } else {
                 p = s[kt][r] * inv;
               }
@@ -173,6 +178,22 @@ __global__ __launch_bounds__(NW * 64) void k_attn_fwd_bf16(AttnArgs a) {
         const bf16x8 fp = pack8(pv);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) o[nt] = mfma_bf16(o[nt], fp, tfrag(sVT, LPT, nt * 16 + c, kp * 32, g));
+      }
+    }
+    if (a.mask && a.drop.thr) {
+      // the four g-lanes of a query hold disjoint nibbles: OR them together, lane g == 0 stores the 8 words
+      uint32_t ow[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        uint32_t v = i < MAXKT / 2 ? mw[i] : 0u;
+        v |= (uint32_t)__shfl_xor((int)v, 16, 64);
+        v |= (uint32_t)__shfl_xor((int)v, 32, 64);
+        ow[i] = v;
+      }
+      if (g == 0 && q < L) {
+        uint4* dst = reinterpret_cast<uint4*>(a.mask + ((size_t)bh * L + q) * 8);
+        dst[0] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        dst[1] = make_uint4(ow[4], ow[5], ow[6], ow[7]);
       }
     }
 #pragma unroll
@@ -200,10 +221,20 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_bf16(AttnArgs a) {
   __bf16* sdOT = sKT + HD * LPT;
   float* sLse = reinterpret_cast<float*>(sdOT + HD * LPT);
   float* sDelta = sLse + LP;
+  uint32_t* sM = reinterpret_cast<uint32_t*>(sDelta + LP);   // [LP][8] dropout keep bits (forward's), 0 beyond L
   const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int L = a.L;
   const size_t row_b = (size_t)b * L;
+  const bool use_bits = a.mask != nullptr && a.drop.thr != 0;
+  if (use_bits) {
+    for (int i = threadIdx.x; i < LP * 2; i += NW * 64) {
+      const int r = i >> 1;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (r < L) v = reinterpret_cast<const uint4*>(a.mask + ((size_t)bh * L + r) * 8)[i & 1];
+      reinterpret_cast<uint4*>(sM + r * 8)[i & 1] = v;
+    }
+  }
   stage_bf16<HD, NW * 64>(sQ, sQT, LPT, a.Q + row_b * a.ldq + h * HD, a.ldq, L, LP, a.scale);
   stage_bf16<HD, NW * 64>(sK, sKT, LPT, a.K + row_b * a.ldk + h * HD, a.ldk, L, LP, 1.0f);
   stage_bf16<HD, NW * 64>(sV, nullptr, LPT, a.V + row_b * a.ldv + h * HD, a.ldv, L, LP, 1.0f);
@@ -253,6 +284,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_bf16(AttnArgs a) {
     for (int kp = 0; kp < MAXKT / 2; ++kp) {
       if (2 * kp < nkt) {
         float dsv[8];
+        const uint32_t mword = use_bits ? (sM[q * 8 + kp] >> (4 * g)) : 0u;   // bits 16t + r of this lane's keys
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int kt = 2 * kp + t;
@@ -264,13 +296,19 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_bf16(AttnArgs a) {
               dp = mfma_bf16(dp, rfrag<HD>(sV, kt * 16 + c, kb, g), fdo[kb]);
             }
           }
+          // interior tiles (every key <= every query of the tile, all keys real) need no per-element mask test
+          const bool edge = kt >= nkt || (a.causal && kt == qt) || kt == nqt - 1;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = kt * 16 + 4 * g + r;
-            const bool valid = kt < nkt && key < L && (!a.causal || key <= q);
-            const float p = valid ? __expf(s[r] - lse_q) : 0.f;
+            float p = __expf(s[r] - lse_q);
+            if (edge) {
+              const bool valid = kt < nkt && key < L && (!a.causal || key <= q);
+              p = valid ? p : 0.f;
+            }
             float d = dp[r];
-            if (a.drop.thr) d = adt_keep(key_rng, idx_q + (uint32_t)key, a.drop.thr) ? d * a.drop.scale : 0.f;
+            if (use_bits) d = ((mword >> (16 * t + r)) & 1u) ? d * a.drop.scale : 0.f;
+            else if (a.drop.thr) d = adt_keep(key_rng, idx_q + (uint32_t)key, a.drop.thr) ? d * a.drop.scale : 0.f;
             dsv[4 * t + r] = p * (d - delta_q);
           }
         }
@@ -322,13 +360,18 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_bf16(AttnArgs a) {
               dp = mfma_bf16(dp, rfrag<HD>(sdO, qt * 16 + c, kb, g), fv[kb]);
             }
           }
+          const bool edge = !live || (a.causal && qt == kt) || kt == nqt - 1;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int qq = qt * 16 + 4 * g + r;
-            const bool valid = live && key < L && (!a.causal || key <= qq);
-            const float p = valid ? __expf(s[r] - sLse[qq]) : 0.f;
+            float p = __expf(s[r] - sLse[qq]);      // sLse = +inf for padded queries -> 0
+            if (edge) {
+              const bool valid = live && key < L && (!a.causal || key <= qq);
+              p = valid ? p : 0.f;
+            }
             float ks = 1.0f;
-            if (a.drop.thr)
+            if (use_bits) ks = ((sM[qq * 8 + (kt >> 1)] >> (16 * (kt & 1) + c)) & 1u) ? a.drop.scale : 0.f;
+            else if (a.drop.thr)
               ks = adt_keep(key_rng, (idx_bh + (uint32_t)qq) * (uint32_t)L + (uint32_t)key, a.drop.thr) ? a.drop.scale : 0.f;
             pv[4 * t + r] = p * ks;
             dsv[4 * t + r] = p * (dp[r] * ks - sDelta[qq]);

@@ -377,8 +377,9 @@ int adt_linear_bwd(int prec, const float* dY, int lddy, const float* X, int ldx,
 
 int adt_attn_fwd(int prec, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, int B,
                  int H, int L, int hd, int causal, float p, const uint32_t* seed, uint32_t site,
-                 uint32_t b_offset, float* O, int ldo, float* LSE, void* stream) {
+                 uint32_t b_offset, float* O, int ldo, float* LSE, uint32_t* mask, void* stream) {
   AttnArgs a{};
+  a.mask = mask;
   a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.LSE = LSE;
   a.B = B; a.H = H; a.L = L; a.causal = causal; a.scale = 1.0f / sqrtf((float)hd);
   a.drop = adt_make_drop(p, seed, site); a.bh_offset = b_offset * (uint32_t)H;
@@ -388,8 +389,9 @@ int adt_attn_fwd(int prec, const float* Q, int ldq, const float* K, int ldk, con
 int adt_attn_bwd(int prec, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                  const float* O, int ldo, const float* LSE, const float* dO, int lddo, int B, int H, int L,
                  int hd, int causal, float p, const uint32_t* seed, uint32_t site, uint32_t b_offset,
-                 float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, void* stream) {
+                 float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, const uint32_t* mask, void* stream) {
   AttnArgs a{};
+  a.mask = const_cast<uint32_t*>(mask);
   a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = const_cast<float*>(O); a.ldo = ldo;
   a.LSE = const_cast<float*>(LSE); a.B = B; a.H = H; a.L = L; a.causal = causal; a.scale = 1.0f / sqrtf((float)hd);
   a.drop = adt_make_drop(p, seed, site); a.bh_offset = b_offset * (uint32_t)H;

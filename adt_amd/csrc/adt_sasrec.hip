@@ -55,8 +55,8 @@ bool make_layout(const adt_sasrec_cfg* c, Layout* lo) {
 struct WS {
   int64_t T, d, H, L, nl, B;
   int64_t enc_x, dec_x, f, posl, negl;                                  // (nl+1)*Td each for enc_x/dec_x
-  int64_t e_qn, e_qkv, e_o, e_lse, e_h, e_h2, e_u, e_rec, e_stride;     // per encoder layer
-  int64_t d_dn, d_qkv, d_o1, d_lse1, d_a1, d_q2, d_kv2, d_o2, d_lse2, d_a2, d_u, d_stride;
+  int64_t e_qn, e_qkv, e_o, e_lse, e_h, e_h2, e_u, e_rec, e_mask, e_stride;     // per encoder layer
+  int64_t d_dn, d_qkv, d_o1, d_lse1, d_a1, d_q2, d_kv2, d_o2, d_lse2, d_a2, d_u, d_mask1, d_mask2, d_stride;
   int64_t g_enc_x, g_dec_x, g_f, g_pos, g_neg, g_rec;                   // gradients
   int64_t s1, s2, s3, s4, s5;                                           // backward scratch: Td, Td, 3Td, 2Td, Td
   int64_t loss, norms, scal;
@@ -76,7 +76,7 @@ void make_ws(const adt_sasrec_cfg* c, int B, WS* w) {
   {
     const int64_t s = o;
     w->e_qn = take(Td); w->e_qkv = take(3 * Td); w->e_o = take(Td); w->e_lse = take(lse); w->e_h = take(Td);
-    w->e_h2 = take(Td); w->e_u = take(Td); w->e_rec = take(rec);
+    w->e_h2 = take(Td); w->e_u = take(Td); w->e_rec = take(rec); w->e_mask = take(8 * lse);
     w->e_stride = o - s;
     o = s + w->e_stride * w->nl;
   }
@@ -84,7 +84,7 @@ void make_ws(const adt_sasrec_cfg* c, int B, WS* w) {
     const int64_t s = o;
     w->d_dn = take(Td); w->d_qkv = take(3 * Td); w->d_o1 = take(Td); w->d_lse1 = take(lse); w->d_a1 = take(Td);
     w->d_q2 = take(Td); w->d_kv2 = take(2 * Td); w->d_o2 = take(Td); w->d_lse2 = take(lse); w->d_a2 = take(Td);
-    w->d_u = take(Td);
+    w->d_u = take(Td); w->d_mask1 = take(8 * lse); w->d_mask2 = take(8 * lse);
     w->d_stride = o - s;
     o = s + w->d_stride * w->nl;
   }
@@ -180,7 +180,7 @@ int encoder_forward(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, cons
       CK(adt_launch_fwdchain(prec, 0, a, st));
     }
     CK(adt_attn_fwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, B, H, L, hd, 1, p, seed, enc_site(i, 0), b_offset, o, d,
-                    lse, st));
+                    lse, reinterpret_cast<uint32_t*>(base + w.e_mask), st));
     {  // h = Q + out_proj(o); h2 = LN2(h); u = relu(drop1(conv1 h2)); y = (h2 + drop2(conv2 u)) * mask   (:648-654)
       adt::FwdChainArgs a = fwd_args(T, L, B, H, seq, p, seed, ro);
       a.x = o; a.r0 = qn; a.site1 = enc_site(i, 1); a.site2 = enc_site(i, 2);
@@ -291,14 +291,15 @@ int adt_sasrec_forward(const adt_sasrec_cfg* c, const float* P, float* ws, const
       CK(adt_launch_fwdchain(prec, 1, a, st));
     }
     CK(adt_attn_fwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, B_, H, L, hd, 1, p, seed, dec_site(i, 0), b_offset, o1, d,
-                    lse1, st));
+                    lse1, reinterpret_cast<uint32_t*>(base + w.d_mask1), st));
     {  // a1 = out_proj(o1); q2 = a1 Wq^T + bq
       adt::FwdChainArgs a = fwd_args(T, L, B_, H, dec, 0.f, nullptr, ro);
       a.x = o1; a.W[0] = P + lo.dec(i, D_SOW); a.b[0] = P + lo.dec(i, D_SOB); a.W[1] = einw; a.b[1] = einb;
       a.o0 = a1; a.ld0 = d; a.o2 = q2; a.ld2 = d;
       CK(adt_launch_fwdchain(prec, 3, a, st));
     }
-    CK(adt_attn_fwd(prec, q2, d, kv2, 2 * d, kv2 + d, 2 * d, B_, H, L, hd, 1, p, seed, dec_site(i, 1), b_offset, o2, d, lse2, st));
+    CK(adt_attn_fwd(prec, q2, d, kv2, 2 * d, kv2 + d, 2 * d, B_, H, L, hd, 1, p, seed, dec_site(i, 1), b_offset, o2, d, lse2,
+                    reinterpret_cast<uint32_t*>(base + w.d_mask2), st));
     {  // a2 = out_proj(o2); y = (D + a2 + drop2(conv2 relu(drop1(conv1 a2)))) * mask       (:673-676, :629-633)
       adt::FwdChainArgs a = fwd_args(T, L, B_, H, dec, p, seed, ro);
       a.x = o2; a.r0 = dn; a.site1 = dec_site(i, 2); a.site2 = dec_site(i, 3);
@@ -380,7 +381,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       }
       // cross attention core: dq2 -> s5, dkv2 -> s4
       CK(adt_attn_bwd(prec, q2, d, kv2, 2 * d, kv2 + d, 2 * d, o2, d, lse2, s1, d, B, H, L, hd, 1, p, seed, dec_site(i, 1), b_offset,
-                      s5, d, s4, 2 * d, s4 + d, 2 * d, st));
+                      s5, d, s4, 2 * d, s4 + d, 2 * d, reinterpret_cast<const uint32_t*>(base + w.d_mask2), st));
       {  // q2 = a1 Wq^T, a1 = o1 Wo1^T  -> dO1 (s1)
         adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, dec, 0.f, nullptr, ro);
         a.dqkv = s5; a.lddqkv = d; a.xin = a1; a.o = o1;
@@ -398,7 +399,8 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         CK(adt_launch_bwdchain(prec, 5, a, st));
       }
       CK(adt_attn_bwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, o1, d, lse1, s1, d, B, H, L, hd, 1, p, seed,
-                      dec_site(i, 0), b_offset, s3, 3 * d, s3 + d, 3 * d, s3 + 2 * d, 3 * d, st));
+                      dec_site(i, 0), b_offset, s3, 3 * d, s3 + d, 3 * d, s3 + 2 * d, 3 * d,
+                      reinterpret_cast<const uint32_t*>(base + w.d_mask1), st));
       {  // layer_norm + packed in_proj reverse: gx (+)= LN'(dqkv Win + gy*mask)
         adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, dec, 0.f, nullptr, ro);
         a.dqkv = s3; a.lddqkv = 3 * d; a.gy = gy; a.xin = x;
@@ -450,7 +452,8 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         CK(adt_headcls_bwd(o, d, P + lo.enc(i, E_SW), rec, ws + w.g_rec + i * recsz, (int)w.B, L, H, hd, s1, d, G + lo.enc(i, E_SW),
                            G + lo.enc(i, E_SB), st));
       CK(adt_attn_bwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, o, d, lse, s1, d, (int)w.B, H, L, hd, 1, p, seed,
-                      enc_site(i, 0), b_offset, s3, 3 * d, s3 + d, 3 * d, s3 + 2 * d, 3 * d, st));
+                      enc_site(i, 0), b_offset, s3, 3 * d, s3 + d, 3 * d, s3 + 2 * d, 3 * d,
+                      reinterpret_cast<const uint32_t*>(base + w.e_mask), st));
       {  // attention_layernorm + in_proj reverse: gx += LN'(dq Wq + dh) + dk Wk + dv Wv
         adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, seq, 0.f, nullptr, ro);
         a.dqkv = s3; a.lddqkv = 3 * d; a.dh = s5; a.xin = x;

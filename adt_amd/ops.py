@@ -85,18 +85,18 @@ def linear_bwd(prec, dY, X, W, dW, db, dX=None, beta=False, mask_ids=None, p=0.0
                                           _ld(Radd), _p(radd_ids), _p(dW), _p(db), _stream()), "linear_bwd")
 
 
-def attn_fwd(prec, Q, K, V, B, H, L, causal=True, p=0.0, seed=None, site=0, b_offset=0):
+def attn_fwd(prec, Q, K, V, B, H, L, causal=True, p=0.0, seed=None, site=0, b_offset=0, mask=None):
     """Q, K, V: (B*L, >= H*hd) views (head h in columns [h*hd, (h+1)*hd)); returns O (B*L, H*hd), LSE (B*H*L)."""
     d = Q.shape[1]
     hd = d // H
     O = torch.empty(B * L, d, device=Q.device, dtype=torch.float32)
     LSE = torch.empty(B * H * L, device=Q.device, dtype=torch.float32)
     _lib.check(_lib.load().adt_attn_fwd(prec, _p(_f32(Q)), _ld(Q), _p(_f32(K)), _ld(K), _p(_f32(V)), _ld(V), B, H, L, hd, int(causal),
-                                        float(p), _p(seed), site, b_offset, _p(O), d, _p(LSE), _stream()), "attn_fwd")
+                                        float(p), _p(seed), site, b_offset, _p(O), d, _p(LSE), _p(mask), _stream()), "attn_fwd")
     return O, LSE
 
 
-def attn_bwd(prec, Q, K, V, O, LSE, dO, B, H, L, causal=True, p=0.0, seed=None, site=0, b_offset=0):
+def attn_bwd(prec, Q, K, V, O, LSE, dO, B, H, L, causal=True, p=0.0, seed=None, site=0, b_offset=0, mask=None):
     d = Q.shape[1]
     hd = d // H
     dQ = torch.empty(B * L, d, device=Q.device, dtype=torch.float32)
@@ -104,7 +104,7 @@ def attn_bwd(prec, Q, K, V, O, LSE, dO, B, H, L, causal=True, p=0.0, seed=None, 
     dV = torch.empty_like(dQ)
     _lib.check(_lib.load().adt_attn_bwd(prec, _p(_f32(Q)), _ld(Q), _p(_f32(K)), _ld(K), _p(_f32(V)), _ld(V), _p(_f32(O)), _ld(O),
                                         _p(LSE), _p(_f32(dO)), _ld(dO), B, H, L, hd, int(causal), float(p), _p(seed), site, b_offset,
-                                        _p(dQ), d, _p(dK), d, _p(dV), d, _stream()), "attn_bwd")
+                                        _p(dQ), d, _p(dK), d, _p(dV), d, _p(mask), _stream()), "attn_bwd")
     return dQ, dK, dV
 
 

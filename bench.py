@@ -106,15 +106,16 @@ def roofline_probe(model, trainer, B):
     T = B * L
     dev = model.dev
     qkv = torch.randn(T, 3 * d, device=dev)
-    O, LSE = ops.attn_fwd(model.cfg.prec, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, L, True, CFG["dropout"], model._seed, 16, 0)
+    mask = torch.zeros(B * H * L * 8, device=dev, dtype=torch.int32)   # dropout keep bits, as inside the step
+    O, LSE = ops.attn_fwd(model.cfg.prec, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, L, True, CFG["dropout"], model._seed, 16, 0, mask)
     dO = torch.randn(T, d, device=dev)
     for _ in range(3):
-        ops.attn_bwd(model.cfg.prec, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], O, LSE, dO, B, H, L, True, CFG["dropout"], model._seed, 16, 0)
+        ops.attn_bwd(model.cfg.prec, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], O, LSE, dO, B, H, L, True, CFG["dropout"], model._seed, 16, 0, mask)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     R = 20
     e0.record()
     for _ in range(R):
-        ops.attn_bwd(model.cfg.prec, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], O, LSE, dO, B, H, L, True, CFG["dropout"], model._seed, 16, 0)
+        ops.attn_bwd(model.cfg.prec, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], O, LSE, dO, B, H, L, True, CFG["dropout"], model._seed, 16, 0, mask)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / R

@@ -64,14 +64,16 @@ int adt_linear_bwd(int prec, const float* dY, int lddy, const float* X, int ldx,
 
 /* ---- attention core: _scaled_dot_product_attention (sasrec/modules.py:21-64) incl. head split/merge
  * (:457-468,:517); also torch.nn.MultiheadAttention's core for the decoder (:661-662,:669-672).
- * O = dropout(softmax(Q K^T / sqrt(hd) + causal)) V per (b, h); LSE saved for the backward. */
+ * O = dropout(softmax(Q K^T / sqrt(hd) + causal)) V per (b, h); LSE saved for the backward.
+ * mask (optional, B*H*L x 8 uint32): the bf16 forward stores its dropout keep decisions as bits (query-major, bit
+ * key % 32 of word key / 32) and the backward reads them instead of re-hashing; NULL = regenerate from the hash. */
 int adt_attn_fwd(int prec, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, int B,
                  int H, int L, int hd, int causal, float p, const uint32_t* seed, uint32_t site,
-                 uint32_t b_offset, float* O, int ldo, float* LSE, void* stream);
+                 uint32_t b_offset, float* O, int ldo, float* LSE, uint32_t* mask, void* stream);
 int adt_attn_bwd(int prec, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                  const float* O, int ldo, const float* LSE, const float* dO, int lddo, int B, int H, int L,
                  int hd, int causal, float p, const uint32_t* seed, uint32_t site, uint32_t b_offset,
-                 float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, void* stream);
+                 float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, const uint32_t* mask, void* stream);
 
 /* ---- independence head classifier: SparseInputLinear + log_softmax (sasrec/modules.py:648-649,679-703).
  * rec rows are in the reference's order (row l*B + b = token (b, l); sasrec/modules.py:518). */

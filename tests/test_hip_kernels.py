@@ -208,6 +208,16 @@ def test_attention_fwd_bwd(ops, prec, H, hd, L, causal, p):
     check(dQ.view(B, L, d), wq, TOL[prec] * 2, "attn dQ")
     check(dK.view(B, L, d), wk, TOL[prec] * 2, "attn dK")
     check(dV.view(B, L, d), wv, TOL[prec] * 2, "attn dV")
+    if p > 0:
+        # dropout keep-bit buffer: the forward records its decisions, the backward reads them instead of re-hashing
+        mask = torch.zeros(B * H * L * 8, device=dev(), dtype=torch.int32)
+        O2, LSE2 = ops.attn_fwd(prec, qkv_t[:, :d], qkv_t[:, d:2 * d], qkv_t[:, 2 * d:], B, H, L, causal, p, seed_t(seed), site, boff, mask)
+        assert torch.equal(O2, O)
+        dQ2, dK2, dV2 = ops.attn_bwd(prec, qkv_t[:, :d], qkv_t[:, d:2 * d], qkv_t[:, 2 * d:], O2, LSE2, T_(do.reshape(B * L, d)), B, H, L,
+                                     causal, p, seed_t(seed), site, boff, mask)
+        check(dQ2.view(B, L, d), wq, TOL[prec] * 2, "attn dQ (mask bits)")
+        check(dK2.view(B, L, d), wk, TOL[prec] * 2, "attn dK (mask bits)")
+        check(dV2.view(B, L, d), wv, TOL[prec] * 2, "attn dV (mask bits)")
 
 
 def test_attention_softmax_extremes(ops):
