@@ -38,6 +38,40 @@ ADT_DEVICE_INLINE void stage_bf16(__bf16* rowimg, __bf16* timg, int LPT, const f
   }
 }
 
+// One 8-element chunk (row r, columns c8..c8+7) of a staged tensor, as loaded from global memory.
+struct Chunk8 { float4 lo, hi; };
+
+template <int HD>
+ADT_DEVICE_INLINE Chunk8 chunk_load(const float* g, int ld, int i, int L, int LP) {
+  constexpr int V8 = HD / 8;
+  const int r = i / V8, c8 = (i % V8) * 8;
+  Chunk8 x;
+  x.lo = make_float4(0.f, 0.f, 0.f, 0.f);
+  x.hi = x.lo;
+  if (i < LP * V8 && r < L) {
+    x.lo = *reinterpret_cast<const float4*>(g + (size_t)r * ld + c8);
+    x.hi = *reinterpret_cast<const float4*>(g + (size_t)r * ld + c8 + 4);
+  }
+  return x;
+}
+
+template <int HD>
+ADT_DEVICE_INLINE void chunk_store(__bf16* rowimg, __bf16* timg, int LPT, const Chunk8& x, int i, int LP, float mul) {
+  constexpr int RS = BImg<HD>::RS;
+  constexpr int V8 = HD / 8;
+  if (i >= LP * V8) return;
+  const int r = i / V8, c8 = (i % V8) * 8;
+  const float v[8] = {x.lo.x, x.lo.y, x.lo.z, x.lo.w, x.hi.x, x.hi.y, x.hi.z, x.hi.w};
+  bf16x8 b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) b[j] = (__bf16)(v[j] * mul);
+  if (rowimg) *reinterpret_cast<bf16x8*>(rowimg + r * RS + c8) = b;
+  if (timg) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) timg[(c8 + j) * LPT + r] = b[j];
+  }
+}
+
 // 8 contiguous hd-elements of one row (operand with the lane on the row, contraction over hd)
 template <int HD>
 ADT_DEVICE_INLINE bf16x8 rfrag(const __bf16* rowimg, int row, int kb, int g) {
@@ -85,8 +119,21 @@ __global__ __launch_bounds__(NW * 64) void k_attn_fwd_bf16(AttnArgs a) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int L = a.L;
   const size_t row_b = (size_t)b * L;
-  stage_bf16<HD, NW * 64>(sK, nullptr, LPT, a.K + row_b * a.ldk + h * HD, a.ldk, L, LP, 1.0f);
-  stage_bf16<HD, NW * 64>(nullptr, sVT, LPT, a.V + row_b * a.ldv + h * HD, a.ldv, L, LP, 1.0f);
+  {
+    // all global loads of the staging are issued before the first conversion: one memory latency, not one per image
+    constexpr int NIT = (LP * (HD / 8) + NW * 64 - 1) / (NW * 64);
+    Chunk8 ck[NIT], cv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      ck[it] = chunk_load<HD>(a.K + row_b * a.ldk + h * HD, a.ldk, threadIdx.x + it * NW * 64, L, LP);
+      cv[it] = chunk_load<HD>(a.V + row_b * a.ldv + h * HD, a.ldv, threadIdx.x + it * NW * 64, L, LP);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      chunk_store<HD>(sK, nullptr, LPT, ck[it], threadIdx.x + it * NW * 64, LP, 1.0f);
+      chunk_store<HD>(nullptr, sVT, LPT, cv[it], threadIdx.x + it * NW * 64, LP, 1.0f);
+    }
+  }
   __syncthreads();
   const uint32_t key_rng = drop_key(a.drop);
   const int nqt = (L + 15) / 16;
@@ -235,23 +282,34 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_bf16(AttnArgs a) {
       reinterpret_cast<uint4*>(sM + r * 8)[i & 1] = v;
     }
   }
-  stage_bf16<HD, NW * 64>(sQ, sQT, LPT, a.Q + row_b * a.ldq + h * HD, a.ldq, L, LP, a.scale);
-  stage_bf16<HD, NW * 64>(sK, sKT, LPT, a.K + row_b * a.ldk + h * HD, a.ldk, L, LP, 1.0f);
-  stage_bf16<HD, NW * 64>(sV, nullptr, LPT, a.V + row_b * a.ldv + h * HD, a.ldv, L, LP, 1.0f);
-  stage_bf16<HD, NW * 64>(sdO, sdOT, LPT, a.dO + row_b * a.lddo + h * HD, a.lddo, L, LP, 1.0f);
   {
-    constexpr int V4 = HD / 4;
-    for (int i = threadIdx.x; i < LP * V4; i += NW * 64) {
-      const int r = i / V4, c4 = i % V4;
-      float part = 0.f;
-      if (r < L) {
-        const float4 v = *reinterpret_cast<const float4*>(a.dO + (row_b + r) * a.lddo + h * HD + 4 * c4);
-        const float4 o = *reinterpret_cast<const float4*>(a.O + (row_b + r) * a.ldo + h * HD + 4 * c4);
-        part = v.x * o.x + v.y * o.y + v.z * o.z + v.w * o.w;
-      }
+    // all global loads of the staging (Q, K, V, dO, O) are issued before the first conversion; delta = rowsum(dO*O)
+    // comes from the same dO / O chunks (the HD/8 lanes of a row are adjacent)
+    constexpr int V8 = HD / 8;
+    constexpr int NIT = (LP * V8 + NW * 64 - 1) / (NW * 64);
+    Chunk8 cq[NIT], ck[NIT], cv[NIT], cd[NIT], co[NIT];
 #pragma unroll
-      for (int off = V4 / 2; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-      if (c4 == 0) {
+    for (int it = 0; it < NIT; ++it) {
+      const int i = threadIdx.x + it * NW * 64;
+      cq[it] = chunk_load<HD>(a.Q + row_b * a.ldq + h * HD, a.ldq, i, L, LP);
+      ck[it] = chunk_load<HD>(a.K + row_b * a.ldk + h * HD, a.ldk, i, L, LP);
+      cv[it] = chunk_load<HD>(a.V + row_b * a.ldv + h * HD, a.ldv, i, L, LP);
+      cd[it] = chunk_load<HD>(a.dO + row_b * a.lddo + h * HD, a.lddo, i, L, LP);
+      co[it] = chunk_load<HD>(a.O + row_b * a.ldo + h * HD, a.ldo, i, L, LP);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = threadIdx.x + it * NW * 64;
+      chunk_store<HD>(sQ, sQT, LPT, cq[it], i, LP, a.scale);
+      chunk_store<HD>(sK, sKT, LPT, ck[it], i, LP, 1.0f);
+      chunk_store<HD>(sV, nullptr, LPT, cv[it], i, LP, 1.0f);
+      chunk_store<HD>(sdO, sdOT, LPT, cd[it], i, LP, 1.0f);
+      float part = cd[it].lo.x * co[it].lo.x + cd[it].lo.y * co[it].lo.y + cd[it].lo.z * co[it].lo.z + cd[it].lo.w * co[it].lo.w +
+                   cd[it].hi.x * co[it].hi.x + cd[it].hi.y * co[it].hi.y + cd[it].hi.z * co[it].hi.z + cd[it].hi.w * co[it].hi.w;
+#pragma unroll
+      for (int off = V8 / 2; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+      const int r = i / V8;
+      if (i < LP * V8 && (i % V8) == 0) {
         sDelta[r] = part;
         sLse[r] = (r < L) ? a.LSE[(size_t)bh * L + r] : INFINITY;
       }
