@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Train SASRec-ADT on the HIP hot path on the seeded synthetic ml-1m-shaped dataset and report NDCG@10 / HR@10 / AUC on
+the SAME frozen candidate sets the reference run (tools/ref_train_ndcg.py -> tests/golden/ref_ndcg_ml1m.json) used.
+    python tools/gpu_ndcg_run.py --preset ml1m --epochs 30 --seeds 23 24 25 --out gpurun_out/ndcg_ours.json
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def run(preset, epochs, eval_every, seed, precision, hidden=64, maxlen=200, data=None):
+    import torch
+    from adt_amd.sasrec import synth, utils as U
+    from adt_amd.sasrec.model import SASRecADT
+    from adt_amd.sasrec.trainer import FusedTrainer
+    hist, usernum, itemnum = data
+    user_train = {u: (v if len(v) < 3 else v[:-2]) for u, v in hist.items()}
+    user_valid = {u: ([] if len(v) < 3 else [v[-2]]) for u, v in hist.items()}
+    user_test = {u: ([] if len(v) < 3 else [v[-1]]) for u, v in hist.items()}
+
+    class A:
+        pass
+    a = A()
+    a.device, a.num_heads, a.maxlen, a.num_layers, a.hidden_units, a.dropout, a.precision = "cuda:0", 2, maxlen, 2, hidden, 0.5, precision
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    model = SASRecADT(usernum, itemnum, a)
+    for _, p in model.named_parameters():
+        try:
+            torch.nn.init.xavier_normal_(p.data)
+        except Exception:
+            pass
+    model.train()
+    lam1, lam2 = U.get_lambdas("ml-1m")
+    tr = FusedTrainer(model, lam1, lam2, lr=1e-3, weight_decay=1e-3, clip=5.0, use_graph=True, seed=seed)
+    warp = U.WarpDataset(user_train, usernum, itemnum, maxlen)
+    sampler = U.PopularSampler(user_train, user_valid, user_test, usernum, itemnum, 100)
+    evals = {m: U.EvalDataset(user_train, user_valid, user_test, usernum, itemnum, maxlen, sampler, mode=m, frozen=True, seed=23)
+             for m in ("val", "test")}
+    rng = np.random.RandomState(seed)
+    log = {"seed": seed, "evals": [], "loss": []}
+    t_train = 0.0
+    nseq = 0
+    for epoch in range(epochs):
+        t0 = time.time()
+        losses = []
+        for u, seq, dec, pos, neg in warp.epoch_batches(256, rng):
+            tr.step(seq, dec, pos, neg)
+            nseq += len(u)
+        torch.cuda.synchronize()
+        t_train += time.time() - t0
+        log["loss"].append(float(tr.loss()))
+        if (epoch + 1) % eval_every == 0 or epoch + 1 == epochs:
+            model.eval()
+            rec = {"epoch": epoch + 1}
+            for m in ("val", "test"):
+                (ndcg, hr), auc = U.evaluate_loader(model, evals[m].batches(512), None, m, [5, 10])
+                rec[m] = {"ndcg10": ndcg[10], "hr10": hr[10], "ndcg5": ndcg[5], "hr5": hr[5], "auc": auc}
+            model.train()
+            log["evals"].append(rec)
+            print(seed, rec, flush=True)
+    log["train_seconds_incl_host_sampling"] = t_train
+    log["sequences_per_sec_incl_host_sampling"] = nseq / t_train
+    return log
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--preset", default="ml1m")
+    ap.add_argument("--epochs", type=int, default=30)
+    ap.add_argument("--eval_every", type=int, default=10)
+    ap.add_argument("--seeds", type=int, nargs="+", default=[23])
+    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    from adt_amd.sasrec import synth
+    data = synth.generate(a.preset, 23)
+    runs = [run(a.preset, a.epochs, a.eval_every, s, a.precision, data=data) for s in a.seeds]
+    os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+    with open(a.out, "w") as f:
+        json.dump({"preset": a.preset, "precision": a.precision, "runs": runs}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
