@@ -16,7 +16,23 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SOURCES + HEADERS)
 
 
+HOST_SRC = "adt_hostdata.cpp"
+HOST_OUT = os.path.join(HERE, "libadt_host.so")
+
+
+def build_host(force=False, verbose=True):
+    """Host-side batch sampler (plain g++, OpenMP): no GPU code."""
+    if not force and os.path.exists(HOST_OUT) and os.path.getmtime(HOST_OUT) >= os.path.getmtime(os.path.join(HERE, HOST_SRC)):
+        return HOST_OUT
+    cmd = [os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-o", HOST_OUT, HOST_SRC]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=HERE)
+    return HOST_OUT
+
+
 def build(force=False, verbose=True):
+    build_host(force, verbose)
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

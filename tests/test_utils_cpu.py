@@ -77,3 +77,25 @@ def test_synthetic_generator_is_deterministic():
     h2, _, _ = synth.generate("tiny", 23)
     assert h1 == h2 and nu == 64 and ni == 120
     assert all(len(set(v)) == len(v) and min(v) >= 1 and max(v) <= ni for v in h1.values())
+
+
+def test_native_batch_sampler_matches_numpy_sampler():
+    """libadt_host.so (C++/OpenMP) vs the numpy sampler: identical seq/dec/pos, negatives obey the same contract."""
+    from adt_amd.sasrec import synth
+    h, nu, ni = synth.generate("tiny", 23)
+    tr = {u: (v if len(v) < 3 else v[:-2]) for u, v in h.items()}
+    wn = U.WarpDataset(tr, nu, ni, 20, native=True)
+    wp = U.WarpDataset(tr, nu, ni, 20, native=False)
+    if wn._native is None:
+        import pytest
+        pytest.skip("libadt_host.so not built")
+    users = list(range(1, nu + 1))
+    bn, bp = wn.sample_batch(users, np.random.RandomState(0)), wp.sample_batch(users, np.random.RandomState(0))
+    for k in (1, 2, 3):
+        assert (bn[k] == bp[k]).all()
+    assert ((bn[4] != 0) == (bp[4] != 0)).all()
+    for b, u in enumerate(users):
+        ng = bn[4][b]
+        assert not (set(ng[ng != 0].tolist()) & set(tr[u])) and ng.max() <= ni
+    b2 = wn.sample_batch(users, np.random.RandomState(0))
+    assert (b2[4] != bn[4]).any()      # a fresh stream every call
