@@ -74,8 +74,9 @@ ADT_DEVICE_INLINE void ffn_bwd_tile(const BwdChainArgs& a, float* scr, Coop<PREC
 
 // ---- encoder: y = mask(h2 + FFN(h2)), h2 = LN2(h), h = Qn + o Wo^T + bo ------------------------------------
 // W0 = conv2, W1 = conv1, W2 = out_proj ; out0 = dh (gradient wrt h == wrt Qn residual), out1 = dO
-template <int PREC, int NW>
+template <int PREC, int NW, int HC>   // HC: compile-time cap on the number of heads of the fused classifier (0 = none)
 __global__ __launch_bounds__(NW * 64) void k_enc_post_bwd(BwdChainArgs a) {
+  constexpr int HCM = HC > 0 ? HC : 1;
   BWD_PROLOGUE(3)
   stage_wimg<PREC, NW * 64>(lds.w[0], a.W0, true);
   stage_wimg<PREC, NW * 64>(lds.w[1], a.W1, true);
@@ -88,21 +89,21 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_bwd(BwdChainArgs a) {
   acc_zero(dW2); acc_zero(dW1); acc_zero(dWo);
   vacc_zero(db2); vacc_zero(db1); vacc_zero(dbo); vacc_zero(dgm); vacc_zero(dbt);
   // head classifier: column 16nt+c of this lane is element jcol of head hcol[nt]
-  const bool cls = a.drec != nullptr;
+  const bool cls = HC > 0 && a.drec != nullptr;
   const int hd = 64 / (a.H > 0 ? a.H : 1);
   int hcol[4];
-  float wcls[4][MAXH];
-  VAcc dws[MAXH];          // dws[cc].v[nt]: partial of dWs[cc][jcol(nt)] over this lane's rows
-  float dbs_acc[MAXH];
+  float wcls[4][HCM];
+  VAcc dws[HCM];          // dws[cc].v[nt]: partial of dWs[cc][jcol(nt)] over this lane's rows
+  float dbs_acc[HCM];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     hcol[nt] = (16 * nt + c) / hd;
     const int j = 16 * nt + c - hcol[nt] * hd;
 #pragma unroll
-    for (int cc = 0; cc < MAXH; ++cc) wcls[nt][cc] = (cls && cc < a.H) ? a.Ws[cc * hd + j] : 0.f;
+    for (int cc = 0; cc < HCM; ++cc) wcls[nt][cc] = (cls && cc < a.H) ? a.Ws[cc * hd + j] : 0.f;
   }
 #pragma unroll
-  for (int cc = 0; cc < MAXH; ++cc) { vacc_zero(dws[cc]); dbs_acc[cc] = 0.f; }
+  for (int cc = 0; cc < HCM; ++cc) { vacc_zero(dws[cc]); dbs_acc[cc] = 0.f; }
   RowRegs gy_rows = rows_load(a.gy, 64, tile * 16, a.T, lane);
   RowRegs h_rows = rows_load(a.xin, 64, tile * 16, a.T, lane);
   for (int rnd = 0; rnd < nrounds; ++rnd, tile += tstride) {
@@ -160,15 +161,15 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_bwd(BwdChainArgs a) {
         if (row0 + rl < a.T) {
 #pragma unroll 1
           for (int h = 0; h < a.H; ++h) {
-            float dz[MAXH];
+            float dz[HCM];
             float sd = 0.f;
 #pragma unroll
-            for (int cc = 0; cc < MAXH; ++cc) {
+            for (int cc = 0; cc < HCM; ++cc) {
               dz[cc] = (cc < a.H) ? lds.cls[256 + rl * HH + h * a.H + cc] : 0.f;
               sd += dz[cc];
             }
 #pragma unroll
-            for (int cc = 0; cc < MAXH; ++cc)
+            for (int cc = 0; cc < HCM; ++cc)
               if (cc < a.H) {
                 dz[cc] -= __expf(lds.cls[rl * HH + h * a.H + cc]) * sd;
                 if (c == 0) dbs_acc[cc] += dz[cc];
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_bwd(BwdChainArgs a) {
               if (hcol[nt] == h) {
                 float add = 0.f;
 #pragma unroll
-                for (int cc = 0; cc < MAXH; ++cc)
+                for (int cc = 0; cc < HCM; ++cc)
                   if (cc < a.H) {
                     add += dz[cc] * wcls[nt][cc];
                     dws[cc].v[nt] += dz[cc] * o.v[nt][r];
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_bwd(BwdChainArgs a) {
     // classifier weight gradient: H column-sum vectors folded modulo hd; bias: one value per (wave, g) through LDS
     float* red = reinterpret_cast<float*>(lds.coop);
 #pragma unroll
-    for (int cc = 0; cc < MAXH; ++cc) {
+    for (int cc = 0; cc < HCM; ++cc) {
       if (cc < a.H) {
         const VAcc* const accs[1] = {&dws[cc]};
         float* const dst[1] = {a.dWs + cc * hd};
@@ -205,12 +206,12 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_bwd(BwdChainArgs a) {
     __syncthreads();
     if (c == 0) {
 #pragma unroll
-      for (int cc = 0; cc < MAXH; ++cc) red[(w * 4 + g) * MAXH + cc] = dbs_acc[cc];
+      for (int cc = 0; cc < HCM; ++cc) red[(w * 4 + g) * HCM + cc] = dbs_acc[cc];
     }
     __syncthreads();
     if ((int)threadIdx.x < a.H) {
       float sb = 0.f;
-      for (int i = 0; i < NW * 4; ++i) sb += red[i * MAXH + threadIdx.x];
+      for (int i = 0; i < NW * 4; ++i) sb += red[i * HCM + threadIdx.x];
       atomicAdd(a.dbs + threadIdx.x, sb);
     }
   }

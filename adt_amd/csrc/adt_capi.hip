@@ -171,7 +171,9 @@ static int launch_bwdchain_t(int which, const BwdChainArgs& a, hipStream_t s) {
   const void* fn = nullptr;
   size_t smem = 0;
   switch (which) {
-    case 0: fn = (const void*)k_enc_post_bwd<PREC, NW>; smem = BwdLds<PREC, NW, 3>::bytes; break;
+    case 0: fn = (const void*)k_enc_post_bwd<PREC, NW, 0>; smem = BwdLds<PREC, NW, 3>::bytes; break;
+    case 6: fn = (const void*)k_enc_post_bwd<PREC, NW, 2>; smem = BwdLds<PREC, NW, 3>::bytes; break;
+    case 7: fn = (const void*)k_enc_post_bwd<PREC, NW, 4>; smem = BwdLds<PREC, NW, 3>::bytes; break;
     case 1: fn = (const void*)k_dec_post_bwd<PREC, NW>; smem = BwdLds<PREC, NW, 3>::bytes; break;
     case 2: fn = (const void*)k_pre_bwd<PREC, NW, true>; smem = BwdLds<PREC, NW, 3>::bytes; break;
     case 3: fn = (const void*)k_pre_bwd<PREC, NW, false>; smem = BwdLds<PREC, NW, 3>::bytes; break;
@@ -180,7 +182,7 @@ static int launch_bwdchain_t(int which, const BwdChainArgs& a, hipStream_t s) {
     default: return adt_set_error("bwdchain: bad kernel id %d", which);
   }
   if (smem > 160 * 1024) return adt_set_error("bwdchain %d: %zu B of LDS", which, smem);
-  static bool done[6] = {false, false, false, false, false, false};
+  static bool done[8] = {false, false, false, false, false, false, false, false};
   if (!done[which]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return adt_set_error("bwdchain: hipFuncSetAttribute");
@@ -207,13 +209,16 @@ static int launch_fwdchain_t(int which, const FwdChainArgs& a, hipStream_t s) {
   switch (which) {
     case 0: fn = (const void*)k_pre_fwd<PREC, NW, true>; smem = FwdLds<PREC, NW, 3>::bytes; break;
     case 1: fn = (const void*)k_pre_fwd<PREC, NW, false>; smem = FwdLds<PREC, NW, 3>::bytes; break;
-    case 2: fn = (const void*)k_enc_post_fwd<PREC, NW>; smem = FwdLds<PREC, NW, 3>::bytes; break;
+    case 2: fn = (const void*)k_enc_post_fwd<PREC, NW, 0>; smem = FwdLds<PREC, NW, 3>::bytes; break;
+    case 6: fn = (const void*)k_enc_post_fwd<PREC, NW, 2>; smem = FwdLds<PREC, NW, 3>::bytes; break;
+    case 7: fn = (const void*)k_enc_post_fwd<PREC, NW, 4>; smem = FwdLds<PREC, NW, 3>::bytes; break;
+    case 8: fn = (const void*)k_enc_post_fwd<PREC, NW, 8>; smem = FwdLds<PREC, NW, 3>::bytes; break;
     case 3: fn = (const void*)k_dec_mid_fwd<PREC, NW>; smem = FwdLds<PREC, NW, 2>::bytes; break;
     case 4: fn = (const void*)k_dec_post_fwd<PREC, NW>; smem = FwdLds<PREC, NW, 3>::bytes; break;
     case 5: fn = (const void*)k_final_fwd<PREC, NW>; smem = FwdLds<PREC, NW, 4>::bytes; break;
     default: return adt_set_error("fwdchain: bad kernel id %d", which);
   }
-  static bool done[6] = {false, false, false, false, false, false};
+  static bool done[9] = {false, false, false, false, false, false, false, false, false};
   if (!done[which]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return adt_set_error("fwdchain: hipFuncSetAttribute");

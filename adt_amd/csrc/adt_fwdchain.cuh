@@ -97,8 +97,9 @@ __global__ __launch_bounds__(NW * 64) void k_pre_fwd(FwdChainArgs a) {
 
 // ---- encoder post: h = qn + o Wo^T + bo ; h2 = LN2(h) ; u = relu(drop1(h2 W1^T + b1)) ; y = (h2 + drop2(u W2^T + b2)) * mask
 // W0 = out_proj, W1 = conv1, W2 = conv2 ; o0 = h, o1 = u, o2 = y ; optional head classifier on o -> rec
-template <int PREC, int NW>
+template <int PREC, int NW, int HC>   // HC: compile-time cap on the number of heads of the fused classifier (0 = none)
 __global__ __launch_bounds__(NW * 64) void k_enc_post_fwd(FwdChainArgs a) {
+  constexpr int HCM = HC > 0 ? HC : 1;
   FWD_PROLOGUE(3)
   stage_wimg<PREC, NW * 64>(lds.w[0], a.W[0], false);
   stage_wimg<PREC, NW * 64>(lds.w[1], a.W[1], false);
@@ -107,13 +108,13 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_fwd(FwdChainArgs a) {
   const uint32_t key1 = adt_site_key(seedv, a.site1), key2 = adt_site_key(seedv, a.site2);
   const int hd = 64 / a.H;
   int hcol[4];
-  float wcls[4][MAXH];
+  float wcls[4][HCM];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     hcol[nt] = (16 * nt + c) / hd;
     const int j = 16 * nt + c - hcol[nt] * hd;
 #pragma unroll
-    for (int cc = 0; cc < MAXH; ++cc) wcls[nt][cc] = (a.rec && cc < a.H) ? a.Ws[cc * hd + j] : 0.f;
+    for (int cc = 0; cc < HCM; ++cc) wcls[nt][cc] = (a.rec && cc < a.H) ? a.Ws[cc * hd + j] : 0.f;
   }
   for (int tile = blockIdx.x * NW + w; tile < ntiles; tile += tstride) {
     const int row0 = tile * 16;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_fwd(FwdChainArgs a) {
     rows_to_scr(lds.scr, a.x, 64, row0, a.T, lane);
     wave_fence();
     const AFrags<PREC> ao = scr_to_a<PREC>(lds.scr, c, g);
-    if (a.rec) {
+    if (HC > 0 && a.rec) {
       // head classifier (sasrec/modules.py:648-649): z[h][cc] = sum_j o[h*hd + j] Ws[cc][j] + bs[cc]; log-softmax over cc.
       // Column 16nt+c of this lane belongs to head hcol[nt]; one 16-lane row reduction per (row, head, class).
       const CT o = scr_to_ct(lds.scr, c, g);
@@ -131,9 +132,9 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_fwd(FwdChainArgs a) {
         const int row = row0 + 4 * g + r;
 #pragma unroll 1
         for (int h = 0; h < a.H; ++h) {
-          float z[MAXH];
+          float z[HCM];
 #pragma unroll
-          for (int cc = 0; cc < MAXH; ++cc) {
+          for (int cc = 0; cc < HCM; ++cc) {
             z[cc] = -INFINITY;
             if (cc < a.H) {
               float s = 0.f;
@@ -144,16 +145,16 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_fwd(FwdChainArgs a) {
           }
           float m = z[0];
 #pragma unroll
-          for (int cc = 1; cc < MAXH; ++cc) m = fmaxf(m, z[cc]);
+          for (int cc = 1; cc < HCM; ++cc) m = fmaxf(m, z[cc]);
           float se = 0.f;
 #pragma unroll
-          for (int cc = 0; cc < MAXH; ++cc) se += (cc < a.H) ? __expf(z[cc] - m) : 0.f;
+          for (int cc = 0; cc < HCM; ++cc) se += (cc < a.H) ? __expf(z[cc] - m) : 0.f;
           const float lz = m + __logf(se);
           if (c == 0 && row < a.T) {
             const int b = row / a.L, l = row - b * a.L;
             float* dst = a.rec + ((size_t)(l * a.B + b) * a.H + h) * a.H;
 #pragma unroll
-            for (int cc = 0; cc < MAXH; ++cc)
+            for (int cc = 0; cc < HCM; ++cc)
               if (cc < a.H) dst[cc] = z[cc] - lz;
           }
         }

@@ -189,8 +189,12 @@ int encoder_forward(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, cons
       a.W[2] = P + lo.enc(i, E_C2W); a.b[2] = P + lo.enc(i, E_C2B);
       a.gamma = P + lo.enc(i, E_LN2W); a.beta = P + lo.enc(i, E_LN2B);
       a.o0 = h; a.ld0 = d; a.o1 = u; a.ld1 = d; a.o2 = y; a.ld2 = d;
-      if (training_outputs) { a.rec = rec; a.Ws = P + lo.enc(i, E_SW); a.bs = P + lo.enc(i, E_SB); }
-      CK(adt_launch_fwdchain(prec, 2, a, st));
+      int which = 2;
+      if (training_outputs) {
+        a.rec = rec; a.Ws = P + lo.enc(i, E_SW); a.bs = P + lo.enc(i, E_SB);
+        which = H <= 2 ? 6 : (H <= 4 ? 7 : 8);     // classifier width specialisations
+      }
+      CK(adt_launch_fwdchain(prec, which, a, st));
     }
   }
   // log_feats = last_layernorm(encoder out); pos/neg logits; [k2, v2] of every decoder layer   (model.py:48, :72-76)
@@ -442,11 +446,13 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.db0 = G + lo.enc(i, E_C2B); a.db1 = G + lo.enc(i, E_C1B); a.db2 = G + lo.enc(i, E_OB);
         a.dgamma = G + lo.enc(i, E_LN2W); a.dbeta = G + lo.enc(i, E_LN2B);
         a.out0 = s5; a.out1 = s1;
+        int which = 0;
         if (H > 1 && H <= 4) {   // independence-head classifier reverse, fused (sasrec/modules.py:648-649; main.py:160-169)
+          which = H <= 2 ? 6 : 7;
           a.rec = rec; a.drec = ws + w.g_rec + i * recsz; a.Ws = P + lo.enc(i, E_SW); a.dWs = G + lo.enc(i, E_SW);
           a.dbs = G + lo.enc(i, E_SB); a.H = H;
         }
-        CK(adt_launch_bwdchain(prec, 0, a, st));
+        CK(adt_launch_bwdchain(prec, which, a, st));
       }
       if (H > 4)   // wider classifiers: separate kernel
         CK(adt_headcls_bwd(o, d, P + lo.enc(i, E_SW), rec, ws + w.g_rec + i * recsz, (int)w.B, L, H, hd, s1, d, G + lo.enc(i, E_SW),
