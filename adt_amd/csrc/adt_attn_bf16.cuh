@@ -338,7 +338,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_bf16(AttnArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) dq[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const uint32_t idx_q = (idx_bh + (uint32_t)q) * (uint32_t)L;
-#pragma unroll
+#pragma unroll 1
     for (int kp = 0; kp < MAXKT / 2; ++kp) {
       if (2 * kp < nkt) {
         float dsv[8];
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_bf16(AttnArgs a) {
       dv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int qp0 = a.causal ? kt / 2 : 0;
-#pragma unroll
+#pragma unroll 1
     for (int qp = 0; qp < MAXKT / 2; ++qp) {
       if (qp >= qp0 && 2 * qp < nqt) {
         float pv[8], dsv[8];
