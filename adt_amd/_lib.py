@@ -49,6 +49,25 @@ SIGNATURES = {
     "adt_nll_seed": (_I, [_P, _I, _I, _F, _P, _P, _P, _P]),
     "adt_clip_adam": (_I, [_P, _P, _P, _P, _L, _L, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
     "adt_score_rank": (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
+    # ---- general ("wide") stage kernels
+    "adt_dense_fwd": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _F, _P, _U, _U, _P, _I, _P, _P, _I, _P, _P]),
+    "adt_dense_bwd": (_I, [_I, _P, _I, _I, _I, _I, _P, _F, _P, _U, _U, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P]),
+    "adt_attn_masked_fwd": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _F, _F, _P, _U, _U, _P, _I, _P, _P]),
+    "adt_attn_masked_bwd": (_I, [_I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _F, _F, _P, _U, _U,
+                                 _P, _I, _P, _I, _P, _I, _P]),
+    "adt_embed_sum_fwd": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _P, _P]),
+    "adt_dropact_fwd": (_I, [_P, _L, _F, _P, _U, _U, _I, _P, _P]),
+    "adt_dropact_bwd": (_I, [_P, _P, _L, _F, _P, _U, _U, _I, _P, _I, _P]),
+    "adt_gather_rows": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P]),
+    "adt_scatter_rows": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P]),
+    "adt_ce_rows": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P]),
+    "adt_clip_adam_l2": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
+    "adt_score_rank_bias": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "adt_wattn_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P, _U, _U, _P, _I, _P, _I, _P, _P]),
+    "adt_wattn_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F,
+                           _P, _U, _U, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "adt_wdist_bpr": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "adt_wdist_full": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P]),
     "adt_sasrec_param_layout": (_L, [_CP, _P]),
     "adt_sasrec_workspace_floats": (_L, [_CP, _I]),
     "adt_sasrec_ws_offset": (_L, [_CP, _I, _I, _I]),

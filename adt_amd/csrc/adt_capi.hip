@@ -485,9 +485,30 @@ int adt_clip_adam(float* P, float* G, float* M, float* V, int64_t n, int64_t nE,
   return check_launch("clip_adam");
 }
 
+int adt_clip_adam_l2(float* P, float* G, float* M, float* V, int64_t n, float l2, float clip, float lr, float b1, float b2,
+                     float eps, float grad_scale, float* scal, void* stream) {
+  OptArgs a{};
+  a.P = P; a.G = G; a.M = M; a.Vv = V; a.n = (size_t)n; a.nE = 0; a.wd = 0.f; a.clip = clip; a.lr = lr;
+  a.b1 = b1; a.b2 = b2; a.eps = eps; a.scal = scal; a.grad_scale = grad_scale; a.l2 = l2;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(scal + 64, 0, 128 * sizeof(float), s) != hipSuccess) return adt_set_error("clip_adam_l2: memset");
+  hipLaunchKernelGGL(k_wd_gradnorm, dim3(grid_for((size_t)n, 256, 512)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_adam, dim3(grid_for((size_t)n, 256, 1024)), dim3(256), 0, s, a);
+  return check_launch("clip_adam_l2");
+}
+
+int adt_score_rank_bias(const float* F, int ldf, const float* E, const float* bias, const int32_t* cand, int B, int C, int d,
+                        float* logits, int32_t* rank, void* stream) {
+  ScoreArgs a{F, ldf, E, cand, B, C, d, logits, rank, bias};
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_score, dim3(grid_for((size_t)B * C, 16, 4096)), dim3(256), 0, s, a);
+  if (rank) hipLaunchKernelGGL(k_rank, dim3(grid_for(B, 4, 1024)), dim3(256), 0, s, a);
+  return check_launch("score_rank_bias");
+}
+
 int adt_score_rank(const float* F, int ldf, const float* E, const int32_t* cand, int B, int C, int d,
                    float* logits, int32_t* rank, void* stream) {
-  ScoreArgs a{F, ldf, E, cand, B, C, d, logits, rank};
+  ScoreArgs a{F, ldf, E, cand, B, C, d, logits, rank, nullptr};
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_score, dim3(grid_for((size_t)B * C, 16, 4096)), dim3(256), 0, s, a);
   if (rank) hipLaunchKernelGGL(k_rank, dim3(grid_for(B, 4, 1024)), dim3(256), 0, s, a);

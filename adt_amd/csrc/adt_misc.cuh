@@ -380,6 +380,7 @@ struct OptArgs {
   float* scal;       // device scalars: [0] ||E||^2  [1] ||g||^2  [2] step (float)  [3] wd loss term ; [64..128) partial
                      // sums of ||E||^2, [128..192) partial sums of ||g||^2 (64 sub-slots each: no same-address contention)
   float grad_scale;  // multiply grads first (1/world for averaged all-reduce; normally 1)
+  float l2;          // Adam's coupled weight_decay (bert4rec/trainer.py:41): g += l2 * p AFTER clipping; 0 = off
 };
 
 __global__ __launch_bounds__(256) void k_sumsq(const float* x, size_t n, float* out) {
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(256) void k_adam(OptArgs a) {
   const float bc1 = 1.0f - powf(a.b1, t), bc2 = 1.0f - powf(a.b2, t);
   const float step = a.lr / bc1, rs2 = 1.0f / sqrtf(bc2);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
-    const float g = a.G[i] * coef;
+    const float g = a.G[i] * coef + a.l2 * a.P[i];
     const float m = a.b1 * a.M[i] + (1.0f - a.b1) * g;
     const float v = a.b2 * a.Vv[i] + (1.0f - a.b2) * g * g;
     a.M[i] = m;
@@ -446,6 +447,7 @@ struct ScoreArgs {
   int B, C, d;
   float* logits;             // B x C
   int* rank;                 // B (may be null)
+  const float* bias;         // optional per-item bias (bert4rec/model/bert.py:89 mask_bias)
 };
 
 __global__ __launch_bounds__(256) void k_score(ScoreArgs a) {
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(256) void k_score(ScoreArgs a) {
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (sub == 0) a.logits[i] = s;
+    if (sub == 0) a.logits[i] = s + (a.bias ? a.bias[item] : 0.f);
   }
 }
 

@@ -1,0 +1,137 @@
+// Row / elementwise kernels shared by the BERT4Rec-ADT and STOSA-ADT paths: summed embeddings, dropout+activation,
+// masked-row gather/scatter, softmax cross-entropy over all items.  HBM-bound: float4 accesses, wave reductions.
+#pragma once
+#include "adt_common.cuh"
+#include "adt_gemm.cuh"
+
+namespace adt {
+
+// X[row] = E[ids[row]] * scale + P[row % L] (+ S0): bert4rec/model/modules.py:42-46 (word + position + sentence 0),
+// stosa/models.py:183-210 (item + position).  Unlike sasrec's embedding no padding mask is applied here.
+struct EmbedSumArgs {
+  const int* ids; const float* E; const float* P; const float* S0;
+  float scale; int T, L, d;
+  float* X;
+};
+
+__global__ __launch_bounds__(256) void k_embed_sum_fwd(EmbedSumArgs a) {
+  const int V = a.d / 4;
+  const size_t n = (size_t)a.T * V;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / V), c4 = (int)(i % V) * 4;
+    const float4 e = *reinterpret_cast<const float4*>(a.E + (size_t)a.ids[row] * a.d + c4);
+    const float4 p = *reinterpret_cast<const float4*>(a.P + (size_t)(row % a.L) * a.d + c4);
+    float4 v = make_float4(e.x * a.scale + p.x, e.y * a.scale + p.y, e.z * a.scale + p.z, e.w * a.scale + p.w);
+    if (a.S0) {
+      const float4 s = *reinterpret_cast<const float4*>(a.S0 + c4);
+      v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+    }
+    *reinterpret_cast<float4*>(a.X + (size_t)row * a.d + c4) = v;
+  }
+}
+
+// Y = act(dropout(X)) / dX (+)= dY * act'(dropout(X)) * keep / (1 - p); element index idx_offset + i
+struct DropActArgs {
+  const float* X; const float* dY; float* Y; float* dX;
+  size_t n; DropCfg drop; uint32_t idx_offset; int act; int accumulate;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_dropact(DropActArgs a) {
+  const uint32_t key = drop_key(a.drop);
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < a.n; i += (size_t)gridDim.x * 1024) {
+    float x[4], o[4];
+    *reinterpret_cast<float4*>(x) = *reinterpret_cast<const float4*>(a.X + i);
+    float dy[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BWD) {
+      *reinterpret_cast<float4*>(dy) = *reinterpret_cast<const float4*>(a.dY + i);
+      if (a.accumulate) *reinterpret_cast<float4*>(o) = *reinterpret_cast<const float4*>(a.dX + i);
+      else o[0] = o[1] = o[2] = o[3] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float ks = 1.0f;
+      if (a.drop.thr) ks = adt_keep(key, a.idx_offset + (uint32_t)(i + j), a.drop.thr) ? a.drop.scale : 0.f;
+      const float u = x[j] * ks;
+      if constexpr (BWD) o[j] += dy[j] * act_grad(a.act, u) * ks;
+      else o[j] = act_apply(a.act, u);
+    }
+    if constexpr (BWD) *reinterpret_cast<float4*>(a.dX + i) = *reinterpret_cast<float4*>(o);
+    else *reinterpret_cast<float4*>(a.Y + i) = *reinterpret_cast<float4*>(o);
+  }
+}
+
+// out[i] = F[rows[i]] (gather) / dF[rows[i]] (+)= G[i] (scatter; rows are distinct)
+struct RowsArgs {
+  const float* src; int lds; float* dst; int ldd; const int* rows; int M, d; int scatter; int accumulate;
+  const int* m_dev;   // optional DEVICE row count: M = min(M, *m_dev)
+};
+
+__global__ __launch_bounds__(256) void k_rows(RowsArgs a) {
+  const int V = a.d / 4;
+  const int M = (a.m_dev && *a.m_dev < a.M) ? *a.m_dev : a.M;
+  const size_t n = (size_t)M * V;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int m = (int)(i / V), c4 = (int)(i % V) * 4;
+    const int r = a.rows[m];
+    const size_t so = a.scatter ? (size_t)m * a.lds + c4 : (size_t)r * a.lds + c4;
+    const size_t dof = a.scatter ? (size_t)r * a.ldd + c4 : (size_t)m * a.ldd + c4;
+    float4 v = *reinterpret_cast<const float4*>(a.src + so);
+    if (a.accumulate) {
+      const float4 o = *reinterpret_cast<const float4*>(a.dst + dof);
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    *reinterpret_cast<float4*>(a.dst + dof) = v;
+  }
+}
+
+// nn.CrossEntropyLoss(ignore_index=0) over all items (bert4rec/trainer.py:45,113-115): one workgroup per row of the
+// (M x V) logits; loss slot += w * (lse - z[label]); logits are overwritten with w * (softmax - onehot), w = *inv_count
+// (1 / number of non-ignored labels of the GLOBAL batch); rows with label 0 get zero gradient.
+struct CeArgs {
+  float* logits; int ld; const int* labels; int M, V; const float* inv_count; float* loss; const int* m_dev;
+};
+
+ADT_DEVICE_INLINE float block_max256(float v, float* sbuf) {
+  v = wave_max(v);
+  if ((threadIdx.x & 63) == 0) sbuf[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float r = fmaxf(fmaxf(sbuf[0], sbuf[1]), fmaxf(sbuf[2], sbuf[3]));
+  __syncthreads();
+  return r;
+}
+ADT_DEVICE_INLINE float block_sum256(float v, float* sbuf) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sbuf[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float r = (sbuf[0] + sbuf[1]) + (sbuf[2] + sbuf[3]);
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_ce_rows(CeArgs a) {
+  __shared__ float sbuf[4];
+  const float w = *a.inv_count;
+  const int M = (a.m_dev && *a.m_dev < a.M) ? *a.m_dev : a.M;
+  for (int m = blockIdx.x; m < M; m += gridDim.x) {
+    float* z = a.logits + (size_t)m * a.ld;
+    const int label = a.labels[m];
+    if (label == 0) {
+      for (int j = threadIdx.x; j < a.V; j += 256) z[j] = 0.f;
+      continue;
+    }
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < a.V; j += 256) mx = fmaxf(mx, z[j]);
+    mx = block_max256(mx, sbuf);
+    float s = 0.f;
+    for (int j = threadIdx.x; j < a.V; j += 256) s += expf(z[j] - mx);
+    s = block_sum256(s, sbuf);
+    const float lse = mx + logf(s);
+    if (threadIdx.x == 0) atomicAdd(a.loss + (m & 63), w * (lse - z[label]));
+    __syncthreads();   // z[label] read before it is overwritten
+    const float inv = 1.0f / s;
+    for (int j = threadIdx.x; j < a.V; j += 256) z[j] = w * (expf(z[j] - mx) * inv - (j == label ? 1.0f : 0.f));
+  }
+}
+
+}  // namespace adt

@@ -1,0 +1,266 @@
+// C ABI (include/adt_hip.h, "wide" section): launch wrappers for the general dense layers, the masked attention and
+// the row kernels used by the BERT4Rec-ADT and STOSA-ADT paths.  Host code only enqueues work on the caller's stream.
+#include "adt_host.h"
+
+#include "adt_attn_gen.cuh"
+#include "adt_gemm.cuh"
+#include "adt_stosa.cuh"
+#include "adt_wide.cuh"
+
+using namespace adt;
+
+static int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return adt_set_error("%s: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+static int grid_for(size_t work_items, int per_block, int cap) {
+  size_t g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > (size_t)cap) g = cap;
+  return (int)g;
+}
+
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ---- masked attention dispatch ---------------------------------------------------------------------------------
+template <int PREC, int HD, int MAXKT>
+static int launch_attn_gen(bool bwd, const AttnGenArgs& a, hipStream_t s) {
+  constexpr int NW = 8;
+  const size_t smem = bwd ? AttnGenLds<PREC, HD, MAXKT>::bwd_bytes : AttnGenLds<PREC, HD, MAXKT>::fwd_bytes;
+  if (smem > 160 * 1024) return adt_set_error("masked attention: L=%d hd=%d prec=%d needs %zu B of LDS (> 160 KB)", a.a.L, HD, PREC, smem);
+  const void* fn = bwd ? (const void*)k_attn_gen_bwd<PREC, HD, MAXKT, NW> : (const void*)k_attn_gen_fwd<PREC, HD, MAXKT, NW>;
+  static bool done[2] = {false, false};
+  if (!done[bwd ? 1 : 0]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return adt_set_error("masked attention: hipFuncSetAttribute(%zu)", smem);
+    done[bwd ? 1 : 0] = true;
+  }
+  AttnGenArgs args = a;
+  void* kargs[] = {&args};
+  if (hipLaunchKernel(fn, dim3(a.a.B * a.a.H), dim3(NW * 64), kargs, smem, s) != hipSuccess) return adt_set_error("masked attention: launch failed");
+  return check_launch(bwd ? "attn_masked_bwd" : "attn_masked_fwd");
+}
+
+template <int PREC, int HD>
+static int dispatch_attn_gen_l(bool bwd, const AttnGenArgs& a, hipStream_t s) {
+  if (a.a.L <= 64) return launch_attn_gen<PREC, HD, 4>(bwd, a, s);
+  if (a.a.L <= 128) return launch_attn_gen<PREC, HD, 8>(bwd, a, s);
+  if (a.a.L <= 224) return launch_attn_gen<PREC, HD, 14>(bwd, a, s);
+  return adt_set_error("masked attention: L=%d > 224 unsupported", a.a.L);
+}
+
+template <int PREC>
+static int dispatch_attn_gen(bool bwd, int hd, const AttnGenArgs& a, hipStream_t s) {
+  if (hd == 16) return dispatch_attn_gen_l<PREC, 16>(bwd, a, s);
+  if (hd == 32) return dispatch_attn_gen_l<PREC, 32>(bwd, a, s);
+  if (hd == 64) return dispatch_attn_gen_l<PREC, 64>(bwd, a, s);
+  return adt_set_error("masked attention: head_dim=%d unsupported (16/32/64)", hd);
+}
+
+template <int PREC>
+static int launch_dense_fwd(const DenseFwdArgs& a, hipStream_t s) {
+  if (a.N > 64) hipLaunchKernelGGL((k_dense_fwd<PREC, 128>), dim3((a.N + 127) / 128, (a.T + GBM - 1) / GBM), dim3(GTH), 0, s, a);
+  else hipLaunchKernelGGL((k_dense_fwd<PREC, 64>), dim3(1, (a.T + GBM - 1) / GBM), dim3(GTH), 0, s, a);
+  return check_launch("dense_fwd");
+}
+
+template <int PREC>
+static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
+  DenseBwdArgs a = a0;
+  const int T = a.G.T, N = a.G.N, K = a.K;
+  if (a.dX) {
+    if (K > 64) hipLaunchKernelGGL((k_dense_bwd_dx<PREC, 128>), dim3((K + 127) / 128, (T + GBM - 1) / GBM), dim3(GTH), 0, s, a);
+    else hipLaunchKernelGGL((k_dense_bwd_dx<PREC, 64>), dim3(1, (T + GBM - 1) / GBM), dim3(GTH), 0, s, a);
+  }
+  if (a.dW) {
+    const int bn = K > 64 ? 128 : 64;
+    const int gx = (K + bn - 1) / bn, gy = (N + GBM - 1) / GBM;
+    // split T so that about 1024 workgroups are in flight; chunks are multiples of 32 rows
+    int splits = (1024 + gx * gy - 1) / (gx * gy);
+    int chunk = ((T + splits - 1) / splits + 31) / 32 * 32;
+    if (chunk < 32) chunk = 32;
+    splits = (T + chunk - 1) / chunk;
+    a.t_chunk = chunk;
+    if (bn == 128) hipLaunchKernelGGL((k_dense_bwd_dw<PREC, 128>), dim3(gx, gy, splits), dim3(GTH), 0, s, a);
+    else hipLaunchKernelGGL((k_dense_bwd_dw<PREC, 64>), dim3(gx, gy, splits), dim3(GTH), 0, s, a);
+  }
+  return check_launch("dense_bwd");
+}
+
+extern "C" {
+
+int adt_dense_fwd(int prec, const float* X, int ldx, const float* W, int ldw, const float* b, int T, int K, int N, int act, float* U,
+                  int ldu, float p, const uint32_t* seed, uint32_t site, uint32_t row_offset, const float* R, int ldr,
+                  const int32_t* mask_ids, float* Y, int ldy, const int32_t* t_dev, void* stream) {
+  if (T <= 0 || K <= 0 || N <= 0) return adt_set_error("dense_fwd: empty shape");
+  if ((ldx % 4) || (ldw % 4) || !aligned16(X) || !aligned16(W)) return adt_set_error("dense_fwd: operands must be 16-byte aligned with ld %% 4 == 0");
+  if (act < 0 || act > ACT_ELU1) return adt_set_error("dense_fwd: act=%d", act);
+  DenseFwdArgs a{};
+  a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.b = b; a.T = T; a.K = K; a.N = N; a.Y = Y; a.ldy = ldy; a.U = U; a.ldu = ldu; a.act = act;
+  a.drop = adt_make_drop(p, seed, site); a.row_offset = row_offset; a.R = R; a.ldr = ldr; a.ids = mask_ids; a.t_dev = t_dev;
+  return prec == ADT_PREC_F32 ? launch_dense_fwd<PREC_F32>(a, (hipStream_t)stream) : launch_dense_fwd<PREC_BF16>(a, (hipStream_t)stream);
+}
+
+int adt_dense_bwd(int prec, const float* dY, int lddy, int T, int K, int N, const int32_t* mask_ids, float p, const uint32_t* seed,
+                  uint32_t site, uint32_t row_offset, int act, const float* U, int ldu, const float* X, int ldx, const float* W, int ldw,
+                  float* dX, int lddx, int beta, float* dW, int lddw, float* db, const int32_t* t_dev, void* stream) {
+  if (T <= 0 || K <= 0 || N <= 0) return adt_set_error("dense_bwd: empty shape");
+  if ((lddy % 4) || !aligned16(dY) || (dW && ((ldx % 4) || !aligned16(X))) || (dX && ((ldw % 4) || !aligned16(W))))
+    return adt_set_error("dense_bwd: operands must be 16-byte aligned with ld %% 4 == 0");
+  if (act != ACT_NONE && !U) return adt_set_error("dense_bwd: activation gradient needs the saved pre-activation U");
+  DenseBwdArgs a{};
+  a.G.dY = dY; a.G.lddy = lddy; a.G.T = T; a.G.N = N; a.G.U = U; a.G.ldu = ldu; a.G.act = act;
+  a.G.drop = adt_make_drop(p, seed, site); a.G.row_offset = row_offset; a.G.ids = mask_ids;
+  a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.K = K; a.dX = dX; a.lddx = lddx; a.beta = beta; a.dW = dW; a.lddw = lddw; a.db = db; a.t_dev = t_dev;
+  return prec == ADT_PREC_F32 ? launch_dense_bwd<PREC_F32>(a, (hipStream_t)stream) : launch_dense_bwd<PREC_BF16>(a, (hipStream_t)stream);
+}
+
+static int fill_attn(AttnGenArgs& g, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, int B, int H, int L, int hd,
+                     int causal, const int32_t* kid, float fill, float p, const uint32_t* seed, uint32_t site, uint32_t b_offset) {
+  if ((ldq % 4) || (ldk % 4) || (ldv % 4) || (hd % 8)) return adt_set_error("masked attention: ld %% 4, hd %% 8");
+  g.a.Q = Q; g.a.ldq = ldq; g.a.K = K; g.a.ldk = ldk; g.a.V = V; g.a.ldv = ldv; g.a.B = B; g.a.H = H; g.a.L = L; g.a.causal = causal;
+  g.a.scale = 1.0f / sqrtf((float)hd); g.a.drop = adt_make_drop(p, seed, site); g.a.bh_offset = b_offset * (uint32_t)H;
+  g.kid = kid; g.fill = fill;
+  return 0;
+}
+
+int adt_attn_masked_fwd(int prec, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, int B, int H, int L, int hd,
+                        int causal, const int32_t* key_ids, float fill, float p, const uint32_t* seed, uint32_t site, uint32_t b_offset,
+                        float* O, int ldo, float* LSE, void* stream) {
+  AttnGenArgs g{};
+  if (fill_attn(g, Q, ldq, K, ldk, V, ldv, B, H, L, hd, causal, key_ids, fill, p, seed, site, b_offset)) return -1;
+  g.a.O = O; g.a.ldo = ldo; g.a.LSE = LSE;
+  return prec == ADT_PREC_F32 ? dispatch_attn_gen<PREC_F32>(false, hd, g, (hipStream_t)stream) : dispatch_attn_gen<PREC_BF16>(false, hd, g, (hipStream_t)stream);
+}
+
+int adt_attn_masked_bwd(int prec, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
+                        const float* LSE, const float* dO, int lddo, int B, int H, int L, int hd, int causal, const int32_t* key_ids,
+                        float fill, float p, const uint32_t* seed, uint32_t site, uint32_t b_offset, float* dQ, int lddq, float* dK,
+                        int lddk, float* dV, int lddv, void* stream) {
+  AttnGenArgs g{};
+  if (fill_attn(g, Q, ldq, K, ldk, V, ldv, B, H, L, hd, causal, key_ids, fill, p, seed, site, b_offset)) return -1;
+  if ((ldo % 4) || (lddo % 4) || (lddq % 4) || (lddk % 4) || (lddv % 4)) return adt_set_error("masked attention bwd: ld %% 4");
+  g.a.O = const_cast<float*>(O); g.a.ldo = ldo; g.a.LSE = const_cast<float*>(LSE); g.a.dO = dO; g.a.lddo = lddo;
+  g.a.dQ = dQ; g.a.lddq = lddq; g.a.dK = dK; g.a.lddk = lddk; g.a.dV = dV; g.a.lddv = lddv;
+  return prec == ADT_PREC_F32 ? dispatch_attn_gen<PREC_F32>(true, hd, g, (hipStream_t)stream) : dispatch_attn_gen<PREC_BF16>(true, hd, g, (hipStream_t)stream);
+}
+
+int adt_embed_sum_fwd(const int32_t* ids, const float* E, const float* P, const float* S0, float scale, int T, int L, int d, float* X,
+                      void* stream) {
+  if (d % 4) return adt_set_error("embed_sum_fwd: d %% 4");
+  EmbedSumArgs a{ids, E, P, S0, scale, T, L, d, X};
+  hipLaunchKernelGGL(k_embed_sum_fwd, dim3(grid_for((size_t)T * d / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("embed_sum_fwd");
+}
+
+int adt_dropact_fwd(const float* X, int64_t n, float p, const uint32_t* seed, uint32_t site, uint32_t idx_offset, int act, float* Y,
+                    void* stream) {
+  if (n % 4) return adt_set_error("dropact_fwd: n %% 4");
+  DropActArgs a{};
+  a.X = X; a.Y = Y; a.n = (size_t)n; a.drop = adt_make_drop(p, seed, site); a.idx_offset = idx_offset; a.act = act;
+  hipLaunchKernelGGL(k_dropact<false>, dim3(grid_for((size_t)n / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("dropact_fwd");
+}
+
+int adt_dropact_bwd(const float* dY, const float* X, int64_t n, float p, const uint32_t* seed, uint32_t site, uint32_t idx_offset, int act,
+                    float* dX, int accumulate, void* stream) {
+  if (n % 4) return adt_set_error("dropact_bwd: n %% 4");
+  DropActArgs a{};
+  a.X = X; a.dY = dY; a.dX = dX; a.n = (size_t)n; a.drop = adt_make_drop(p, seed, site); a.idx_offset = idx_offset; a.act = act;
+  a.accumulate = accumulate;
+  hipLaunchKernelGGL(k_dropact<true>, dim3(grid_for((size_t)n / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("dropact_bwd");
+}
+
+int adt_gather_rows(const float* F, int ldf, const int32_t* rows, int M, const int32_t* m_dev, int d, float* out, int ldo, void* stream) {
+  if (M <= 0) return 0;
+  if ((d % 4) || (ldf % 4) || (ldo % 4)) return adt_set_error("gather_rows: d, ld %% 4");
+  RowsArgs a{F, ldf, out, ldo, rows, M, d, 0, 0, m_dev};
+  hipLaunchKernelGGL(k_rows, dim3(grid_for((size_t)M * d / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("gather_rows");
+}
+
+int adt_scatter_rows(const float* G, int ldg, const int32_t* rows, int M, const int32_t* m_dev, int d, float* dF, int lddf, int accumulate,
+                     void* stream) {
+  if (M <= 0) return 0;
+  if ((d % 4) || (ldg % 4) || (lddf % 4)) return adt_set_error("scatter_rows: d, ld %% 4");
+  RowsArgs a{G, ldg, dF, lddf, rows, M, d, 1, accumulate, m_dev};
+  hipLaunchKernelGGL(k_rows, dim3(grid_for((size_t)M * d / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("scatter_rows");
+}
+
+int adt_ce_rows(float* logits, int ld, const int32_t* labels, int M, const int32_t* m_dev, int V, const float* inv_count, float* loss64,
+                void* stream) {
+  if (M <= 0) return 0;
+  CeArgs a{logits, ld, labels, M, V, inv_count, loss64, m_dev};
+  hipLaunchKernelGGL(k_ce_rows, dim3(M < 4096 ? M : 4096), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("ce_rows");
+}
+
+// ---- STOSA-ADT (adt_stosa.cuh) ----------------------------------------------------------------------------------
+int adt_wattn_fwd(const float* Qm, int ldqm, const float* Qc, int ldqc, const float* Km, int ldkm, const float* Kc, int ldkc,
+                  const float* Vm, int ldvm, const float* Vc, int ldvc, const int32_t* key_ids, int B, int H, int L, int hd, float p,
+                  const uint32_t* seed, uint32_t site, uint32_t b_offset, float* Om, int ldom, float* Oc, int ldoc, float* LSE,
+                  void* stream) {
+  if (hd != 16 && hd != 32 && hd != 64) return adt_set_error("wattn: head_dim=%d unsupported (16/32/64)", hd);
+  if (L > 256) return adt_set_error("wattn: L=%d > 256 unsupported", L);
+  WAttnArgs a{};
+  a.Qm = Qm; a.ldqm = ldqm; a.Qc = Qc; a.ldqc = ldqc; a.Km = Km; a.ldkm = ldkm; a.Kc = Kc; a.ldkc = ldkc; a.Vm = Vm; a.ldvm = ldvm;
+  a.Vc = Vc; a.ldvc = ldvc; a.kid = key_ids; a.B = B; a.H = H; a.L = L; a.hd = hd; a.scale = 1.0f / sqrtf((float)hd);
+  a.drop = adt_make_drop(p, seed, site); a.bh_offset = b_offset * (uint32_t)H; a.Om = Om; a.ldom = ldom; a.Oc = Oc; a.ldoc = ldoc; a.LSE = LSE;
+  const size_t smem = wattn_lds_bytes(L, hd, false);
+  if (smem > 160 * 1024) return adt_set_error("wattn_fwd: %zu B of LDS", smem);
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute((const void*)k_wattn_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return adt_set_error("wattn_fwd: hipFuncSetAttribute");
+    done = true;
+  }
+  hipLaunchKernelGGL(k_wattn_fwd, dim3(B * H), dim3(256), smem, (hipStream_t)stream, a);
+  return check_launch("wattn_fwd");
+}
+
+int adt_wattn_bwd(const float* Qm, int ldqm, const float* Qc, int ldqc, const float* Km, int ldkm, const float* Kc, int ldkc,
+                  const float* Vm, int ldvm, const float* Vc, int ldvc, const int32_t* key_ids, const float* Om, int ldom, const float* Oc,
+                  int ldoc, const float* LSE, const float* dOm, int lddom, const float* dOc, int lddoc, int B, int H, int L, int hd, float p,
+                  const uint32_t* seed, uint32_t site, uint32_t b_offset, float* dQm, float* dQc, float* dKm, float* dKc, float* dVm,
+                  float* dVc, int ldd, void* stream) {
+  if (hd != 16 && hd != 32 && hd != 64) return adt_set_error("wattn: head_dim=%d unsupported (16/32/64)", hd);
+  if (L > 256) return adt_set_error("wattn: L=%d > 256 unsupported", L);
+  WAttnArgs a{};
+  a.Qm = Qm; a.ldqm = ldqm; a.Qc = Qc; a.ldqc = ldqc; a.Km = Km; a.ldkm = ldkm; a.Kc = Kc; a.ldkc = ldkc; a.Vm = Vm; a.ldvm = ldvm;
+  a.Vc = Vc; a.ldvc = ldvc; a.kid = key_ids; a.B = B; a.H = H; a.L = L; a.hd = hd; a.scale = 1.0f / sqrtf((float)hd);
+  a.drop = adt_make_drop(p, seed, site); a.bh_offset = b_offset * (uint32_t)H;
+  a.Om = const_cast<float*>(Om); a.ldom = ldom; a.Oc = const_cast<float*>(Oc); a.ldoc = ldoc; a.LSE = const_cast<float*>(LSE);
+  a.dOm = dOm; a.lddom = lddom; a.dOc = dOc; a.lddoc = lddoc;
+  a.dQm = dQm; a.dQc = dQc; a.dKm = dKm; a.dKc = dKc; a.dVm = dVm; a.dVc = dVc; a.ldd = ldd;
+  const size_t smem = wattn_lds_bytes(L, hd, true);
+  if (smem > 160 * 1024) return adt_set_error("wattn_bwd: %zu B of LDS", smem);
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute((const void*)k_wattn_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return adt_set_error("wattn_bwd: hipFuncSetAttribute");
+    done = true;
+  }
+  hipLaunchKernelGGL(k_wattn_bwd, dim3(B * H), dim3(256), smem, (hipStream_t)stream, a);
+  return check_launch("wattn_bwd");
+}
+
+int adt_wdist_bpr(const float* Sm, const float* Sc, int lds, const float* Em, const float* Ec, const int32_t* pos, const int32_t* neg, int T,
+                  int d, float pvn_weight, const float* inv_count, float* dSm, float* dSc, int ldds, float* dEm, float* dEc, float* loss3,
+                  void* stream) {
+  if (d % 64) return adt_set_error("wdist_bpr: d=%d must be a multiple of 64", d);
+  WBprArgs a{Sm, Sc, lds, Em, Ec, pos, neg, T, d, pvn_weight, inv_count, dSm, dSc, ldds, dEm, dEc, loss3};
+  hipLaunchKernelGGL(k_wdist_bpr, dim3(grid_for(T, 4, 2048)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("wdist_bpr");
+}
+
+int adt_wdist_full(const float* Sm, const float* Sc, int lds, const float* Em, const float* Ec, int B, int V, int d, float* dist, int ldo,
+                   void* stream) {
+  if (d % 4) return adt_set_error("wdist_full: d %% 4");
+  WFullArgs a{Sm, Sc, lds, Em, Ec, B, V, d, dist, ldo};
+  hipLaunchKernelGGL(k_wdist_full, dim3(grid_for((size_t)B * V, 16, 4096)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("wdist_full");
+}
+
+}  // extern "C"

@@ -169,3 +169,148 @@ def score_rank(F, ldf, E, cand, B, C, want_rank=True):
     rank = torch.empty(B, device=E.device, dtype=torch.int32) if want_rank else None
     _lib.check(_lib.load().adt_score_rank(_p(F), ldf, _p(E), _p(cand), B, C, d, _p(logits), _p(rank), _stream()), "score_rank")
     return logits, rank
+
+
+# ---- general ("wide") stage kernels: BERT4Rec-ADT, STOSA-ADT (include/adt_hip.h) ------------------------------------
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_ELU, ACT_ELU1 = 0, 1, 2, 3, 4
+
+
+def dense_fwd(prec, X, W, b=None, act=ACT_NONE, save_u=False, p=0.0, seed=None, site=0, row_offset=0, R=None, mask_ids=None, Y=None,
+              t_dev=None, ldy=None):
+    """Y = mask(R + dropout(act(X W^T + b))); returns (Y, U) with U the saved pre-activation (or None)."""
+    T, K = X.shape
+    N = W.shape[0]
+    if Y is None:
+        ldy = N if ldy is None else ldy
+        Y = torch.empty(T, ldy, device=X.device, dtype=torch.float32)[:, :N]
+    U = torch.empty(T, N, device=X.device, dtype=torch.float32) if save_u else None
+    _lib.check(_lib.load().adt_dense_fwd(prec, _p(_f32(X)), _ld(X), _p(_f32(W)), _ld(W), _p(b), T, K, N, act, _p(U), _ld(U), float(p), _p(seed),
+                                         site, row_offset, _p(R), _ld(R), _p(mask_ids), _p(Y), _ld(Y), _p(t_dev), _stream()), "dense_fwd")
+    return Y, U
+
+
+def dense_bwd(prec, dY, X, W, dW=None, db=None, dX=None, beta=False, act=ACT_NONE, U=None, p=0.0, seed=None, site=0, row_offset=0,
+              mask_ids=None, t_dev=None):
+    """G = dY * mask * dropmask * act'(U); dX (+)= G W; dW += G^T X; db += colsum(G)."""
+    T, N = dY.shape
+    K = W.shape[1]
+    _lib.check(_lib.load().adt_dense_bwd(prec, _p(_f32(dY)), _ld(dY), T, K, N, _p(mask_ids), float(p), _p(seed), site, row_offset, act, _p(U),
+                                         _ld(U), _p(X), _ld(X), _p(_f32(W)), _ld(W), _p(dX), _ld(dX), int(beta), _p(dW), _ld(dW) if dW is not None else 0,
+                                         _p(db), _p(t_dev), _stream()), "dense_bwd")
+
+
+def attn_masked_fwd(prec, Q, K, V, B, H, L, causal=False, key_ids=None, fill=-1e9, p=0.0, seed=None, site=0, b_offset=0):
+    d = Q.shape[1]
+    hd = d // H
+    O = torch.empty(B * L, d, device=Q.device, dtype=torch.float32)
+    LSE = torch.empty(B * H * L, device=Q.device, dtype=torch.float32)
+    _lib.check(_lib.load().adt_attn_masked_fwd(prec, _p(_f32(Q)), _ld(Q), _p(_f32(K)), _ld(K), _p(_f32(V)), _ld(V), B, H, L, hd, int(causal),
+                                               _p(key_ids), float(fill), float(p), _p(seed), site, b_offset, _p(O), d, _p(LSE), _stream()),
+               "attn_masked_fwd")
+    return O, LSE
+
+
+def attn_masked_bwd(prec, Q, K, V, O, LSE, dO, B, H, L, causal=False, key_ids=None, fill=-1e9, p=0.0, seed=None, site=0, b_offset=0, out=None):
+    d = Q.shape[1]
+    hd = d // H
+    if out is None:
+        dQ = torch.empty(B * L, d, device=Q.device, dtype=torch.float32)
+        dK = torch.empty_like(dQ)
+        dV = torch.empty_like(dQ)
+    else:
+        dQ, dK, dV = out
+    _lib.check(_lib.load().adt_attn_masked_bwd(prec, _p(_f32(Q)), _ld(Q), _p(_f32(K)), _ld(K), _p(_f32(V)), _ld(V), _p(_f32(O)), _ld(O), _p(LSE),
+                                               _p(_f32(dO)), _ld(dO), B, H, L, hd, int(causal), _p(key_ids), float(fill), float(p), _p(seed), site,
+                                               b_offset, _p(dQ), _ld(dQ), _p(dK), _ld(dK), _p(dV), _ld(dV), _stream()), "attn_masked_bwd")
+    return dQ, dK, dV
+
+
+def embed_sum_fwd(ids, E, P, L, S0=None, scale=1.0):
+    T = ids.numel()
+    d = E.shape[1]
+    X = torch.empty(T, d, device=E.device, dtype=torch.float32)
+    _lib.check(_lib.load().adt_embed_sum_fwd(_p(_i32(ids)), _p(_f32(E)), _p(_f32(P)), _p(S0), float(scale), T, L, d, _p(X), _stream()), "embed_sum_fwd")
+    return X
+
+
+def dropact_fwd(X, p, seed, site, idx_offset=0, act=ACT_NONE):
+    Y = torch.empty_like(X)
+    _lib.check(_lib.load().adt_dropact_fwd(_p(_f32(X)), X.numel(), float(p), _p(seed), site, idx_offset, act, _p(Y), _stream()), "dropact_fwd")
+    return Y
+
+
+def dropact_bwd(dY, X, p, seed, site, dX, accumulate, idx_offset=0, act=ACT_NONE):
+    _lib.check(_lib.load().adt_dropact_bwd(_p(_f32(dY)), _p(_f32(X)), X.numel(), float(p), _p(seed), site, idx_offset, act, _p(dX), int(accumulate),
+                                           _stream()), "dropact_bwd")
+
+
+def gather_rows(F, rows, M=None, m_dev=None):
+    M = rows.numel() if M is None else M
+    d = F.shape[1]
+    out = torch.empty(M, d, device=F.device, dtype=torch.float32)
+    _lib.check(_lib.load().adt_gather_rows(_p(_f32(F)), _ld(F), _p(_i32(rows)), M, _p(m_dev), d, _p(out), d, _stream()), "gather_rows")
+    return out
+
+
+def scatter_rows(G, rows, dF, accumulate, M=None, m_dev=None):
+    M = rows.numel() if M is None else M
+    _lib.check(_lib.load().adt_scatter_rows(_p(_f32(G)), _ld(G), _p(_i32(rows)), M, _p(m_dev), G.shape[1], _p(dF), _ld(dF), int(accumulate), _stream()),
+               "scatter_rows")
+
+
+def ce_rows(logits, labels, V, inv_count, loss64, M=None, m_dev=None):
+    M = logits.shape[0] if M is None else M
+    _lib.check(_lib.load().adt_ce_rows(_p(_f32(logits)), _ld(logits), _p(_i32(labels)), M, _p(m_dev), V, _p(inv_count), _p(loss64), _stream()), "ce_rows")
+
+
+def clip_adam_l2(P, G, M, V, l2, clip, lr, b1, b2, eps, scal, grad_scale=1.0, n=None):
+    n = P.numel() if n is None else n
+    _lib.check(_lib.load().adt_clip_adam_l2(_p(P), _p(G), _p(M), _p(V), n, float(l2), float(clip), float(lr), float(b1), float(b2), float(eps),
+                                            float(grad_scale), _p(scal), _stream()), "clip_adam_l2")
+
+
+def score_rank_bias(F, ldf, E, bias, cand, B, C, want_rank=True):
+    d = E.shape[1]
+    logits = torch.empty(B, C, device=E.device, dtype=torch.float32)
+    rank = torch.empty(B, device=E.device, dtype=torch.int32) if want_rank else None
+    _lib.check(_lib.load().adt_score_rank_bias(_p(F), ldf, _p(E), _p(bias), _p(cand), B, C, d, _p(logits), _p(rank), _stream()), "score_rank_bias")
+    return logits, rank
+
+
+def wattn_fwd(Qm, Qc, Km, Kc, Vm, Vc, key_ids, B, H, L, p=0.0, seed=None, site=0, b_offset=0):
+    d = Qm.shape[1]
+    hd = d // H
+    Om = torch.empty(B * L, d, device=Qm.device, dtype=torch.float32)
+    Oc = torch.empty_like(Om)
+    LSE = torch.empty(B * H * L, device=Qm.device, dtype=torch.float32)
+    _lib.check(_lib.load().adt_wattn_fwd(_p(_f32(Qm)), _ld(Qm), _p(_f32(Qc)), _ld(Qc), _p(_f32(Km)), _ld(Km), _p(_f32(Kc)), _ld(Kc), _p(_f32(Vm)), _ld(Vm),
+                                         _p(_f32(Vc)), _ld(Vc), _p(_i32(key_ids)), B, H, L, hd, float(p), _p(seed), site, b_offset, _p(Om), d, _p(Oc), d,
+                                         _p(LSE), _stream()), "wattn_fwd")
+    return Om, Oc, LSE
+
+
+def wattn_bwd(Qm, Qc, Km, Kc, Vm, Vc, key_ids, Om, Oc, LSE, dOm, dOc, B, H, L, p=0.0, seed=None, site=0, b_offset=0):
+    d = Qm.shape[1]
+    hd = d // H
+    outs = [torch.empty(B * L, d, device=Qm.device, dtype=torch.float32) for _ in range(6)]
+    _lib.check(_lib.load().adt_wattn_bwd(_p(_f32(Qm)), _ld(Qm), _p(_f32(Qc)), _ld(Qc), _p(_f32(Km)), _ld(Km), _p(_f32(Kc)), _ld(Kc), _p(_f32(Vm)), _ld(Vm),
+                                         _p(_f32(Vc)), _ld(Vc), _p(_i32(key_ids)), _p(Om), _ld(Om), _p(Oc), _ld(Oc), _p(LSE), _p(_f32(dOm)), _ld(dOm),
+                                         _p(_f32(dOc)), _ld(dOc), B, H, L, hd, float(p), _p(seed), site, b_offset, *[_p(o) for o in outs], d, _stream()),
+               "wattn_bwd")
+    return outs
+
+
+def wdist_bpr(Sm, Sc, Em, Ec, pos, neg, pvn_weight, inv_count, dEm, dEc, loss3):
+    T, d = Sm.shape
+    dSm = torch.empty(T, d, device=Sm.device, dtype=torch.float32)
+    dSc = torch.empty_like(dSm)
+    _lib.check(_lib.load().adt_wdist_bpr(_p(_f32(Sm)), _p(_f32(Sc)), _ld(Sm), _p(Em), _p(Ec), _p(_i32(pos)), _p(_i32(neg)), T, d, float(pvn_weight),
+                                         _p(inv_count), _p(dSm), _p(dSc), d, _p(dEm), _p(dEc), _p(loss3), _stream()), "wdist_bpr")
+    return dSm, dSc
+
+
+def wdist_full(Sm, Sc, Em, Ec, V):
+    B, d = Sm.shape
+    dist = torch.empty(B, V, device=Sm.device, dtype=torch.float32)
+    _lib.check(_lib.load().adt_wdist_full(_p(_f32(Sm)), _p(_f32(Sc)), _ld(Sm), _p(Em), _p(Ec), B, V, d, _p(dist), V, _stream()), "wdist_full")
+    return dist

@@ -1,0 +1,199 @@
+"""Host-side plumbing shared by the BERT4Rec-ADT and STOSA-ADT models: one flat fp32 parameter buffer with the
+reference's state_dict names as views, and a small launch tape that strings the C-ABI stage kernels
+(include/adt_hip.h, "wide" section) into a forward pass and its reverse.
+
+Nothing here computes on the host or through torch operators: tensors are allocated with torch (device memory,
+streams, HIP-graph capture) and every arithmetic step is a kernel of libadt_hip.so.  A missing library raises.
+"""
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+
+class _Holder(torch.nn.Module):
+    """Plain container so that named_parameters()/state_dict() reproduce the reference's dotted names."""
+
+
+def _set_nested(root, dotted, param):
+    parts = dotted.split(".")
+    m = root
+    for p in parts[:-1]:
+        if not hasattr(m, p):
+            m.add_module(p, _Holder())
+        m = getattr(m, p)
+    m.register_parameter(parts[-1], param)
+
+
+class FlatModule(torch.nn.Module):
+    """nn.Module whose parameters are views into ONE flat fp32 GPU buffer (`flat`), with an identically laid-out
+    gradient buffer (`flat_grad`): the optimizer and the gradient all-reduce see one array.  Tensors start on 16-byte
+    boundaries; tensors listed consecutively with sizes that are multiples of 4 floats are contiguous, which is what
+    lets q/k/v projections run as one GEMM over a (3d, d) view."""
+
+    def _build_flat(self, table, device):
+        self.lib = _lib.load()   # raises when the HIP library is missing: no fallback
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise _lib.AdtError("%s (adt_amd) needs a GPU device, got %r" % (type(self).__name__, device))
+        self.table = list(table)
+        off = 0
+        self._views = {}
+        for name, shape in self.table:
+            n = int(np.prod(shape))
+            self._views[name] = (off, n, tuple(shape))
+            off += (n + 3) // 4 * 4
+        self.n_flat = off
+        self.flat = torch.zeros(off, device=self.dev, dtype=torch.float32)
+        self.flat_grad = torch.zeros_like(self.flat)
+        for name, shape in self.table:
+            o, n, _ = self._views[name]
+            _set_nested(self, name, torch.nn.Parameter(self.flat[o:o + n].view(shape), requires_grad=True))
+        self._seed = torch.zeros(1, device=self.dev, dtype=torch.int32)   # uint32 bits of the dropout seed, device resident
+        self._step_seed = 0
+
+    def _apply(self, fn, recurse=True):
+        probe = fn(self.flat)
+        if probe.device != self.flat.device or probe.dtype != self.flat.dtype:
+            raise _lib.AdtError("%s (adt_amd) parameters live in one flat fp32 GPU buffer; .to(%s, %s) is unsupported"
+                                % (type(self).__name__, probe.device, probe.dtype))
+        return self
+
+    def P(self, name):
+        o, n, shape = self._views[name]
+        return self.flat[o:o + n].view(shape)
+
+    def G(self, name):
+        o, n, shape = self._views[name]
+        return self.flat_grad[o:o + n].view(shape)
+
+    def span(self, first, last, shape, grad=False):
+        """One view over the consecutive tensors first..last (e.g. query/key/value weights as (3d, d))."""
+        o0 = self._views[first][0]
+        o1, n1, _ = self._views[last]
+        buf = self.flat_grad if grad else self.flat
+        v = buf[o0:o1 + n1]
+        assert v.numel() == int(np.prod(shape)), (first, last, shape, v.numel())
+        return v.view(shape)
+
+    def set_seed(self, seed):
+        self._seed.fill_(int(np.array([seed & 0xFFFFFFFF], dtype=np.uint32).view(np.int32)[0]))
+
+    def next_seed(self):
+        self._step_seed += 1
+        self.set_seed(self._step_seed * 2654435761 + 12345)
+
+    def ids(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.dev, dtype=torch.int32).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=np.int32)).to(self.dev)
+
+    def load_numpy(self, P):
+        for k, v in P.items():
+            self.P(k).copy_(torch.from_numpy(np.ascontiguousarray(v)))
+
+
+class Act:
+    """An activation and (lazily) its gradient buffer."""
+    __slots__ = ("t", "g")
+
+    def __init__(self, t):
+        self.t = t
+        self.g = None
+
+
+def add_into(dst, src):
+    """dst += src through the library's elementwise kernel (dropout off, identity activation)."""
+    ops.dropact_bwd(src, src, 0.0, None, 0, dst, True)
+
+
+def give(a, g):
+    """Hand gradient `g` (complete, not used again by the caller) to activation `a`."""
+    if a.g is None:
+        a.g = g
+    else:
+        add_into(a.g, g)
+
+
+class Tape:
+    """Forward launches + the closures that undo them.  `prec`: ops.PREC_*; `seed`: device uint32; `row_offset`: first
+    global token row of this data-parallel shard (dropout indices are global)."""
+
+    def __init__(self, model, prec, training, row_offset=0, b_offset=0):
+        self.m, self.prec, self.training = model, prec, training
+        self.seed = model._seed
+        self.row_offset, self.b_offset = row_offset, b_offset
+        self.bw = []
+
+    def p_eff(self, p):
+        return float(p) if self.training else 0.0
+
+    def backward(self):
+        for f in reversed(self.bw):
+            f()
+        self.bw = []
+
+    # ---- Linear (+ activation, dropout, residual) -------------------------------------------------------------------
+    def dense(self, x, W, b, gW, gb, act=ops.ACT_NONE, p=0.0, site=0, R=None, t_dev=None, ldy=None):
+        p = self.p_eff(p)
+        Y, U = ops.dense_fwd(self.prec, x.t, W, b, act, act != ops.ACT_NONE, p, self.seed, site, self.row_offset, None if R is None else R.t,
+                             None, None, t_dev, ldy)
+        y = Act(Y)
+
+        def bw():
+            if y.g is None:
+                return
+            if x.g is None:
+                x.g = torch.empty_like(x.t)
+                beta = False
+            else:
+                beta = True
+            ops.dense_bwd(self.prec, y.g, x.t, W, gW, gb, x.g, beta, act, U, p, self.seed, site, self.row_offset, None, t_dev)
+            if R is not None:
+                give(R, y.g)
+        self.bw.append(bw)
+        return y
+
+    def layernorm(self, x, w, b, gw, gb, eps):
+        y = Act(ops.layernorm_fwd(x.t, w, b, eps))
+
+        def bw():
+            if y.g is None:
+                return
+            acc = x.g is not None
+            if not acc:
+                x.g = torch.empty_like(x.t)
+            ops.layernorm_bwd(y.g, x.t, w, eps, x.g, acc, gw, gb)
+        self.bw.append(bw)
+        return y
+
+    def dropact(self, x, p, site, act=ops.ACT_NONE):
+        p = self.p_eff(p)
+        if p == 0.0 and act == ops.ACT_NONE:
+            return x
+        off = self.row_offset * x.t.shape[1]
+        y = Act(ops.dropact_fwd(x.t, p, self.seed, site, off, act))
+
+        def bw():
+            if y.g is None:
+                return
+            acc = x.g is not None
+            if not acc:
+                x.g = torch.empty_like(x.t)
+            ops.dropact_bwd(y.g, x.t, p, self.seed, site, x.g, acc, off, act)
+        self.bw.append(bw)
+        return y
+
+    def headcls(self, o, Ws, bs, gWs, gbs):
+        """Independence head classifier + log_softmax on (T, H*hd) attention outputs, natural (b, l) row order."""
+        T = o.t.shape[0]
+        rec = Act(ops.headcls_fwd(o.t, Ws, bs, 1, T))
+
+        def bw():
+            if rec.g is None:
+                return
+            if o.g is None:
+                o.g = torch.zeros_like(o.t)
+            ops.headcls_bwd(o.t, Ws, rec.t, rec.g, 1, T, o.g, gWs, gbs)
+        self.bw.append(bw)
+        return rec

@@ -124,6 +124,83 @@ int adt_clip_adam(float* P, float* G, float* M, float* V, int64_t n, int64_t nE,
 int adt_score_rank(const float* F, int ldf, const float* E, const int32_t* cand, int B, int C, int d,
                    float* logits, int32_t* rank, void* stream);
 
+/* ==== general ("wide") stage kernels: BERT4Rec-ADT, STOSA-ADT and d > 64 configurations ======================= */
+#define ADT_ACT_NONE 0
+#define ADT_ACT_RELU 1
+#define ADT_ACT_GELU 2   /* nn.GELU(), erf form (bert4rec/model/modules.py:125) */
+#define ADT_ACT_ELU 3    /* nn.ELU() (stosa/modules.py:477) */
+#define ADT_ACT_ELU1 4   /* ELU(x) + 1 (stosa/modules.py:236-238) */
+
+/* torch.nn.Linear with its surrounding elementwise ops, any K / N (bert4rec/model/modules.py:59-75,128-139,
+ * bert.py:48-51,80-90; stosa/modules.py:199-212,477-487): Y = mask(R + dropout(act(X W^T + b))); W is N x K with row
+ * stride ldw; U (optional) receives the pre-activation X W^T + b for the backward.  t_dev (optional, DEVICE int): only
+ * rows < min(T, *t_dev) are computed -- batches of masked rows whose count changes per step under a captured graph. */
+int adt_dense_fwd(int prec, const float* X, int ldx, const float* W, int ldw, const float* b, int T, int K, int N,
+                  int act, float* U, int ldu, float p, const uint32_t* seed, uint32_t site, uint32_t row_offset,
+                  const float* R, int ldr, const int32_t* mask_ids, float* Y, int ldy, const int32_t* t_dev, void* stream);
+/* G = dY * mask * dropmask * act'(U);  dX = (beta ? dX : 0) + G W (dX NULL = skip);  dW += G^T X, db += colsum(G)
+ * (dW NULL = skip; db may be NULL). */
+int adt_dense_bwd(int prec, const float* dY, int lddy, int T, int K, int N, const int32_t* mask_ids, float p,
+                  const uint32_t* seed, uint32_t site, uint32_t row_offset, int act, const float* U, int ldu,
+                  const float* X, int ldx, const float* W, int ldw, float* dX, int lddx, int beta, float* dW, int lddw,
+                  float* db, const int32_t* t_dev, void* stream);
+
+/* Masked attention core, bidirectional or causal, with key padding: bert4rec/model/modules.py:76-101.  Scores of masked
+ * keys (key_ids[b*L + j] <= 0, or j > i when causal) are REPLACED by `fill` (-1e9 in the reference) and carry no
+ * gradient; key_ids may be NULL. */
+int adt_attn_masked_fwd(int prec, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, int B, int H,
+                        int L, int hd, int causal, const int32_t* key_ids, float fill, float p, const uint32_t* seed,
+                        uint32_t site, uint32_t b_offset, float* O, int ldo, float* LSE, void* stream);
+int adt_attn_masked_bwd(int prec, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O,
+                        int ldo, const float* LSE, const float* dO, int lddo, int B, int H, int L, int hd, int causal,
+                        const int32_t* key_ids, float fill, float p, const uint32_t* seed, uint32_t site, uint32_t b_offset,
+                        float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, void* stream);
+
+/* X[row] = E[ids[row]] * scale + P[row % L] (+ S0): bert4rec/model/modules.py:42-46, stosa/models.py:183-210 */
+int adt_embed_sum_fwd(const int32_t* ids, const float* E, const float* P, const float* S0, float scale, int T, int L,
+                      int d, float* X, void* stream);
+/* Y = act(dropout(X)) over n elements (index idx_offset + i); backward dX (+)= dY * act'(dropout(X)) * keep/(1-p) */
+int adt_dropact_fwd(const float* X, int64_t n, float p, const uint32_t* seed, uint32_t site, uint32_t idx_offset, int act,
+                    float* Y, void* stream);
+int adt_dropact_bwd(const float* dY, const float* X, int64_t n, float p, const uint32_t* seed, uint32_t site,
+                    uint32_t idx_offset, int act, float* dX, int accumulate, void* stream);
+/* out[i] = F[rows[i]];  dF[rows[i]] (+)= G[i] (distinct rows): the masked positions of bert4rec/trainer.py:113-115.
+ * m_dev (optional, DEVICE int) caps M like t_dev above. */
+int adt_gather_rows(const float* F, int ldf, const int32_t* rows, int M, const int32_t* m_dev, int d, float* out, int ldo,
+                    void* stream);
+int adt_scatter_rows(const float* G, int ldg, const int32_t* rows, int M, const int32_t* m_dev, int d, float* dF, int lddf,
+                     int accumulate, void* stream);
+/* nn.CrossEntropyLoss(ignore_index=0) (bert4rec/trainer.py:45,113-115) on M rows of V logits: loss64[m & 63] += w *
+ * (lse - z[label]); logits overwritten by w * (softmax - onehot); w = *inv_count; label 0 => zero row. */
+int adt_ce_rows(float* logits, int ld, const int32_t* labels, int M, const int32_t* m_dev, int V, const float* inv_count,
+                float* loss64, void* stream);
+/* adt_clip_adam plus Adam's coupled weight_decay l2 (g += l2 * p after clipping): bert4rec/trainer.py:41,137-138 */
+int adt_clip_adam_l2(float* P, float* G, float* M, float* V, int64_t n, float l2, float clip, float lr, float b1, float b2,
+                     float eps, float grad_scale, float* scal, void* stream);
+/* adt_score_rank with a per-item bias (bert4rec/model/bert.py:89,110-116) */
+int adt_score_rank_bias(const float* F, int ldf, const float* E, const float* bias, const int32_t* cand, int B, int C,
+                        int d, float* logits, int32_t* rank, void* stream);
+
+/* ---- STOSA-ADT: Wasserstein attention (stosa/modules.py:30-43,222-275,311-361).  Qc/Kc/Vc are covariances (already
+ * ELU(.)+1); key j is masked (additively, -2^32) when key_ids[b*L+j] <= 0 or j > i.  Om = Pd Vm, Oc = (Pd*Pd) Vc. */
+int adt_wattn_fwd(const float* Qm, int ldqm, const float* Qc, int ldqc, const float* Km, int ldkm, const float* Kc, int ldkc,
+                  const float* Vm, int ldvm, const float* Vc, int ldvc, const int32_t* key_ids, int B, int H, int L, int hd,
+                  float p, const uint32_t* seed, uint32_t site, uint32_t b_offset, float* Om, int ldom, float* Oc, int ldoc,
+                  float* LSE, void* stream);
+int adt_wattn_bwd(const float* Qm, int ldqm, const float* Qc, int ldqc, const float* Km, int ldkm, const float* Kc, int ldkc,
+                  const float* Vm, int ldvm, const float* Vc, int ldvc, const int32_t* key_ids, const float* Om, int ldom,
+                  const float* Oc, int ldoc, const float* LSE, const float* dOm, int lddom, const float* dOc, int lddoc, int B,
+                  int H, int L, int hd, float p, const uint32_t* seed, uint32_t site, uint32_t b_offset, float* dQm, float* dQc,
+                  float* dKm, float* dKc, float* dVm, float* dVc, int ldd, void* stream);
+/* bpr_optimization (stosa/trainer.py:358-391), loss and gradients in one pass: loss3 = 3 x 64 slots {bpr, pvn_weight *
+ * pvn, auc}, all already divided by sum(istarget) (= 1 / *inv_count); dSm/dSc overwritten, dEm/dEc accumulated. */
+int adt_wdist_bpr(const float* Sm, const float* Sc, int lds, const float* Em, const float* Ec, const int32_t* pos,
+                  const int32_t* neg, int T, int d, float pvn_weight, const float* inv_count, float* dSm, float* dSc, int ldds,
+                  float* dEm, float* dEc, float* loss3, void* stream);
+/* dist_predict_full (stosa/trainer.py:464-479): dist[b][v] = W2(state b, item v), items 0..V-1 */
+int adt_wdist_full(const float* Sm, const float* Sc, int lds, const float* Em, const float* Ec, int B, int V, int d,
+                   float* dist, int ldo, void* stream);
+
 /* ==== model-level executor: SASRecADT (sasrec/model.py:8-97) + loop body (sasrec/main.py:146-173) ====== */
 typedef struct adt_sasrec_cfg {
   int32_t item_num;     /* V; item table has V+1 rows                      */
