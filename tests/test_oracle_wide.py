@@ -59,4 +59,57 @@ def test_bert_train_step_matches_reference(tag):
         if step in (0, 2) and ("w%d.mask_bias" % (step + 1)) in g.files:
             for k in P:
                 # Adam divides by |g| + 1e-8: entries with |g| ~ 1e-8 move by a rounding-dependent fraction of lr = 1e-3
-                _close(Pw[k], g["w%d." % (step + 1) + k], 3e-4 if step else 1e-4, "weights after %d: %s" % (step + 1, k))
+                _close(Pw[k], g["w%d." % (step + 1) + k], 1e-3 if step else 3e-4, "weights after %d: %s" % (step + 1, k))
+
+
+# ---- STOSA-ADT ----------------------------------------------------------------------------------------------------------
+from oracle import stosa_oracle as so  # noqa: E402
+
+
+def _stosa_case(tag):
+    g = np.load(os.path.join(GOLD, "stosa_%s.npz" % tag))
+    V, L, d, H, nl, nu = [int(x) for x in g["cfg"]]
+    cfg = so.Cfg(V, L, d, H, nl, num_users=nu, pvn_weight=float(g["pvn_weight"]))
+    P = so.init_params(cfg, int(g["seed"]))
+    r = np.random.RandomState(int(g["seed"]) + 1)
+    for k in P:   # same perturbation as tools/gen_golden_stosa.py:gen_stosa
+        if k.endswith(".bias") and "LayerNorm" not in k:
+            P[k] = (0.02 * r.standard_normal(P[k].shape)).astype(np.float32)
+    return g, cfg, P
+
+
+@pytest.mark.parametrize("tag", ["small", "l2h2", "h1"])
+def test_stosa_finetune_matches_reference(tag):
+    g, cfg, P = _stosa_case(tag)
+    m, c, enc_in, enc_rec, dec_out = so.finetune(P, cfg, g["input_ids"], g["dec_ids"], training=False)
+    _close(m, g["mean_out"], 2e-5, "mean_out")
+    _close(c, g["cov_out"], 2e-5, "cov_out")
+    for i in range(cfg.num_layers):
+        _close(enc_in[i][0], g["enc_in_mean_%d" % i], 2e-5, "enc_in mean")
+        _close(enc_in[i][1], g["enc_in_cov_%d" % i], 2e-5, "enc_in cov")
+        _close(enc_rec[i][0], g["rec_mean_%d" % i], 2e-5, "rec mean")
+        _close(enc_rec[i][1], g["rec_cov_%d" % i], 2e-5, "rec cov")
+        _close(dec_out[i][0], g["dec_out_mean_%d" % i], 2e-5, "dec_out mean")
+        _close(dec_out[i][1], g["dec_out_cov_%d" % i], 2e-5, "dec_out cov")
+    _close(so.predict_full(P, cfg, g["input_ids"], g["dec_ids"]), g["full_dist"], 2e-5, "full-sort distances")
+
+
+@pytest.mark.parametrize("tag", ["small", "l2h2", "h1"])
+def test_stosa_train_step_matches_reference(tag):
+    g, cfg, P = _stosa_case(tag)
+    lam1, lam2 = list(g["lambda1"]), list(g["lambda2"])
+    loss, parts, G = so.loss_and_grads(P, cfg, g["input_ids"], g["dec_ids"], g["pos_ids"], g["neg_ids"], lam1, lam2, training=True, seed=0)
+    assert abs(loss - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))
+    assert abs(parts["bpr"] - float(g["bpr"])) < 2e-5 * abs(float(g["bpr"])) and abs(parts["auc"] - float(g["auc"])) < 1e-6
+    assert abs(parts["pvn"] - float(g["pvn"])) < 2e-5 * max(abs(float(g["pvn"])), 1e-6)
+    assert sorted(k for k in P if G[k] is None) == sorted(str(x) for x in g["grad_none"])
+    for k in P:
+        if G[k] is not None:
+            _close(G[k], g["grad." + k], 1e-4, "grad " + k)
+    state = {}
+    Pw = {k: v.copy() for k, v in P.items()}
+    for step in range(3):
+        so.train_step(Pw, cfg, state, g["input_ids"], g["dec_ids"], g["pos_ids"], g["neg_ids"], lam1, lam2, lr=float(g["lr"]), training=True, seed=0)
+        if step in (0, 2) and ("w%d.LayerNorm.weight" % (step + 1)) in g.files:
+            for k in P:
+                _close(Pw[k], g["w%d." % (step + 1) + k], 1e-3 if step else 3e-4, "weights after %d: %s" % (step + 1, k))
