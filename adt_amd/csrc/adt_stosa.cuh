@@ -65,6 +65,23 @@ ADT_DEVICE_INLINE void w_stage(float* dst, const float* g, int ld, int L, int hd
   }
 }
 
+// A query with no attendable key (the left-padded prefix) has EVERY score shifted by the mask: in fp32 x - 2^32 rounds to a
+// multiple of 512, so all of them collapse to -2^32 and the row is uniform over all L keys.  -2^32 + log(L) is not
+// representable, so such rows keep the reference's rounding but drop the common shift (softmax is shift-invariant and
+// (x + MASK) - MASK is exact): probabilities and gradients are unchanged, the saved LSE stays accurate.
+ADT_DEVICE_INLINE float w_score(float x, bool masked, bool dead_row) {
+  if (dead_row) return (x + W_MASK) - W_MASK;
+  return masked ? x + W_MASK : x;
+}
+
+ADT_DEVICE_INLINE void w_mark_dead(float* sDead, const float* sKv, int L, int Lp) {
+  for (int i = threadIdx.x; i < Lp; i += 256) {
+    float cnt = 0.f;
+    for (int j = 0; j <= i && j < L; ++j) cnt += sKv[j];
+    sDead[i] = cnt == 0.f ? 1.f : 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_wattn_fwd(WAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int L = a.L, hd = a.hd, RS = hd + 1, Lp = (L + 63) / 64 * 64;
@@ -72,17 +89,15 @@ __global__ __launch_bounds__(256) void k_wattn_fwd(WAttnArgs a) {
   float* sKs = sKm + L * RS;         // sqrt(cov)
   float* sVm = sKs + L * RS;
   float* sVc = sVm + L * RS;
-  float* sNk = sVc + L * RS;         // |mk|^2 + sum(Sk)   [Lp]
-  float* sKv = sNk + Lp;             // key validity (1/0) [Lp]
+  float* sDead = sVc + L * RS;       // 1 where query i has no attendable key (j <= i, real item)   [Lp]
+  float* sKv = sDead + Lp;           // key validity (1/0) [Lp]
   float* sWave = sKv + Lp;           // per wave: P row [Lp], P^2 row [Lp], (unused) [Lp], q mean [hd], q sqrt cov [hd], 2*hd spare
   const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const size_t row_b = (size_t)b * L;
-  for (int i = threadIdx.x; i < Lp; i += 256) {
-    sNk[i] = 0.f;
-    sKv[i] = (i < L && a.kid[row_b + i] > 0) ? 1.f : 0.f;
-  }
+  for (int i = threadIdx.x; i < Lp; i += 256) sKv[i] = (i < L && a.kid[row_b + i] > 0) ? 1.f : 0.f;
   __syncthreads();
+  w_mark_dead(sDead, sKv, L, Lp);
   // reference order (modules.py:31-41): mean part and covariance part are summed separately, then added
   w_stage<false, true>(sKm, a.Km + row_b * a.ldkm + h * hd, a.ldkm, L, hd, nullptr);
   w_stage<true, false>(sKs, a.Kc + row_b * a.ldkc + h * hd, a.ldkc, L, hd, nullptr);
@@ -110,6 +125,7 @@ __global__ __launch_bounds__(256) void k_wattn_fwd(WAttnArgs a) {
     }
     qn_m = wave_sum(qn_m);
     qn_c = wave_sum(qn_c);
+    const bool dead_i = sDead[i] != 0.f;
     float s[W_KPL];
     float m = -INFINITY;
 #pragma unroll
@@ -126,8 +142,7 @@ __global__ __launch_bounds__(256) void k_wattn_fwd(WAttnArgs a) {
           kn_c += ks * ks;      // = clamp(cov): equals sum(cov) for cov >= 1e-24
         }
         const float wd = ((-2.0f * dm + qn_m) + kn_m) + ((-2.0f * dc + qn_c) + kn_c);
-        const bool masked = j > i || sKv[j] == 0.f;
-        s[t] = (-wd) / sq_hd + (masked ? W_MASK : 0.f);
+        s[t] = w_score((-wd) / sq_hd, j > i || sKv[j] == 0.f, dead_i);
         m = fmaxf(m, s[t]);
       }
     }
@@ -185,8 +200,8 @@ __global__ __launch_bounds__(256) void k_wattn_bwd(WAttnArgs a) {
   float* sKv = sA3 + L * RS;         // key validity [Lp]
   float* sDelta = sKv + Lp;          // [Lp] sum_j P_ij dP_ij
   float* sLse = sDelta + Lp;         // [Lp]
-  float* sNq = sLse + Lp;            // [Lp] (phase B) |mq|^2 + sum(Sq) split: stored as the two partial sums interleaved? no: see below
-  float* sWave = sNq + Lp;           // per wave: 3 rows [Lp] + 4 vectors [hd]
+  float* sDead = sLse + Lp;          // [Lp] 1 where query i has no attendable key
+  float* sWave = sDead + Lp;           // per wave: 3 rows [Lp] + 4 vectors [hd]
   const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const size_t row_b = (size_t)b * L;
@@ -213,6 +228,8 @@ __global__ __launch_bounds__(256) void k_wattn_bwd(WAttnArgs a) {
   w_stage<false, false>(sA2, a.Vm + row_b * a.ldvm + h * hd, a.ldvm, L, hd, nullptr);
   w_stage<false, false>(sA3, a.Vc + row_b * a.ldvc + h * hd, a.ldvc, L, hd, nullptr);
   __syncthreads();
+  w_mark_dead(sDead, sKv, L, Lp);
+  __syncthreads();
 
   // ---- pass A ---------------------------------------------------------------------------------------------------
   for (int i = w; i < L; i += 4) {
@@ -230,6 +247,7 @@ __global__ __launch_bounds__(256) void k_wattn_bwd(WAttnArgs a) {
     qn_m = wave_sum(qn_m);
     qn_c = wave_sum(qn_c);
     const float lse = sLse[i];
+    const bool dead_i = sDead[i] != 0.f;
     const uint32_t idx_q = (idx_bh + (uint32_t)i) * (uint32_t)L;
     float p[W_KPL], dp[W_KPL];
     float delta = 0.f;
@@ -249,8 +267,7 @@ __global__ __launch_bounds__(256) void k_wattn_bwd(WAttnArgs a) {
           gc += sV3[d0] * sA3[j * RS + d0];
         }
         const float wd = ((-2.0f * dm + qn_m) + kn_m) + ((-2.0f * dc + qn_c) + kn_c);
-        const bool masked = j > i || sKv[j] == 0.f;
-        const float sv = (-wd) / sq_hd + (masked ? W_MASK : 0.f);
+        const float sv = w_score((-wd) / sq_hd, j > i || sKv[j] == 0.f, dead_i);
         const float pr = expf(sv - lse);
         float ks_ = 1.0f;
         if (a.drop.thr) ks_ = adt_keep(key_rng, idx_q + (uint32_t)j, a.drop.thr) ? a.drop.scale : 0.f;
@@ -293,8 +310,6 @@ __global__ __launch_bounds__(256) void k_wattn_bwd(WAttnArgs a) {
 
   // ---- phase B staging: the query side over the same LDS -----------------------------------------------------------
   __syncthreads();
-  for (int i = threadIdx.x; i < Lp; i += 256) sNq[i] = 0.f;
-  __syncthreads();
   w_stage<false, true>(sA0, a.Qm + row_b * a.ldqm + h * hd, a.ldqm, L, hd, nullptr);
   w_stage<true, false>(sA1, a.Qc + row_b * a.ldqc + h * hd, a.ldqc, L, hd, nullptr);
   w_stage<false, false>(sA2, a.dOm + row_b * a.lddom + h * hd, a.lddom, L, hd, nullptr);
@@ -336,8 +351,7 @@ __global__ __launch_bounds__(256) void k_wattn_bwd(WAttnArgs a) {
             gc += sA3[i * RS + d0] * sV3[d0];
           }
           const float wd = ((-2.0f * dm + qn_m) + kn_m) + ((-2.0f * dc + qn_c) + kn_c);
-          const bool masked = j > i || key_pad;
-          const float sv = (-wd) / sq_hd + (masked ? W_MASK : 0.f);
+          const float sv = w_score((-wd) / sq_hd, j > i || key_pad, sDead[i] != 0.f);
           const float pr = expf(sv - sLse[i]);
           float ks_ = 1.0f;
           if (a.drop.thr) ks_ = adt_keep(key_rng, (idx_bh + (uint32_t)i) * (uint32_t)L + (uint32_t)j, a.drop.thr) ? a.drop.scale : 0.f;

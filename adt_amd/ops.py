@@ -289,13 +289,16 @@ def wattn_fwd(Qm, Qc, Km, Kc, Vm, Vc, key_ids, B, H, L, p=0.0, seed=None, site=0
     return Om, Oc, LSE
 
 
-def wattn_bwd(Qm, Qc, Km, Kc, Vm, Vc, key_ids, Om, Oc, LSE, dOm, dOc, B, H, L, p=0.0, seed=None, site=0, b_offset=0):
+def wattn_bwd(Qm, Qc, Km, Kc, Vm, Vc, key_ids, Om, Oc, LSE, dOm, dOc, B, H, L, p=0.0, seed=None, site=0, b_offset=0, out=None):
+    """out: optional (dQm, dQc, dKm, dKc, dVm, dVc) views sharing one row stride."""
     d = Qm.shape[1]
     hd = d // H
-    outs = [torch.empty(B * L, d, device=Qm.device, dtype=torch.float32) for _ in range(6)]
+    outs = [torch.empty(B * L, d, device=Qm.device, dtype=torch.float32) for _ in range(6)] if out is None else list(out)
+    ldd = _ld(outs[0])
+    assert all(_ld(o) == ldd for o in outs)
     _lib.check(_lib.load().adt_wattn_bwd(_p(_f32(Qm)), _ld(Qm), _p(_f32(Qc)), _ld(Qc), _p(_f32(Km)), _ld(Km), _p(_f32(Kc)), _ld(Kc), _p(_f32(Vm)), _ld(Vm),
                                          _p(_f32(Vc)), _ld(Vc), _p(_i32(key_ids)), _p(Om), _ld(Om), _p(Oc), _ld(Oc), _p(LSE), _p(_f32(dOm)), _ld(dOm),
-                                         _p(_f32(dOc)), _ld(dOc), B, H, L, hd, float(p), _p(seed), site, b_offset, *[_p(o) for o in outs], d, _stream()),
+                                         _p(_f32(dOc)), _ld(dOc), B, H, L, hd, float(p), _p(seed), site, b_offset, *[_p(o) for o in outs], ldd, _stream()),
                "wattn_bwd")
     return outs
 

@@ -17,6 +17,19 @@ def _close(a, b, tol, what):
     assert err < tol, "%s: rel err %.3g (tol %.1g)" % (what, err, tol)
 
 
+def _adam_close(got, want, lr, nsteps, what, gref=None):
+    """Adam moves every entry by about lr per step, by lr * g / (|g| + 1e-8) on the first: entries whose gradient is of the
+    order of eps move by a rounding-dependent fraction of lr, so post-step weights are compared in units of lr (a wrong
+    bias correction, beta or weight-decay coupling is off by >= 0.1 lr on most entries)."""
+    diff = np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64))
+    if gref is not None:      # first step: entries with |g| >> eps must agree tightly; eps-dominated ones within one lr
+        big = np.abs(gref) > 1e-6
+        assert (diff[big].max() if big.any() else 0.0) < 0.02 * lr, "weights after 1 step: %s: %.3g lr" % (what, diff[big].max() / lr)
+        assert diff.max() < lr, what
+    else:
+        assert diff.max() < 0.3 * lr, "weights after %d steps: %s: abs err %.3g lr" % (nsteps, what, diff.max() / lr)
+
+
 def _bert_case(tag):
     g = np.load(os.path.join(GOLD, "bert_%s.npz" % tag))
     V, L, d, H, nl, inner = [int(x) for x in g["cfg"]]
@@ -59,7 +72,7 @@ def test_bert_train_step_matches_reference(tag):
         if step in (0, 2) and ("w%d.mask_bias" % (step + 1)) in g.files:
             for k in P:
                 # Adam divides by |g| + 1e-8: entries with |g| ~ 1e-8 move by a rounding-dependent fraction of lr = 1e-3
-                _close(Pw[k], g["w%d." % (step + 1) + k], 1e-3 if step else 3e-4, "weights after %d: %s" % (step + 1, k))
+                _adam_close(Pw[k], g["w%d." % (step + 1) + k], float(g["lr"]), step + 1, k, g["grad." + k] if step == 0 and ("grad." + k) in g.files else None)
 
 
 # ---- STOSA-ADT ----------------------------------------------------------------------------------------------------------
@@ -112,4 +125,4 @@ def test_stosa_train_step_matches_reference(tag):
         so.train_step(Pw, cfg, state, g["input_ids"], g["dec_ids"], g["pos_ids"], g["neg_ids"], lam1, lam2, lr=float(g["lr"]), training=True, seed=0)
         if step in (0, 2) and ("w%d.LayerNorm.weight" % (step + 1)) in g.files:
             for k in P:
-                _close(Pw[k], g["w%d." % (step + 1) + k], 1e-3 if step else 3e-4, "weights after %d: %s" % (step + 1, k))
+                _adam_close(Pw[k], g["w%d." % (step + 1) + k], float(g["lr"]), step + 1, k, g["grad." + k] if step == 0 and ("grad." + k) in g.files else None)

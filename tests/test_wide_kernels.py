@@ -217,3 +217,80 @@ def test_clip_adam_l2_and_score_bias():
     want = np.einsum("bd,bcd->bc", F_, E[cand]) + bias[cand]
     assert rel(logits.cpu().numpy(), want) < 1e-5
     assert np.array_equal(rank.cpu().numpy(), (want[:, 1:] > want[:, :1]).sum(1))
+
+
+# ---- STOSA-ADT kernels ----------------------------------------------------------------------------------------------------
+def wattn_oracle(t6, ids, B, H, L, p, seed, site, b_off, dOm, dOc):
+    from oracle import stosa_oracle as so
+    d = t6[0].shape[1]
+    hd = d // H
+    vs = [tp.leaf(x) for x in t6]
+
+    def split(x):
+        return tp.transpose(tp.reshape(x, (B, L, H, hd)), (0, 2, 1, 3))
+    qm, qc, km, kc, vm, vc = [split(v) for v in vs]
+    s = tp.div_const(tp.neg(so.wasserstein_distance_matmul(qm, qc, km, kc)), np.sqrt(hd))
+    s = tp.add_const(s, so._mask(ids))
+    pr = tp.dropout(tp.softmax(s), p, seed, site, tp.idx_attn(B, H, L, b_off))
+    om = tp.reshape(tp.transpose(tp.matmul(pr, vm), (0, 2, 1, 3)), (B * L, d))
+    oc = tp.reshape(tp.transpose(tp.matmul(tp.square(pr), vc), (0, 2, 1, 3)), (B * L, d))
+    loss = tp.add(tp.sum_(tp.mul_mask(om, dOm)), tp.sum_(tp.mul_mask(oc, dOc)))
+    tp.backward(loss)
+    return om.v, oc.v, [v.g for v in vs]
+
+
+@pytest.mark.parametrize("B,H,L,hd,p", [(3, 4, 20, 16, 0.0), (2, 2, 37, 32, 0.3), (2, 1, 100, 64, 0.2), (2, 4, 100, 16, 0.3)])
+def test_wasserstein_attention(B, H, L, hd, p):
+    from adt_amd import ops
+    r = np.random.RandomState(B * 100 + L + hd)
+    d = H * hd
+    T = B * L
+    qm, km, vm = (r.standard_normal((T, d)).astype(np.float32) for _ in range(3))
+    qc, kc, vc = (np.exp(0.5 * r.standard_normal((T, d))).astype(np.float32) for _ in range(3))   # covariances > 0
+    ids = r.randint(1, 50, size=(B, L)).astype(np.int32)
+    ids[0, : L // 3] = 0          # left padding: the padded prefix rows are fully masked (uniform attention, gradient kept)
+    dOm, dOc = r.standard_normal((T, d)).astype(np.float32), r.standard_normal((T, d)).astype(np.float32)
+    seed, site, b_off = 4321, 16, 3
+    om, oc, grads = wattn_oracle((qm, qc, km, kc, vm, vc), ids, B, H, L, p, seed, site, b_off, dOm, dOc)
+    sd = seed_tensor(seed)
+    g = [T_(x) for x in (qm, qc, km, kc, vm, vc)]
+    kid = T_(ids.reshape(-1))
+    Om, Oc, LSE = ops.wattn_fwd(*g, kid, B, H, L, p, sd, site, b_off)
+    assert rel(Om.cpu().numpy(), om) < 3e-5 and rel(Oc.cpu().numpy(), oc) < 3e-5
+    outs = ops.wattn_bwd(*g, kid, Om, Oc, LSE, T_(dOm), T_(dOc), B, H, L, p, sd, site, b_off)
+    for name, got, want in zip(("dQm", "dQc", "dKm", "dKc", "dVm", "dVc"), outs, grads):
+        assert rel(got.cpu().numpy(), want) < 1e-4, name
+
+
+def test_wasserstein_bpr_and_full_sort():
+    from adt_amd import ops
+    from oracle import stosa_oracle as so
+    r = np.random.RandomState(12)
+    B, L, d, V = 5, 12, 64, 40
+    T = B * L
+    cfg = so.Cfg(V, L, d, 4, 1, pvn_weight=0.3)
+    Em, Ec = r.standard_normal((V, d)).astype(np.float32), r.standard_normal((V, d)).astype(np.float32)
+    sm = r.standard_normal((B, L, d)).astype(np.float32)
+    sc = np.exp(0.3 * r.standard_normal((B, L, d))).astype(np.float32)
+    pos = r.randint(1, V, size=(B, L))
+    neg = r.randint(1, V, size=(B, L))
+    pos[0, :4] = 0
+    neg[0, :4] = 0
+    Vv = {"item_mean_embeddings.weight": tp.leaf(Em), "item_cov_embeddings.weight": tp.leaf(Ec)}
+    vsm, vsc = tp.leaf(sm), tp.leaf(sc)
+    loss, auc, pvn = so.bpr_terms(Vv, cfg, vsm, vsc, pos, neg)
+    tp.backward(tp.add(loss, pvn))
+    inv = torch.tensor([1.0 / float((pos > 0).sum())], device=dev(), dtype=torch.float32)
+    dEm, dEc = torch.zeros(V, d, device=dev()), torch.zeros(V, d, device=dev())
+    loss3 = torch.zeros(192, device=dev())
+    dSm, dSc = ops.wdist_bpr(T_(sm.reshape(T, d)), T_(sc.reshape(T, d)), T_(Em), T_(Ec), T_(pos.reshape(-1).astype(np.int32)),
+                             T_(neg.reshape(-1).astype(np.int32)), 0.3, inv, dEm, dEc, loss3)
+    l3 = loss3.view(3, 64).sum(1).cpu().numpy()
+    assert abs(l3[0] - float(loss.v)) < 2e-5 * abs(float(loss.v)) and abs(l3[1] - float(pvn.v)) < 2e-5 * abs(float(pvn.v)) and abs(l3[2] - auc) < 1e-6
+    assert rel(dSm.cpu().numpy(), vsm.g.reshape(T, d)) < 3e-5 and rel(dSc.cpu().numpy(), vsc.g.reshape(T, d)) < 3e-5
+    assert rel(dEm.cpu().numpy(), Vv["item_mean_embeddings.weight"].g) < 3e-5
+    assert rel(dEc.cpu().numpy(), Vv["item_cov_embeddings.weight"].g) < 3e-5
+    last_m, last_c = sm[:, -1, :], sc[:, -1, :]
+    want = so.wasserstein_distance_matmul(tp.const(last_m), tp.const(last_c), tp.const(Em), tp.elu(tp.const(Ec), True)).v
+    got = ops.wdist_full(T_(last_m), T_(last_c), T_(Em), T_(Ec), V)
+    assert rel(got.cpu().numpy(), want) < 2e-5
