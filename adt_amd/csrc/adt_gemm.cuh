@@ -175,6 +175,7 @@ struct DenseFwdArgs {
   int act;
   DropCfg drop; uint32_t row_offset;   // idx = (row + row_offset) * N + col
   const float* R; int ldr;    // optional residual
+  const float* R2; int ldr2;  // optional second residual (sasrec decoder: dec_input + (x + ffn(x)), modules.py:672-673)
   const int* ids;             // optional row mask
   const int* t_dev;           // optional DEVICE row count: only rows < min(T, *t_dev) are computed (masked-row batches
                               // whose size changes per step under a captured graph)
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(GTH) void k_dense_fwd(DenseFwdArgs a) {
         v = act_apply(a.act, v);
         if (a.drop.thr) v = adt_keep(key, (uint32_t)(row + a.row_offset) * (uint32_t)a.N + (uint32_t)col, a.drop.thr) ? v * a.drop.scale : 0.f;
         if (a.R) v += a.R[(size_t)row * a.ldr + col];
+        if (a.R2) v += a.R2[(size_t)row * a.ldr2 + col];
         if (a.ids && a.ids[row] == 0) v = 0.f;
         a.Y[(size_t)row * a.ldy + col] = v;
       }

@@ -134,4 +134,51 @@ __global__ __launch_bounds__(256) void k_ce_rows(CeArgs a) {
   }
 }
 
+// dst = (beta ? dst : 0) + alpha * src * (ids == NULL || ids[i / d] != 0): candidate mixing of the supernet
+// (sasrec/super_modules.py:42-49: sum_k w_k * layer_k(x)) and masked residual gradients.
+struct AxpyArgs {
+  float* dst; const float* src; float alpha; int beta; size_t n; const int* ids; int d;
+};
+
+__global__ __launch_bounds__(256) void k_axpy(AxpyArgs a) {
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < a.n; i += (size_t)gridDim.x * 1024) {
+    float4 v = *reinterpret_cast<const float4*>(a.src + i);
+    const float m = (a.ids && a.ids[i / a.d] == 0) ? 0.f : a.alpha;
+    v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+    if (a.beta) {
+      const float4 o = *reinterpret_cast<const float4*>(a.dst + i);
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    *reinterpret_cast<float4*>(a.dst + i) = v;
+  }
+}
+
+// log_softmax over rows of H <= 8 values (the second log_softmax of SuperEncoder.forward, sasrec/super_modules.py:49) and
+// its backward dX (+)= dY - softmax(X) * sum(dY), with softmax(X) = exp(Y).
+struct LsmArgs {
+  const float* X; float* Y; const float* dY; float* dX; size_t rows; int H; int accumulate;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_logsoftmax_rows(LsmArgs a) {
+  for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < a.rows; r += (size_t)gridDim.x * 256) {
+    float v[8];
+    if constexpr (!BWD) {
+      float m = -INFINITY;
+      for (int j = 0; j < a.H; ++j) { v[j] = a.X[r * a.H + j]; m = fmaxf(m, v[j]); }
+      float s = 0.f;
+      for (int j = 0; j < a.H; ++j) s += expf(v[j] - m);
+      const float lz = m + logf(s);
+      for (int j = 0; j < a.H; ++j) a.Y[r * a.H + j] = v[j] - lz;
+    } else {
+      float sd = 0.f;
+      for (int j = 0; j < a.H; ++j) { v[j] = a.dY[r * a.H + j]; sd += v[j]; }
+      for (int j = 0; j < a.H; ++j) {
+        const float g = v[j] - expf(a.Y[r * a.H + j]) * sd;
+        a.dX[r * a.H + j] = (a.accumulate ? a.dX[r * a.H + j] : 0.f) + g;
+      }
+    }
+  }
+}
+
 }  // namespace adt

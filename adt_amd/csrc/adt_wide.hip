@@ -93,13 +93,13 @@ extern "C" {
 
 int adt_dense_fwd(int prec, const float* X, int ldx, const float* W, int ldw, const float* b, int T, int K, int N, int act, float* U,
                   int ldu, float p, const uint32_t* seed, uint32_t site, uint32_t row_offset, const float* R, int ldr,
-                  const int32_t* mask_ids, float* Y, int ldy, const int32_t* t_dev, void* stream) {
+                  const float* R2, int ldr2, const int32_t* mask_ids, float* Y, int ldy, const int32_t* t_dev, void* stream) {
   if (T <= 0 || K <= 0 || N <= 0) return adt_set_error("dense_fwd: empty shape");
   if ((ldx % 4) || (ldw % 4) || !aligned16(X) || !aligned16(W)) return adt_set_error("dense_fwd: operands must be 16-byte aligned with ld %% 4 == 0");
   if (act < 0 || act > ACT_ELU1) return adt_set_error("dense_fwd: act=%d", act);
   DenseFwdArgs a{};
   a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.b = b; a.T = T; a.K = K; a.N = N; a.Y = Y; a.ldy = ldy; a.U = U; a.ldu = ldu; a.act = act;
-  a.drop = adt_make_drop(p, seed, site); a.row_offset = row_offset; a.R = R; a.ldr = ldr; a.ids = mask_ids; a.t_dev = t_dev;
+  a.drop = adt_make_drop(p, seed, site); a.row_offset = row_offset; a.R = R; a.ldr = ldr; a.R2 = R2; a.ldr2 = ldr2; a.ids = mask_ids; a.t_dev = t_dev;
   return prec == ADT_PREC_F32 ? launch_dense_fwd<PREC_F32>(a, (hipStream_t)stream) : launch_dense_fwd<PREC_BF16>(a, (hipStream_t)stream);
 }
 
@@ -197,6 +197,27 @@ int adt_ce_rows(float* logits, int ld, const int32_t* labels, int M, const int32
   CeArgs a{logits, ld, labels, M, V, inv_count, loss64, m_dev};
   hipLaunchKernelGGL(k_ce_rows, dim3(M < 4096 ? M : 4096), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("ce_rows");
+}
+
+int adt_axpy(float* dst, const float* src, float alpha, int accumulate, int64_t n, const int32_t* mask_ids, int d, void* stream) {
+  if (n % 4 || (mask_ids && (d <= 0 || d % 4))) return adt_set_error("axpy: n, d %% 4");
+  AxpyArgs a{dst, src, alpha, accumulate, (size_t)n, mask_ids, d};
+  hipLaunchKernelGGL(k_axpy, dim3(grid_for((size_t)n / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("axpy");
+}
+
+int adt_log_softmax_fwd(const float* X, int64_t rows, int H, float* Y, void* stream) {
+  if (H < 1 || H > 8) return adt_set_error("log_softmax: H=%d (1..8)", H);
+  LsmArgs a{X, Y, nullptr, nullptr, (size_t)rows, H, 0};
+  hipLaunchKernelGGL(k_logsoftmax_rows<false>, dim3(grid_for((size_t)rows, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("log_softmax_fwd");
+}
+
+int adt_log_softmax_bwd(const float* Y, const float* dY, int64_t rows, int H, float* dX, int accumulate, void* stream) {
+  if (H < 1 || H > 8) return adt_set_error("log_softmax: H=%d (1..8)", H);
+  LsmArgs a{nullptr, const_cast<float*>(Y), dY, dX, (size_t)rows, H, accumulate};
+  hipLaunchKernelGGL(k_logsoftmax_rows<true>, dim3(grid_for((size_t)rows, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("log_softmax_bwd");
 }
 
 // ---- STOSA-ADT (adt_stosa.cuh) ----------------------------------------------------------------------------------

@@ -176,7 +176,7 @@ ACT_NONE, ACT_RELU, ACT_GELU, ACT_ELU, ACT_ELU1 = 0, 1, 2, 3, 4
 
 
 def dense_fwd(prec, X, W, b=None, act=ACT_NONE, save_u=False, p=0.0, seed=None, site=0, row_offset=0, R=None, mask_ids=None, Y=None,
-              t_dev=None, ldy=None):
+              t_dev=None, ldy=None, R2=None):
     """Y = mask(R + dropout(act(X W^T + b))); returns (Y, U) with U the saved pre-activation (or None)."""
     T, K = X.shape
     N = W.shape[0]
@@ -185,7 +185,7 @@ def dense_fwd(prec, X, W, b=None, act=ACT_NONE, save_u=False, p=0.0, seed=None, 
         Y = torch.empty(T, ldy, device=X.device, dtype=torch.float32)[:, :N]
     U = torch.empty(T, N, device=X.device, dtype=torch.float32) if save_u else None
     _lib.check(_lib.load().adt_dense_fwd(prec, _p(_f32(X)), _ld(X), _p(_f32(W)), _ld(W), _p(b), T, K, N, act, _p(U), _ld(U), float(p), _p(seed),
-                                         site, row_offset, _p(R), _ld(R), _p(mask_ids), _p(Y), _ld(Y), _p(t_dev), _stream()), "dense_fwd")
+                                         site, row_offset, _p(R), _ld(R), _p(R2), _ld(R2), _p(mask_ids), _p(Y), _ld(Y), _p(t_dev), _stream()), "dense_fwd")
     return Y, U
 
 
@@ -317,3 +317,19 @@ def wdist_full(Sm, Sc, Em, Ec, V):
     dist = torch.empty(B, V, device=Sm.device, dtype=torch.float32)
     _lib.check(_lib.load().adt_wdist_full(_p(_f32(Sm)), _p(_f32(Sc)), _ld(Sm), _p(Em), _p(Ec), B, V, d, _p(dist), V, _stream()), "wdist_full")
     return dist
+
+
+def axpy(dst, src, alpha=1.0, accumulate=True, mask_ids=None, d=0):
+    """dst = (accumulate ? dst : 0) + alpha * src * rowmask."""
+    _lib.check(_lib.load().adt_axpy(_p(dst), _p(_f32(src)), float(alpha), int(accumulate), src.numel(), _p(mask_ids), d, _stream()), "axpy")
+    return dst
+
+
+def log_softmax_fwd(X, H):
+    Y = torch.empty_like(X)
+    _lib.check(_lib.load().adt_log_softmax_fwd(_p(_f32(X)), X.numel() // H, H, _p(Y), _stream()), "log_softmax_fwd")
+    return Y
+
+
+def log_softmax_bwd(Y, dY, H, dX, accumulate):
+    _lib.check(_lib.load().adt_log_softmax_bwd(_p(Y), _p(_f32(dY)), Y.numel() // H, H, _p(dX), int(accumulate), _stream()), "log_softmax_bwd")

@@ -134,10 +134,11 @@ class Tape:
         self.bw = []
 
     # ---- Linear (+ activation, dropout, residual) -------------------------------------------------------------------
-    def dense(self, x, W, b, gW, gb, act=ops.ACT_NONE, p=0.0, site=0, R=None, t_dev=None, ldy=None):
+    def dense(self, x, W, b, gW, gb, act=ops.ACT_NONE, p=0.0, site=0, R=None, t_dev=None, ldy=None, R2=None, mask_ids=None):
+        """y = mask(R + R2 + dropout(act(x W^T + b))).  With a row mask the residuals receive the masked gradient."""
         p = self.p_eff(p)
         Y, U = ops.dense_fwd(self.prec, x.t, W, b, act, act != ops.ACT_NONE, p, self.seed, site, self.row_offset, None if R is None else R.t,
-                             None, None, t_dev, ldy)
+                             mask_ids, None, t_dev, ldy, None if R2 is None else R2.t)
         y = Act(Y)
 
         def bw():
@@ -148,9 +149,48 @@ class Tape:
                 beta = False
             else:
                 beta = True
-            ops.dense_bwd(self.prec, y.g, x.t, W, gW, gb, x.g, beta, act, U, p, self.seed, site, self.row_offset, None, t_dev)
-            if R is not None:
-                give(R, y.g)
+            ops.dense_bwd(self.prec, y.g, x.t, W, gW, gb, x.g, beta, act, U, p, self.seed, site, self.row_offset, mask_ids, t_dev)
+            for res in (R, R2):
+                if res is None:
+                    continue
+                if mask_ids is None and R2 is None:
+                    give(res, y.g)          # y.g is not used again: hand the buffer over
+                else:
+                    g = torch.empty_like(y.g)
+                    ops.axpy(g, y.g, 1.0, False, mask_ids, y.g.shape[1])
+                    give(res, g)
+        self.bw.append(bw)
+        return y
+
+    def mix(self, parts):
+        """sum_k w_k * a_k (supernet candidate mixing, sasrec/super_modules.py:42-49)."""
+        out = torch.empty_like(parts[0][0].t)
+        for k, (a, w) in enumerate(parts):
+            ops.axpy(out, a.t, w, k > 0)
+        y = Act(out)
+
+        def bw():
+            if y.g is None:
+                return
+            for a, w in parts:
+                if a.g is None:
+                    a.g = torch.empty_like(a.t)
+                    ops.axpy(a.g, y.g, w, False)
+                else:
+                    ops.axpy(a.g, y.g, w, True)
+        self.bw.append(bw)
+        return y
+
+    def log_softmax(self, x, H):
+        y = Act(ops.log_softmax_fwd(x.t, H))
+
+        def bw():
+            if y.g is None:
+                return
+            acc = x.g is not None
+            if not acc:
+                x.g = torch.empty_like(x.t)
+            ops.log_softmax_bwd(y.t, y.g, H, x.g, acc)
         self.bw.append(bw)
         return y
 

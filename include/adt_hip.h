@@ -137,7 +137,8 @@ int adt_score_rank(const float* F, int ldf, const float* E, const int32_t* cand,
  * rows < min(T, *t_dev) are computed -- batches of masked rows whose count changes per step under a captured graph. */
 int adt_dense_fwd(int prec, const float* X, int ldx, const float* W, int ldw, const float* b, int T, int K, int N,
                   int act, float* U, int ldu, float p, const uint32_t* seed, uint32_t site, uint32_t row_offset,
-                  const float* R, int ldr, const int32_t* mask_ids, float* Y, int ldy, const int32_t* t_dev, void* stream);
+                  const float* R, int ldr, const float* R2, int ldr2, const int32_t* mask_ids, float* Y, int ldy,
+                  const int32_t* t_dev, void* stream);
 /* G = dY * mask * dropmask * act'(U);  dX = (beta ? dX : 0) + G W (dX NULL = skip);  dW += G^T X, db += colsum(G)
  * (dW NULL = skip; db may be NULL). */
 int adt_dense_bwd(int prec, const float* dY, int lddy, int T, int K, int N, const int32_t* mask_ids, float p,
@@ -174,6 +175,13 @@ int adt_scatter_rows(const float* G, int ldg, const int32_t* rows, int M, const 
  * (lse - z[label]); logits overwritten by w * (softmax - onehot); w = *inv_count; label 0 => zero row. */
 int adt_ce_rows(float* logits, int ld, const int32_t* labels, int M, const int32_t* m_dev, int V, const float* inv_count,
                 float* loss64, void* stream);
+/* dst = (accumulate ? dst : 0) + alpha * src * (mask_ids == NULL || mask_ids[i / d] != 0): the candidate mixing of the
+ * supernet (sasrec/super_modules.py:42-49, :79-83) and masked residual gradients */
+int adt_axpy(float* dst, const float* src, float alpha, int accumulate, int64_t n, const int32_t* mask_ids, int d,
+             void* stream);
+/* log_softmax over rows of H <= 8 values (sasrec/super_modules.py:49) / dX (+)= dY - exp(Y) * sum(dY) */
+int adt_log_softmax_fwd(const float* X, int64_t rows, int H, float* Y, void* stream);
+int adt_log_softmax_bwd(const float* Y, const float* dY, int64_t rows, int H, float* dX, int accumulate, void* stream);
 /* adt_clip_adam plus Adam's coupled weight_decay l2 (g += l2 * p after clipping): bert4rec/trainer.py:41,137-138 */
 int adt_clip_adam_l2(float* P, float* G, float* M, float* V, int64_t n, float l2, float clip, float lr, float b1, float b2,
                      float eps, float grad_scale, float* scal, void* stream);

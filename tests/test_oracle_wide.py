@@ -126,3 +126,50 @@ def test_stosa_train_step_matches_reference(tag):
         if step in (0, 2) and ("w%d.LayerNorm.weight" % (step + 1)) in g.files:
             for k in P:
                 _adam_close(Pw[k], g["w%d." % (step + 1) + k], float(g["lr"]), step + 1, k, g["grad." + k] if step == 0 and ("grad." + k) in g.files else None)
+
+
+# ---- SASRec-ADT supernet ----------------------------------------------------------------------------------------------------
+from oracle import super_oracle as su  # noqa: E402
+
+
+def _super_case(tag):
+    g = np.load(os.path.join(GOLD, "super_%s.npz" % tag))
+    V, L, d, H, nl = [int(x) for x in g["cfg"]]
+    cfg = su.Cfg(V, L, d, H, nl, g["rec_choice"], g["ind_choice"])
+    return g, cfg, su.init_params(cfg, int(g["seed"]))
+
+
+@pytest.mark.parametrize("tag", ["c3", "l2"])
+def test_supernet_matches_reference(tag):
+    g, cfg, P = _super_case(tag)
+    cand = [float(x) for x in g["cand"]]
+    block, rec_w, ind_w = su.cand_to_block(cfg, cand)
+    shared = su.get_shared(cfg, block)
+    assert [list(s[0]) for s in shared] == g["shared_idx"].tolist()
+    np.testing.assert_allclose(np.array([s[1] for s in shared]), g["shared_weights"], rtol=1e-12)
+    pl, nl, ei, do, rc = su.forward(P, cfg, block, g["seq"], g["dec"], g["pos"], g["neg"])
+    _close(pl, g["pos_logits"], 2e-5, "pos_logits")
+    _close(nl, g["neg_logits"], 2e-5, "neg_logits")
+    for i in range(cfg.num_layers):
+        _close(ei[i], g["enc_in_%d" % i], 2e-5, "enc_in")
+        _close(do[i], g["dec_out_%d" % i], 2e-5, "dec_out")
+        # the reference's rec rows are permuted by the (L,B,E)->(B,L,..) view (sasrec/modules.py:518): compare row-sorted
+        a, b = rc[i].reshape(-1, cfg.num_heads ** 2), g["rec_%d" % i].reshape(-1, cfg.num_heads ** 2)
+        _close(a[np.lexsort(a.T)], b[np.lexsort(b.T)], 2e-5, "rec")
+    _close(su.predict(P, cfg, block, g["seq"], g["items"]), g["predict"], 2e-5, "predict")
+    loss, G = su.loss_and_grads(P, cfg, cand, g["seq"], g["dec"], g["pos"], g["neg"], training=True, seed=0)
+    assert abs(loss - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))
+    none = set(str(x) for x in g["grad_none"])
+    assert set(k for k in P if G[k] is None) == none
+    for k in P:
+        if G[k] is not None:
+            _close(G[k], g["grad." + k], 1e-4, "grad " + k)
+    state = {}
+    Pw = {k: v.copy() for k, v in P.items()}
+    _, tn = su.train_step(Pw, cfg, state, cand, g["seq"], g["dec"], g["pos"], g["neg"], lr=float(g["lr"]), weight_decay=float(g["wd"]),
+                          clip=float(g["clip"]), training=True, seed=0)
+    assert abs(tn - float(g["grad_norm"])) < 2e-5 * float(g["grad_norm"])
+    for k in [f[3:] for f in g.files if f.startswith("w1.")]:
+        _adam_close(Pw[k], g["w1." + k], float(g["lr"]), 1, k, g["grad." + k])
+    for k in none:
+        assert np.array_equal(Pw[k], P[k])      # grad None: untouched, not even by the weight decay
