@@ -181,4 +181,39 @@ __global__ __launch_bounds__(256) void k_logsoftmax_rows(LsmArgs a) {
   }
 }
 
+// ||g||^2 of a flat range into 64 partial slots, and Adam on a flat range with a caller-supplied step count: the supernet's
+// optimizer state is per candidate layer (torch.optim.Adam skips parameters whose grad is None -- no moment decay, no
+// step increment, no weight decay -- sasrec/evolution.py:109,314-316), while clip_grad_norm_ uses the global norm.
+struct RangeOptArgs {
+  float* P; float* G; float* M; float* V; size_t n;
+  float l2, clip, lr, b1, b2, eps, step;
+  const float* gn2_slots;   // 64 partial sums of ||g||^2 over ALL parameters
+  float* out64;
+};
+
+__global__ __launch_bounds__(256) void k_sumsq64(RangeOptArgs a) {
+  __shared__ float sbuf[4];
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) acc += a.G[i] * a.G[i];
+  const float s = block_sum256(acc, sbuf);
+  if (threadIdx.x == 0) atomicAdd(a.out64 + (blockIdx.x & 63), s);
+}
+
+__global__ __launch_bounds__(256) void k_adam_range(RangeOptArgs a) {
+  __shared__ float sbuf[4];
+  float v0 = threadIdx.x < 64 ? a.gn2_slots[threadIdx.x] : 0.f;
+  const float gn2 = block_sum256(v0, sbuf);
+  const float coef = fminf(1.0f, a.clip / (sqrtf(gn2) + 1e-6f));
+  const float bc1 = 1.0f - powf(a.b1, a.step), bc2 = 1.0f - powf(a.b2, a.step);
+  const float stepsz = a.lr / bc1, rs2 = 1.0f / sqrtf(bc2);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+    const float g = a.G[i] * coef + a.l2 * a.P[i];
+    const float m = a.b1 * a.M[i] + (1.0f - a.b1) * g;
+    const float v = a.b2 * a.V[i] + (1.0f - a.b2) * g * g;
+    a.M[i] = m;
+    a.V[i] = v;
+    a.P[i] -= stepsz * m / (sqrtf(v) * rs2 + a.eps);
+  }
+}
+
 }  // namespace adt

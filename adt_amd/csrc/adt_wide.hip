@@ -220,6 +220,22 @@ int adt_log_softmax_bwd(const float* Y, const float* dY, int64_t rows, int H, fl
   return check_launch("log_softmax_bwd");
 }
 
+int adt_grad_sumsq(const float* G, int64_t n, float* out64, void* stream) {
+  RangeOptArgs a{};
+  a.G = const_cast<float*>(G); a.n = (size_t)n; a.out64 = out64;
+  if (hipMemsetAsync(out64, 0, 64 * sizeof(float), (hipStream_t)stream) != hipSuccess) return adt_set_error("grad_sumsq: memset");
+  hipLaunchKernelGGL(k_sumsq64, dim3(grid_for((size_t)n, 256, 512)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("grad_sumsq");
+}
+
+int adt_adam_range(float* P, float* G, float* M, float* V, int64_t n, float l2, float clip, float lr, float b1, float b2, float eps, float step,
+                   const float* gn2_slots, void* stream) {
+  if (n <= 0) return 0;
+  RangeOptArgs a{P, G, M, V, (size_t)n, l2, clip, lr, b1, b2, eps, step, gn2_slots, nullptr};
+  hipLaunchKernelGGL(k_adam_range, dim3(grid_for((size_t)n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("adam_range");
+}
+
 // ---- STOSA-ADT (adt_stosa.cuh) ----------------------------------------------------------------------------------
 int adt_wattn_fwd(const float* Qm, int ldqm, const float* Qc, int ldqc, const float* Km, int ldkm, const float* Kc, int ldkc,
                   const float* Vm, int ldvm, const float* Vc, int ldvc, const int32_t* key_ids, int B, int H, int L, int hd, float p,

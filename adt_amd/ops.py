@@ -96,15 +96,18 @@ def attn_fwd(prec, Q, K, V, B, H, L, causal=True, p=0.0, seed=None, site=0, b_of
     return O, LSE
 
 
-def attn_bwd(prec, Q, K, V, O, LSE, dO, B, H, L, causal=True, p=0.0, seed=None, site=0, b_offset=0, mask=None):
+def attn_bwd(prec, Q, K, V, O, LSE, dO, B, H, L, causal=True, p=0.0, seed=None, site=0, b_offset=0, mask=None, out=None):
     d = Q.shape[1]
     hd = d // H
-    dQ = torch.empty(B * L, d, device=Q.device, dtype=torch.float32)
-    dK = torch.empty_like(dQ)
-    dV = torch.empty_like(dQ)
+    if out is None:
+        dQ = torch.empty(B * L, d, device=Q.device, dtype=torch.float32)
+        dK = torch.empty_like(dQ)
+        dV = torch.empty_like(dQ)
+    else:
+        dQ, dK, dV = out
     _lib.check(_lib.load().adt_attn_bwd(prec, _p(_f32(Q)), _ld(Q), _p(_f32(K)), _ld(K), _p(_f32(V)), _ld(V), _p(_f32(O)), _ld(O),
                                         _p(LSE), _p(_f32(dO)), _ld(dO), B, H, L, hd, int(causal), float(p), _p(seed), site, b_offset,
-                                        _p(dQ), d, _p(dK), d, _p(dV), d, _p(mask), _stream()), "attn_bwd")
+                                        _p(dQ), _ld(dQ), _p(dK), _ld(dK), _p(dV), _ld(dV), _p(mask), _stream()), "attn_bwd")
     return dQ, dK, dV
 
 
@@ -333,3 +336,12 @@ def log_softmax_fwd(X, H):
 
 def log_softmax_bwd(Y, dY, H, dX, accumulate):
     _lib.check(_lib.load().adt_log_softmax_bwd(_p(Y), _p(_f32(dY)), Y.numel() // H, H, _p(dX), int(accumulate), _stream()), "log_softmax_bwd")
+
+
+def grad_sumsq(G, out64):
+    _lib.check(_lib.load().adt_grad_sumsq(_p(G), G.numel(), _p(out64), _stream()), "grad_sumsq")
+
+
+def adam_range(P, G, M, V, l2, clip, lr, b1, b2, eps, step, gn2_slots):
+    _lib.check(_lib.load().adt_adam_range(_p(P), _p(G), _p(M), _p(V), P.numel(), float(l2), float(clip), float(lr), float(b1), float(b2), float(eps),
+                                          float(step), _p(gn2_slots), _stream()), "adam_range")

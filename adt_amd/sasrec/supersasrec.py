@@ -1,0 +1,355 @@
+"""SuperSASRecModel on the MI355X hot path -- drop-in for the reference's sasrec/supersasrec.py (+ super_modules.py,
+base_super_modules.py): the weight-sharing supernet the evolutionary lambda search trains and evaluates.
+
+Per depth there are rec_size * ind_size candidate encoder layers and as many decoder layers; `set_choice(block_cand)`
+selects four of them and their bilinear weights, and a forward pass runs those four on the same input and mixes them
+(classifier log-probabilities are mixed, then log_softmax'd again: super_modules.py:42-49).  Every candidate layer runs on
+the same stage kernels as the plain model (dense layers on MFMA, causal attention with LDS-resident K/V, LayerNorm,
+head classifier); the mixing and its reverse are one axpy kernel per candidate.
+
+`SuperTrainer.step()` is the loop body of SearcherEvolution._train_warmup (sasrec/evolution.py:286-316): BCE +
+rec_weights[i] * MSE + ind_weights[stale i] * NLL, backward, clip_grad_norm_, Adam with coupled weight decay -- with
+torch's semantics for parameters whose grad is None (candidates that were not mixed in keep their moments, their own
+step count and are not decayed).
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from ..wide import Act, FlatModule, Tape, give
+
+LN_EPS = 1e-8
+SITE_EMB_SEQ, SITE_EMB_DEC = 1, 2
+CAND_SITE = 4096
+
+_ENC = ["attention_layernorm.weight", "attention_layernorm.bias", "attention_layer.in_proj_weight", "attention_layer.in_proj_bias",
+        "attention_layer.out_proj.weight", "attention_layer.out_proj.bias", "forward_layernorm.weight", "forward_layernorm.bias",
+        "forward_layer.conv1.weight", "forward_layer.conv1.bias", "forward_layer.conv2.weight", "forward_layer.conv2.bias", "sparse.weight", "sparse.bias"]
+_DEC = ["layer_norm.weight", "layer_norm.bias", "slf_attn.in_proj_weight", "slf_attn.in_proj_bias", "slf_attn.out_proj.weight", "slf_attn.out_proj.bias",
+        "enc_attn.in_proj_weight", "enc_attn.in_proj_bias", "enc_attn.out_proj.weight", "enc_attn.out_proj.bias", "pos_ffn.conv1.weight",
+        "pos_ffn.conv1.bias", "pos_ffn.conv2.weight", "pos_ffn.conv2.bias", "pos_ffn_layernorm.weight", "pos_ffn_layernorm.bias"]
+
+
+def _shapes(d, H):
+    hd = d // H
+    enc = [(d,), (d,), (3 * d, d), (3 * d,), (d, d), (d,), (d,), (d,), (d, d, 1), (d,), (d, d, 1), (d,), (H, hd), (H,)]
+    dec = [(d,), (d,), (3 * d, d), (3 * d,), (d, d), (d,), (3 * d, d), (3 * d,), (d, d), (d,), (d, d, 1), (d,), (d, d, 1), (d,), (d,), (d,)]
+    return enc, dec
+
+
+def enc_sites(i, k):
+    b = 16 + 8 * i + CAND_SITE * (k + 1)
+    return {"attn": b, "ffn1": b + 1, "ffn2": b + 2}
+
+
+def dec_sites(i, k):
+    b = 128 + 8 * i + CAND_SITE * (k + 1)
+    return {"slf": b, "enc": b + 1, "ffn1": b + 2, "ffn2": b + 3}
+
+
+def get_position(weight, choice):
+    """BaseSuperModule._get_position (sasrec/base_super_modules.py:15-19)."""
+    i1 = int(np.where(choice > weight)[0][0])
+    i0 = i1 - 1
+    p0 = (weight - choice[i0]) / (choice[i1] - choice[i0])
+    return i0, i1, p0, 1 - p0
+
+
+def get_shared(rec_choice, ind_choice, cand):
+    """BaseSuperModule._get_shared (:21-40): per depth the four candidate indices (both pairs strided by rec_size, as in the
+    reference) and their weights (p1 p3, p0 p3, p1 p2, p0 p2)."""
+    rs = len(rec_choice)
+    out = []
+    for i in range(len(cand) // 2):
+        i0, i1, p0, p1 = get_position(cand[2 * i], rec_choice)
+        i2, i3, p2, p3 = get_position(cand[2 * i + 1], ind_choice)
+        out.append(((i0 * rs + i2, i1 * rs + i2, i0 * rs + i3, i1 * rs + i3), (p1 * p3, p0 * p3, p1 * p2, p0 * p2)))
+    return out
+
+
+class SuperSASRecModel(FlatModule):
+    def __init__(self, usernum, itemnum, rec_choice, ind_choice, args):
+        super().__init__()
+        self.usernum, self.itemnum = usernum, itemnum
+        self.num_heads, self.maxlen, self.num_layers = args.num_heads, args.maxlen, args.num_layers
+        self.hidden_units, self.dropout = args.hidden_units, float(args.dropout)
+        self.rec_choice, self.ind_choice = np.asarray(rec_choice, np.float64), np.asarray(ind_choice, np.float64)
+        self.block = len(self.rec_choice) * len(self.ind_choice)
+        self.prec = {"f32": ops.PREC_F32, "fp32": ops.PREC_F32, "bf16": ops.PREC_BF16}[getattr(args, "precision", "bf16")]
+        d, H = self.hidden_units, self.num_heads
+        if d != 64 or (d // H) not in (16, 32, 64):
+            raise _lib.AdtError("SuperSASRecModel (adt_amd): built for hidden_units=64 with head size 16/32/64, got d=%d H=%d" % (d, H))
+        es, ds = _shapes(d, H)
+        table = [("item_emb.weight", (itemnum + 1, d)), ("pos_emb.weight", (args.maxlen, d))]
+        for i in range(self.num_layers):
+            for c in range(self.block):
+                table += [("encoder.encoder_layers.%d.%d.%s" % (i, c, n), s) for n, s in zip(_ENC, es)]
+        for i in range(self.num_layers):
+            for c in range(self.block):
+                table += [("decoder.decoder_layers.%d.%d.%s" % (i, c, n), s) for n, s in zip(_DEC, ds)]
+        self._build_flat(table, args.device)
+        g = torch.Generator(device="cpu").manual_seed(torch.initial_seed() % (1 << 31))
+        for name, shape in self.table:     # evolution.py:103-107: xavier_normal_ on >= 2-D tensors; 1-D keep torch defaults
+            v = self.P(name)
+            if len(shape) >= 2:
+                fan = shape[0] + shape[1] * (shape[2] if len(shape) > 2 else 1)
+                v.copy_(torch.randn(shape, generator=g) * math.sqrt(2.0 / fan))
+            elif "norm.weight" in name:
+                v.fill_(1.0)
+        self.shared = [((0, 0, 0, 0), (0.0, 0.0, 0.0, 0.0)) for _ in range(self.num_layers)]
+
+    def set_choice(self, cand):
+        """supersasrec.py:113-115 / base_super_modules.py:42-57."""
+        self.shared = get_shared(self.rec_choice, self.ind_choice, np.asarray(cand, np.float64))
+
+    def layer_range(self, kind, depth, cand):
+        """Flat [lo, hi) of the trainable tensors of one candidate layer (pos_ffn_layernorm, never used, is excluded;
+        so is the head classifier when there is a single head)."""
+        names = _ENC if kind == "encoder" else _DEC
+        last = names[-3] if kind == "decoder" else (names[-1] if self.num_heads > 1 else names[-3])
+        p = "%s.%s_layers.%d.%d." % (kind, kind, depth, cand)
+        lo = self._views[p + names[0]][0]
+        o, n, _ = self._views[p + last]
+        return lo, o + (n + 3) // 4 * 4
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _embed(self, tp, ids, site):
+        P, G = self.P, self.G
+        L = self.maxlen
+        p = tp.p_eff(self.dropout)
+        x = Act(ops.embed_fwd(ids, P("item_emb.weight"), P("pos_emb.weight"), L, p, self._seed, site, tp.row_offset))
+
+        def bw():
+            if x.g is not None:
+                ops.embed_bwd(ids, x.g, L, p, self._seed, site, G("item_emb.weight"), G("pos_emb.weight"), tp.row_offset)
+        tp.bw.append(bw)
+        return x
+
+    def _attn(self, tp, q, kv, B, site, qkv=None):
+        """Causal attention on packed projections; q: (T, d) Act, kv: (T, 2d) Act (or qkv: one (T, 3d) Act)."""
+        d, H, L = self.hidden_units, self.num_heads, self.maxlen
+        p = tp.p_eff(self.dropout)
+        if qkv is not None:
+            Q, K, V = qkv.t[:, :d], qkv.t[:, d:2 * d], qkv.t[:, 2 * d:]
+        else:
+            Q, K, V = q.t, kv.t[:, :d], kv.t[:, d:]
+        O, LSE = ops.attn_fwd(self.prec, Q, K, V, B, H, L, True, p, self._seed, site, tp.b_offset)
+        o = Act(O)
+
+        def bw():
+            if o.g is None:
+                return
+            if qkv is not None:
+                qkv.g = torch.empty_like(qkv.t)
+                out = (qkv.g[:, :d], qkv.g[:, d:2 * d], qkv.g[:, 2 * d:])
+            else:
+                q.g, kv.g = torch.empty_like(q.t), torch.empty_like(kv.t)
+                out = (q.g, kv.g[:, :d], kv.g[:, d:])
+            ops.attn_bwd(self.prec, Q, K, V, O, LSE, o.g, B, H, L, True, p, self._seed, site, tp.b_offset, out=out)
+        tp.bw.append(bw)
+        return o
+
+    def _conv(self, name, grad=False):
+        d = self.hidden_units
+        return (self.G(name) if grad else self.P(name)).view(d, d)
+
+    def _enc_layer(self, tp, p, x, ids, B, st):
+        """EncoderLayer.forward (sasrec/modules.py:644-655) -> (seqs, head-classifier log-probabilities)."""
+        P, G = self.P, self.G
+        d = self.hidden_units
+        Q = tp.layernorm(x, P(p + ".attention_layernorm.weight"), P(p + ".attention_layernorm.bias"), G(p + ".attention_layernorm.weight"),
+                         G(p + ".attention_layernorm.bias"), LN_EPS)
+        W, b, gW, gb = P(p + ".attention_layer.in_proj_weight"), P(p + ".attention_layer.in_proj_bias"), G(p + ".attention_layer.in_proj_weight"), \
+            G(p + ".attention_layer.in_proj_bias")
+        q = tp.dense(Q, W[:d], b[:d], gW[:d], gb[:d])           # q from LN(x) ...
+        kv = tp.dense(x, W[d:], b[d:], gW[d:], gb[d:])          # ... k, v from the un-normalised x (modules.py:646-647)
+        o = self._attn(tp, q, kv, B, st["attn"])
+        rec = tp.headcls(o, P(p + ".sparse.weight"), P(p + ".sparse.bias"), G(p + ".sparse.weight"), G(p + ".sparse.bias"))
+        ow = p + ".attention_layer.out_proj"
+        h = tp.dense(o, P(ow + ".weight"), P(ow + ".bias"), G(ow + ".weight"), G(ow + ".bias"), R=Q)
+        h2 = tp.layernorm(h, P(p + ".forward_layernorm.weight"), P(p + ".forward_layernorm.bias"), G(p + ".forward_layernorm.weight"),
+                          G(p + ".forward_layernorm.bias"), LN_EPS)
+        c1, c2 = p + ".forward_layer.conv1", p + ".forward_layer.conv2"
+        f1 = tp.dense(h2, self._conv(c1 + ".weight"), P(c1 + ".bias"), self._conv(c1 + ".weight", True), G(c1 + ".bias"), act=ops.ACT_RELU,
+                      p=self.dropout, site=st["ffn1"])
+        y = tp.dense(f1, self._conv(c2 + ".weight"), P(c2 + ".bias"), self._conv(c2 + ".weight", True), G(c2 + ".bias"), p=self.dropout,
+                     site=st["ffn2"], R=h2, mask_ids=ids)
+        return y, rec
+
+    def _dec_layer(self, tp, p, x, enc, ids, B, st):
+        """DecoderLayer.forward (sasrec/modules.py:666-677)."""
+        P, G = self.P, self.G
+        d = self.hidden_units
+        D = tp.layernorm(x, P(p + ".layer_norm.weight"), P(p + ".layer_norm.bias"), G(p + ".layer_norm.weight"), G(p + ".layer_norm.bias"), LN_EPS)
+        s, e = p + ".slf_attn", p + ".enc_attn"
+        qkv = tp.dense(D, P(s + ".in_proj_weight"), P(s + ".in_proj_bias"), G(s + ".in_proj_weight"), G(s + ".in_proj_bias"))
+        o1 = self._attn(tp, None, None, B, st["slf"], qkv=qkv)
+        a1 = tp.dense(o1, P(s + ".out_proj.weight"), P(s + ".out_proj.bias"), G(s + ".out_proj.weight"), G(s + ".out_proj.bias"))
+        W, b, gW, gb = P(e + ".in_proj_weight"), P(e + ".in_proj_bias"), G(e + ".in_proj_weight"), G(e + ".in_proj_bias")
+        q2 = tp.dense(a1, W[:d], b[:d], gW[:d], gb[:d])
+        kv2 = tp.dense(enc, W[d:], b[d:], gW[d:], gb[d:])
+        o2 = self._attn(tp, q2, kv2, B, st["enc"])
+        a2 = tp.dense(o2, P(e + ".out_proj.weight"), P(e + ".out_proj.bias"), G(e + ".out_proj.weight"), G(e + ".out_proj.bias"))
+        c1, c2 = p + ".pos_ffn.conv1", p + ".pos_ffn.conv2"
+        f1 = tp.dense(a2, self._conv(c1 + ".weight"), P(c1 + ".bias"), self._conv(c1 + ".weight", True), G(c1 + ".bias"), act=ops.ACT_RELU,
+                      p=self.dropout, site=st["ffn1"])
+        return tp.dense(f1, self._conv(c2 + ".weight"), P(c2 + ".bias"), self._conv(c2 + ".weight", True), G(c2 + ".bias"), p=self.dropout,
+                        site=st["ffn2"], R=a2, R2=D, mask_ids=ids)
+
+    def _encode(self, tp, seq, B):
+        x = self._embed(tp, seq, SITE_EMB_SEQ)
+        enc_in, recs = [], []
+        for i, (idxs, ws) in enumerate(self.shared):
+            enc_in.append(x)
+            outs, inds = [], []
+            for k, (idx, w) in enumerate(zip(idxs, ws)):
+                y, rec = self._enc_layer(tp, "encoder.encoder_layers.%d.%d" % (i, idx), x, seq, B, enc_sites(i, k))
+                outs.append((y, float(w)))
+                inds.append((rec, float(w)))
+            x = tp.mix(outs)
+            recs.append(tp.log_softmax(tp.mix(inds), self.num_heads))
+        return x, enc_in, recs
+
+    def _decode(self, tp, dec, feats, B):
+        y = self._embed(tp, dec, SITE_EMB_DEC)
+        outs = []
+        for i, (idxs, ws) in enumerate(self.shared):
+            parts = [(self._dec_layer(tp, "decoder.decoder_layers.%d.%d" % (i, idx), y, feats, dec, B, dec_sites(i, k)), float(w))
+                     for k, (idx, w) in enumerate(zip(idxs, ws))]
+            y = tp.mix(parts)
+            outs.append(y)
+        return outs
+
+    @torch.no_grad()
+    def forward(self, user_ids, log_seqs, dec_seqs, pos_seqs, neg_seqs):
+        """supersasrec.py:81-94 -> (pos_logits, neg_logits, encoder_layer_input, decoder_layer_output [reversed], rec_layer_ind)
+        as plain tensors (training goes through SuperTrainer.step)."""
+        seq, dec, pos, neg = (self.ids(a) for a in (log_seqs, dec_seqs, pos_seqs, neg_seqs))
+        B, L = seq.shape
+        d, H = self.hidden_units, self.num_heads
+        if self.training:
+            self.next_seed()
+        tp = Tape(self, self.prec, self.training)
+        feats, enc_in, recs = self._encode(tp, seq.view(-1), B)
+        dec_outs = self._decode(tp, dec.view(-1), feats, B)
+        pl, nl = ops.logits_fwd(feats.t, self.P("item_emb.weight"), pos.view(-1), neg.view(-1))
+        dec_outs.reverse()
+        return (pl.view(B, L), nl.view(B, L), [a.t.view(B, L, d) for a in enc_in], [a.t.view(B, L, d) for a in dec_outs],
+                [r.t.view(B, L, H, H) for r in recs])
+
+    @torch.no_grad()
+    def predict(self, user_ids, log_seqs, item_indices, full=False, want_rank=False):
+        """supersasrec.py:96-111."""
+        seq = self.ids(log_seqs)
+        B, L = seq.shape
+        was = self.training
+        self.eval()
+        tp = Tape(self, self.prec, False)
+        feats, _, _ = self._encode(tp, seq.view(-1), B)
+        self.train(was)
+        d = self.hidden_units
+        cand = None if full else self.ids(item_indices)
+        C = self.itemnum + 1 if full else cand.shape[1]
+        logits, rank = ops.score_rank(feats.t[L - 1:], L * d, self.P("item_emb.weight"), cand, B, C, want_rank)
+        return (logits, rank) if want_rank else logits
+
+    def loss_forward_backward(self, ids, rec_w, ind_w, norms, loss_slots, b_offset=0):
+        """Forward, the warm-up loss (sasrec/evolution.py:296-313) and backward into flat_grad.  ids: device int32 (seq, dec,
+        pos, neg) (B, L); norms: device {n_bce, n_mse, n_nll}; loss_slots: (2 + 2*num_layers) x 64 {bce_pos, bce_neg, mse.., nll..}."""
+        seq, dec, pos, neg = ids
+        B, L = seq.shape
+        nl, H = self.num_layers, self.num_heads
+        tp = Tape(self, self.prec, self.training, row_offset=b_offset * L, b_offset=b_offset)
+        feats, enc_in, recs = self._encode(tp, seq.view(-1), B)
+        dec_outs = self._decode(tp, dec.view(-1), feats, B)
+        E, gE = self.P("item_emb.weight"), self.G("item_emb.weight")
+        pl, nlg = ops.logits_fwd(feats.t, E, pos.view(-1), neg.view(-1))
+        dpos, dneg = ops.bce_seed(pl, nlg, pos.view(-1), norms, loss_slots[0:2].view(-1))
+        give(feats, ops.logits_bwd(feats.t, E, pos.view(-1), neg.view(-1), dpos, dneg, gE))
+        i = 0
+        for i in range(nl):
+            a, bq = enc_in[i], dec_outs[nl - 1 - i]
+            if a.g is None:
+                a.g = torch.zeros_like(a.t)
+            g_b = torch.empty_like(bq.t)
+            ops.mse_seed(a.t, bq.t, rec_w[i], norms, a.g, True, g_b, loss_slots[2 + i])
+            give(bq, g_b)
+        if H > 1:
+            for l in range(nl):
+                recs[l].g = torch.empty_like(recs[l].t)
+                ops.nll_seed(recs[l].t, H, ind_w[i], norms, recs[l].g, loss_slots[2 + nl + l])    # stale index i (evolution.py:313)
+        tp.backward()
+
+
+class SuperTrainer:
+    """One warm-up optimisation step of the supernet with torch.optim.Adam's per-parameter bookkeeping: only the embeddings
+    and the candidate layers that were mixed in are clipped (global norm), decayed and stepped, each with its own step count."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip=5.0, seed=2022):
+        self.model = model
+        self.lr, self.betas, self.eps, self.wd, self.clip = lr, betas, eps, weight_decay, clip
+        dev = model.dev
+        self.m, self.v = torch.zeros_like(model.flat), torch.zeros_like(model.flat)
+        self.gn2 = torch.zeros(64, device=dev, dtype=torch.float32)
+        self.loss_slots = torch.zeros(2 + 2 * model.num_layers, 64, device=dev, dtype=torch.float32)
+        self.steps = {}       # (lo, hi) -> Adam step count of that range
+        self._emb_range = (0, model._views["encoder.encoder_layers.0.0." + _ENC[0]][0])
+        self.rec_weights = [0.0] * model.num_layers
+        self.ind_weights = [0.0] * model.num_layers
+        model.set_seed(seed * 1000003 + 12345)
+
+    @staticmethod
+    def get_weight(choices, prob):
+        """SearcherEvolution._get_weight (sasrec/evolution.py:123-137)."""
+        split = 1 / (len(choices) - 1)
+        idx = 0
+        while prob > split:
+            idx += 1
+            prob -= split
+        rd = prob / split
+        return choices[idx] * (1 - rd) + choices[idx + 1] * rd
+
+    def set_choice(self, cand):
+        """SearcherEvolution._set_choice (evolution.py:139-153): probabilities -> loss weights + the model's block choice."""
+        m = self.model
+        block = []
+        for i in range(0, 2 * m.num_layers, 2):
+            rw, iw = self.get_weight(m.rec_choice, cand[i]), self.get_weight(m.ind_choice, cand[i + 1])
+            self.rec_weights[i // 2], self.ind_weights[i // 2] = rw, iw
+            block += [rw, iw]
+        m.set_choice(np.array(block))
+
+    def step(self, seq, dec, pos, neg):
+        m = self.model
+        m.train()
+        ids = tuple(m.ids(a) for a in (seq, dec, pos, neg))
+        B, L = ids[0].shape
+        T = B * L
+        n_bce = float(np.count_nonzero(np.asarray(pos)))
+        norms = torch.tensor([n_bce, float(T * m.hidden_units), float(T * m.num_heads)], device=m.dev, dtype=torch.float32)
+        m._seed.add_(-1640531535)
+        self.loss_slots.zero_()
+        m.flat_grad.zero_()
+        m.loss_forward_backward(ids, self.rec_weights, self.ind_weights, norms, self.loss_slots)
+        ops.grad_sumsq(m.flat_grad, self.gn2)
+        ranges = [self._emb_range]
+        for depth, (idxs, _) in enumerate(m.shared):
+            for idx in sorted(set(idxs)):
+                ranges += [m.layer_range("encoder", depth, idx), m.layer_range("decoder", depth, idx)]
+        for lo, hi in ranges:
+            t = self.steps.get((lo, hi), 0) + 1
+            self.steps[(lo, hi)] = t
+            ops.adam_range(m.flat[lo:hi], m.flat_grad[lo:hi], self.m[lo:hi], self.v[lo:hi], self.wd, self.clip, self.lr, self.betas[0],
+                           self.betas[1], self.eps, t, self.gn2)
+
+    def loss(self):
+        m = self.model
+        nl = m.num_layers
+        s = self.loss_slots.sum(1)
+        w = [1.0, 1.0] + list(self.rec_weights) + [self.ind_weights[nl - 1] if m.num_heads > 1 else 0.0] * nl
+        return (s * torch.tensor(w, device=m.dev, dtype=torch.float32)).sum()
+
+    def grad_norm(self):
+        return self.gn2.sum().sqrt()

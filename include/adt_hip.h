@@ -185,6 +185,13 @@ int adt_log_softmax_bwd(const float* Y, const float* dY, int64_t rows, int H, fl
 /* adt_clip_adam plus Adam's coupled weight_decay l2 (g += l2 * p after clipping): bert4rec/trainer.py:41,137-138 */
 int adt_clip_adam_l2(float* P, float* G, float* M, float* V, int64_t n, float l2, float clip, float lr, float b1, float b2,
                      float eps, float grad_scale, float* scal, void* stream);
+/* Optimizer pieces for the supernet (sasrec/evolution.py:109,314-316): the squared norm of ALL gradients into 64 partial
+ * slots (clip_grad_norm_ is global), then Adam with coupled weight decay on one flat range with the caller's step count for
+ * that range -- torch skips parameters whose grad is None (the candidate layers that were not mixed in), so every
+ * candidate layer carries its own step count and moments. */
+int adt_grad_sumsq(const float* G, int64_t n, float* out64, void* stream);
+int adt_adam_range(float* P, float* G, float* M, float* V, int64_t n, float l2, float clip, float lr, float b1, float b2,
+                   float eps, float step, const float* gn2_slots, void* stream);
 /* adt_score_rank with a per-item bias (bert4rec/model/bert.py:89,110-116) */
 int adt_score_rank_bias(const float* F, int ldf, const float* E, const float* bias, const int32_t* cand, int B, int C,
                         int d, float* logits, int32_t* rank, void* stream);
