@@ -255,6 +255,10 @@ class SuperSASRecModel(FlatModule):
         logits, rank = ops.score_rank(feats.t[L - 1:], L * d, self.P("item_emb.weight"), cand, B, C, want_rank)
         return (logits, rank) if want_rank else logits
 
+    def predict_rank(self, log_seqs, item_indices, want_rank=True):
+        """(scores, rank of column 0) -- the interface adt_amd.sasrec.utils.evaluate_loader drives."""
+        return self.predict(None, log_seqs, item_indices, full=item_indices is None, want_rank=True)
+
     def loss_forward_backward(self, ids, rec_w, ind_w, norms, loss_slots, b_offset=0):
         """Forward, the warm-up loss (sasrec/evolution.py:296-313) and backward into flat_grad.  ids: device int32 (seq, dec,
         pos, neg) (B, L); norms: device {n_bce, n_mse, n_nll}; loss_slots: (2 + 2*num_layers) x 64 {bce_pos, bce_neg, mse.., nll..}."""
