@@ -5,9 +5,11 @@
 // (mean/cov projections, DistIntermediate) and the d = 256 template of sasrec/modules.py:84-137,618-633.
 //
 // Tiling: 128 x BN (128 | 64) output tile per 256-thread workgroup, BK = 32 contraction step, both operands in LDS
-// as fp32 rows of 32 k-values (stride 36), next k-step's global loads issued before the current MFMAs.  Operands
-// whose contraction index is the slow global index are transposed while they are written to LDS, so the MFMA
-// loop is the same for all three products.  mma16<PREC>: exact-fp32 (v_mfma_f32_16x16x4_f32) or bf16 operands.
+// as rows of 32 k-values, next k-step's global loads issued before the current MFMAs.  Operands whose contraction
+// index is the slow global index are transposed while they are written to LDS, so the MFMA loop is the same for all
+// three products.  bf16 mode: tiles are converted to bf16 once, on the way into LDS (row stride 40 elements), and each
+// wave runs 32x32x16 MFMAs on a 64x64 (or 32x64) sub-tile -- one ds_read_b128 per operand fragment, no conversion in
+// the loop.  Exact mode: fp32 tiles (stride 36) and v_mfma_f32_16x16x4_f32 through mma16<PREC_F32>.
 #pragma once
 #include "adt_common.cuh"
 
@@ -34,7 +36,13 @@ ADT_DEVICE_INLINE float act_grad(int act, float u) {
   }
 }
 
-constexpr int GBM = 128, GBK = 32, GRS = GBK + 4, GTH = 256;
+constexpr int GBM = 128, GBK = 32, GTH = 256;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 gbf16x4 __attribute__((ext_vector_type(4)));
+
+template <int PREC> struct GemmLds;
+template <> struct GemmLds<PREC_F32> { typedef float T; static constexpr int RS = GBK + 4; };
+template <> struct GemmLds<PREC_BF16> { typedef __bf16 T; static constexpr int RS = GBK + 8; };
 
 // ---- operand sources: value(row, col..col+3) as a float4 of the logical ROW-MAJOR matrix the GEMM reads -----
 struct PlainSrc {
@@ -99,20 +107,28 @@ ADT_DEVICE_INLINE void tile_fetch(float4 (&reg)[ROWS * 8 / GTH], const Src& s, i
     }
   }
 }
-template <int ROWS, bool TRANS>
-ADT_DEVICE_INLINE void tile_commit(float* tile, const float4 (&reg)[ROWS * 8 / GTH]) {
+template <int PREC, int ROWS, bool TRANS>
+ADT_DEVICE_INLINE void tile_commit(typename GemmLds<PREC>::T* tile, const float4 (&reg)[ROWS * 8 / GTH]) {
+  typedef typename GemmLds<PREC>::T T;
+  constexpr int RS = GemmLds<PREC>::RS;
 #pragma unroll
   for (int it = 0; it < ROWS * 8 / GTH; ++it) {
     const int f = threadIdx.x + it * GTH;
     if constexpr (!TRANS) {
       const int i = f >> 3, j4 = (f & 7) * 4;
-      *reinterpret_cast<float4*>(tile + i * GRS + j4) = reg[it];
+      if constexpr (PREC == PREC_BF16) {
+        gbf16x4 v;
+        v[0] = (__bf16)reg[it].x; v[1] = (__bf16)reg[it].y; v[2] = (__bf16)reg[it].z; v[3] = (__bf16)reg[it].w;
+        *reinterpret_cast<gbf16x4*>(tile + i * RS + j4) = v;
+      } else {
+        *reinterpret_cast<float4*>(tile + i * RS + j4) = reg[it];
+      }
     } else {
       const int j = f / (ROWS / 4), i4 = (f % (ROWS / 4)) * 4;
-      tile[(i4 + 0) * GRS + j] = reg[it].x;
-      tile[(i4 + 1) * GRS + j] = reg[it].y;
-      tile[(i4 + 2) * GRS + j] = reg[it].z;
-      tile[(i4 + 3) * GRS + j] = reg[it].w;
+      tile[(i4 + 0) * RS + j] = (T)reg[it].x;
+      tile[(i4 + 1) * RS + j] = (T)reg[it].y;
+      tile[(i4 + 2) * RS + j] = (T)reg[it].z;
+      tile[(i4 + 3) * RS + j] = (T)reg[it].w;
     }
   }
 }
@@ -122,50 +138,115 @@ template <int BN> struct GemmShape {
   static constexpr int TM = GBM / WM / 16, TN = BN / WN / 16;   // 16x16 tiles per wave: 4x4 or 2x4
 };
 
+// Accumulators of one wave's sub-tile and the (row, col) of every element: 16x16 tiles (col = c, row = 4g + r) in the exact
+// mode, 32x32 tiles (col = lane % 32, row = 8 (e / 4) + 4 (lane / 32) + e % 4) in the bf16 mode.
+template <int PREC, int BN>
+struct GemmAcc {
+  using S = GemmShape<BN>;
+  static constexpr bool B16 = PREC == PREC_BF16;
+  static constexpr int TM = B16 ? S::TM / 2 : S::TM, TN = B16 ? S::TN / 2 : S::TN;
+  f32x4 a16[B16 ? 1 : TM][B16 ? 1 : TN];
+  f32x16 a32[B16 ? TM : 1][B16 ? TN : 1];
+
+  ADT_DEVICE_INLINE void zero() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (B16) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) a32[i][j][e] = 0.f;
+        } else {
+          a16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+  }
+
+  template <class F>
+  ADT_DEVICE_INLINE void foreach(int m0, int n0, F f) const {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wm = w / S::WN, wn = w % S::WN;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (B16) {
+          const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) f(m0 + (wm * TM + i) * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3), col, a32[i][j][e]);
+        } else {
+          const int col = n0 + (wn * TN + j) * 16 + (lane & 15);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) f(m0 + (wm * TM + i) * 16 + 4 * (lane >> 4) + r, col, a16[i][j][r]);
+        }
+      }
+  }
+};
+
 // C tile (GBM x BN) += A (GBM x kdim) * B^T (BN x kdim); sums k over [k_begin, k_end).  Optional per-row sums of
 // the A tile (rowsum: one float per thread < GBM) for the bias gradient.
 template <int PREC, int BN, bool TA, bool TB, class SrcA, class SrcB, bool ROWSUM>
-ADT_DEVICE_INLINE void gemm_core(f32x4 (&acc)[GemmShape<BN>::TM][GemmShape<BN>::TN], const SrcA& A, const SrcB& Bs, int m0, int n0,
-                                 int k_begin, int k_end, float* sA, float* sB, float& rowsum) {
+ADT_DEVICE_INLINE void gemm_core(GemmAcc<PREC, BN>& acc, const SrcA& A, const SrcB& Bs, int m0, int n0, int k_begin, int k_end,
+                                 typename GemmLds<PREC>::T* sA, typename GemmLds<PREC>::T* sB, float& rowsum) {
   using S = GemmShape<BN>;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  using AC = GemmAcc<PREC, BN>;
+  constexpr int RS = GemmLds<PREC>::RS;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w / S::WN, wn = w % S::WN;
   float4 ra[GBM * 8 / GTH], rb[BN * 8 / GTH];
   tile_fetch<GBM, TA>(ra, A, m0, k_begin);
   tile_fetch<BN, TB>(rb, Bs, n0, k_begin);
+  auto compute = [&]() {
+    if constexpr (ROWSUM) {
+      if (threadIdx.x < GBM) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < GBK; ++j) s += (float)sA[threadIdx.x * RS + j];
+        rowsum += s;
+      }
+    }
+    if constexpr (PREC == PREC_BF16) {
+      const int r32 = lane & 31, kg = lane >> 5;
+#pragma unroll
+      for (int ks = 0; ks < GBK / 16; ++ks) {
+        bf16x8 fa[AC::TM], fb[AC::TN];
+#pragma unroll
+        for (int i = 0; i < AC::TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sA + ((wm * AC::TM + i) * 32 + r32) * RS + ks * 16 + 8 * kg);
+#pragma unroll
+        for (int j = 0; j < AC::TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sB + ((wn * AC::TN + j) * 32 + r32) * RS + ks * 16 + 8 * kg);
+#pragma unroll
+        for (int i = 0; i < AC::TM; ++i)
+#pragma unroll
+          for (int j = 0; j < AC::TN; ++j) acc.a32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc.a32[i][j], 0, 0, 0);
+      }
+    } else {
+      const int c = lane & 15, g = lane >> 4;
+      Frag8 fa[S::TM], fb[S::TN];
+#pragma unroll
+      for (int i = 0; i < S::TM; ++i) fa[i] = frag_contig(sA + ((wm * S::TM + i) * 16 + c) * RS + 8 * g);
+#pragma unroll
+      for (int j = 0; j < S::TN; ++j) fb[j] = frag_contig(sB + ((wn * S::TN + j) * 16 + c) * RS + 8 * g);
+#pragma unroll
+      for (int i = 0; i < S::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < S::TN; ++j) acc.a16[i][j] = mma16<PREC_F32>(acc.a16[i][j], fa[i], fb[j]);
+    }
+  };
+  // (a second register stage -- two k-steps of loads in flight -- was measured slower: the extra 32 VGPRs cost a wave per SIMD)
   for (int k0 = k_begin; k0 < k_end; k0 += GBK) {
     __syncthreads();   // previous step's readers done
-    tile_commit<GBM, TA>(sA, ra);
-    tile_commit<BN, TB>(sB, rb);
+    tile_commit<PREC, GBM, TA>(sA, ra);
+    tile_commit<PREC, BN, TB>(sB, rb);
     __syncthreads();
     if (k0 + GBK < k_end) {
       tile_fetch<GBM, TA>(ra, A, m0, k0 + GBK);
       tile_fetch<BN, TB>(rb, Bs, n0, k0 + GBK);
     }
-    if constexpr (ROWSUM) {
-      if (threadIdx.x < GBM) {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < GBK; j += 4) {
-          const float4 v = *reinterpret_cast<const float4*>(sA + threadIdx.x * GRS + j);
-          s += (v.x + v.y) + (v.z + v.w);
-        }
-        rowsum += s;
-      }
-    }
-    Frag8 fa[S::TM], fb[S::TN];
-#pragma unroll
-    for (int i = 0; i < S::TM; ++i) fa[i] = frag_contig(sA + ((wm * S::TM + i) * 16 + c) * GRS + 8 * g);
-#pragma unroll
-    for (int j = 0; j < S::TN; ++j) fb[j] = frag_contig(sB + ((wn * S::TN + j) * 16 + c) * GRS + 8 * g);
-#pragma unroll
-    for (int i = 0; i < S::TM; ++i)
-#pragma unroll
-      for (int j = 0; j < S::TN; ++j) acc[i][j] = mma16<PREC>(acc[i][j], fa[i], fb[j]);
+    compute();
   }
 }
 
-// ---- forward: Y = mask(R + dropout(act(X W^T + b))) ----------------------------------------------------------
+// ---- forward: Y = mask(R + R2 + dropout(act(X W^T + b))) -----------------------------------------------------
 struct DenseFwdArgs {
   const float* X; int ldx;
   const float* W; int ldw; const float* b;
@@ -183,41 +264,30 @@ struct DenseFwdArgs {
 
 template <int PREC, int BN>
 __global__ __launch_bounds__(GTH) void k_dense_fwd(DenseFwdArgs a) {
-  using S = GemmShape<BN>;
-  __shared__ __attribute__((aligned(16))) float sA[GBM * GRS];
-  __shared__ __attribute__((aligned(16))) float sB[BN * GRS];
+  typedef typename GemmLds<PREC>::T LT;
+  __shared__ __attribute__((aligned(16))) LT sA[GBM * GemmLds<PREC>::RS];
+  __shared__ __attribute__((aligned(16))) LT sB[BN * GemmLds<PREC>::RS];
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * GBM;
   if (a.t_dev && a.T > *a.t_dev) a.T = *a.t_dev;
   if (m0 >= a.T) return;
-  f32x4 acc[S::TM][S::TN] = {};
+  GemmAcc<PREC, BN> acc;
+  acc.zero();
   const PlainSrc A{a.X, a.ldx, a.T, a.K};
   const PlainSrc Bw{a.W, a.ldw, a.N, a.K};
   float dummy = 0.f;
   gemm_core<PREC, BN, false, false, PlainSrc, PlainSrc, false>(acc, A, Bw, m0, n0, 0, a.K, sA, sB, dummy);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-  const int wm = w / S::WN, wn = w % S::WN;
   const uint32_t key = drop_key(a.drop);
-#pragma unroll
-  for (int j = 0; j < S::TN; ++j) {
-    const int col = n0 + (wn * S::TN + j) * 16 + c;
-    if (col >= a.N) continue;
-    const float bias = a.b ? a.b[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < S::TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + (wm * S::TM + i) * 16 + 4 * g + r;
-        if (row >= a.T) continue;
-        float v = acc[i][j][r] + bias;
-        if (a.U) a.U[(size_t)row * a.ldu + col] = v;
-        v = act_apply(a.act, v);
-        if (a.drop.thr) v = adt_keep(key, (uint32_t)(row + a.row_offset) * (uint32_t)a.N + (uint32_t)col, a.drop.thr) ? v * a.drop.scale : 0.f;
-        if (a.R) v += a.R[(size_t)row * a.ldr + col];
-        if (a.R2) v += a.R2[(size_t)row * a.ldr2 + col];
-        if (a.ids && a.ids[row] == 0) v = 0.f;
-        a.Y[(size_t)row * a.ldy + col] = v;
-      }
-  }
+  acc.foreach(m0, n0, [&](int row, int col, float v) {
+    if (row >= a.T || col >= a.N) return;
+    if (a.b) v += a.b[col];
+    if (a.U) a.U[(size_t)row * a.ldu + col] = v;
+    v = act_apply(a.act, v);
+    if (a.drop.thr) v = adt_keep(key, (uint32_t)(row + a.row_offset) * (uint32_t)a.N + (uint32_t)col, a.drop.thr) ? v * a.drop.scale : 0.f;
+    if (a.R) v += a.R[(size_t)row * a.ldr + col];
+    if (a.R2) v += a.R2[(size_t)row * a.ldr2 + col];
+    if (a.ids && a.ids[row] == 0) v = 0.f;
+    a.Y[(size_t)row * a.ldy + col] = v;
+  });
 }
 
 // ---- input gradient: dX = (beta ? dX : 0) + G W ----------------------------------------------------------------
@@ -229,50 +299,45 @@ struct DenseBwdArgs {
   float* dX; int lddx; int beta;
   float* dW; int lddw; float* db;   // accumulated with atomics
   int t_chunk;                // rows of T per blockIdx.z (weight gradient)
+  int n_chunk;                // columns of N per blockIdx.z (input gradient; gridDim.z > 1: partials are added with atomics)
   const int* t_dev;           // optional DEVICE row count (see DenseFwdArgs)
 };
 
 template <int PREC, int BN>
 __global__ __launch_bounds__(GTH) void k_dense_bwd_dx(DenseBwdArgs a) {
-  using S = GemmShape<BN>;
-  __shared__ __attribute__((aligned(16))) float sA[GBM * GRS];
-  __shared__ __attribute__((aligned(16))) float sB[BN * GRS];
+  typedef typename GemmLds<PREC>::T LT;
+  __shared__ __attribute__((aligned(16))) LT sA[GBM * GemmLds<PREC>::RS];
+  __shared__ __attribute__((aligned(16))) LT sB[BN * GemmLds<PREC>::RS];
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * GBM;   // n0 indexes K (the columns of dX)
-  f32x4 acc[S::TM][S::TN] = {};
   GradSrc G = a.G;
   if (a.t_dev && G.T > *a.t_dev) G.T = *a.t_dev;
   if (m0 >= G.T) return;
+  GemmAcc<PREC, BN> acc;
+  acc.zero();
   G.key = drop_key(G.drop);
   const PlainSrc Bw{a.W, a.ldw, G.N, a.K};   // read transposed: tile[kcol][n] = W[n][kcol]
   float dummy = 0.f;
-  const int kend = (G.N + GBK - 1) / GBK * GBK;
-  gemm_core<PREC, BN, false, true, GradSrc, PlainSrc, false>(acc, G, Bw, m0, n0, 0, kend, sA, sB, dummy);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-  const int wm = w / S::WN, wn = w % S::WN;
-#pragma unroll
-  for (int j = 0; j < S::TN; ++j) {
-    const int col = n0 + (wn * S::TN + j) * 16 + c;
-    if (col >= a.K) continue;
-#pragma unroll
-    for (int i = 0; i < S::TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + (wm * S::TM + i) * 16 + 4 * g + r;
-        if (row >= G.T) continue;
-        float* dst = a.dX + (size_t)row * a.lddx + col;
-        *dst = (a.beta ? *dst : 0.f) + acc[i][j][r];
-      }
-  }
+  const int kall = (G.N + GBK - 1) / GBK * GBK;
+  const int kbeg = gridDim.z > 1 ? blockIdx.z * a.n_chunk : 0;
+  const int kend = gridDim.z > 1 ? (kbeg + a.n_chunk < kall ? kbeg + a.n_chunk : kall) : kall;
+  if (kbeg >= kend) return;
+  gemm_core<PREC, BN, false, true, GradSrc, PlainSrc, false>(acc, G, Bw, m0, n0, kbeg, kend, sA, sB, dummy);
+  const bool split = gridDim.z > 1;     // long contraction (all-item logits): the host zeroes dX first unless beta
+  acc.foreach(m0, n0, [&](int row, int col, float v) {
+    if (row >= G.T || col >= a.K) return;
+    float* dst = a.dX + (size_t)row * a.lddx + col;
+    if (split) atomicAdd(dst, v);
+    else *dst = (a.beta ? *dst : 0.f) + v;
+  });
 }
 
 // ---- weight gradient: dW += G^T X, db += colsum(G); T split over blockIdx.z, partials added with atomics ------
 template <int PREC, int BN>
 __global__ __launch_bounds__(GTH) void k_dense_bwd_dw(DenseBwdArgs a) {
-  using S = GemmShape<BN>;
-  __shared__ __attribute__((aligned(16))) float sA[GBM * GRS];
-  __shared__ __attribute__((aligned(16))) float sB[BN * GRS];
+  typedef typename GemmLds<PREC>::T LT;
+  __shared__ __attribute__((aligned(16))) LT sA[GBM * GemmLds<PREC>::RS];
+  __shared__ __attribute__((aligned(16))) LT sB[BN * GemmLds<PREC>::RS];
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * GBM;   // m0 indexes N (rows of dW), n0 indexes K (its columns)
-  f32x4 acc[S::TM][S::TN] = {};
   GradSrc G = a.G;
   if (a.t_dev && G.T > *a.t_dev) G.T = *a.t_dev;
   G.key = drop_key(G.drop);
@@ -281,6 +346,8 @@ __global__ __launch_bounds__(GTH) void k_dense_bwd_dw(DenseBwdArgs a) {
   int t1 = t0 + a.t_chunk;
   if (t1 > G.T) t1 = G.T;
   if (t0 >= t1) return;
+  GemmAcc<PREC, BN> acc;
+  acc.zero();
   const int kend = t0 + (t1 - t0 + GBK - 1) / GBK * GBK;
   // rows beyond t1 inside the last 32-step belong to the next chunk: bound both sources at t1
   GradSrc Gc = G; Gc.T = t1;
@@ -288,21 +355,10 @@ __global__ __launch_bounds__(GTH) void k_dense_bwd_dw(DenseBwdArgs a) {
   float rowsum = 0.f;
   if (a.db && blockIdx.x == 0) gemm_core<PREC, BN, true, true, GradSrc, PlainSrc, true>(acc, Gc, Xc, m0, n0, t0, kend, sA, sB, rowsum);
   else gemm_core<PREC, BN, true, true, GradSrc, PlainSrc, false>(acc, Gc, Xc, m0, n0, t0, kend, sA, sB, rowsum);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-  const int wm = w / S::WN, wn = w % S::WN;
-#pragma unroll
-  for (int j = 0; j < S::TN; ++j) {
-    const int col = n0 + (wn * S::TN + j) * 16 + c;
-    if (col >= a.K) continue;
-#pragma unroll
-    for (int i = 0; i < S::TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + (wm * S::TM + i) * 16 + 4 * g + r;
-        if (row >= G.N) continue;
-        atomicAdd(a.dW + (size_t)row * a.lddw + col, acc[i][j][r]);
-      }
-  }
+  acc.foreach(m0, n0, [&](int row, int col, float v) {
+    if (row >= G.N || col >= a.K) return;
+    atomicAdd(a.dW + (size_t)row * a.lddw + col, v);
+  });
   if (a.db && blockIdx.x == 0 && threadIdx.x < GBM && m0 + (int)threadIdx.x < G.N) atomicAdd(a.db + m0 + threadIdx.x, rowsum);
 }
 

@@ -71,8 +71,19 @@ static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
   DenseBwdArgs a = a0;
   const int T = a.G.T, N = a.G.N, K = a.K;
   if (a.dX) {
-    if (K > 64) hipLaunchKernelGGL((k_dense_bwd_dx<PREC, 128>), dim3((K + 127) / 128, (T + GBM - 1) / GBM), dim3(GTH), 0, s, a);
-    else hipLaunchKernelGGL((k_dense_bwd_dx<PREC, 64>), dim3(1, (T + GBM - 1) / GBM), dim3(GTH), 0, s, a);
+    const int gx = K > 64 ? (K + 127) / 128 : 1, gy = (T + GBM - 1) / GBM;
+    // long contractions over few output tiles (the all-item logits: N = V + 100) are split over blockIdx.z
+    int splits = 1;
+    if (N >= 4096 && gx * gy < 1024) {
+      splits = (2048 + gx * gy - 1) / (gx * gy);
+      if (splits > 32) splits = 32;
+      a.n_chunk = ((N + splits - 1) / splits + GBK - 1) / GBK * GBK;
+      splits = (N + a.n_chunk - 1) / a.n_chunk;
+      if (splits > 1 && !a.beta && hipMemset2DAsync(a.dX, (size_t)a.lddx * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)T, s) != hipSuccess)
+        return adt_set_error("dense_bwd: memset");
+    }
+    if (K > 64) hipLaunchKernelGGL((k_dense_bwd_dx<PREC, 128>), dim3(gx, gy, splits), dim3(GTH), 0, s, a);
+    else hipLaunchKernelGGL((k_dense_bwd_dx<PREC, 64>), dim3(gx, gy, splits), dim3(GTH), 0, s, a);
   }
   if (a.dW) {
     const int bn = K > 64 ? 128 : 64;
