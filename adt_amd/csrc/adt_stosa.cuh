@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void k_wattn_bwd(WAttnArgs a) {
       if (part == 0) {
         // W = |mq|^2 + sum(Sq) + ... - 2 (mq . mk + sqrt(Sq) . sqrt(Sk))
         a.dQm[(row_b + i) * a.ldd + h * hd + d0] = 2.0f * sV0[d0] * dwsum - 2.0f * am;
-        a.dQc[(row_b + i) * a.ldd + h * hd + d0] = dwsum - as / sV1[d0];
+        a.dQc[(row_b + i) * a.ldd + h * hd + d0] = dwsum - (sV1[d0] > 1e-12f ? as / sV1[d0] : 0.f);   // clamp(min=1e-24) gates the sqrt path
       }
     }
   }
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void k_wattn_bwd(WAttnArgs a) {
       }
       if (part == 0) {
         a.dKm[(row_b + j) * a.ldd + h * hd + d0] = 2.0f * sV0[d0] * dwsum - 2.0f * am;
-        a.dKc[(row_b + j) * a.ldd + h * hd + d0] = dwsum - as / sV1[d0];
+        a.dKc[(row_b + j) * a.ldd + h * hd + d0] = dwsum - (sV1[d0] > 1e-12f ? as / sV1[d0] : 0.f);
         a.dVm[(row_b + j) * a.ldd + h * hd + d0] = vm;
         a.dVc[(row_b + j) * a.ldd + h * hd + d0] = vc;
       }
@@ -448,11 +448,13 @@ __global__ __launch_bounds__(256) void k_wdist_bpr(WBprArgs a) {
         const float pm = a.Em[(size_t)ip * a.d + c], ps = w_sqrt_cov(w_elu1(pe));
         const float nm = a.Em[(size_t)in * a.d + c], ns = w_sqrt_cov(w_elu1(ne));
         dsm = g_pos * 2.0f * (sm - pm) + g_neg * 2.0f * (sm - nm);
-        dsc = g_pos * (ss - ps) / ss + g_neg * (ss - ns) / ss;
+        // torch.clamp(cov, min=1e-24) passes no gradient below the clamp: the 1/sqrt factors are gated
+        const float iss = ss > 1e-12f ? 1.0f / ss : 0.f, ips = ps > 1e-12f ? 1.0f / ps : 0.f, ins = ns > 1e-12f ? 1.0f / ns : 0.f;
+        dsc = g_pos * (ss - ps) * iss + g_neg * (ss - ns) * iss;
         const float dpm = -g_pos * 2.0f * (sm - pm) + g_pvn * 2.0f * (pm - nm);
-        const float dpc = -g_pos * (ss - ps) / ps + g_pvn * (ps - ns) / ps;
+        const float dpc = -g_pos * (ss - ps) * ips + g_pvn * (ps - ns) * ips;
         const float dnm = -g_neg * 2.0f * (sm - nm) - g_pvn * 2.0f * (pm - nm);
-        const float dnc = -g_neg * (ss - ns) / ns - g_pvn * (ps - ns) / ns;
+        const float dnc = -g_neg * (ss - ns) * ins - g_pvn * (ps - ns) * ins;
         atomicAdd(a.dEm + (size_t)ip * a.d + c, dpm);
         atomicAdd(a.dEc + (size_t)ip * a.d + c, dpc * w_elu_grad(pe));
         if (in > 0) {

