@@ -74,6 +74,25 @@ ADT_DEVICE_INLINE float w_score(float x, bool masked, bool dead_row) {
   return masked ? x + W_MASK : x;
 }
 
+// The scaled negative Wasserstein distance of one (query, key) pair, computed by ONE sequence of fused multiply-adds so that
+// the forward pass and both backward passes reproduce it bit for bit: on fully masked rows x - 2^32 is quantised to multiples
+// of 512 (see w_score), and a last-bit difference between the forward's and the backward's x would flip that rounding and
+// turn exp(s - LSE) into exp(+-512).  (sum(cov) is taken as sum(sqrt(cov)^2): identical for cov >= 1e-24.)
+ADT_DEVICE_INLINE float w_pair_x(const float* qm, const float* qs, const float* km, const float* ks, int hd, float sq_hd) {
+  float dm = 0.f, dc = 0.f, nqm = 0.f, nqc = 0.f, nkm = 0.f, nkc = 0.f;
+  for (int d0 = 0; d0 < hd; ++d0) {
+    const float a = qm[d0], b = qs[d0], c = km[d0], e = ks[d0];
+    dm = fmaf(a, c, dm);
+    dc = fmaf(b, e, dc);
+    nqm = fmaf(a, a, nqm);
+    nqc = fmaf(b, b, nqc);
+    nkm = fmaf(c, c, nkm);
+    nkc = fmaf(e, e, nkc);
+  }
+  const float wd = (fmaf(-2.0f, dm, nqm) + nkm) + (fmaf(-2.0f, dc, nqc) + nkc);
+  return (-wd) / sq_hd;
+}
+
 ADT_DEVICE_INLINE void w_mark_dead(float* sDead, const float* sKv, int L, int Lp) {
   for (int i = threadIdx.x; i < Lp; i += 256) {
     float cnt = 0.f;
@@ -114,17 +133,10 @@ __global__ __launch_bounds__(256) void k_wattn_fwd(WAttnArgs a) {
   const int nparts = 64 / nd;                  // partitions of the key range (hd = 16: 4, 32: 2, 64: 1)
   for (int i = w; i < L; i += 4) {
     // query row -> per-wave LDS (broadcast reads below); norms of the query
-    float qn_m = 0.f, qn_c = 0.f;
     for (int d0 = lane; d0 < hd; d0 += 64) {
-      const float qm = a.Qm[(row_b + i) * a.ldqm + h * hd + d0];
-      const float qc = a.Qc[(row_b + i) * a.ldqc + h * hd + d0];
-      sQm[d0] = qm;
-      sQs[d0] = w_sqrt_cov(qc);
-      qn_m += qm * qm;
-      qn_c += qc;
+      sQm[d0] = a.Qm[(row_b + i) * a.ldqm + h * hd + d0];
+      sQs[d0] = w_sqrt_cov(a.Qc[(row_b + i) * a.ldqc + h * hd + d0]);
     }
-    qn_m = wave_sum(qn_m);
-    qn_c = wave_sum(qn_c);
     const bool dead_i = sDead[i] != 0.f;
     float s[W_KPL];
     float m = -INFINITY;
@@ -133,16 +145,7 @@ __global__ __launch_bounds__(256) void k_wattn_fwd(WAttnArgs a) {
       const int j = lane + 64 * t;
       s[t] = -INFINITY;
       if (j < L) {
-        float dm = 0.f, dc = 0.f, kn_m = 0.f, kn_c = 0.f;
-        for (int d0 = 0; d0 < hd; ++d0) {
-          const float km = sKm[j * RS + d0], ks = sKs[j * RS + d0];
-          dm += sQm[d0] * km;
-          dc += sQs[d0] * ks;
-          kn_m += km * km;
-          kn_c += ks * ks;      // = clamp(cov): equals sum(cov) for cov >= 1e-24
-        }
-        const float wd = ((-2.0f * dm + qn_m) + kn_m) + ((-2.0f * dc + qn_c) + kn_c);
-        s[t] = w_score((-wd) / sq_hd, j > i || sKv[j] == 0.f, dead_i);
+        s[t] = w_score(w_pair_x(sQm, sQs, sKm + j * RS, sKs + j * RS, hd, sq_hd), j > i || sKv[j] == 0.f, dead_i);
         m = fmaxf(m, s[t]);
       }
     }
@@ -233,19 +236,12 @@ __global__ __launch_bounds__(256) void k_wattn_bwd(WAttnArgs a) {
 
   // ---- pass A ---------------------------------------------------------------------------------------------------
   for (int i = w; i < L; i += 4) {
-    float qn_m = 0.f, qn_c = 0.f;
     for (int d0 = lane; d0 < hd; d0 += 64) {
-      const float qm = a.Qm[(row_b + i) * a.ldqm + h * hd + d0];
-      const float qc = a.Qc[(row_b + i) * a.ldqc + h * hd + d0];
-      sV0[d0] = qm;
-      sV1[d0] = w_sqrt_cov(qc);
+      sV0[d0] = a.Qm[(row_b + i) * a.ldqm + h * hd + d0];
+      sV1[d0] = w_sqrt_cov(a.Qc[(row_b + i) * a.ldqc + h * hd + d0]);
       sV2[d0] = a.dOm[(row_b + i) * a.lddom + h * hd + d0];
       sV3[d0] = a.dOc[(row_b + i) * a.lddoc + h * hd + d0];
-      qn_m += qm * qm;
-      qn_c += qc;
     }
-    qn_m = wave_sum(qn_m);
-    qn_c = wave_sum(qn_c);
     const float lse = sLse[i];
     const bool dead_i = sDead[i] != 0.f;
     const uint32_t idx_q = (idx_bh + (uint32_t)i) * (uint32_t)L;
@@ -256,18 +252,12 @@ __global__ __launch_bounds__(256) void k_wattn_bwd(WAttnArgs a) {
       const int j = lane + 64 * t;
       p[t] = 0.f; dp[t] = 0.f;
       if (j < L) {
-        float dm = 0.f, dc = 0.f, kn_m = 0.f, kn_c = 0.f, gm = 0.f, gc = 0.f;
+        float gm = 0.f, gc = 0.f;
         for (int d0 = 0; d0 < hd; ++d0) {
-          const float km = sA0[j * RS + d0], ks = sA1[j * RS + d0];
-          dm += sV0[d0] * km;
-          dc += sV1[d0] * ks;
-          kn_m += km * km;
-          kn_c += ks * ks;
           gm += sV2[d0] * sA2[j * RS + d0];
           gc += sV3[d0] * sA3[j * RS + d0];
         }
-        const float wd = ((-2.0f * dm + qn_m) + kn_m) + ((-2.0f * dc + qn_c) + kn_c);
-        const float sv = w_score((-wd) / sq_hd, j > i || sKv[j] == 0.f, dead_i);
+        const float sv = w_score(w_pair_x(sV0, sV1, sA0 + j * RS, sA1 + j * RS, hd, sq_hd), j > i || sKv[j] == 0.f, dead_i);
         const float pr = expf(sv - lse);
         float ks_ = 1.0f;
         if (a.drop.thr) ks_ = adt_keep(key_rng, idx_q + (uint32_t)j, a.drop.thr) ? a.drop.scale : 0.f;
@@ -303,7 +293,7 @@ __global__ __launch_bounds__(256) void k_wattn_bwd(WAttnArgs a) {
       if (part == 0) {
         // W = |mq|^2 + sum(Sq) + ... - 2 (mq . mk + sqrt(Sq) . sqrt(Sk))
         a.dQm[(row_b + i) * a.ldd + h * hd + d0] = 2.0f * sV0[d0] * dwsum - 2.0f * am;
-        a.dQc[(row_b + i) * a.ldd + h * hd + d0] = dwsum - (sV1[d0] > 1e-12f ? as / sV1[d0] : 0.f);   // clamp(min=1e-24) gates the sqrt path
+        a.dQc[(row_b + i) * a.ldd + h * hd + d0] = dwsum - (sV1[d0] > 1.00001e-12f ? as / sV1[d0] : 0.f);   // clamp(min=1e-24) gates the sqrt path (cov = 0 exactly -> no gradient)
       }
     }
   }
@@ -318,20 +308,12 @@ __global__ __launch_bounds__(256) void k_wattn_bwd(WAttnArgs a) {
 
   // ---- pass B: wave owns key j, lanes over queries i ------------------------------------------------------------------
   for (int j = w; j < L; j += 4) {
-    float kn_m = 0.f, kn_c = 0.f;
     for (int d0 = lane; d0 < hd; d0 += 64) {
-      const float km = a.Km[(row_b + j) * a.ldkm + h * hd + d0];
-      const float kc = a.Kc[(row_b + j) * a.ldkc + h * hd + d0];
-      const float ks = w_sqrt_cov(kc);
-      sV0[d0] = km;
-      sV1[d0] = ks;
+      sV0[d0] = a.Km[(row_b + j) * a.ldkm + h * hd + d0];
+      sV1[d0] = w_sqrt_cov(a.Kc[(row_b + j) * a.ldkc + h * hd + d0]);
       sV2[d0] = a.Vm[(row_b + j) * a.ldvm + h * hd + d0];
       sV3[d0] = a.Vc[(row_b + j) * a.ldvc + h * hd + d0];
-      kn_m += km * km;
-      kn_c += ks * ks;
     }
-    kn_m = wave_sum(kn_m);
-    kn_c = wave_sum(kn_c);
     const bool key_pad = sKv[j] == 0.f;
     float dwsum = 0.f;
 #pragma unroll
@@ -340,18 +322,12 @@ __global__ __launch_bounds__(256) void k_wattn_bwd(WAttnArgs a) {
       if (i < Lp) {
         float dwv = 0.f, pd = 0.f;
         if (i < L) {
-          float dm = 0.f, dc = 0.f, qn_m = 0.f, qn_c = 0.f, gm = 0.f, gc = 0.f;
+          float gm = 0.f, gc = 0.f;
           for (int d0 = 0; d0 < hd; ++d0) {
-            const float qm = sA0[i * RS + d0], qs = sA1[i * RS + d0];
-            dm += qm * sV0[d0];
-            dc += qs * sV1[d0];
-            qn_m += qm * qm;
-            qn_c += qs * qs;
             gm += sA2[i * RS + d0] * sV2[d0];
             gc += sA3[i * RS + d0] * sV3[d0];
           }
-          const float wd = ((-2.0f * dm + qn_m) + kn_m) + ((-2.0f * dc + qn_c) + kn_c);
-          const float sv = w_score((-wd) / sq_hd, j > i || key_pad, sDead[i] != 0.f);
+          const float sv = w_score(w_pair_x(sA0 + i * RS, sA1 + i * RS, sV0, sV1, hd, sq_hd), j > i || key_pad, sDead[i] != 0.f);
           const float pr = expf(sv - sLse[i]);
           float ks_ = 1.0f;
           if (a.drop.thr) ks_ = adt_keep(key_rng, (idx_bh + (uint32_t)i) * (uint32_t)L + (uint32_t)j, a.drop.thr) ? a.drop.scale : 0.f;
@@ -381,7 +357,7 @@ __global__ __launch_bounds__(256) void k_wattn_bwd(WAttnArgs a) {
       }
       if (part == 0) {
         a.dKm[(row_b + j) * a.ldd + h * hd + d0] = 2.0f * sV0[d0] * dwsum - 2.0f * am;
-        a.dKc[(row_b + j) * a.ldd + h * hd + d0] = dwsum - (sV1[d0] > 1e-12f ? as / sV1[d0] : 0.f);
+        a.dKc[(row_b + j) * a.ldd + h * hd + d0] = dwsum - (sV1[d0] > 1.00001e-12f ? as / sV1[d0] : 0.f);
         a.dVm[(row_b + j) * a.ldd + h * hd + d0] = vm;
         a.dVc[(row_b + j) * a.ldd + h * hd + d0] = vc;
       }
@@ -449,7 +425,7 @@ __global__ __launch_bounds__(256) void k_wdist_bpr(WBprArgs a) {
         const float nm = a.Em[(size_t)in * a.d + c], ns = w_sqrt_cov(w_elu1(ne));
         dsm = g_pos * 2.0f * (sm - pm) + g_neg * 2.0f * (sm - nm);
         // torch.clamp(cov, min=1e-24) passes no gradient below the clamp: the 1/sqrt factors are gated
-        const float iss = ss > 1e-12f ? 1.0f / ss : 0.f, ips = ps > 1e-12f ? 1.0f / ps : 0.f, ins = ns > 1e-12f ? 1.0f / ns : 0.f;
+        const float iss = ss > 1.00001e-12f ? 1.0f / ss : 0.f, ips = ps > 1.00001e-12f ? 1.0f / ps : 0.f, ins = ns > 1.00001e-12f ? 1.0f / ns : 0.f;
         dsc = g_pos * (ss - ps) * iss + g_neg * (ss - ns) * iss;
         const float dpm = -g_pos * 2.0f * (sm - pm) + g_pvn * 2.0f * (pm - nm);
         const float dpc = -g_pos * (ss - ps) * ips + g_pvn * (ps - ns) * ips;
