@@ -121,8 +121,14 @@ def roofline_probe(model, trainer, B):
     ms = e0.elapsed_time(e1) / R
     alg_bytes = B * H * 8 * L * (d // H) * 4
     achieved = alg_bytes / (ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes of this same command,
+    # corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py): a profiler measurement, committed under profiles/
+    traffic = None
+    pmc = os.path.join(REPO, "profiles", "r01_attn_bwd_pmc.json")
+    if os.path.exists(pmc):
+        traffic = round(json.load(open(pmc))["traffic_bytes"])
     return {"bound": "hbm", "kernel": "k_attn_bwd", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(ms * 1e3, 2),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_us": round(ms * 1e3, 2),
             "algorithmic_bytes_per_launch": alg_bytes}
 
 
