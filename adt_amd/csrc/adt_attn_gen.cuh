@@ -395,4 +395,220 @@ __global__ __launch_bounds__(NW * 64) void k_attn_gen_bwd(AttnGenArgs ga) {
   }
 }
 
+// Chunked backward for head sizes whose (b, h) images do not fit in LDS at once (hd = 128, the d = 256 / 2-head template of
+// sasrec/templates/ml-1m.json): the resident side is staged in NCH chunks of LP / NCH rows -- keys (K, V, K^T) in pass A,
+// queries (Q, dO, Q^T, dO^T) in pass B -- while every wave keeps the dQ (pass A) or dK, dV (pass B) accumulators of its (up
+// to two) tiles in registers across the chunks.  Same arithmetic as k_attn_gen_bwd (P from the saved LSE, no cross-wave sums).
+template <int PREC, int HD, int MAXKT, int NCH>
+struct AttnChunkLds {
+  typedef typename Img<PREC>::E E;
+  static constexpr int LP = MAXKT * 16, LPC = LP / NCH, LPTC = LPC + 8, RS = HD + 8;
+  static constexpr size_t bwd_bytes = (size_t)(2 * LPC * RS + 2 * HD * LPTC) * sizeof(E) + 2 * LP * sizeof(float) + 2 * LP * sizeof(int);
+};
+
+template <int PREC, int HD, int MAXKT, int NCH, int NW>
+__global__ __launch_bounds__(NW * 64) void k_attn_gen_bwd_chunked(AttnGenArgs ga) {
+  typedef Img<PREC> I;
+  typedef typename I::E E;
+  typedef typename I::F F;
+  const AttnArgs& a = ga.a;
+  constexpr int LP = MAXKT * 16, LPC = LP / NCH, LPTC = LPC + 8, RS = HD + 8, NT = HD / 16, KB = (HD + 31) / 32, V8 = HD / 8;
+  constexpr int QPW = (MAXKT + NW - 1) / NW;       // tiles a wave owns
+  constexpr int TPC = LPC / 16;                    // 16-row tiles per chunk (even)
+  static_assert(LPC % 32 == 0, "chunks hold whole tile pairs");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  E* sR0 = reinterpret_cast<E*>(smem_raw);   // pass A: K chunk   | pass B: Q chunk (scaled)
+  E* sR1 = sR0 + LPC * RS;                    // pass A: V chunk   | pass B: dO chunk
+  E* sT0 = sR1 + LPC * RS;                    // pass A: K^T chunk | pass B: Q^T chunk (scaled)
+  E* sT1 = sT0 + HD * LPTC;                   //                   | pass B: dO^T chunk
+  float* sLse = reinterpret_cast<float*>(sT1 + HD * LPTC);
+  float* sDelta = sLse + LP;
+  int* sKv = reinterpret_cast<int*>(sDelta + LP);
+  int* sDead = sKv + LP;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int L = a.L;
+  const size_t row_b = (size_t)b * L;
+  const float* gQ = a.Q + row_b * a.ldq + h * HD;
+  const float* gK = a.K + row_b * a.ldk + h * HD;
+  const float* gV = a.V + row_b * a.ldv + h * HD;
+  const float* gdO = a.dO + row_b * a.lddo + h * HD;
+  const float* gO = a.O + row_b * a.ldo + h * HD;
+  for (int i = threadIdx.x; i < LP * V8; i += NW * 64) {
+    const int r = i / V8, c8 = (i % V8) * 8;
+    float part = 0.f;
+    if (r < L) {
+      const float4 d0 = *reinterpret_cast<const float4*>(gdO + (size_t)r * a.lddo + c8), d1 = *reinterpret_cast<const float4*>(gdO + (size_t)r * a.lddo + c8 + 4);
+      const float4 o0 = *reinterpret_cast<const float4*>(gO + (size_t)r * a.ldo + c8), o1 = *reinterpret_cast<const float4*>(gO + (size_t)r * a.ldo + c8 + 4);
+      part = d0.x * o0.x + d0.y * o0.y + d0.z * o0.z + d0.w * o0.w + d1.x * o1.x + d1.y * o1.y + d1.z * o1.z + d1.w * o1.w;
+    }
+#pragma unroll
+    for (int off = V8 / 2; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if ((i % V8) == 0) {
+      sDelta[r] = part;
+      sLse[r] = (r < L) ? a.LSE[(size_t)bh * L + r] : INFINITY;
+    }
+  }
+  for (int i = threadIdx.x; i < LP; i += NW * 64) sKv[i] = (i < L && (!ga.kid || ga.kid[row_b + i] > 0)) ? 1 : 0;
+  __syncthreads();
+  mark_dead_rows<NW * 64>(sDead, sKv, L, LP, a.causal);
+  const uint32_t key_rng = drop_key(a.drop);
+  const uint32_t idx_bh = (uint32_t)(bh + a.bh_offset) * (uint32_t)L;
+  const int nqt = (L + 15) / 16;
+
+  // ---- pass A: dQ, key chunks resident --------------------------------------------------------------------------------
+  {
+    f32x4 dq[QPW][NT];
+#pragma unroll
+    for (int t = 0; t < QPW; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) dq[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int r0 = ch * LPC;
+      if (r0 >= L) break;
+      __syncthreads();
+      const int Lc = L - r0 < LPC ? L - r0 : LPC;
+      stage_img<PREC, HD, NW * 64>(sR0, sT0, LPTC, gK + (size_t)r0 * a.ldk, a.ldk, Lc, LPC, 1.0f);
+      stage_img<PREC, HD, NW * 64>(sR1, nullptr, LPTC, gV + (size_t)r0 * a.ldv, a.ldv, Lc, LPC, 1.0f);
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < QPW; ++t) {
+        const int qt = w + t * NW;
+        if (qt >= nqt) continue;
+        const int q = qt * 16 + c;
+        const float lse_q = sLse[q], delta_q = sDelta[q];
+        const float fill_q = sDead[q] ? 0.f : ga.fill;
+        F fq[KB], fdo[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          fq[kb] = gfrag<PREC, HD>(gQ, a.ldq, q, q < L, kb, g, a.scale);
+          fdo[kb] = gfrag<PREC, HD>(gdO, a.lddo, q, q < L, kb, g, 1.0f);
+        }
+        const uint32_t idx_q = (idx_bh + (uint32_t)q) * (uint32_t)L;
+#pragma unroll 1
+        for (int kp = 0; kp < TPC / 2; ++kp) {
+          if (r0 + kp * 32 >= L) break;
+          float dsv[8];
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const int ktl = 2 * kp + tt;                  // tile inside the chunk
+            f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+              sacc = I::mma(sacc, rfrag_g<PREC, HD>(sR0, ktl * 16 + c, kb, g), fq[kb]);
+              dp = I::mma(dp, rfrag_g<PREC, HD>(sR1, ktl * 16 + c, kb, g), fdo[kb]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = r0 + ktl * 16 + 4 * g + r;  // < LP
+              const bool masked = (a.causal && key > q) || !sKv[key];
+              const float sv = masked ? fill_q : sacc[r];
+              const float p = key < L ? __expf(sv - lse_q) : 0.f;
+              float d = dp[r];
+              if (a.drop.thr) d = adt_keep(key_rng, idx_q + (uint32_t)key, a.drop.thr) ? d * a.drop.scale : 0.f;
+              dsv[4 * tt + r] = masked ? 0.f : p * (d - delta_q);
+            }
+          }
+          const F fds = I::pack(dsv);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) dq[t][nt] = I::mma(dq[t][nt], fds, I::slot8(sT0 + (nt * 16 + c) * LPTC + kp * 32, g));
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < QPW; ++t) {
+      const int qt = w + t * NW;
+      if (qt >= nqt) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qq = qt * 16 + 4 * g + r;
+          if (qq < L) a.dQ[(row_b + qq) * a.lddq + h * HD + nt * 16 + c] = dq[t][nt][r] * a.scale;
+        }
+    }
+  }
+
+  // ---- pass B: dK, dV, query chunks resident ---------------------------------------------------------------------------
+  {
+    f32x4 dk[QPW][NT], dv[QPW][NT];
+#pragma unroll
+    for (int t = 0; t < QPW; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) { dk[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int r0 = ch * LPC;
+      if (r0 >= L) break;
+      __syncthreads();
+      const int Lc = L - r0 < LPC ? L - r0 : LPC;
+      stage_img<PREC, HD, NW * 64>(sR0, sT0, LPTC, gQ + (size_t)r0 * a.ldq, a.ldq, Lc, LPC, a.scale);
+      stage_img<PREC, HD, NW * 64>(sR1, sT1, LPTC, gdO + (size_t)r0 * a.lddo, a.lddo, Lc, LPC, 1.0f);
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < QPW; ++t) {
+        const int kt = w + t * NW;
+        if (kt >= nqt) continue;
+        const int key = kt * 16 + c;
+        const bool key_ok = key < L;
+        const bool key_attend = sKv[key] != 0;
+        F fk[KB], fv[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          fk[kb] = gfrag<PREC, HD>(gK, a.ldk, key, key_ok, kb, g, 1.0f);
+          fv[kb] = gfrag<PREC, HD>(gV, a.ldv, key, key_ok, kb, g, 1.0f);
+        }
+#pragma unroll 1
+        for (int qp = 0; qp < TPC / 2; ++qp) {
+          if (r0 + qp * 32 >= L) break;
+          float pv[8], dsv[8];
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const int qtl = 2 * qp + tt;
+            f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+              sacc = I::mma(sacc, rfrag_g<PREC, HD>(sR0, qtl * 16 + c, kb, g), fk[kb]);
+              dp = I::mma(dp, rfrag_g<PREC, HD>(sR1, qtl * 16 + c, kb, g), fv[kb]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int qq = r0 + qtl * 16 + 4 * g + r;     // < LP
+              const bool masked = (a.causal && key > qq) || !key_attend;
+              const float sv = masked ? (sDead[qq] ? 0.f : ga.fill) : sacc[r];
+              const float p = key_ok ? __expf(sv - sLse[qq]) : 0.f;   // sLse = +inf for padded queries
+              float ks = 1.0f;
+              if (a.drop.thr) ks = adt_keep(key_rng, (idx_bh + (uint32_t)qq) * (uint32_t)L + (uint32_t)key, a.drop.thr) ? a.drop.scale : 0.f;
+              pv[4 * tt + r] = p * ks;
+              dsv[4 * tt + r] = masked ? 0.f : p * (dp[r] * ks - sDelta[qq]);
+            }
+          }
+          const F fp = I::pack(pv), fds = I::pack(dsv);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            dv[t][nt] = I::mma(dv[t][nt], fp, I::slot8(sT1 + (nt * 16 + c) * LPTC + qp * 32, g));
+            dk[t][nt] = I::mma(dk[t][nt], fds, I::slot8(sT0 + (nt * 16 + c) * LPTC + qp * 32, g));
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < QPW; ++t) {
+      const int kt = w + t * NW;
+      if (kt >= nqt) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kk = kt * 16 + 4 * g + r;
+          if (kk < L) {
+            a.dK[(row_b + kk) * a.lddk + h * HD + nt * 16 + c] = dk[t][nt][r];
+            a.dV[(row_b + kk) * a.lddv + h * HD + nt * 16 + c] = dv[t][nt][r];
+          }
+        }
+    }
+  }
+}
+
 }  // namespace adt

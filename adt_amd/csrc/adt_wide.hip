@@ -51,12 +51,36 @@ static int dispatch_attn_gen_l(bool bwd, const AttnGenArgs& a, hipStream_t s) {
   return adt_set_error("masked attention: L=%d > 224 unsupported", a.a.L);
 }
 
+// hd = 128 (sasrec d = 256, H = 2): forward with the whole (b, h) resident, backward staged in NCH chunks
+template <int PREC, int MAXKT, int NCH>
+static int launch_attn_gen_128(bool bwd, const AttnGenArgs& a, hipStream_t s) {
+  constexpr int NW = 8, HD = 128;
+  if (!bwd) return launch_attn_gen<PREC, HD, MAXKT>(false, a, s);
+  const size_t smem = AttnChunkLds<PREC, HD, MAXKT, NCH>::bwd_bytes;
+  if (smem > 160 * 1024) return adt_set_error("masked attention bwd: L=%d hd=128 prec=%d needs %zu B of LDS (> 160 KB)", a.a.L, PREC, smem);
+  const void* fn = (const void*)k_attn_gen_bwd_chunked<PREC, HD, MAXKT, NCH, NW>;
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return adt_set_error("masked attention: hipFuncSetAttribute(%zu)", smem);
+    done = true;
+  }
+  AttnGenArgs args = a;
+  void* kargs[] = {&args};
+  if (hipLaunchKernel(fn, dim3(a.a.B * a.a.H), dim3(NW * 64), kargs, smem, s) != hipSuccess) return adt_set_error("masked attention: launch failed");
+  return check_launch("attn_masked_bwd(hd128)");
+}
+
 template <int PREC>
 static int dispatch_attn_gen(bool bwd, int hd, const AttnGenArgs& a, hipStream_t s) {
   if (hd == 16) return dispatch_attn_gen_l<PREC, 16>(bwd, a, s);
   if (hd == 32) return dispatch_attn_gen_l<PREC, 32>(bwd, a, s);
   if (hd == 64) return dispatch_attn_gen_l<PREC, 64>(bwd, a, s);
-  return adt_set_error("masked attention: head_dim=%d unsupported (16/32/64)", hd);
+  if (hd == 128) {
+    if (a.a.L <= 64) return launch_attn_gen_128<PREC, 4, 1>(bwd, a, s);
+    if (a.a.L <= 256) return launch_attn_gen_128<PREC, 16, 2>(bwd, a, s);
+    return adt_set_error("masked attention: L=%d > 256 unsupported at head_dim 128", a.a.L);
+  }
+  return adt_set_error("masked attention: head_dim=%d unsupported (16/32/64/128)", hd);
 }
 
 template <int PREC>

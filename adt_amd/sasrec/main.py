@@ -118,7 +118,13 @@ def main(argv=None):
     val_ds = U.EvalDataset(user_train, user_valid, user_test, usernum, itemnum, args.maxlen, sampler, "val", args.eval_set, args.frozen_eval)
     test_ds = U.EvalDataset(user_train, user_valid, user_test, usernum, itemnum, args.maxlen, sampler, "test", args.eval_set, args.frozen_eval)
 
-    model = SASRecADT(usernum, itemnum, args).to(args.device)
+    wide = args.hidden_units != 64     # the fused executor is 64-wide; other widths (the d = 256 template) take the general kernels
+    if wide:
+        from .model_wide import SASRecADTWide, WideSasrecTrainer
+        model = SASRecADTWide(usernum, itemnum, args)
+        args.loop = "fused"
+    else:
+        model = SASRecADT(usernum, itemnum, args).to(args.device)
     for _, prm in model.named_parameters():       # sasrec/main.py:95-99
         try:
             torch.nn.init.xavier_normal_(prm.data)
@@ -135,7 +141,10 @@ def main(argv=None):
     ks = [5, 10]
     logf = open(os.path.join(out_dir, "log.txt"), "w") if rank == 0 else None
     trainer = None
-    if args.loop == "fused":
+    if wide:
+        trainer = WideSasrecTrainer(model, lambdas1, lambdas2, lr=args.lr, betas=(0.9, 0.98), weight_decay=args.weight_decay, clip=args.clip,
+                                    process_group=pg, use_graph=args.use_graph, seed=23)
+    elif args.loop == "fused":
         trainer = FusedTrainer(model, lambdas1, lambdas2, lr=args.lr, betas=(0.9, 0.98), weight_decay=args.weight_decay, clip=args.clip,
                                process_group=pg, use_graph=args.use_graph, seed=23)
     else:

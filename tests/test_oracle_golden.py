@@ -118,6 +118,32 @@ def test_cfga_slice_matches_reference(golden_dir):
     assert abs(so.grad_norm(G) - float(z["total_norm"])) < 1e-4 * float(z["total_norm"])
 
 
+def test_d256_template_width_matches_reference(golden_dir):
+    """The shipped ml-1m template width (hidden_units 256, 2 heads: sasrec/templates/ml-1m.json:11-12) on a short sequence."""
+    from tools.gen_golden_inputs import make_batch, sample_idx
+    z, cfg = load(golden_dir, "sasrec_d256_h2")
+    seed, B = int(z["seed"]), int(z["B"])
+    P = so.init_params(cfg, seed=seed)
+    batch = make_batch(np.random.RandomState(seed + 1), B, cfg.maxlen, cfg.item_num)
+    out = so.forward(P, cfg, *batch, training=True)
+    close(out[0], z["pos_logits"], 5e-5, what="pos_logits")
+    for i in range(cfg.num_layers):
+        for nm, t in (("enc_in", out[2][i]), ("dec_out", out[3][i]), ("rec_ind", so.rec_reference_order(out[4][i]))):
+            t = t.reshape(-1)
+            close(t[sample_idx(t.size, 1024)], z["%s.%d.sample" % (nm, i)], 5e-5, what=nm)
+    loss, parts, seeds = so.loss_and_seeds(P, cfg, out, batch[2], list(z["lam1"]), list(z["lam2"]), float(z["wd"]))
+    assert abs(loss - float(z["loss"])) < 5e-5
+    G = so.backward(P, cfg, out[5], seeds, float(z["wd"]))
+    for k, _ in so.param_shapes(cfg):
+        if "gnone." + k in z.files:
+            assert G[k] is None
+            continue
+        t = G[k].reshape(-1)
+        close(t[sample_idx(t.size)], z["gsample." + k], 1e-7, rtol=1e-3, what="grad sample " + k)
+    assert abs(so.grad_norm(G) - float(z["total_norm"])) < 1e-4 * float(z["total_norm"])
+    close(so.predict(P, cfg, batch[0], z["cand"]), z["predict_cand"], 2e-5, what="predict")
+
+
 def test_metrics_kat(golden_dir):
     z = np.load(os.path.join(golden_dir, "metrics_kat.npz"))
     ranks = np.concatenate([so.rank_of_first(s) for s in z["scores"]])

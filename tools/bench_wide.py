@@ -104,9 +104,38 @@ def run_stosa(args):
                       "dtype": "f32 attention/losses, bf16 dense operands"}))
 
 
+def run_sasrec256(args):
+    """SASRec-ADT at the shipped ml-1m template width (sasrec/templates/ml-1m.json: hidden_units 256, 2 heads, maxlen 200)."""
+    import torch
+    import bench
+    from adt_amd.sasrec.model_wide import SASRecADTWide, WideSasrecTrainer
+    a = Args()
+    a.device, a.num_heads, a.maxlen, a.num_layers, a.hidden_units, a.dropout, a.precision = "cuda:0", 2, 200, 2, 256, 0.5, "bf16"
+    torch.manual_seed(23)
+    m = SASRecADTWide(6040, 3416, a)
+    for _, p in m.named_parameters():
+        try:
+            torch.nn.init.xavier_normal_(p.data)
+        except Exception:
+            pass
+    tr = WideSasrecTrainer(m, bench.CFG["lambdas1"], bench.CFG["lambdas2"], weight_decay=1e-3, use_graph=not args.no_graph, seed=23)
+    batches = bench.synth_batches(4, args.batch, 200, 3416, seed=100)
+    for i in range(args.warmup):
+        tr.step(*batches[i % 4])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        tr.step(*batches[i % 4])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"workload": "SASRec-ADT ml-1m TEMPLATE width: d=256 H=2 (head size 128) L=200 2+2 layers V=3416, batch %d, dropout 0.5, full train step (H2D of ids included)" % args.batch,
+                      "ms_per_step": round(dt / args.steps * 1e3, 3), "sequences_per_s": round(args.batch * args.steps / dt, 1), "loss": round(float(tr.loss()), 4),
+                      "dtype": "bf16"}))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("which", choices=["bert", "stosa"])
+    ap.add_argument("which", choices=["bert", "stosa", "sasrec256"])
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256)
@@ -114,4 +143,4 @@ if __name__ == "__main__":
     ap.add_argument("--mcap", type=float, default=0.3)
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
-    (run_bert if args.which == "bert" else run_stosa)(args)
+    {"bert": run_bert, "stosa": run_stosa, "sasrec256": run_sasrec256}[args.which](args)

@@ -166,6 +166,41 @@ def case_cfga(name, B, seed):
     print(name, "loss", rec["loss"], "norm", rec["total_norm"])
 
 
+def case_sampled(name, V, L, d, H, nl, B, seed, lam1, lam2, wd=1e-3):
+    """Wide configuration (the shipped template: d = 256, H = 2 => head size 128, sasrec/templates/ml-1m.json:11-12) on a
+    short sequence: outputs and gradients as norms + strided samples (weights regenerate from `seed`)."""
+    cfg = so.Cfg(V, L, d, H, nl, dropout=0.0)
+    P = so.init_params(cfg, seed=seed)
+    r = np.random.RandomState(seed + 1)
+    batch = make_batch(r, B, L, V)
+    rec = ref_train_steps(cfg, P, batch, lam1, lam2, wd, 1e-3, 5.0, 1)
+    out = dict(cfg=np.array([V, L, d, H, nl], np.int64), seed=np.int64(seed), B=np.int64(B), lam1=np.array(lam1), lam2=np.array(lam2),
+               wd=np.float64(wd), loss=np.float64(rec["loss"]), total_norm=np.float64(rec["total_norm"]), pos_logits=rec["pos_logits"],
+               neg_logits=rec["neg_logits"])
+    for i in range(nl):
+        for nm in ("enc_in", "dec_out", "rec_ind"):
+            t = rec[nm][i].reshape(-1)
+            out["%s.%d.norm" % (nm, i)] = np.float64(np.sqrt((t.astype(np.float64) ** 2).sum()))
+            out["%s.%d.sample" % (nm, i)] = t[sample_idx(t.size, 1024)]
+    for k, g in rec["grads"].items():
+        if g is None:
+            out["gnone." + k] = np.int8(1)
+        else:
+            t = g.reshape(-1)
+            out["gnorm." + k] = np.float64(np.sqrt((t.astype(np.float64) ** 2).sum()))
+            out["gsample." + k] = t[sample_idx(t.size)]
+    for k, v in rec["weights_step0"].items():
+        out["w1sample." + k] = v.reshape(-1)[sample_idx(v.size)]
+    model, _ = build_ref(cfg, P)
+    model.eval()
+    cand = r.randint(1, V + 1, size=(B, 11)).astype(np.int64)
+    with torch.no_grad():
+        out["cand"] = cand
+        out["predict_cand"] = model.predict(np.zeros(B), batch[0], cand).numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "loss", rec["loss"], "norm", rec["total_norm"])
+
+
 def case_metrics():
     """evaluate_loader (sasrec/utils.py:395-428) on preset score matrices."""
     import utils as ref_utils
@@ -270,6 +305,7 @@ if __name__ == "__main__":
     case_small("sasrec_small_l3", B=5, L=24, d=32, H=2, nl=3, V=80, seed=17,
                lam1=[0.01, 0.2, 0.03], lam2=[0.3, 0.2, 0.05], wd=0.0)
     case_cfga("sasrec_cfga_b8", B=8, seed=23)
+    case_sampled("sasrec_d256_h2", V=50, L=24, d=256, H=2, nl=1, B=3, seed=29, lam1=[0.104292], lam2=[0.100833])
     case_metrics()
     case_data()
     case_config()
