@@ -36,7 +36,8 @@ ADT_DEVICE_INLINE float act_grad(int act, float u) {
   }
 }
 
-constexpr int GBM = 128, GBK = 32, GTH = 256;
+constexpr int GBM = 128, GBK = 32, GTH = 256;   // BK = 64 measured slower at d = 256 (fewer waves per SIMD), faster only at d = 64
+constexpr int GPR = GBK / 4;   // float4 per tile row
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 gbf16x4 __attribute__((ext_vector_type(4)));
 
@@ -91,15 +92,39 @@ struct GradSrc {
 };
 
 // ---- tile movers --------------------------------------------------------------------------------------------
-// LDS tile: ROWS rows (output index) x 32 k.  Direct: tile[i][j] = src(r0 + i, k0 + j).  Transposed:
+// LDS tile: ROWS rows (output index) x GBK k.  Direct: tile[i][j] = src(r0 + i, k0 + j).  Transposed:
 // tile[i][j] = src(k0 + j, r0 + i) (the contraction index is the source's row index).
-template <int ROWS, bool TRANS, class Src>
-ADT_DEVICE_INLINE void tile_fetch(float4 (&reg)[ROWS * 8 / GTH], const Src& s, int r0, int k0) {
+// Interior tiles of a plain matrix (every row and column in range -- all but the edge workgroups / the last k-step): unconditional
+// 16-byte loads from one per-thread base pointer, no per-load bounds arithmetic (the generic path spent more vector instructions
+// on index checks than on the MFMAs' operands).
+template <int ROWS, bool TRANS>
+ADT_DEVICE_INLINE bool tile_fetch_fast(float4 (&reg)[ROWS * GPR / GTH], const PlainSrc& s, int r0, int k0) {
+  const bool interior = TRANS ? (k0 + GBK <= s.rows && r0 + ROWS <= s.cols) : (r0 + ROWS <= s.rows && k0 + GBK <= s.cols);
+  if (!interior) return false;
+  if constexpr (!TRANS) {
+    const float* base = s.p + (size_t)(r0 + threadIdx.x / GPR) * s.ld + k0 + (threadIdx.x % GPR) * 4;
+    const size_t step = (size_t)(GTH / GPR) * s.ld;
 #pragma unroll
-  for (int it = 0; it < ROWS * 8 / GTH; ++it) {
+    for (int it = 0; it < ROWS * GPR / GTH; ++it) reg[it] = *reinterpret_cast<const float4*>(base + it * step);
+  } else {
+    constexpr int PER = ROWS / 4;                       // float4 per source row
+    const float* base = s.p + (size_t)(k0 + threadIdx.x / PER) * s.ld + r0 + (threadIdx.x % PER) * 4;
+    const size_t step = (size_t)(GTH / PER) * s.ld;
+#pragma unroll
+    for (int it = 0; it < ROWS * GPR / GTH; ++it) reg[it] = *reinterpret_cast<const float4*>(base + it * step);
+  }
+  return true;
+}
+template <int ROWS, bool TRANS, class Src>
+ADT_DEVICE_INLINE void tile_fetch(float4 (&reg)[ROWS * GPR / GTH], const Src& s, int r0, int k0) {
+  if constexpr (__is_same(Src, PlainSrc)) {
+    if (tile_fetch_fast<ROWS, TRANS>(reg, s, r0, k0)) return;
+  }
+#pragma unroll
+  for (int it = 0; it < ROWS * GPR / GTH; ++it) {
     const int f = threadIdx.x + it * GTH;
     if constexpr (!TRANS) {
-      const int i = f >> 3, j4 = (f & 7) * 4;
+      const int i = f / GPR, j4 = (f % GPR) * 4;
       reg[it] = s.at(r0 + i, k0 + j4);
     } else {
       const int j = f / (ROWS / 4), i4 = (f % (ROWS / 4)) * 4;
@@ -108,14 +133,14 @@ ADT_DEVICE_INLINE void tile_fetch(float4 (&reg)[ROWS * 8 / GTH], const Src& s, i
   }
 }
 template <int PREC, int ROWS, bool TRANS>
-ADT_DEVICE_INLINE void tile_commit(typename GemmLds<PREC>::T* tile, const float4 (&reg)[ROWS * 8 / GTH]) {
+ADT_DEVICE_INLINE void tile_commit(typename GemmLds<PREC>::T* tile, const float4 (&reg)[ROWS * GPR / GTH]) {
   typedef typename GemmLds<PREC>::T T;
   constexpr int RS = GemmLds<PREC>::RS;
 #pragma unroll
-  for (int it = 0; it < ROWS * 8 / GTH; ++it) {
+  for (int it = 0; it < ROWS * GPR / GTH; ++it) {
     const int f = threadIdx.x + it * GTH;
     if constexpr (!TRANS) {
-      const int i = f >> 3, j4 = (f & 7) * 4;
+      const int i = f / GPR, j4 = (f % GPR) * 4;
       if constexpr (PREC == PREC_BF16) {
         gbf16x4 v;
         v[0] = (__bf16)reg[it].x; v[1] = (__bf16)reg[it].y; v[2] = (__bf16)reg[it].z; v[3] = (__bf16)reg[it].w;
@@ -132,6 +157,8 @@ ADT_DEVICE_INLINE void tile_commit(typename GemmLds<PREC>::T* tile, const float4
     }
   }
 }
+
+template <int PREC, int BN> constexpr size_t gemm_lds_bytes() { return (size_t)(GBM + BN) * GemmLds<PREC>::RS * sizeof(typename GemmLds<PREC>::T); }
 
 template <int BN> struct GemmShape {
   static constexpr int WN = BN == 128 ? 2 : 1, WM = 4 / WN;     // wave grid
@@ -193,7 +220,7 @@ ADT_DEVICE_INLINE void gemm_core(GemmAcc<PREC, BN>& acc, const SrcA& A, const Sr
   constexpr int RS = GemmLds<PREC>::RS;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w / S::WN, wn = w % S::WN;
-  float4 ra[GBM * 8 / GTH], rb[BN * 8 / GTH];
+  float4 ra[GBM * GPR / GTH], rb[BN * GPR / GTH];
   tile_fetch<GBM, TA>(ra, A, m0, k_begin);
   tile_fetch<BN, TB>(rb, Bs, n0, k_begin);
   auto compute = [&]() {
@@ -221,15 +248,18 @@ ADT_DEVICE_INLINE void gemm_core(GemmAcc<PREC, BN>& acc, const SrcA& A, const Sr
       }
     } else {
       const int c = lane & 15, g = lane >> 4;
-      Frag8 fa[S::TM], fb[S::TN];
 #pragma unroll
-      for (int i = 0; i < S::TM; ++i) fa[i] = frag_contig(sA + ((wm * S::TM + i) * 16 + c) * RS + 8 * g);
+      for (int kb = 0; kb < GBK / 32; ++kb) {
+        Frag8 fa[S::TM], fb[S::TN];
 #pragma unroll
-      for (int j = 0; j < S::TN; ++j) fb[j] = frag_contig(sB + ((wn * S::TN + j) * 16 + c) * RS + 8 * g);
+        for (int i = 0; i < S::TM; ++i) fa[i] = frag_contig(sA + ((wm * S::TM + i) * 16 + c) * RS + kb * 32 + 8 * g);
 #pragma unroll
-      for (int i = 0; i < S::TM; ++i)
+        for (int j = 0; j < S::TN; ++j) fb[j] = frag_contig(sB + ((wn * S::TN + j) * 16 + c) * RS + kb * 32 + 8 * g);
 #pragma unroll
-        for (int j = 0; j < S::TN; ++j) acc.a16[i][j] = mma16<PREC_F32>(acc.a16[i][j], fa[i], fb[j]);
+        for (int i = 0; i < S::TM; ++i)
+#pragma unroll
+          for (int j = 0; j < S::TN; ++j) acc.a16[i][j] = mma16<PREC_F32>(acc.a16[i][j], fa[i], fb[j]);
+      }
     }
   };
   // (a second register stage -- two k-steps of loads in flight -- was measured slower: the extra 32 VGPRs cost a wave per SIMD)
@@ -246,6 +276,23 @@ ADT_DEVICE_INLINE void gemm_core(GemmAcc<PREC, BN>& acc, const SrcA& A, const Sr
   }
 }
 
+// XCD-aware block -> tile mapping.  Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its own L2:
+// the tiles that re-read the same operand rows (all column tiles of one row tile; all output tiles of one split-k chunk) are
+// given ids that are congruent mod 8, so they run on ONE XCD and the shared operand is fetched into one L2 once instead of
+// into eight.  grid = xcd_grid(n_outer, n_inner) blocks; (outer, inner) = the tile pair of this block, outer >= n_outer: idle.
+ADT_DEVICE_INLINE void xcd_tile(int n_outer, int n_inner, int& outer, int& inner) {
+  const int bid = blockIdx.x;
+  if (n_outer < 16) {      // too few groups to spread over 8 XCDs: plain row-major mapping (grid = n_outer * n_inner)
+    outer = bid / n_inner;
+    inner = bid % n_inner;
+    return;
+  }
+  const int xcd = bid & 7, local = bid >> 3;
+  outer = (local / n_inner) * 8 + xcd;
+  inner = local % n_inner;
+}
+static inline int xcd_grid(int n_outer, int n_inner) { return n_outer < 16 ? n_outer * n_inner : (n_outer + 7) / 8 * 8 * n_inner; }
+
 // ---- forward: Y = mask(R + R2 + dropout(act(X W^T + b))) -----------------------------------------------------
 struct DenseFwdArgs {
   const float* X; int ldx;
@@ -254,6 +301,7 @@ struct DenseFwdArgs {
   float* Y; int ldy;
   float* U; int ldu;          // optional: pre-activation X W^T + b, saved for the backward of gelu / elu / relu
   int act;
+  int nt_n, nt_m;             // tile counts along N and T (1-D launch, see xcd_tile)
   DropCfg drop; uint32_t row_offset;   // idx = (row + row_offset) * N + col
   const float* R; int ldr;    // optional residual
   const float* R2; int ldr2;  // optional second residual (sasrec decoder: dec_input + (x + ffn(x)), modules.py:672-673)
@@ -265,9 +313,12 @@ struct DenseFwdArgs {
 template <int PREC, int BN>
 __global__ __launch_bounds__(GTH) void k_dense_fwd(DenseFwdArgs a) {
   typedef typename GemmLds<PREC>::T LT;
-  __shared__ __attribute__((aligned(16))) LT sA[GBM * GemmLds<PREC>::RS];
-  __shared__ __attribute__((aligned(16))) LT sB[BN * GemmLds<PREC>::RS];
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * GBM;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
+  LT* sA = reinterpret_cast<LT*>(gemm_smem);
+  LT* sB = sA + GBM * GemmLds<PREC>::RS;
+  int tm, tn;
+  xcd_tile(a.nt_m, a.nt_n, tm, tn);
+  const int n0 = tn * BN, m0 = tm * GBM;
   if (a.t_dev && a.T > *a.t_dev) a.T = *a.t_dev;
   if (m0 >= a.T) return;
   GemmAcc<PREC, BN> acc;
@@ -299,6 +350,7 @@ struct DenseBwdArgs {
   float* dX; int lddx; int beta;
   float* dW; int lddw; float* db;   // accumulated with atomics
   int t_chunk;                // rows of T per blockIdx.z (weight gradient)
+  int nt_a, nt_b, nt_z;       // tile counts of the 1-D launches (see xcd_tile): dx: K tiles, T tiles, N splits; dw: K tiles, N tiles, T splits
   int n_chunk;                // columns of N per blockIdx.z (input gradient; gridDim.z > 1: partials are added with atomics)
   const int* t_dev;           // optional DEVICE row count (see DenseFwdArgs)
 };
@@ -306,9 +358,13 @@ struct DenseBwdArgs {
 template <int PREC, int BN>
 __global__ __launch_bounds__(GTH) void k_dense_bwd_dx(DenseBwdArgs a) {
   typedef typename GemmLds<PREC>::T LT;
-  __shared__ __attribute__((aligned(16))) LT sA[GBM * GemmLds<PREC>::RS];
-  __shared__ __attribute__((aligned(16))) LT sB[BN * GemmLds<PREC>::RS];
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * GBM;   // n0 indexes K (the columns of dX)
+  extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
+  LT* sA = reinterpret_cast<LT*>(gemm_smem);
+  LT* sB = sA + GBM * GemmLds<PREC>::RS;
+  int tm, inner;
+  xcd_tile(a.nt_b, a.nt_a * a.nt_z, tm, inner);                    // all K tiles and N splits of one T tile share its G rows
+  const int zz = inner / a.nt_a;
+  const int n0 = (inner % a.nt_a) * BN, m0 = tm * GBM;     // n0 indexes K (the columns of dX)
   GradSrc G = a.G;
   if (a.t_dev && G.T > *a.t_dev) G.T = *a.t_dev;
   if (m0 >= G.T) return;
@@ -318,11 +374,11 @@ __global__ __launch_bounds__(GTH) void k_dense_bwd_dx(DenseBwdArgs a) {
   const PlainSrc Bw{a.W, a.ldw, G.N, a.K};   // read transposed: tile[kcol][n] = W[n][kcol]
   float dummy = 0.f;
   const int kall = (G.N + GBK - 1) / GBK * GBK;
-  const int kbeg = gridDim.z > 1 ? blockIdx.z * a.n_chunk : 0;
-  const int kend = gridDim.z > 1 ? (kbeg + a.n_chunk < kall ? kbeg + a.n_chunk : kall) : kall;
+  const int kbeg = a.nt_z > 1 ? zz * a.n_chunk : 0;
+  const int kend = a.nt_z > 1 ? (kbeg + a.n_chunk < kall ? kbeg + a.n_chunk : kall) : kall;
   if (kbeg >= kend) return;
   gemm_core<PREC, BN, false, true, GradSrc, PlainSrc, false>(acc, G, Bw, m0, n0, kbeg, kend, sA, sB, dummy);
-  const bool split = gridDim.z > 1;     // long contraction (all-item logits): the host zeroes dX first unless beta
+  const bool split = a.nt_z > 1;     // long contraction (all-item logits): the host zeroes dX first unless beta
   acc.foreach(m0, n0, [&](int row, int col, float v) {
     if (row >= G.T || col >= a.K) return;
     float* dst = a.dX + (size_t)row * a.lddx + col;
@@ -335,14 +391,18 @@ __global__ __launch_bounds__(GTH) void k_dense_bwd_dx(DenseBwdArgs a) {
 template <int PREC, int BN>
 __global__ __launch_bounds__(GTH) void k_dense_bwd_dw(DenseBwdArgs a) {
   typedef typename GemmLds<PREC>::T LT;
-  __shared__ __attribute__((aligned(16))) LT sA[GBM * GemmLds<PREC>::RS];
-  __shared__ __attribute__((aligned(16))) LT sB[BN * GemmLds<PREC>::RS];
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * GBM;   // m0 indexes N (rows of dW), n0 indexes K (its columns)
+  extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
+  LT* sA = reinterpret_cast<LT*>(gemm_smem);
+  LT* sB = sA + GBM * GemmLds<PREC>::RS;
+  int zz, inner;
+  xcd_tile(a.nt_z, a.nt_a * a.nt_b, zz, inner);                    // all output tiles of one T chunk share its G and X rows
+  const int tk = inner % a.nt_a;
+  const int n0 = tk * BN, m0 = (inner / a.nt_a) * GBM;     // m0 indexes N (rows of dW), n0 indexes K (its columns)
   GradSrc G = a.G;
   if (a.t_dev && G.T > *a.t_dev) G.T = *a.t_dev;
   G.key = drop_key(G.drop);
   const PlainSrc Xs{a.X, a.ldx, G.T, a.K};
-  const int t0 = blockIdx.z * a.t_chunk;
+  const int t0 = zz * a.t_chunk;
   int t1 = t0 + a.t_chunk;
   if (t1 > G.T) t1 = G.T;
   if (t0 >= t1) return;
@@ -353,13 +413,13 @@ __global__ __launch_bounds__(GTH) void k_dense_bwd_dw(DenseBwdArgs a) {
   GradSrc Gc = G; Gc.T = t1;
   PlainSrc Xc = Xs; Xc.rows = t1;
   float rowsum = 0.f;
-  if (a.db && blockIdx.x == 0) gemm_core<PREC, BN, true, true, GradSrc, PlainSrc, true>(acc, Gc, Xc, m0, n0, t0, kend, sA, sB, rowsum);
+  if (a.db && tk == 0) gemm_core<PREC, BN, true, true, GradSrc, PlainSrc, true>(acc, Gc, Xc, m0, n0, t0, kend, sA, sB, rowsum);
   else gemm_core<PREC, BN, true, true, GradSrc, PlainSrc, false>(acc, Gc, Xc, m0, n0, t0, kend, sA, sB, rowsum);
   acc.foreach(m0, n0, [&](int row, int col, float v) {
     if (row >= G.N || col >= a.K) return;
     atomicAdd(a.dW + (size_t)row * a.lddw + col, v);
   });
-  if (a.db && blockIdx.x == 0 && threadIdx.x < GBM && m0 + (int)threadIdx.x < G.N) atomicAdd(a.db + m0 + threadIdx.x, rowsum);
+  if (a.db && tk == 0 && threadIdx.x < GBM && m0 + (int)threadIdx.x < G.N) atomicAdd(a.db + m0 + threadIdx.x, rowsum);
 }
 
 }  // namespace adt

@@ -83,10 +83,27 @@ static int dispatch_attn_gen(bool bwd, int hd, const AttnGenArgs& a, hipStream_t
   return adt_set_error("masked attention: head_dim=%d unsupported (16/32/64/128)", hd);
 }
 
+template <class K>
+static int gemm_launch(K kernel, size_t smem, int grid, hipStream_t s, const void* args_ptr, bool& attr_done) {
+  if (!attr_done) {
+    if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return adt_set_error("dense: hipFuncSetAttribute(%zu)", smem);
+    attr_done = true;
+  }
+  void* kargs[] = {const_cast<void*>(args_ptr)};
+  if (hipLaunchKernel((const void*)kernel, dim3(grid), dim3(GTH), kargs, smem, s) != hipSuccess) return adt_set_error("dense: launch failed");
+  return 0;
+}
+
 template <int PREC>
-static int launch_dense_fwd(const DenseFwdArgs& a, hipStream_t s) {
-  if (a.N > 64) hipLaunchKernelGGL((k_dense_fwd<PREC, 128>), dim3((a.N + 127) / 128, (a.T + GBM - 1) / GBM), dim3(GTH), 0, s, a);
-  else hipLaunchKernelGGL((k_dense_fwd<PREC, 64>), dim3(1, (a.T + GBM - 1) / GBM), dim3(GTH), 0, s, a);
+static int launch_dense_fwd(const DenseFwdArgs& a0, hipStream_t s) {
+  DenseFwdArgs a = a0;
+  a.nt_n = a.N > 64 ? (a.N + 127) / 128 : 1;
+  a.nt_m = (a.T + GBM - 1) / GBM;
+  const int grid = xcd_grid(a.nt_m, a.nt_n);      // XCD-aware 1-D launch (xcd_tile)
+  static bool done[2] = {false, false};
+  if (a.N > 64) { if (gemm_launch(k_dense_fwd<PREC, 128>, gemm_lds_bytes<PREC, 128>(), grid, s, &a, done[0])) return -1; }
+  else if (gemm_launch(k_dense_fwd<PREC, 64>, gemm_lds_bytes<PREC, 64>(), grid, s, &a, done[1])) return -1;
   return check_launch("dense_fwd");
 }
 
@@ -106,20 +123,26 @@ static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
       if (splits > 1 && !a.beta && hipMemset2DAsync(a.dX, (size_t)a.lddx * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)T, s) != hipSuccess)
         return adt_set_error("dense_bwd: memset");
     }
-    if (K > 64) hipLaunchKernelGGL((k_dense_bwd_dx<PREC, 128>), dim3(gx, gy, splits), dim3(GTH), 0, s, a);
-    else hipLaunchKernelGGL((k_dense_bwd_dx<PREC, 64>), dim3(gx, gy, splits), dim3(GTH), 0, s, a);
+    a.nt_a = gx; a.nt_b = gy; a.nt_z = splits;
+    const int grid = xcd_grid(gy, gx * splits);
+    static bool done[2] = {false, false};
+    if (K > 64) { if (gemm_launch(k_dense_bwd_dx<PREC, 128>, gemm_lds_bytes<PREC, 128>(), grid, s, &a, done[0])) return -1; }
+    else if (gemm_launch(k_dense_bwd_dx<PREC, 64>, gemm_lds_bytes<PREC, 64>(), grid, s, &a, done[1])) return -1;
   }
   if (a.dW) {
     const int bn = K > 64 ? 128 : 64;
     const int gx = (K + bn - 1) / bn, gy = (N + GBM - 1) / GBM;
     // split T so that about 1024 workgroups are in flight; chunks are multiples of 32 rows
     int splits = (1024 + gx * gy - 1) / (gx * gy);
-    int chunk = ((T + splits - 1) / splits + 31) / 32 * 32;
-    if (chunk < 32) chunk = 32;
+    int chunk = ((T + splits - 1) / splits + GBK - 1) / GBK * GBK;
+    if (chunk < GBK) chunk = GBK;
     splits = (T + chunk - 1) / chunk;
     a.t_chunk = chunk;
-    if (bn == 128) hipLaunchKernelGGL((k_dense_bwd_dw<PREC, 128>), dim3(gx, gy, splits), dim3(GTH), 0, s, a);
-    else hipLaunchKernelGGL((k_dense_bwd_dw<PREC, 64>), dim3(gx, gy, splits), dim3(GTH), 0, s, a);
+    a.nt_a = gx; a.nt_b = gy; a.nt_z = splits;
+    const int grid = xcd_grid(splits, gx * gy);
+    static bool done[2] = {false, false};
+    if (bn == 128) { if (gemm_launch(k_dense_bwd_dw<PREC, 128>, gemm_lds_bytes<PREC, 128>(), grid, s, &a, done[0])) return -1; }
+    else if (gemm_launch(k_dense_bwd_dw<PREC, 64>, gemm_lds_bytes<PREC, 64>(), grid, s, &a, done[1])) return -1;
   }
   return check_launch("dense_bwd");
 }
