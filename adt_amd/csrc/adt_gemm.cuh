@@ -189,6 +189,35 @@ struct GemmAcc {
       }
   }
 
+  // One call per MFMA tile with its NE (16 or 4) elements: rows[e], the common column and the values.  The epilogues use it to
+  // issue all the global loads of a tile (residuals, the old dX) BEFORE the first store: a load placed after a store through
+  // a possibly-aliasing pointer cannot be hoisted by the compiler, and one exposed memory latency per element made the
+  // epilogue the longest part of these kernels.
+  static constexpr int NE = B16 ? 16 : 4;
+  template <class F>
+  ADT_DEVICE_INLINE void foreach_tile(int m0, int n0, F f) const {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wm = w / S::WN, wn = w % S::WN;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int rows[NE];
+        float vals[NE];
+        int col;
+        if constexpr (B16) {
+          col = n0 + (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { rows[e] = m0 + (wm * TM + i) * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3); vals[e] = a32[i][j][e]; }
+        } else {
+          col = n0 + (wn * TN + j) * 16 + (lane & 15);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { rows[r] = m0 + (wm * TM + i) * 16 + 4 * (lane >> 4) + r; vals[r] = a16[i][j][r]; }
+        }
+        f(rows, col, vals);
+      }
+  }
+
   template <class F>
   ADT_DEVICE_INLINE void foreach(int m0, int n0, F f) const {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -328,16 +357,31 @@ __global__ __launch_bounds__(GTH) void k_dense_fwd(DenseFwdArgs a) {
   float dummy = 0.f;
   gemm_core<PREC, BN, false, false, PlainSrc, PlainSrc, false>(acc, A, Bw, m0, n0, 0, a.K, sA, sB, dummy);
   const uint32_t key = drop_key(a.drop);
-  acc.foreach(m0, n0, [&](int row, int col, float v) {
-    if (row >= a.T || col >= a.N) return;
-    if (a.b) v += a.b[col];
-    if (a.U) a.U[(size_t)row * a.ldu + col] = v;
-    v = act_apply(a.act, v);
-    if (a.drop.thr) v = adt_keep(key, (uint32_t)(row + a.row_offset) * (uint32_t)a.N + (uint32_t)col, a.drop.thr) ? v * a.drop.scale : 0.f;
-    if (a.R) v += a.R[(size_t)row * a.ldr + col];
-    if (a.R2) v += a.R2[(size_t)row * a.ldr2 + col];
-    if (a.ids && a.ids[row] == 0) v = 0.f;
-    a.Y[(size_t)row * a.ldy + col] = v;
+  constexpr int NE = GemmAcc<PREC, BN>::NE;
+  acc.foreach_tile(m0, n0, [&](const int (&rows)[NE], int col, const float (&vals)[NE]) {
+    if (col >= a.N) return;
+    const float bias = a.b ? a.b[col] : 0.f;
+    float r1[NE], r2[NE];
+    int keep[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {        // every load of the tile first ...
+      const bool ok = rows[e] < a.T;
+      r1[e] = (ok && a.R) ? a.R[(size_t)rows[e] * a.ldr + col] : 0.f;
+      r2[e] = (ok && a.R2) ? a.R2[(size_t)rows[e] * a.ldr2 + col] : 0.f;
+      keep[e] = (ok && a.ids) ? a.ids[rows[e]] : 1;
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {        // ... then the arithmetic and the stores
+      const int row = rows[e];
+      if (row >= a.T) continue;
+      float v = vals[e] + bias;
+      if (a.U) a.U[(size_t)row * a.ldu + col] = v;
+      v = act_apply(a.act, v);
+      if (a.drop.thr) v = adt_keep(key, (uint32_t)(row + a.row_offset) * (uint32_t)a.N + (uint32_t)col, a.drop.thr) ? v * a.drop.scale : 0.f;
+      v += r1[e] + r2[e];
+      if (keep[e] == 0) v = 0.f;
+      a.Y[(size_t)row * a.ldy + col] = v;
+    }
   });
 }
 
@@ -379,11 +423,19 @@ __global__ __launch_bounds__(GTH) void k_dense_bwd_dx(DenseBwdArgs a) {
   if (kbeg >= kend) return;
   gemm_core<PREC, BN, false, true, GradSrc, PlainSrc, false>(acc, G, Bw, m0, n0, kbeg, kend, sA, sB, dummy);
   const bool split = a.nt_z > 1;     // long contraction (all-item logits): the host zeroes dX first unless beta
-  acc.foreach(m0, n0, [&](int row, int col, float v) {
-    if (row >= G.T || col >= a.K) return;
-    float* dst = a.dX + (size_t)row * a.lddx + col;
-    if (split) atomicAdd(dst, v);
-    else *dst = (a.beta ? *dst : 0.f) + v;
+  constexpr int NE = GemmAcc<PREC, BN>::NE;
+  acc.foreach_tile(m0, n0, [&](const int (&rows)[NE], int col, const float (&vals)[NE]) {
+    if (col >= a.K) return;
+    float old[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) old[e] = (a.beta && !split && rows[e] < G.T) ? a.dX[(size_t)rows[e] * a.lddx + col] : 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      if (rows[e] >= G.T) continue;
+      float* dst = a.dX + (size_t)rows[e] * a.lddx + col;
+      if (split) atomicAdd(dst, vals[e]);
+      else *dst = old[e] + vals[e];
+    }
   });
 }
 
