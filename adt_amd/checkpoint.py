@@ -1,0 +1,97 @@
+"""Checkpoint interop.  Model weights already move both ways through state_dict()/load_state_dict() under the
+reference's names (sasrec/main.py:104-114,205-210; stosa/utils.py:81-86).  The reference never saves optimizer state, so a resumed
+run restarts Adam from zero moments; this module adds what a resumable (data-parallel) run needs:
+
+* trainer_state_dict / load_trainer_state_dict -- the fused trainers' whole optimizer state: the flat first/second moment
+  buffers, the device-resident step counter and clip scalars, the device dropout seed and the host step count.  Loading on every
+  rank (same file) resumes a DP run exactly: the moments are replicated like the weights.
+* to_torch_adam_state / from_torch_adam_state -- the same moments in torch.optim.Adam.state_dict() format, keyed by parameter
+  position in model.parameters() order, so the reference's own `torch.optim.Adam(model.parameters(), ...)` can continue a run
+  started here (optimizer.load_state_dict) and the other way round.  Parameters the reference leaves without gradient (torch
+  Adam creates no state for them) are skipped on export when their moments are identically zero.
+
+Everything is plain device-to-host copies of existing buffers: no arithmetic happens here.
+"""
+import torch
+
+FORMAT = 1
+
+
+def _scal_step(tr):
+    return float(tr.scal[2].item())
+
+
+def trainer_state_dict(tr):
+    sd = {"format": FORMAT, "trainer": type(tr).__name__, "n_flat": int(tr.model.flat.numel()),
+          "exp_avg": tr.m.detach().cpu().clone(), "exp_avg_sq": tr.v.detach().cpu().clone(), "scal": tr.scal.detach().cpu().clone(),
+          "dropout_seed": tr.model._seed.detach().cpu().clone(), "nstep": int(tr.nstep),
+          "hyper": {"lr": tr.lr, "betas": tuple(tr.betas), "eps": tr.eps}}
+    if hasattr(tr, "steps"):       # supernet: one Adam step count per trained parameter range
+        sd["range_steps"] = {"%d:%d" % k: int(v) for k, v in tr.steps.items()}
+    return sd
+
+
+def load_trainer_state_dict(tr, sd):
+    if sd.get("format") != FORMAT:
+        raise ValueError("unknown trainer checkpoint format %r" % (sd.get("format"),))
+    if sd["trainer"] != type(tr).__name__ or sd["n_flat"] != tr.model.flat.numel():
+        raise ValueError("checkpoint of %s with %d parameters does not fit %s with %d"
+                         % (sd["trainer"], sd["n_flat"], type(tr).__name__, tr.model.flat.numel()))
+    tr.m.copy_(sd["exp_avg"])
+    tr.v.copy_(sd["exp_avg_sq"])
+    tr.scal.copy_(sd["scal"])
+    tr.model._seed.copy_(sd["dropout_seed"])
+    tr.nstep = int(sd["nstep"])
+    if hasattr(tr, "steps"):
+        tr.steps = {tuple(int(x) for x in k.split(":")): int(v) for k, v in sd.get("range_steps", {}).items()}
+
+
+def _param_spans(model):
+    base = model.flat.data_ptr()
+    for p in model.parameters():
+        off = (p.data_ptr() - base) // 4
+        assert 0 <= off and off + p.numel() <= model.flat.numel(), "parameter outside the flat buffer"
+        yield p, off
+
+
+def to_torch_adam_state(tr, weight_decay=0.0, skip_untrained=True):
+    """torch.optim.Adam(model.parameters(), lr, betas, eps, weight_decay).state_dict() equivalent of the trainer's state."""
+    step = _scal_step(tr)
+    state, ids = {}, []
+    for i, (p, off) in enumerate(_param_spans(tr.model)):
+        ids.append(i)
+        m = tr.m[off:off + p.numel()].view(p.shape)
+        v = tr.v[off:off + p.numel()].view(p.shape)
+        if skip_untrained and not bool(v.any()) and not bool(m.any()):
+            continue
+        state[i] = {"step": torch.tensor(step), "exp_avg": m.detach().clone(), "exp_avg_sq": v.detach().clone()}
+    group = {"lr": tr.lr, "betas": tuple(tr.betas), "eps": tr.eps, "weight_decay": weight_decay, "amsgrad": False, "maximize": False,
+             "foreach": None, "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False, "params": ids}
+    return {"state": state, "param_groups": [group]}
+
+
+def from_torch_adam_state(tr, osd):
+    """Load torch.optim.Adam.state_dict() moments (parameter order = model.parameters()) into the trainer."""
+    tr.m.zero_()
+    tr.v.zero_()
+    step = 0.0
+    for i, (p, off) in enumerate(_param_spans(tr.model)):
+        st = osd["state"].get(i)
+        if st is None:
+            continue
+        tr.m[off:off + p.numel()].copy_(st["exp_avg"].reshape(-1))
+        tr.v[off:off + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+        step = max(step, float(st["step"]))
+    tr.scal[2] = step
+    tr.nstep = int(step)
+
+
+def save(path, model, trainer):
+    """One file holding the reference-format weights and the trainer state."""
+    torch.save({"model": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "trainer": trainer_state_dict(trainer)}, path)
+
+
+def load(path, model, trainer):
+    ck = torch.load(path, map_location="cpu")
+    model.load_state_dict(ck["model"])
+    load_trainer_state_dict(trainer, ck["trainer"])

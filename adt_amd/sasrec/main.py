@@ -189,8 +189,8 @@ def main(argv=None):
             torch.cuda.synchronize()
             T += time.time() - t0
             model.eval()
-            t_test, auc_test = U.evaluate_loader(model, test_ds.batches(args.eval_batch_size), args, "test", ks)
-            t_valid, auc_valid = U.evaluate_loader(model, val_ds.batches(args.eval_batch_size), args, "val", ks)
+            t_test, auc_test = U.evaluate_loader(model, test_ds.batches(args.eval_batch_size), args, "test", ks, process_group=pg)
+            t_valid, auc_valid = U.evaluate_loader(model, val_ds.batches(args.eval_batch_size), args, "val", ks, process_group=pg)
             model.train()
             if rank == 0:
                 for k in ks:

@@ -48,11 +48,15 @@ class FusedTrainer:
         T = B * m.maxlen
         self._B, self._T = B, T
         n_int = 4 * T + 4   # seq, dec, pos, neg, 3 normalisers (float bits), pad
-        self._host = torch.empty(n_int, dtype=torch.int32).pin_memory()
+        # Pinned staging ring: the H2D copy of step n is asynchronous, so the host may only refill a buffer once the copy that
+        # last read it has executed (its event).  Three buffers keep the host two steps ahead of the device without waiting.
+        self._ring = [torch.empty(n_int, dtype=torch.int32).pin_memory() for _ in range(3)]
+        self._ring_ev = [None] * 3
+        self._ring_i = 0
+        self._host = self._ring[0]
         self._devbuf = torch.empty(n_int, device=m.dev, dtype=torch.int32)
         self._ids = [self._devbuf[i * T:(i + 1) * T].view(B, m.maxlen) for i in range(4)]
         self._norms_dev = self._devbuf[4 * T:4 * T + 3].view(torch.float32)
-        self._host_np = self._host.numpy()
         m.workspace(B)
         self._graph = None
 
@@ -90,7 +94,11 @@ class FusedTrainer:
             if self.nstep == 0:
                 m.set_seed(self.base_seed * 1000003 + 12345)
         T = self._T
-        hn = self._host_np
+        self._ring_i = (self._ring_i + 1) % len(self._ring)
+        if self._ring_ev[self._ring_i] is not None:
+            self._ring_ev[self._ring_i].synchronize()
+        self._host = self._ring[self._ring_i]
+        hn = self._host.numpy()
         hn[0:T] = seq.reshape(-1)
         hn[T:2 * T] = np.asarray(dec).reshape(-1)
         hn[2 * T:3 * T] = np.asarray(pos).reshape(-1)
@@ -112,6 +120,7 @@ class FusedTrainer:
         buf = torch.empty_like(self._devbuf)
         buf.copy_(self._host)
         torch.cuda.synchronize()
+        self._ring_ev[self._ring_i] = None
         return buf
 
     def step_staged(self, buf, b_offset=0):
@@ -125,6 +134,9 @@ class FusedTrainer:
         nothing; see `loss()`."""
         B = self._fill_host(seq, dec, pos, neg, norms)
         self._devbuf.copy_(self._host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._ring_ev[self._ring_i] = ev
         self._run(B, b_offset)
 
     def _run(self, B, b_offset):

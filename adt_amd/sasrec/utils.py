@@ -274,13 +274,56 @@ def metrics_from_ranks(ranks, n_candidates, ks=(5, 10)):
     return (ndcg, hr), float(np.mean((S - (ranks + 1)) / (S - 1)))
 
 
-def evaluate_loader(model, loader, args=None, mode="val", ks=(5, 10)):
+def rank_stats(ranks, n_candidates, ks=(5, 10)):
+    """Additive sufficient statistics of metrics_from_ranks: [N, sum((S-(rank+1))/(S-1)), then per k: hits, sum 1/log2(rank+2)]
+    as float64 -- what data-parallel evaluation sum-reduces across ranks."""
+    ranks = np.asarray(ranks, np.int64)
+    S = 1 + n_candidates
+    out = [float(len(ranks)), float(((S - (ranks + 1)) / (S - 1)).sum())]
+    for k in ks:
+        hit = ranks < k
+        out += [float(hit.sum()), float((1.0 / np.log2(ranks[hit] + 2.0)).sum())]
+    return np.array(out, np.float64)
+
+
+def metrics_from_stats(stats, ks=(5, 10)):
+    n = float(stats[0])
+    ndcg = {k: float(stats[3 + 2 * i]) / n for i, k in enumerate(ks)}
+    hr = {k: float(stats[2 + 2 * i]) / n for i, k in enumerate(ks)}
+    return (ndcg, hr), float(stats[1]) / n
+
+
+def reduce_rank_stats(stats, process_group=None):
+    """Sum the per-rank statistics over the group (gloo on CPU tensors, RCCL needs device tensors: float64 either way)."""
+    import torch
+    import torch.distributed as dist
+    if process_group is None or dist.get_world_size(process_group) == 1:
+        return stats
+    t = torch.from_numpy(np.ascontiguousarray(stats))
+    if dist.get_backend(process_group) == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, group=process_group)
+    return t.cpu().numpy()
+
+
+def evaluate_loader(model, loader, args=None, mode="val", ks=(5, 10), process_group=None):
     """sasrec/utils.py:395-428 -> ((NDCG, HT), AUC).  `loader` yields ((u, seq, item_idx), label) batches (an
-    EvalDataset.batches() generator or a torch DataLoader); scoring and the rank of the positive run on the GPU."""
+    EvalDataset.batches() generator or a torch DataLoader); scoring and the rank of the positive run on the GPU.
+    With a process group, rank r scores batches r, r+W, ... and the additive statistics are sum-reduced, so every rank
+    returns the metrics of the whole user set (identical to the single-process result: the statistics are sums)."""
+    r, W = 0, 1
+    if process_group is not None:
+        import torch.distributed as dist
+        r, W = dist.get_rank(process_group), dist.get_world_size(process_group)
     ranks, ncand = [], None
-    for (u, seq, item_idx), _ in loader:
-        seq, item_idx = np.asarray(seq), np.asarray(item_idx)
-        _, rank = model.predict_rank(seq, item_idx)
-        ranks.append(rank.cpu().numpy())
+    for i, ((u, seq, item_idx), _) in enumerate(loader):
+        item_idx = np.asarray(item_idx)
         ncand = item_idx.shape[1]
-    return metrics_from_ranks(np.concatenate(ranks), ncand, ks)
+        if i % W != r:
+            continue
+        _, rank = model.predict_rank(np.asarray(seq), item_idx)
+        ranks.append(rank.cpu().numpy())
+    ranks = np.concatenate(ranks) if ranks else np.zeros(0, np.int64)
+    if W == 1:
+        return metrics_from_ranks(ranks, ncand, ks)
+    return metrics_from_stats(reduce_rank_stats(rank_stats(ranks, ncand, ks), process_group), ks)

@@ -1,0 +1,181 @@
+"""GPU: resumable training and torch-Adam interop of the fused trainers (adt_amd/checkpoint.py).
+
+* resume: 2 steps -> save (weights under the reference's state_dict names + trainer state) -> fresh model/trainer -> load -> 2 more
+  steps must land on the weights of 4 uninterrupted steps.  Dropout is ON, so the device dropout seed has to be restored too.
+  Gradients are accumulated with float atomics, so two runs differ in the last bits and Adam turns a sign flip of a ~0 gradient into
+  a +-lr move: the bar is "all but 0.1 % of the entries within 1e-5, none further than 4*lr", and the same comparison WITHOUT the
+  trainer state must fail it by a wide margin (which shows the check has teeth).
+  (This test also guards the trainers' host staging: four back-to-back steps must equal 2 + sync + 2.  It caught the flagship
+  trainer refilling its pinned id buffer while the previous step's asynchronous H2D copy was still pending; the buffer is a
+  three-deep ring with one event per slot now.)
+* torch interop: the exported state loads into torch.optim.Adam(model.parameters()), one torch.optim.Adam.step() on given gradients
+  equals one adt_clip_adam launch on the same gradients (<= 2e-6 abs: same bias correction from the same step count), and the
+  export -> import round trip is bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+LR = 1e-3
+
+
+class Args:
+    pass
+
+
+def _sasrec(seed):
+    from adt_amd.sasrec.model import SASRecADT
+    from adt_amd.sasrec.trainer import FusedTrainer
+    a = Args()
+    a.device, a.num_heads, a.maxlen, a.num_layers, a.hidden_units, a.dropout, a.precision = "cuda:0", 2, 40, 2, 64, 0.3, "f32"
+    torch.manual_seed(seed)
+    m = SASRecADT(1, 300, a)
+    for _, p in m.named_parameters():
+        try:
+            torch.nn.init.xavier_normal_(p.data)
+        except Exception:
+            pass
+    m.train()
+    tr = FusedTrainer(m, [0.1, 0.05], [0.1, 0.01], lr=LR, weight_decay=1e-3, clip=5.0, use_graph=False, seed=5)
+    r = np.random.RandomState(1)
+    batches = []
+    for _ in range(4):
+        seq = r.randint(1, 301, size=(16, 40)); seq[:, :7] = 0
+        dec = np.roll(seq, 1, 1); dec[:, 0] = 0
+        pos = r.randint(1, 301, size=(16, 40)) * (seq > 0)
+        neg = r.randint(1, 301, size=(16, 40)) * (seq > 0)
+        batches.append((seq, dec, pos, neg))
+    return m, tr, batches
+
+
+def _bert(seed):
+    from adt_amd.bert4rec.model import BertModel
+    from adt_amd.bert4rec.trainer import FusedBertTrainer
+    a = Args()
+    a.device, a.maxlen, a.num_heads, a.num_layers, a.hidden_units, a.inner_units = "cuda:0", 24, 2, 2, 64, 128
+    a.dropout, a.attention_dropout, a.type_vocab_size, a.precision = 0.2, 0.2, 2, "f32"
+    torch.manual_seed(seed)
+    m = BertModel(1, 200, a)
+    m.train()
+    tr = FusedBertTrainer(m, [0.01, 0.01], [0.01, 0.01], lr=LR, weight_decay=1e-4, clip=5.0, use_graph=False, seed=5)
+    r = np.random.RandomState(2)
+    batches = []
+    for _ in range(4):
+        src = r.randint(1, 201, size=(16, 24)); src[:, :5] = 0
+        lab = np.where(r.rand(16, 24) < 0.3, src, 0)
+        src = np.where(lab > 0, 201, src)
+        dec = np.roll(src, 1, 1); dec[:, 0] = 0
+        batches.append((src, dec, lab))
+    return m, tr, batches
+
+
+def _stosa(seed):
+    from adt_amd.stosa.models import DisenDistSAModel
+    from adt_amd.stosa.trainer import FusedStosaTrainer
+    a = Args()
+    a.item_size, a.hidden_units, a.maxlen, a.num_users, a.dropout, a.attention_dropout = 202, 64, 24, 10, 0.2, 0.2
+    a.num_heads, a.num_layers, a.hidden_act, a.initializer_range, a.distance_metric, a.kernel_param = 2, 1, "gelu", 0.02, "wasserstein", 1.0
+    a.cuda_condition, a.pvn_weight, a.device, a.precision = True, 0.005, "cuda:0", "f32"
+    torch.manual_seed(seed)
+    m = DisenDistSAModel(a)
+    m.train()
+    tr = FusedStosaTrainer(m, [0.002], [0.001], lr=LR, use_graph=False, seed=5)
+    r = np.random.RandomState(3)
+    batches = []
+    for _ in range(4):
+        inp = r.randint(1, 201, size=(16, 24)); inp[:, :5] = 0
+        dec = np.roll(inp, 1, 1); dec[:, 0] = 0
+        pos = r.randint(1, 201, size=(16, 24)) * (inp > 0)
+        neg = r.randint(1, 201, size=(16, 24)) * (inp > 0)
+        batches.append((inp, dec, pos, neg))
+    return m, tr, batches
+
+
+MAKERS = {"sasrec": _sasrec, "bert": _bert, "stosa": _stosa}
+
+
+def _far(a, b):
+    d = (a - b).abs()
+    return float((d > 1e-5).float().mean()), float(d.max())
+
+
+@pytest.mark.parametrize("kind", ["sasrec", "bert", "stosa"])
+def test_resume_equals_uninterrupted(kind, tmp_path):
+    from adt_amd import checkpoint as ck
+    m, tr, batches = MAKERS[kind](11)
+    for b in batches:
+        tr.step(*b)
+    want = m.flat.clone()
+
+    m1, tr1, _ = MAKERS[kind](11)
+    for b in batches[:2]:
+        tr1.step(*b)
+    path = os.path.join(tmp_path, "ck.pt")
+    ck.save(path, m1, tr1)
+    weights_only = {k: v.clone() for k, v in m1.state_dict().items()}
+
+    m2, tr2, _ = MAKERS[kind](99)          # different init: everything must come from the file
+    ck.load(path, m2, tr2)
+    assert tr2.nstep == 2 and float(tr2.scal[2]) == 2.0
+    for b in batches[2:]:
+        tr2.step(*b)
+    frac, worst = _far(m2.flat, want)
+    assert frac < 1e-3 and worst <= 4 * LR, (frac, worst)
+
+    m3, tr3, _ = MAKERS[kind](99)          # weights only (what the reference's checkpoints hold): Adam restarts, dropout stream differs
+    m3.load_state_dict(weights_only)
+    for b in batches[2:]:
+        tr3.step(*b)
+    frac3, _ = _far(m3.flat, want)
+    assert frac3 > 0.2, frac3
+
+
+@pytest.mark.parametrize("kind", ["sasrec", "bert", "stosa"])
+def test_torch_adam_interop(kind):
+    from adt_amd import checkpoint as ck, ops
+    m, tr, batches = MAKERS[kind](11)
+    for b in batches[:3]:
+        tr.step(*b)
+    osd = ck.to_torch_adam_state(tr, skip_untrained=False)
+    params = list(m.parameters())
+    opt = torch.optim.Adam(params, lr=LR, betas=tuple(tr.betas), eps=tr.eps)
+    opt.load_state_dict(osd)
+    assert all(float(opt.state[p]["step"]) == 3.0 for p in params)
+
+    # one torch step vs one library step on the same gradients
+    g = torch.Generator(device="cpu").manual_seed(4)
+    grad = (1e-2 * torch.randn(m.flat.numel(), generator=g)).to(m.flat.device)
+    flat0, m0, v0, s0 = m.flat.clone(), tr.m.clone(), tr.v.clone(), tr.scal.clone()
+    base = m.flat.data_ptr()
+    n_tr = getattr(m, "n_trained_floats", m.flat.numel())   # STOSA: the tail never gets a gradient
+    for p in params:
+        off = (p.data_ptr() - base) // 4
+        if off < n_tr:
+            p.grad = grad[off:off + p.numel()].view(p.shape).clone()
+    opt.step()
+    after_torch = m.flat.clone()
+    m.flat.copy_(flat0)
+    live = torch.zeros_like(grad)
+    for p in params:
+        off = (p.data_ptr() - base) // 4
+        live[off:off + p.numel()] = float(off < n_tr)
+        p.grad = None
+    m.flat_grad.copy_(grad * live)          # alignment gaps between tensors carry no gradient
+    ops.clip_adam(m.flat, m.flat_grad, tr.m, tr.v, 0, 0.0, 1e30, LR, tr.betas[0], tr.betas[1], tr.eps, tr.scal, n=n_tr)
+    torch.cuda.synchronize()
+    assert float((m.flat - after_torch).abs().max()) <= 2e-6
+    assert float(tr.scal[2]) == 4.0
+
+    # export -> import round trip is exact
+    tr.m.copy_(m0); tr.v.copy_(v0); tr.scal.copy_(s0)
+    osd = ck.to_torch_adam_state(tr)
+    m2, tr2, _ = MAKERS[kind](12)
+    ck.from_torch_adam_state(tr2, osd)
+    for p, (p2, off) in zip(params, ck._param_spans(m2)):
+        o1 = (p.data_ptr() - base) // 4
+        assert torch.equal(tr2.m[off:off + p.numel()], m0[o1:o1 + p.numel()])
+        assert torch.equal(tr2.v[off:off + p.numel()], v0[o1:o1 + p.numel()])
+    assert float(tr2.scal[2]) == 3.0 and tr2.nstep == 3

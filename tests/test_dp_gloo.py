@@ -105,3 +105,52 @@ def test_two_ranks_reproduce_single_process_step():
         o += sz
         assert d.max() <= 2 * 1e-3 * 1.01, k
         assert d[~noisy].max(initial=0.0) <= 2e-5, k
+
+
+# ---- sharded evaluation (SURVEY.md 8(e) rule 5) -------------------------------------------------------------------------
+class _RankModel:
+    """Stands in for the HIP model on CPU ranks: the 'rank' of a user is a fixed function of its sequence."""
+
+    def predict_rank(self, seq, item_idx):
+        import torch
+        return None, torch.from_numpy((np.asarray(seq).sum(1) * 7919 % 101).astype(np.int64))
+
+
+def _eval_batches():
+    r = np.random.RandomState(3)
+    for n in (64, 64, 64, 64, 37):          # ragged last batch, odd number of batches
+        seq = r.randint(0, 50, size=(n, 12))
+        yield (np.arange(n), seq, np.zeros((n, 101), np.int64)), None
+
+
+def _eval_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from adt_amd.sasrec import utils as U
+    out = U.evaluate_loader(_RankModel(), _eval_batches(), ks=(5, 10), process_group=dist.group.WORLD)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_evaluation_equals_single_process():
+    from adt_amd.sasrec import utils as U
+    single = U.evaluate_loader(_RankModel(), _eval_batches(), ks=(5, 10))
+    ranks = np.concatenate([_RankModel().predict_rank(b[0][1], None)[1].numpy() for b in _eval_batches()])
+    (nd, hr), auc = U.metrics_from_stats(U.rank_stats(ranks, 101))
+    assert nd == pytest.approx(single[0][0]) and hr == pytest.approx(single[0][1]) and auc == pytest.approx(single[1])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):          # every rank holds the metrics of the whole user set
+        (nd2, hr2), auc2 = outs[r]
+        for k in (5, 10):
+            assert nd2[k] == pytest.approx(single[0][0][k], abs=1e-12) and hr2[k] == pytest.approx(single[0][1][k], abs=1e-12)
+        assert auc2 == pytest.approx(single[1], abs=1e-12)
