@@ -478,7 +478,7 @@ int adt_clip_adam(float* P, float* G, float* M, float* V, int64_t n, int64_t nE,
   a.P = P; a.G = G; a.M = M; a.Vv = V; a.n = (size_t)n; a.nE = (size_t)nE; a.wd = wd; a.clip = clip; a.lr = lr;
   a.b1 = b1; a.b2 = b2; a.eps = eps; a.scal = scal; a.grad_scale = grad_scale;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(scal + 64, 0, 128 * sizeof(float), s) != hipSuccess) return adt_set_error("clip_adam: memset");
+  if (adt::zero_f32_async(scal + 64, 128, s)) return adt_set_error("clip_adam: zero");
   if (wd != 0.f && nE > 0) hipLaunchKernelGGL(k_sumsq, dim3(grid_for((size_t)nE, 256, 256)), dim3(256), 0, s, (const float*)P, (size_t)nE, scal + 64);
   hipLaunchKernelGGL(k_wd_gradnorm, dim3(grid_for((size_t)n, 256, 512)), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_adam, dim3(grid_for((size_t)n, 256, 1024)), dim3(256), 0, s, a);
@@ -491,7 +491,7 @@ int adt_clip_adam_l2(float* P, float* G, float* M, float* V, int64_t n, float l2
   a.P = P; a.G = G; a.M = M; a.Vv = V; a.n = (size_t)n; a.nE = 0; a.wd = 0.f; a.clip = clip; a.lr = lr;
   a.b1 = b1; a.b2 = b2; a.eps = eps; a.scal = scal; a.grad_scale = grad_scale; a.l2 = l2;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(scal + 64, 0, 128 * sizeof(float), s) != hipSuccess) return adt_set_error("clip_adam_l2: memset");
+  if (adt::zero_f32_async(scal + 64, 128, s)) return adt_set_error("clip_adam_l2: zero");
   hipLaunchKernelGGL(k_wd_gradnorm, dim3(grid_for((size_t)n, 256, 512)), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_adam, dim3(grid_for((size_t)n, 256, 1024)), dim3(256), 0, s, a);
   return check_launch("clip_adam_l2");

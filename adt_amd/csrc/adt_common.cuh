@@ -112,3 +112,40 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 #define ADT_DEVICE_INLINE __device__ __forceinline__
+
+// Zero-fill as an ordinary kernel.  The library never uses hipMemsetAsync: its entry points are captured into HIP graphs by the
+// trainers, and on this stack a captured memset NODE was observed to start writing a stale non-zero pattern after a few hundred
+// replays (the gradient-norm accumulators then read ~4e30 or NaN for the rest of the process; see DESIGN.md "graph memset").
+// A kernel node has no such state.
+namespace adt {
+static __global__ __launch_bounds__(256) void k_zero_f32(float* p, size_t n) {
+  if (((uintptr_t)p & 15) == 0) {      // 16-byte stores over the aligned body, scalar tail
+    const size_t n4 = n / 4;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0.f;
+    return;
+  }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0.f;
+}
+static __global__ __launch_bounds__(256) void k_zero_rows_f32(float* p, size_t ld, int cols, size_t rows) {
+  const size_t n = rows * (size_t)cols;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[(i / cols) * ld + (i % cols)] = 0.f;
+}
+static inline int zero_rows_f32_async(float* p, size_t ld, int cols, size_t rows, hipStream_t s) {
+  const size_t n = rows * (size_t)cols;
+  if (n == 0) return 0;
+  size_t blocks = (n + 1023) / 1024;
+  if (blocks > 2048) blocks = 2048;
+  if (ld == (size_t)cols) hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)blocks), dim3(256), 0, s, p, n);
+  else hipLaunchKernelGGL(k_zero_rows_f32, dim3((unsigned)blocks), dim3(256), 0, s, p, ld, cols, rows);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+static inline int zero_f32_async(float* p, size_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  size_t blocks = (n + 4095) / 4096;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)blocks), dim3(256), 0, s, p, n);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+}  // namespace adt

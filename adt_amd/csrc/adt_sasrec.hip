@@ -325,7 +325,7 @@ int adt_sasrec_loss_seed(const adt_sasrec_cfg* c, float* ws, const int32_t* pos,
   const int64_t Td = up64(w.T * w.d), rec = up64(w.T * w.H * w.H);
   float* loss = ws + w.loss;
   const float* norms = ws + w.norms;
-  if (hipMemsetAsync(loss, 0, 64 * (2 + 2 * nl) * sizeof(float), (hipStream_t)st) != hipSuccess) return adt_set_error("loss memset");
+  if (adt::zero_f32_async(loss, (size_t)64 * (2 + 2 * nl), (hipStream_t)st)) return adt_set_error("loss zero");
   CK(adt_bce_seed(ws + w.posl, ws + w.negl, pos, T, norms, ws + w.g_pos, ws + w.g_neg, loss, st));
   for (int i = 0; i < nl; ++i)   // enc_in[i] pairs with dec_out_rev[i] = DEC_X[nl - i]      (sasrec/main.py:155-158)
     CK(adt_mse_seed(ws + w.enc_x + i * Td, ws + w.dec_x + (nl - i) * Td, w.T * w.d, lambdas1[i], norms, ws + w.g_enc_x + i * Td, 0,
@@ -353,8 +353,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   const float* f = ws + w.f;
   if (phase == 0 || phase == 1) {
     // d log_feats (overwrites g_f) and item-table rows of pos/neg      (sasrec/model.py:72-76)
-    if (hipMemsetAsync(ws + w.rep, 0, (size_t)NREP * w.rep_stride * sizeof(float), (hipStream_t)st) != hipSuccess)
-      return adt_set_error("replica memset");
+    if (adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
     CK(adt_logits_bwd_df(P + lo.item(), pos, neg, ws + w.g_pos, ws + w.g_neg, T, d, gf, d, st));
     CK(adt_item_scatter(pos, f, d, ws + w.g_pos, T, d, 1.0f, 0.f, nullptr, 0, 0, ws + w.rep, NREP, w.rep_stride, st));
     CK(adt_item_scatter(neg, f, d, ws + w.g_neg, T, d, 1.0f, 0.f, nullptr, 0, 0, ws + w.rep, NREP, w.rep_stride, st));
@@ -470,8 +469,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         CK(adt_launch_bwdchain(prec, 2, a, st));
       }
     }
-    if (phase == 2 && hipMemsetAsync(ws + w.rep, 0, (size_t)NREP * w.rep_stride * sizeof(float), (hipStream_t)st) != hipSuccess)
-      return adt_set_error("replica memset");
+    if (phase == 2 && adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
     CK(adt_posemb_bwd(seq, ws + w.g_enc_x, T, L, d, p, seed, SITE_EMB_SEQ, ro, G + lo.posw(), st));
     CK(adt_item_scatter(seq, ws + w.g_enc_x, d, nullptr, T, d, sqrtf((float)d), p, seed, SITE_EMB_SEQ, ro, ws + w.rep, NREP, w.rep_stride, st));
     CK(adt_replica_reduce(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, NREP, w.rep_stride, st));

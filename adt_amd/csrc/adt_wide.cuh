@@ -216,4 +216,65 @@ __global__ __launch_bounds__(256) void k_adam_range(RangeOptArgs a) {
   }
 }
 
+// ---- full-sort selection (stosa/trainer.py:598-612) -------------------------------------------------------------------------------
+// One workgroup per user row: push the seen items (CSR) to 1e24, then pick the k smallest distances in ascending order.  Each
+// thread keeps the minimum of its own strided slice in registers; a round is one block arg-min over the 256 slice minima, after
+// which only the winning thread rescans its slice (N/256 elements, L2 resident).  Ties go to the smaller item id.  The row is
+// consumed: seen entries become 1e24, selected entries +inf.
+struct TopkArgs {
+  float* dist; int ld; int B; int N;
+  const int32_t* indptr; const int32_t* indices;
+  int k; int32_t* out_idx; float* out_val;
+};
+
+__device__ __forceinline__ bool topk_less(float v, int i, float bv, int bi) { return v < bv || (v == bv && (unsigned)i < (unsigned)bi); }
+
+__global__ __launch_bounds__(256) void k_topk_masked(TopkArgs a) {
+  __shared__ float s_v[4];
+  __shared__ int s_i[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float* row = a.dist + (size_t)b * a.ld;
+  if (a.indptr) {
+    for (int j = a.indptr[b] + tid; j < a.indptr[b + 1]; j += 256) {
+      int it = a.indices[j];
+      if (it >= 0 && it < a.N) row[it] = 1e24f;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  const float INF = __builtin_inff();
+  float bv = INF;
+  int bi = 0x7fffffff;
+  for (int i = tid; i < a.N; i += 256) {
+    float v = row[i];
+    if (v < INF && topk_less(v, i, bv, bi)) { bv = v; bi = i; }   // +inf / NaN entries are never selected
+  }
+  for (int r = 0; r < a.k; ++r) {
+    float wv = bv;
+    int wi = bi;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      float ov = __shfl_xor(wv, o);
+      int oi = __shfl_xor(wi, o);
+      if (topk_less(ov, oi, wv, wi)) { wv = ov; wi = oi; }
+    }
+    if ((tid & 63) == 0) { s_v[tid >> 6] = wv; s_i[tid >> 6] = wi; }
+    __syncthreads();
+    wv = s_v[0]; wi = s_i[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (topk_less(s_v[w], s_i[w], wv, wi)) { wv = s_v[w]; wi = s_i[w]; }
+    if (tid == 0) { a.out_idx[(size_t)b * a.k + r] = wi; if (a.out_val) a.out_val[(size_t)b * a.k + r] = wv; }
+    if (wi != 0x7fffffff && (wi & 255) == tid) {   // my element won: retire it and refresh my slice minimum
+      row[wi] = INF;
+      bv = INF; bi = 0x7fffffff;
+      for (int i = tid; i < a.N; i += 256) {
+        float v = (i == wi) ? INF : row[i];
+        if (v < INF && topk_less(v, i, bv, bi)) { bv = v; bi = i; }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace adt

@@ -120,8 +120,7 @@ static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
       if (splits > 32) splits = 32;
       a.n_chunk = ((N + splits - 1) / splits + GBK - 1) / GBK * GBK;
       splits = (N + a.n_chunk - 1) / a.n_chunk;
-      if (splits > 1 && !a.beta && hipMemset2DAsync(a.dX, (size_t)a.lddx * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)T, s) != hipSuccess)
-        return adt_set_error("dense_bwd: memset");
+      if (splits > 1 && !a.beta && adt::zero_rows_f32_async(a.dX, (size_t)a.lddx, K, (size_t)T, s)) return adt_set_error("dense_bwd: zero");
     }
     a.nt_a = gx; a.nt_b = gy; a.nt_z = splits;
     const int grid = xcd_grid(gy, gx * splits);
@@ -281,7 +280,7 @@ int adt_log_softmax_bwd(const float* Y, const float* dY, int64_t rows, int H, fl
 int adt_grad_sumsq(const float* G, int64_t n, float* out64, void* stream) {
   RangeOptArgs a{};
   a.G = const_cast<float*>(G); a.n = (size_t)n; a.out64 = out64;
-  if (hipMemsetAsync(out64, 0, 64 * sizeof(float), (hipStream_t)stream) != hipSuccess) return adt_set_error("grad_sumsq: memset");
+  if (adt::zero_f32_async(out64, 64, (hipStream_t)stream)) return adt_set_error("grad_sumsq: zero");
   hipLaunchKernelGGL(k_sumsq64, dim3(grid_for((size_t)n, 256, 512)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("grad_sumsq");
 }
@@ -356,6 +355,17 @@ int adt_wdist_full(const float* Sm, const float* Sc, int lds, const float* Em, c
   WFullArgs a{Sm, Sc, lds, Em, Ec, B, V, d, dist, ldo};
   hipLaunchKernelGGL(k_wdist_full, dim3(grid_for((size_t)B * V, 16, 4096)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("wdist_full");
+}
+
+int adt_topk_masked(float* dist, int ld, int B, int N, const int32_t* indptr, const int32_t* indices, int k, int32_t* out_idx,
+                    float* out_val, void* stream) {
+  if (B <= 0) return 0;
+  if (k <= 0 || k > N) return adt_set_error("topk_masked: need 0 < k <= N");
+  if (ld < N) return adt_set_error("topk_masked: ld < N");
+  if ((indptr == nullptr) != (indices == nullptr)) return adt_set_error("topk_masked: indptr and indices go together");
+  TopkArgs a{dist, ld, B, N, indptr, indices, k, out_idx, out_val};
+  hipLaunchKernelGGL(k_topk_masked, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("topk_masked");
 }
 
 }  // extern "C"

@@ -322,6 +322,15 @@ def wdist_full(Sm, Sc, Em, Ec, V):
     return dist
 
 
+def topk_masked(dist, k, indptr=None, indices=None, want_val=False):
+    """k smallest entries per row in ascending order after pushing the CSR-listed columns to 1e24; `dist` is consumed."""
+    B, N = dist.shape
+    idx = torch.empty(B, k, device=dist.device, dtype=torch.int32)
+    val = torch.empty(B, k, device=dist.device, dtype=torch.float32) if want_val else None
+    _lib.check(_lib.load().adt_topk_masked(_p(dist), dist.stride(0), B, N, _p(indptr), _p(indices), k, _p(idx), _p(val), _stream()), "topk_masked")
+    return (idx, val) if want_val else idx
+
+
 def axpy(dst, src, alpha=1.0, accumulate=True, mask_ids=None, d=0):
     """dst = (accumulate ? dst : 0) + alpha * src * rowmask."""
     _lib.check(_lib.load().adt_axpy(_p(dst), _p(_f32(src)), float(alpha), int(accumulate), src.numel(), _p(mask_ids), d, _stream()), "axpy")

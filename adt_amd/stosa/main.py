@@ -69,7 +69,7 @@ def _write_synthetic(path, users=22363, items=12101, seed=42):
 def _evaluate(trainer, ds, matrix, batch_size):
     def gen():
         for users, inp, dec, pos, neg, ans in ds.epoch_batches(batch_size, shuffle=False):
-            yield inp, matrix[users].toarray() > 0, ans
+            yield inp, matrix[users], ans
     pred, answers = trainer.full_sort(gen())
     return get_full_sort_score(answers, pred)
 

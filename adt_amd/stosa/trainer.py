@@ -106,18 +106,30 @@ class FusedStosaTrainer:
     # ------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def full_sort(self, batches, topk=40):
-        """Full-sort evaluation (stosa/trainer.py:583-612) over an iterable of (input_ids (B, L), seen (B, item_size) bool or
-        None, answers (B, A)): rank all items by ascending distance with the seen items pushed to 1e24, keep `topk`;
-        returns (pred_list (N, topk), answers (N, A)) for get_full_sort_score."""
+        """Full-sort evaluation (stosa/trainer.py:583-612) over an iterable of (input_ids (B, L), seen, answers (B, A)): rank all
+        items by ascending distance with the seen items pushed to 1e24 and keep `topk`, all on the device (adt_wdist_full +
+        adt_topk_masked); only the (B, topk) ids come back.  `seen` is the users' rows of the train/valid rating matrix as a scipy
+        CSR matrix, a dense (B, item_size) 0/1 array, or None.  Returns (pred_list (N, topk), answers (N, A)) for
+        get_full_sort_score."""
         preds, answers = [], []
+        dev = self.model.dev
         for input_ids, seen, ans in batches:
-            dist = self.model.predict_full(input_ids).cpu().numpy().copy()
+            dist = self.model.predict_full(input_ids)
+            indptr = indices = None
             if seen is not None:
-                dist[np.asarray(seen) > 0] = 1e24
-            ind = np.argpartition(dist, topk)[:, :topk]
-            arr = dist[np.arange(len(dist))[:, None], ind]
-            order = np.argsort(arr)
-            preds.append(ind[np.arange(len(dist))[:, None], order])
+                if hasattr(seen, "tocsr"):
+                    csr = seen.tocsr()
+                    ip, ix = csr.indptr, csr.indices
+                else:
+                    rows, cols = np.nonzero(np.asarray(seen))
+                    ip = np.zeros(dist.shape[0] + 1, np.int64)
+                    np.cumsum(np.bincount(rows, minlength=dist.shape[0]), out=ip[1:])
+                    ix = cols
+                indptr = torch.from_numpy(np.ascontiguousarray(ip, dtype=np.int32)).to(dev)
+                indices = torch.from_numpy(np.ascontiguousarray(ix, dtype=np.int32)).to(dev)
+                if indices.numel() == 0:
+                    indptr = indices = None
+            preds.append(ops.topk_masked(dist, topk, indptr, indices).cpu().numpy().astype(np.int64))
             answers.append(np.asarray(ans))
         return np.concatenate(preds), np.concatenate(answers)
 

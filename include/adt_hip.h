@@ -216,6 +216,13 @@ int adt_wdist_bpr(const float* Sm, const float* Sc, int lds, const float* Em, co
 int adt_wdist_full(const float* Sm, const float* Sc, int lds, const float* Em, const float* Ec, int B, int V, int d,
                    float* dist, int ldo, void* stream);
 
+/* Full-sort selection (stosa/trainer.py:598-612: rating_pred[train_matrix[users].toarray() > 0] = 1e+24, np.argpartition(.., 40),
+ * np.argsort of the 40): per row b, set dist[b][indices[indptr[b]..indptr[b+1])] = 1e24 (CSR of the seen items; both NULL = no
+ * mask), then write the k smallest entries in ascending order (ties: smaller id) to out_idx (B, k) / out_val (B, k, may be
+ * NULL).  `dist` (B rows of N floats, row stride ld) is consumed. */
+int adt_topk_masked(float* dist, int ld, int B, int N, const int32_t* indptr, const int32_t* indices, int k, int32_t* out_idx,
+                    float* out_val, void* stream);
+
 /* ==== model-level executor: SASRecADT (sasrec/model.py:8-97) + loop body (sasrec/main.py:146-173) ====== */
 typedef struct adt_sasrec_cfg {
   int32_t item_num;     /* V; item table has V+1 rows                      */

@@ -78,3 +78,15 @@ def test_host_side_helpers_without_gpu():
     ws = lib.adt_sasrec_workspace_floats(ctypes.byref(cfg), 256)
     assert ws > 0 and ws * 4 < 4 << 30
     assert lib.adt_sasrec_ws_offset(ctypes.byref(cfg), 256, 0, 1) == 256 * 200 * 64
+
+
+def test_library_issues_no_memset_nodes():
+    """The entry points are captured into HIP graphs by the trainers.  A captured hipMemsetAsync node was observed on the MI355X box
+    to start writing a stale non-zero pattern after a few hundred replays (gradient-norm accumulators reading ~4e30 / NaN for the rest
+    of the process, which silently disables or saturates clipping; DESIGN.md "graph memset"), so the library zero-fills with its own
+    kernel and must not import any hipMemset* entry point."""
+    import subprocess
+    so = os.path.join(REPO, "adt_amd", "csrc", "libadt_hip.so")
+    out = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True, check=True).stdout
+    assert "hipLaunchKernel" in out
+    assert not [l for l in out.splitlines() if "hipMemset" in l], out

@@ -294,3 +294,33 @@ def test_wasserstein_bpr_and_full_sort():
     want = so.wasserstein_distance_matmul(tp.const(last_m), tp.const(last_c), tp.const(Em), tp.elu(tp.const(Ec), True)).v
     got = ops.wdist_full(T_(last_m), T_(last_c), T_(Em), T_(Ec), V)
     assert rel(got.cpu().numpy(), want) < 2e-5
+
+
+@pytest.mark.parametrize("B,N,k", [(7, 1000, 40), (3, 12103, 40), (5, 41, 40), (2, 300, 1), (4, 70000, 40)])
+def test_topk_masked_selection_is_exact(B, N, k):
+    """adt_topk_masked vs the reference's numpy path (stosa/trainer.py:598-612: mask to 1e24, argpartition, argsort): integer
+    output, tie-free inputs => identical ids in identical order; the distances written back are the masked inputs, bit-exact."""
+    from adt_amd import ops
+    r = np.random.RandomState(B * 1000 + N)
+    dist = r.permutation(B * N).reshape(B, N).astype(np.float32) * 0.5 + 3.0     # distinct values, exact in fp32 (< 2^24)
+    lens = r.randint(0, min(N - 1, 200), size=B)
+    lens[0] = 0
+    if N > 60:
+        lens[-1] = N - 17                                   # fewer unmasked entries than k: the tail is filled from the masked ones
+    ip = np.zeros(B + 1, np.int32)
+    ip[1:] = np.cumsum(lens)
+    ix = np.concatenate([r.choice(N, size=l, replace=False) for l in lens]).astype(np.int32) if ip[-1] else np.zeros(0, np.int32)
+    ref = dist.copy()
+    for b in range(B):
+        ref[b, ix[ip[b]:ip[b + 1]]] = 1e24
+    want = np.argsort(ref, axis=1, kind="stable")[:, :k]
+    idx, val = ops.topk_masked(T_(dist), k, T_(ip) if len(ix) else None, T_(ix) if len(ix) else None, want_val=True)
+    idx, val = idx.cpu().numpy(), val.cpu().numpy()
+    assert np.array_equal(idx, want)
+    assert np.array_equal(val, np.take_along_axis(ref, want, 1))
+    # strided rows (a column slice of a wider matrix) and no mask
+    wide = T_(np.concatenate([dist, dist[:, :5]], 1))
+    idx2 = ops.topk_masked(wide[:, :N], k).cpu().numpy()
+    assert np.array_equal(idx2, np.argsort(dist, axis=1, kind="stable")[:, :k])
+    with pytest.raises(Exception):
+        ops.topk_masked(T_(dist), N + 1)
