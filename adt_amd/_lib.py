@@ -73,6 +73,7 @@ SIGNATURES = {
                            _P, _U, _U, _P, _P, _P, _P, _P, _P, _I, _P]),
     "adt_wdist_bpr": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _I, _P, _P, _P, _P]),
     "adt_wdist_full": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P]),
+    "adt_dense_rows_enable": (_I, [_I]),
     "adt_topk_masked": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "adt_sasrec_param_layout": (_L, [_CP, _P]),
     "adt_sasrec_workspace_floats": (_L, [_CP, _I]),

@@ -66,6 +66,8 @@ struct GradSrc {
   const float* U; int ldu; int act;
   DropCfg drop; uint32_t key; uint32_t row_offset;
   const int* ids;
+  int idx_ld, idx_off;          // dropout index = (t + row_offset) * idx_ld + idx_off + n (a column chunk of a wider layer keeps the
+                                // layer's own indices); the host sets idx_ld = N, idx_off = 0 for a whole layer
   ADT_DEVICE_INLINE float4 at(int t, int n) const {
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (t < T && n < N && !(ids && ids[t] == 0)) {
@@ -77,7 +79,7 @@ struct GradSrc {
         for (int j = 0; j < 4; ++j) if (j < lim) v[j] = q[j];
       }
       if (drop.thr) {
-        const uint32_t base = (uint32_t)(t + row_offset) * (uint32_t)N + (uint32_t)n;
+        const uint32_t base = (uint32_t)(t + row_offset) * (uint32_t)idx_ld + (uint32_t)(idx_off + n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = adt_keep(key, base + j, drop.thr) ? v[j] * drop.scale : 0.f;
       }

@@ -4,6 +4,7 @@
 
 #include "adt_attn_gen.cuh"
 #include "adt_gemm.cuh"
+#include "adt_dense_rows.cuh"
 #include "adt_stosa.cuh"
 #include "adt_wide.cuh"
 
@@ -95,8 +96,99 @@ static int gemm_launch(K kernel, size_t smem, int grid, hipStream_t s, const voi
   return 0;
 }
 
+
+// ---- row-streaming kernels (adt_dense_rows.cuh): bf16 operands, contraction 64 / 128 / 256 ---------------------------------------
+static int g_rows_enabled = 1;      // adt_dense_rows_enable(0) routes everything to the tiled kernels (A/B measurements, tests)
+
+template <class KFn, class Args>
+static int rows_launch(KFn kernel, const Args& a, int n_panels, int pc, int contraction, int T, hipStream_t s, bool& attr_done) {
+  const size_t smem = rows_lds_bytes(contraction, pc);
+  if (!attr_done) {
+    if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return adt_set_error("dense rows: hipFuncSetAttribute(%zu)", smem);
+    attr_done = true;
+  }
+  // one workgroup per CU and panel group; never more row groups than 16-row tiles / waves
+  const int ntiles = (T + 15) / 16;
+  int nrg = 256 / n_panels;
+  if (smem <= 64 * 1024) nrg *= 2;
+  const int need = (ntiles + ROWS_NW - 1) / ROWS_NW;
+  if (nrg > need) nrg = need;
+  if (nrg < 1) nrg = 1;
+  Args args = a;
+  int np = n_panels, pcv = pc;
+  void* kargs[] = {&args, &np, &pcv};
+  if (hipLaunchKernel((const void*)kernel, dim3(nrg * n_panels), dim3(ROWS_NW * 64), kargs, smem, s) != hipSuccess) return adt_set_error("dense rows: launch failed");
+  return 0;
+}
+
+static bool rows_fwd_ok(const DenseFwdArgs& a) {
+  if (!g_rows_enabled) return false;
+  if (!(a.K == 64 || a.K == 128 || a.K == 256) || (a.N % 4) || (a.ldy % 4) || !aligned16(a.Y)) return false;
+  if (a.N > 1024) return false;                                  // the all-item logits stay on the tiled kernel
+  if (a.b && !aligned16(a.b)) return false;
+  if (a.U && ((a.ldu % 4) || !aligned16(a.U))) return false;
+  if (a.R && ((a.ldr % 4) || !aligned16(a.R))) return false;
+  if (a.R2 && ((a.ldr2 % 4) || !aligned16(a.R2))) return false;
+  return true;
+}
+
+static int launch_dense_fwd_rows(const DenseFwdArgs& a, hipStream_t s) {
+  const int pc = a.N >= ROWS_PC ? ROWS_PC : (a.N + 15) / 16 * 16;
+  const int n_panels = (a.N + pc - 1) / pc;
+  static bool done[3] = {false, false, false};
+  int rc;
+  // residual loads run one chunk of CH column tiles ahead (double buffered in registers): 8 tiles, or 4 when there are two residuals
+  if (a.R2) {
+    static bool done4[3] = {false, false, false};
+    if (a.K == 64) rc = rows_launch(k_dense_fwd_rows<2, 4>, a, n_panels, pc, 64, a.T, s, done4[0]);
+    else if (a.K == 128) rc = rows_launch(k_dense_fwd_rows<4, 4>, a, n_panels, pc, 128, a.T, s, done4[1]);
+    else rc = rows_launch(k_dense_fwd_rows<8, 4>, a, n_panels, pc, 256, a.T, s, done4[2]);
+  } else if (a.K == 64) rc = rows_launch(k_dense_fwd_rows<2, 8>, a, n_panels, pc, 64, a.T, s, done[0]);
+  else if (a.K == 128) rc = rows_launch(k_dense_fwd_rows<4, 8>, a, n_panels, pc, 128, a.T, s, done[1]);
+  else rc = rows_launch(k_dense_fwd_rows<8, 8>, a, n_panels, pc, 256, a.T, s, done[2]);
+  return rc ? rc : check_launch("dense_fwd(rows)");
+}
+
+static bool rows_dx_ok(const DenseBwdArgs& a) {
+  if (!g_rows_enabled || !a.dX) return false;
+  const int N = a.G.N;
+  if ((N % 64) || N > 1024 || (a.K % 4) || (a.lddx % 4) || !aligned16(a.dX) || (a.G.lddy % 4) || !aligned16(a.G.dY)) return false;
+  if (a.G.act != ACT_NONE && ((a.G.ldu % 4) || !aligned16(a.G.U))) return false;
+  return true;
+}
+
+// contraction chunks of <= 256 columns of G / rows of W; every chunk after the first accumulates
+static int launch_dense_dx_rows(const DenseBwdArgs& a0, hipStream_t s) {
+  const int N = a0.G.N;
+  static bool done[6] = {false, false, false, false, false, false};
+  const bool has_u = a0.G.act != ACT_NONE;
+  for (int n0 = 0; n0 < N;) {
+    // with an activation the saved pre-activation rides along in registers: contraction chunks of 128 instead of 256
+    int chunk = (N - n0 >= 256 && !has_u) ? 256 : (N - n0 >= 128 ? 128 : 64);
+    DenseBwdArgs a = a0;
+    a.G.dY = a0.G.dY + n0; a.G.U = a0.G.U ? a0.G.U + n0 : nullptr; a.G.N = chunk; a.G.idx_off = a0.G.idx_off + n0;
+    a.W = a0.W + (size_t)n0 * a0.ldw;
+    a.beta = (n0 > 0) ? 1 : a0.beta;
+    a.dW = nullptr; a.db = nullptr;
+    const int pc = a.K >= ROWS_PC ? ROWS_PC : (a.K + 15) / 16 * 16;
+    const int n_panels = (a.K + pc - 1) / pc;
+    int rc;
+    if (has_u) {
+      if (chunk == 64) rc = rows_launch(k_dense_dx_rows<2, true>, a, n_panels, pc, 64, a.G.T, s, done[3]);
+      else rc = rows_launch(k_dense_dx_rows<4, true>, a, n_panels, pc, 128, a.G.T, s, done[4]);
+    } else if (chunk == 64) rc = rows_launch(k_dense_dx_rows<2, false>, a, n_panels, pc, 64, a.G.T, s, done[0]);
+    else if (chunk == 128) rc = rows_launch(k_dense_dx_rows<4, false>, a, n_panels, pc, 128, a.G.T, s, done[1]);
+    else rc = rows_launch(k_dense_dx_rows<8, false>, a, n_panels, pc, 256, a.G.T, s, done[2]);
+    if (rc) return rc;
+    n0 += chunk;
+  }
+  return check_launch("dense_bwd_dx(rows)");
+}
+
 template <int PREC>
 static int launch_dense_fwd(const DenseFwdArgs& a0, hipStream_t s) {
+  if (PREC == PREC_BF16 && rows_fwd_ok(a0)) return launch_dense_fwd_rows(a0, s);
   DenseFwdArgs a = a0;
   a.nt_n = a.N > 64 ? (a.N + 127) / 128 : 1;
   a.nt_m = (a.T + GBM - 1) / GBM;
@@ -111,6 +203,10 @@ template <int PREC>
 static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
   DenseBwdArgs a = a0;
   const int T = a.G.T, N = a.G.N, K = a.K;
+  if (PREC == PREC_BF16 && rows_dx_ok(a)) {
+    if (launch_dense_dx_rows(a, s)) return -1;
+    a.dX = nullptr;
+  }
   if (a.dX) {
     const int gx = K > 64 ? (K + 127) / 128 : 1, gy = (T + GBM - 1) / GBM;
     // long contractions over few output tiles (the all-item logits: N = V + 100) are split over blockIdx.z
@@ -148,6 +244,12 @@ static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
 
 extern "C" {
 
+int adt_dense_rows_enable(int on) {
+  const int was = g_rows_enabled;
+  g_rows_enabled = on ? 1 : 0;
+  return was;
+}
+
 int adt_dense_fwd(int prec, const float* X, int ldx, const float* W, int ldw, const float* b, int T, int K, int N, int act, float* U,
                   int ldu, float p, const uint32_t* seed, uint32_t site, uint32_t row_offset, const float* R, int ldr,
                   const float* R2, int ldr2, const int32_t* mask_ids, float* Y, int ldy, const int32_t* t_dev, void* stream) {
@@ -169,7 +271,7 @@ int adt_dense_bwd(int prec, const float* dY, int lddy, int T, int K, int N, cons
   if (act != ACT_NONE && !U) return adt_set_error("dense_bwd: activation gradient needs the saved pre-activation U");
   DenseBwdArgs a{};
   a.G.dY = dY; a.G.lddy = lddy; a.G.T = T; a.G.N = N; a.G.U = U; a.G.ldu = ldu; a.G.act = act;
-  a.G.drop = adt_make_drop(p, seed, site); a.G.row_offset = row_offset; a.G.ids = mask_ids;
+  a.G.drop = adt_make_drop(p, seed, site); a.G.row_offset = row_offset; a.G.ids = mask_ids; a.G.idx_ld = N; a.G.idx_off = 0;
   a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.K = K; a.dX = dX; a.lddx = lddx; a.beta = beta; a.dW = dW; a.lddw = lddw; a.db = db; a.t_dev = t_dev;
   return prec == ADT_PREC_F32 ? launch_dense_bwd<PREC_F32>(a, (hipStream_t)stream) : launch_dense_bwd<PREC_BF16>(a, (hipStream_t)stream);
 }

@@ -354,3 +354,9 @@ def grad_sumsq(G, out64):
 def adam_range(P, G, M, V, l2, clip, lr, b1, b2, eps, step, gn2_slots):
     _lib.check(_lib.load().adt_adam_range(_p(P), _p(G), _p(M), _p(V), P.numel(), float(l2), float(clip), float(lr), float(b1), float(b2), float(eps),
                                           float(step), _p(gn2_slots), _stream()), "adam_range")
+
+
+def dense_rows_enable(on):
+    """bf16 dense layers: True = row-streaming kernels where the shape allows (default), False = always the tiled kernels.
+    Returns the previous setting."""
+    return bool(_lib.load().adt_dense_rows_enable(int(bool(on))))

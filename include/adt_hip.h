@@ -131,6 +131,10 @@ int adt_score_rank(const float* F, int ldf, const float* E, const int32_t* cand,
 #define ADT_ACT_ELU 3    /* nn.ELU() (stosa/modules.py:477) */
 #define ADT_ACT_ELU1 4   /* ELU(x) + 1 (stosa/modules.py:236-238) */
 
+/* Kernel selection for the dense layers in bf16 mode: 1 (default) = row-streaming kernels (adt_dense_rows.cuh) where the shape
+ * allows (contraction 64/128/256 per chunk, N <= 1024), 0 = always the tiled kernels.  Returns the previous setting.  Results
+ * agree to bf16 rounding either way; the switch exists for A/B measurements and tests. */
+int adt_dense_rows_enable(int on);
 /* torch.nn.Linear with its surrounding elementwise ops, any K / N (bert4rec/model/modules.py:59-75,128-139,
  * bert.py:48-51,80-90; stosa/modules.py:199-212,477-487): Y = mask(R + dropout(act(X W^T + b))); W is N x K with row
  * stride ldw; U (optional) receives the pre-activation X W^T + b for the backward.  t_dev (optional, DEVICE int): only

@@ -324,3 +324,44 @@ def test_topk_masked_selection_is_exact(B, N, k):
     assert np.array_equal(idx2, np.argsort(dist, axis=1, kind="stable")[:, :k])
     with pytest.raises(Exception):
         ops.topk_masked(T_(dist), N + 1)
+
+
+@pytest.mark.parametrize("T,K,N,act", [(1000, 256, 256, 0), (333, 256, 768, 2), (4100, 64, 64, 4), (517, 128, 1024, 1), (260, 256, 100, 3), (48, 64, 256, 2)])
+def test_dense_rows_kernels_match_tiled(T, K, N, act):
+    """The row-streaming bf16 kernels (adt_dense_rows.cuh) against the tiled ones on the same inputs: same bf16 operands and fp32
+    accumulation, different summation order => 2e-5 of the output magnitude (forward, incl. bias / activation / dropout /
+    residuals / row mask / device row count / saved pre-activation) and 2e-5 on dX through the full prologue (mask, dropout,
+    act') with the contraction chunked (N = 768, 1024) and accumulated into an existing dX (beta)."""
+    from adt_amd import ops
+    r = np.random.RandomState(T + K + N)
+    X = T_(r.standard_normal((T, K)).astype(np.float32))
+    W = T_((r.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    b = T_((0.1 * r.standard_normal(N)).astype(np.float32))
+    R = T_(r.standard_normal((T, N)).astype(np.float32))
+    R2 = T_(r.standard_normal((T, N)).astype(np.float32))
+    ids = T_((r.rand(T) > 0.2).astype(np.int32))
+    seed = T_(np.array([12345], np.int32))
+    tdev = T_(np.array([T - 37 if T > 100 else T], np.int32))
+    dY = T_(r.standard_normal((T, N)).astype(np.float32))
+    dX0 = T_(r.standard_normal((T, K)).astype(np.float32))
+    outs, U_shared = [], None
+    for rows in (False, True):
+        was = ops.dense_rows_enable(rows)
+        try:
+            Y, U = ops.dense_fwd(ops.PREC_BF16, X, W, b, act, act != 0, 0.3, seed, 7, 11, R, ids, None, tdev, None, R2)
+            Y2, _ = ops.dense_fwd(ops.PREC_BF16, X, W, None, 0)
+            if U_shared is None:
+                # both backward kernels get the SAME saved pre-activation: a last-bit difference in U moves act'(U) across a
+                # bf16 rounding boundary now and then, which is a 0.4 % change of one operand, not a kernel difference
+                U_shared = U
+            dX = dX0.clone()
+            ops.dense_bwd(ops.PREC_BF16, dY, X, W, None, None, dX, True, act, U_shared, 0.3, seed, 7, 11, ids, tdev)
+            dX2 = torch.empty_like(dX0)
+            ops.dense_bwd(ops.PREC_BF16, dY, X, W, None, None, dX2, False)
+        finally:
+            ops.dense_rows_enable(was)
+        n_live = int(tdev.item())
+        outs.append([t[:n_live].cpu().numpy() for t in (Y, U if U is not None else Y, dX, Y2, dX2)])
+    for a, bb, name in zip(outs[0], outs[1], ("Y", "U", "dX", "Y_plain", "dX_plain")):
+        assert np.isfinite(bb).all(), name
+        assert np.abs(a - bb).max() <= 2e-5 * max(1.0, np.abs(a).max()), (name, np.abs(a - bb).max(), np.abs(a).max())

@@ -31,7 +31,11 @@ def run(preset, epochs, eval_every, seed, precision, hidden=64, maxlen=200, data
     a.device, a.num_heads, a.maxlen, a.num_layers, a.hidden_units, a.dropout, a.precision = "cuda:0", 2, maxlen, 2, hidden, 0.5, precision
     torch.manual_seed(seed)
     np.random.seed(seed)
-    model = SASRecADT(usernum, itemnum, a)
+    if hidden != 64:       # the template width (d = 256) runs on the general kernels, as adt_amd/sasrec/main.py routes it
+        from adt_amd.sasrec.model_wide import SASRecADTWide, WideSasrecTrainer
+        model = SASRecADTWide(usernum, itemnum, a)
+    else:
+        model = SASRecADT(usernum, itemnum, a)
     for _, p in model.named_parameters():
         try:
             torch.nn.init.xavier_normal_(p.data)
@@ -39,7 +43,8 @@ def run(preset, epochs, eval_every, seed, precision, hidden=64, maxlen=200, data
             pass
     model.train()
     lam1, lam2 = U.get_lambdas("ml-1m")
-    tr = FusedTrainer(model, lam1, lam2, lr=1e-3, weight_decay=1e-3, clip=5.0, use_graph=True, seed=seed)
+    Trainer = FusedTrainer if hidden == 64 else WideSasrecTrainer
+    tr = Trainer(model, lam1, lam2, lr=1e-3, weight_decay=1e-3, clip=5.0, use_graph=True, seed=seed)
     warp = U.WarpDataset(user_train, usernum, itemnum, maxlen)
     sampler = U.PopularSampler(user_train, user_valid, user_test, usernum, itemnum, 100)
     evals = {m: U.EvalDataset(user_train, user_valid, user_test, usernum, itemnum, maxlen, sampler, mode=m, frozen=True, seed=23)
@@ -78,11 +83,13 @@ def main():
     ap.add_argument("--eval_every", type=int, default=10)
     ap.add_argument("--seeds", type=int, nargs="+", default=[23])
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--maxlen", type=int, default=200)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     from adt_amd.sasrec import synth
     data = synth.generate(a.preset, 23)
-    runs = [run(a.preset, a.epochs, a.eval_every, s, a.precision, data=data) for s in a.seeds]
+    runs = [run(a.preset, a.epochs, a.eval_every, s, a.precision, hidden=a.hidden, maxlen=a.maxlen, data=data) for s in a.seeds]
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     with open(a.out, "w") as f:
         json.dump({"preset": a.preset, "precision": a.precision, "runs": runs}, f, indent=1)
