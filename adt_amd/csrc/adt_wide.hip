@@ -1,5 +1,6 @@
 // C ABI (include/adt_hip.h, "wide" section): launch wrappers for the general dense layers, the masked attention and
 // the row kernels used by the BERT4Rec-ADT and STOSA-ADT paths.  Host code only enqueues work on the caller's stream.
+#include <cstdlib>
 #include "adt_host.h"
 
 #include "adt_attn_gen.cuh"
@@ -227,8 +228,12 @@ static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
   if (a.dW) {
     const int bn = K > 64 ? 128 : 64;
     const int gx = (K + bn - 1) / bn, gy = (N + GBM - 1) / GBM;
-    // split T so that about 1024 workgroups are in flight; chunks are multiples of 32 rows
-    int splits = (1024 + gx * gy - 1) / (gx * gy);
+    // split T so that enough workgroups are in flight while each still amortises the 16 K atomics of its flush over >= 10
+    // k-steps; the targets are measured (tools/bench_dense.py at T = 51,200: 4 tiles 78 us @512 vs 98 @1024; 12 tiles 223 @2048
+    // vs 247 @1024; 16 tiles 565 @1024 vs 602 @2048)
+    const int tiles = gx * gy;
+    const int target_wgs = tiles <= 4 ? 512 : (tiles <= 12 ? 2048 : 1024);
+    int splits = (target_wgs + tiles - 1) / tiles;
     int chunk = ((T + splits - 1) / splits + GBK - 1) / GBK * GBK;
     if (chunk < GBK) chunk = GBK;
     splits = (T + chunk - 1) / chunk;

@@ -50,10 +50,13 @@ def main():
             ops.dense_rows_enable(rows)
             t_f = timeit(lambda: ops.dense_fwd(ops.PREC_BF16, X, W, b, act, False, p, seed, 3, 0, R, None, Y))
             t_x = timeit(lambda: ops.dense_bwd(ops.PREC_BF16, dY, X, W, None, None, dX, False, act, U, p, seed, 3))
+            dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
+            t_w = timeit(lambda: ops.dense_bwd(ops.PREC_BF16, dY, X, W, dW, db, None, False, act, U, p, seed, 3))
             by_f = 4.0 * T * (K + N * (2 if res else 1))
             by_x = 4.0 * T * (K + N * (2 if act else 1))
-            print("K=%4d N=%4d act=%d p=%.1f res=%d %-6s fwd %7.1f us %6.1f TF/s %6.0f GB/s | dx %7.1f us %6.1f TF/s %6.0f GB/s"
-                  % (K, N, act, p, int(res), "rows" if rows else "tiled", t_f, flops / t_f * 1e-6, by_f / t_f * 1e-3, t_x, flops / t_x * 1e-6, by_x / t_x * 1e-3), flush=True)
+            print("K=%4d N=%4d act=%d p=%.1f res=%d %-6s fwd %7.1f us %6.1f TF/s %6.0f GB/s | dx %7.1f us %6.1f TF/s %6.0f GB/s | dw %7.1f us %6.1f TF/s"
+                  % (K, N, act, p, int(res), "rows" if rows else "tiled", t_f, flops / t_f * 1e-6, by_f / t_f * 1e-3, t_x, flops / t_x * 1e-6, by_x / t_x * 1e-3,
+                     t_w, flops / t_w * 1e-6), flush=True)
         ops.dense_rows_enable(True)
 
 
