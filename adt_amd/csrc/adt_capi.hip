@@ -421,7 +421,7 @@ int adt_headcls_bwd(const float* O, int ldo, const float* Ws, const float* rec, 
   a.O = O; a.ldo = ldo; a.Ws = Ws; a.B = B; a.L = L; a.H = H; a.hd = hd; a.rec = const_cast<float*>(rec);
   a.drec = drec; a.dO = dO; a.lddo = lddo; a.dWs = dWs; a.dbs = dbs;
   const size_t smem = (size_t)(H * hd + H) * sizeof(float);
-  hipLaunchKernelGGL(k_headcls_bwd, dim3(grid_for((size_t)B * L, 4, 256)), dim3(256), smem, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_headcls_bwd, dim3(grid_for((size_t)B * L, 16, 1024)), dim3(256), smem, (hipStream_t)stream, a);
   return check_launch("headcls_bwd");
 }
 

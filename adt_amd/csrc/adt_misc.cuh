@@ -183,27 +183,42 @@ __global__ __launch_bounds__(256) void k_headcls_bwd(HeadClsArgs a) {
       acc[cc] = 0.f;
       accb[cc] = 0.f;
     }
-    for (int tok = wave; tok < T; tok += nwaves) {
-      const int b = tok / a.L, l = tok % a.L;
-      const size_t ro = ((size_t)(l * a.B + b) * a.H + h) * a.H;
-      float dz[MAXH];
-      float sd = 0.f;
+    // TU tokens per iteration: all of their loads are issued before the first dependent use (the dO read-modify-write would
+    // otherwise serialise one memory latency per token)
+    constexpr int TU = 4;
+    for (int tok0 = wave * TU; tok0 < T; tok0 += nwaves * TU) {
+      float dzr[TU][MAXH], rc[TU][MAXH], ovv[TU], dold[TU];
 #pragma unroll
-      for (int cc = 0; cc < MAXH; ++cc) {
-        dz[cc] = (live && cc < a.H) ? a.drec[ro + cc] : 0.f;
-        sd += dz[cc];
-      }
-      const float ov = live ? a.O[(size_t)tok * a.ldo + col] : 0.f;
-      float dov = 0.f;
+      for (int u = 0; u < TU; ++u) {
+        const int tok = tok0 + u;
+        const bool ok = live && tok < T;
+        const int b = ok ? tok / a.L : 0, l = ok ? tok % a.L : 0;
+        const size_t ro = ((size_t)(l * a.B + b) * a.H + h) * a.H;
 #pragma unroll
-      for (int cc = 0; cc < MAXH; ++cc)
-        if (cc < a.H) {
-          dz[cc] -= (live ? expf(a.rec[ro + cc]) : 0.f) * sd;
-          dov += dz[cc] * wreg[cc];
-          acc[cc] += dz[cc] * ov;
-          if (j == 0) accb[cc] += dz[cc];
+        for (int cc = 0; cc < MAXH; ++cc) {
+          dzr[u][cc] = (ok && cc < a.H) ? a.drec[ro + cc] : 0.f;
+          rc[u][cc] = (ok && cc < a.H) ? a.rec[ro + cc] : -INFINITY;
         }
-      if (live) a.dO[(size_t)tok * a.lddo + col] += dov;
+        ovv[u] = ok ? a.O[(size_t)tok * a.ldo + col] : 0.f;
+        dold[u] = ok ? a.dO[(size_t)tok * a.lddo + col] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < TU; ++u) {
+        const int tok = tok0 + u;
+        float sd = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < MAXH; ++cc) sd += dzr[u][cc];
+        float dov = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < MAXH; ++cc)
+          if (cc < a.H) {
+            const float dz = dzr[u][cc] - expf(rc[u][cc]) * sd;
+            dov += dz * wreg[cc];
+            acc[cc] += dz * ovv[u];
+            if (j == 0) accb[cc] += dz;
+          }
+        if (live && tok < T) a.dO[(size_t)tok * a.lddo + col] = dold[u] + dov;
+      }
     }
     if (live) {
 #pragma unroll

@@ -277,4 +277,22 @@ __global__ __launch_bounds__(256) void k_topk_masked(TopkArgs a) {
   }
 }
 
+// ---- the upstream gradient of a dense layer pulled back through its epilogue, materialised once ---------------------------------
+// out[t][n] = dY[t][n] * (ids[t] != 0) * dropmask((t + row_offset) * N + n) * act'(U[t][n])  (GradSrc::at, adt_gemm.cuh).  For
+// layers with an activation the backward GEMMs otherwise re-derive this per output-column tile (weight gradient) and need the
+// saved pre-activation as a second register-resident operand (input gradient: twice the passes); one elementwise pass is cheaper.
+struct GradSrcOutArgs { GradSrc G; float* out; int ldo; const int* t_dev; };
+
+__global__ __launch_bounds__(256) void k_gradsrc(GradSrcOutArgs a) {
+  GradSrc G = a.G;
+  if (a.t_dev && G.T > *a.t_dev) G.T = *a.t_dev;
+  G.key = drop_key(G.drop);
+  const int n4 = G.N / 4;
+  const size_t total = (size_t)G.T * n4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int t = (int)(i / n4), n = (int)(i % n4) * 4;
+    *reinterpret_cast<float4*>(a.out + (size_t)t * a.ldo + n) = G.at(t, n);
+  }
+}
+
 }  // namespace adt

@@ -475,4 +475,17 @@ int adt_topk_masked(float* dist, int ld, int B, int N, const int32_t* indptr, co
   return check_launch("topk_masked");
 }
 
+int adt_dense_gradsrc(const float* dY, int lddy, int T, int N, const int32_t* mask_ids, float p, const uint32_t* seed, uint32_t site,
+                      uint32_t row_offset, int act, const float* U, int ldu, float* G, int ldg, const int32_t* t_dev, void* stream) {
+  if (T <= 0 || N <= 0) return 0;
+  if ((N % 4) || (lddy % 4) || (ldg % 4) || !aligned16(dY) || !aligned16(G)) return adt_set_error("dense_gradsrc: N, ld %% 4 and 16-byte alignment required");
+  if (act != ACT_NONE && (!U || (ldu % 4) || !aligned16(U))) return adt_set_error("dense_gradsrc: activation needs the saved pre-activation");
+  GradSrcOutArgs a{};
+  a.G.dY = dY; a.G.lddy = lddy; a.G.T = T; a.G.N = N; a.G.U = U; a.G.ldu = ldu; a.G.act = act;
+  a.G.drop = adt_make_drop(p, seed, site); a.G.row_offset = row_offset; a.G.ids = mask_ids; a.G.idx_ld = N; a.G.idx_off = 0;
+  a.out = G; a.ldo = ldg; a.t_dev = t_dev;
+  hipLaunchKernelGGL(k_gradsrc, dim3(grid_for((size_t)T * (N / 4), 1024, 4096)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("dense_gradsrc");
+}
+
 }  // extern "C"

@@ -356,6 +356,15 @@ def adam_range(P, G, M, V, l2, clip, lr, b1, b2, eps, step, gn2_slots):
                                           float(step), _p(gn2_slots), _stream()), "adam_range")
 
 
+def dense_gradsrc(dY, act, U, p=0.0, seed=None, site=0, row_offset=0, mask_ids=None, t_dev=None):
+    """G = dY * rowmask * dropmask * act'(U), materialised (see adt_dense_gradsrc)."""
+    T, N = dY.shape
+    G = torch.empty(T, N, device=dY.device, dtype=torch.float32)
+    _lib.check(_lib.load().adt_dense_gradsrc(_p(_f32(dY)), _ld(dY), T, N, _p(mask_ids), float(p), _p(seed), site, row_offset, act, _p(U), _ld(U),
+                                             _p(G), N, _p(t_dev), _stream()), "dense_gradsrc")
+    return G
+
+
 def dense_rows_enable(on):
     """bf16 dense layers: True = row-streaming kernels where the shape allows (default), False = always the tiled kernels.
     Returns the previous setting."""

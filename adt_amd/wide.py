@@ -149,7 +149,13 @@ class Tape:
                 beta = False
             else:
                 beta = True
-            ops.dense_bwd(self.prec, y.g, x.t, W, gW, gb, x.g, beta, act, U, p, self.seed, site, self.row_offset, mask_ids, t_dev)
+            if act != ops.ACT_NONE and y.g.shape[1] >= 256:
+                # wide layers with an activation: pull the gradient through the epilogue once (one elementwise pass) instead of
+                # inside every column tile of the two backward GEMMs
+                G = ops.dense_gradsrc(y.g, act, U, p, self.seed, site, self.row_offset, mask_ids, t_dev)
+                ops.dense_bwd(self.prec, G, x.t, W, gW, gb, x.g, beta, ops.ACT_NONE, None, 0.0, None, 0, 0, None, t_dev)
+            else:
+                ops.dense_bwd(self.prec, y.g, x.t, W, gW, gb, x.g, beta, act, U, p, self.seed, site, self.row_offset, mask_ids, t_dev)
             for res in (R, R2):
                 if res is None:
                     continue

@@ -131,6 +131,12 @@ int adt_score_rank(const float* F, int ldf, const float* E, const int32_t* cand,
 #define ADT_ACT_ELU 3    /* nn.ELU() (stosa/modules.py:477) */
 #define ADT_ACT_ELU1 4   /* ELU(x) + 1 (stosa/modules.py:236-238) */
 
+/* G[t][n] = dY[t][n] * (mask_ids[t] != 0) * dropmask * act'(U[t][n]): the gradient reaching the pre-activation of a dense layer
+ * (the backward of the epilogue of adt_dense_fwd: bert4rec/model/modules.py:128-139 GELU + dropout, sasrec/modules.py:618-633 relu
+ * + dropout), written once so that adt_dense_bwd can run on it with act = none, p = 0 (same arithmetic as its fused prologue). */
+int adt_dense_gradsrc(const float* dY, int lddy, int T, int N, const int32_t* mask_ids, float p, const uint32_t* seed,
+                      uint32_t site, uint32_t row_offset, int act, const float* U, int ldu, float* G, int ldg,
+                      const int32_t* t_dev, void* stream);
 /* Kernel selection for the dense layers in bf16 mode: 1 (default) = row-streaming kernels (adt_dense_rows.cuh) where the shape
  * allows (contraction 64/128/256 per chunk, N <= 1024), 0 = always the tiled kernels.  Returns the previous setting.  Results
  * agree to bf16 rounding either way; the switch exists for A/B measurements and tests. */

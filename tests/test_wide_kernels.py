@@ -365,3 +365,31 @@ def test_dense_rows_kernels_match_tiled(T, K, N, act):
     for a, bb, name in zip(outs[0], outs[1], ("Y", "U", "dX", "Y_plain", "dX_plain")):
         assert np.isfinite(bb).all(), name
         assert np.abs(a - bb).max() <= 2e-5 * max(1.0, np.abs(a).max()), (name, np.abs(a - bb).max(), np.abs(a).max())
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_dense_gradsrc_equals_fused_prologue(prec):
+    """adt_dense_gradsrc + a plain adt_dense_bwd against adt_dense_bwd with the fused prologue (row mask, dropout, GELU'):
+    the materialised G is the same fp32 value the fused path forms, so dX / dW / db agree to summation order."""
+    from adt_amd import ops
+    P = ops.PREC_F32 if prec == "f32" else ops.PREC_BF16
+    r = np.random.RandomState(5)
+    T, K, N = 700, 256, 512
+    X = T_(r.standard_normal((T, K)).astype(np.float32))
+    W = T_((r.standard_normal((N, K)) / 16).astype(np.float32))
+    U = T_(r.standard_normal((T, N)).astype(np.float32))
+    dY = T_(r.standard_normal((T, N)).astype(np.float32))
+    ids = T_((r.rand(T) > 0.2).astype(np.int32))
+    seed = T_(np.array([99], np.int32))
+    tdev = T_(np.array([T - 21], np.int32))
+    outs = []
+    for fused in (True, False):
+        dX = torch.zeros(T, K, device=dev()); dW = torch.zeros(N, K, device=dev()); db = torch.zeros(N, device=dev())
+        if fused:
+            ops.dense_bwd(P, dY, X, W, dW, db, dX, False, ops.ACT_GELU, U, 0.25, seed, 5, 13, ids, tdev)
+        else:
+            G = ops.dense_gradsrc(dY, ops.ACT_GELU, U, 0.25, seed, 5, 13, ids, tdev)
+            ops.dense_bwd(P, G, X, W, dW, db, dX, False, ops.ACT_NONE, None, 0.0, None, 0, 0, None, tdev)
+        outs.append([t.cpu().numpy() for t in (dX[:T - 21], dW, db)])
+    for a, b, name in zip(outs[0], outs[1], ("dX", "dW", "db")):
+        assert np.abs(a - b).max() <= 3e-5 * max(1.0, np.abs(a).max()), (name, np.abs(a - b).max(), np.abs(a).max())
