@@ -318,4 +318,124 @@ __global__ __launch_bounds__(ROWS_NW * 64) void k_dense_dx_rows(DenseBwdArgs a, 
   }
 }
 
+
+// ---- weight gradient: dW += G^T X, db += colsum(G); T split over workgroups, partials added with atomics ----------------------------
+// Output block 256 (n) x 128 (k) per 512-thread workgroup, 64 rows of T per stage, double-buffered LDS, ONE barrier per stage.
+// Both operands are contracted over their slow (row) index, so they go to LDS "octet-interleaved": element (t, col) of a stage
+// lives at ((t / 8) * COLS + col) * 8 + t % 8 -- the eight t of an octet are the eight k-slots of one MFMA lane, i.e. one
+// ds_read_b128 per operand fragment and no transposition anywhere: the staging thread that owns (octet, 4 columns) loads its
+// 8 rows x 16 bytes with coalesced 16-byte loads and writes four packed 16-byte words (the X side: 4 rows, 8-byte words).
+// acc[r] = dW[n0 + 16 nt + 4g + r][k0 + 16 kt + c].
+constexpr int DW_BN = 256, DW_BK = 128, DW_TS = 64, DW_NTH = 512;
+constexpr size_t DW_LDS_BYTES = 2 * (size_t)(8 * DW_BN * 8 + 8 * DW_BK * 8) * sizeof(__bf16);     // 96 KB
+
+struct DwStage { float4 g[8]; float4 x[4]; };
+
+__global__ __launch_bounds__(DW_NTH) void k_dense_dw_rows(DenseBwdArgs a, int n_blocks, int k_blocks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rows_smem[];
+  __bf16* sG = reinterpret_cast<__bf16*>(rows_smem);                    // [2][8][DW_BN][8]
+  __bf16* sX = sG + 2 * 8 * DW_BN * 8;                                  // [2][8][DW_BK][8]
+  const int tiles = n_blocks * k_blocks;
+  const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int n0 = (tile / k_blocks) * DW_BN, k0 = (tile % k_blocks) * DW_BK;
+  GradSrc G = a.G;
+  if (a.t_dev && G.T > *a.t_dev) G.T = *a.t_dev;
+  G.key = drop_key(G.drop);
+  const int t_begin = split * a.t_chunk;
+  int t_end = t_begin + a.t_chunk;
+  if (t_end > G.T) t_end = G.T;
+  if (t_begin >= t_end) return;
+  G.T = t_end;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
+  // staging roles
+  const int go = tid >> 6, gn = (tid & 63) * 4;                          // G: octet go, columns gn..gn+3, rows 8 go + 0..7
+  const int xo = tid >> 6, xh = (tid >> 5) & 1, xc = (tid & 31) * 4;     // X: octet xo, rows 8 xo + 4 xh + 0..3, columns xc..xc+3
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool want_db = a.db != nullptr && k0 == 0;
+  auto load_stage = [&](DwStage& s, int t0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s.g[j] = G.at(t0 + 8 * go + j, n0 + gn);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = t0 + 8 * xo + 4 * xh + j, k = k0 + xc;
+      s.x[j] = (t < t_end && k < a.K) ? *reinterpret_cast<const float4*>(a.X + (size_t)t * a.ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_stage = [&](const DwStage& s, int buf) {
+    __bf16* dg = sG + ((size_t)(buf * 8 + go) * DW_BN + gn) * 8;
+    const float* f = reinterpret_cast<const float*>(s.g);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {      // column gn + q: the 8 rows of the octet
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (__bf16)f[4 * j + q];
+      *reinterpret_cast<bf16x8*>(dg + q * 8) = v;
+      if (want_db) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[q] += f[4 * j + q];
+      }
+    }
+    __bf16* dx = sX + ((size_t)(buf * 8 + xo) * DW_BK + xc) * 8 + 4 * xh;
+    const float* fx = reinterpret_cast<const float*>(s.x);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      gbf16x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (__bf16)fx[4 * j + q];
+      *reinterpret_cast<gbf16x4*>(dx + q * 8) = v;
+    }
+  };
+  const int wn = (w & 3) * 64, wk = (w >> 2) * 64;     // this wave's 64 x 64 sub-block
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  DwStage st;
+  load_stage(st, t_begin);
+  store_stage(st, 0);
+  __syncthreads();
+  const int nstages = (t_end - t_begin + DW_TS - 1) / DW_TS;
+  for (int s = 0; s < nstages; ++s) {
+    const bool more = s + 1 < nstages;
+    if (more) load_stage(st, t_begin + (s + 1) * DW_TS);
+    const __bf16* bg = sG + (size_t)((s & 1) * 8) * DW_BN * 8;
+    const __bf16* bx = sX + (size_t)((s & 1) * 8) * DW_BK * 8;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(bg + ((size_t)(kb * 4 + g) * DW_BN + wn + i * 16 + c) * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bx + ((size_t)(kb * 4 + g) * DW_BK + wk + j * 16 + c) * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_stage(st, (s + 1) & 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = n0 + wn + i * 16 + 4 * g + r, col = k0 + wk + j * 16 + c;
+        if (row < a.G.N && col < a.K) atomicAdd(a.dW + (size_t)row * a.lddw + col, acc[i][j][r]);
+      }
+  if (want_db) {
+    // the eight octet-threads of a column meet in LDS first: ONE global atomic per column and workgroup (hundreds of workgroups
+    // hitting the same 256 addresses eight times each cost more than the whole product)
+    float* sdb = reinterpret_cast<float*>(rows_smem);          // the stage buffers are free after the last barrier
+    if (tid < DW_BN) sdb[tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomicAdd(sdb + gn + q, bsum[q]);
+    __syncthreads();
+    if (tid < DW_BN && n0 + tid < a.G.N) atomicAdd(a.db + n0 + tid, sdb[tid]);
+  }
+}
+
 }  // namespace adt

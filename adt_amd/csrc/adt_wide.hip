@@ -225,6 +225,29 @@ static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
     if (K > 64) { if (gemm_launch(k_dense_bwd_dx<PREC, 128>, gemm_lds_bytes<PREC, 128>(), grid, s, &a, done[0])) return -1; }
     else if (gemm_launch(k_dense_bwd_dx<PREC, 64>, gemm_lds_bytes<PREC, 64>(), grid, s, &a, done[1])) return -1;
   }
+  // the 256 x 128-block kernel pays off from four output blocks on (N = 768: 127 us vs 225 us tiled); at two blocks (256 x 256)
+  // its 32 K atomics per workgroup cost what the deeper stages save (84 us vs 77 us)
+  if (a.dW && PREC == PREC_BF16 && g_rows_enabled && ((N + DW_BN - 1) / DW_BN) * ((K + DW_BK - 1) / DW_BK) >= 4 && (N % 4) == 0 && (K % 4) == 0 && (a.ldx % 4) == 0 &&
+      aligned16(a.X) && (a.G.lddy % 4) == 0 && aligned16(a.G.dY) && (a.G.act == ACT_NONE || ((a.G.ldu % 4) == 0 && aligned16(a.G.U)))) {
+    const int n_blocks = (N + DW_BN - 1) / DW_BN, k_blocks = (K + DW_BK - 1) / DW_BK, tiles = n_blocks * k_blocks;
+    // one workgroup per CU (96 KB of LDS): 256 workgroups when the T chunks stay >= 4 stages, chunks are multiples of 64 rows
+    int splits = tiles >= 256 ? 1 : 256 / tiles;
+    int chunk = ((T + splits - 1) / splits + DW_TS - 1) / DW_TS * DW_TS;
+    if (chunk < DW_TS) chunk = DW_TS;
+    splits = (T + chunk - 1) / chunk;
+    a.t_chunk = chunk;
+    static bool done = false;
+    if (!done) {
+      if (hipFuncSetAttribute((const void*)k_dense_dw_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_LDS_BYTES) != hipSuccess)
+        return adt_set_error("dense dw rows: hipFuncSetAttribute");
+      done = true;
+    }
+    DenseBwdArgs args = a;
+    int nb = n_blocks, kb = k_blocks;
+    void* kargs[] = {&args, &nb, &kb};
+    if (hipLaunchKernel((const void*)k_dense_dw_rows, dim3(splits * tiles), dim3(DW_NTH), kargs, DW_LDS_BYTES, s) != hipSuccess) return adt_set_error("dense dw rows: launch failed");
+    a.dW = nullptr;
+  }
   if (a.dW) {
     const int bn = K > 64 ? 128 : 64;
     const int gx = (K + bn - 1) / bn, gy = (N + GBM - 1) / GBM;
