@@ -326,7 +326,8 @@ def test_topk_masked_selection_is_exact(B, N, k):
         ops.topk_masked(T_(dist), N + 1)
 
 
-@pytest.mark.parametrize("T,K,N,act", [(1000, 256, 256, 0), (333, 256, 768, 2), (4100, 64, 64, 4), (517, 128, 1024, 1), (260, 256, 100, 3), (48, 64, 256, 2)])
+@pytest.mark.parametrize("T,K,N,act", [(1000, 256, 256, 0), (333, 256, 768, 2), (4100, 64, 64, 4), (517, 128, 1024, 1), (260, 256, 100, 3), (48, 64, 256, 2),
+                                         (700, 1024, 256, 2), (300, 512, 128, 0)])
 def test_dense_rows_kernels_match_tiled(T, K, N, act):
     """The row-streaming bf16 kernels (adt_dense_rows.cuh) against the tiled ones on the same inputs: same bf16 operands and fp32
     accumulation, different summation order => 2e-5 of the output magnitude (forward, incl. bias / activation / dropout /

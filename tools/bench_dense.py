@@ -30,7 +30,7 @@ def main():
     dev = torch.device("cuda:0")
     T = int(os.environ.get("BENCH_T", "51200"))
     shapes = [(256, 256, 0, 0.0, False), (256, 768, 0, 0.0, False), (256, 256, 1, 0.5, True), (256, 1024, 2, 0.2, False), (64, 64, 0, 0.3, True),
-              (64, 256, 2, 0.3, False)]
+              (64, 256, 2, 0.3, False), (1024, 256, 0, 0.2, True)]
     if len(sys.argv) > 1:
         shapes = [shapes[int(i)] for i in sys.argv[1:]]
     seed = torch.tensor([123], device=dev, dtype=torch.int32)
