@@ -336,7 +336,11 @@ __global__ __launch_bounds__(DW_NTH) void k_dense_dw_rows(DenseBwdArgs a, int n_
   __bf16* sG = reinterpret_cast<__bf16*>(rows_smem);                    // [2][8][DW_BN][8]
   __bf16* sX = sG + 2 * 8 * DW_BN * 8;                                  // [2][8][DW_BK][8]
   const int tiles = n_blocks * k_blocks;
-  const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  // all output blocks of one T chunk run on ONE XCD (xcd_tile): the chunk's G and X rows are fetched into that L2 once instead
+  // of once per block (N = 1024, K = 256: 8 blocks, 630 MB of reads without the mapping against 262 MB of distinct data)
+  int split, tile;
+  xcd_tile(a.nt_z, tiles, split, tile);
+  if (split >= a.nt_z) return;
   const int n0 = (tile / k_blocks) * DW_BN, k0 = (tile % k_blocks) * DW_BK;
   GradSrc G = a.G;
   if (a.t_dev && G.T > *a.t_dev) G.T = *a.t_dev;

@@ -126,7 +126,6 @@ static int rows_launch(KFn kernel, const Args& a, int n_panels, int pc, int cont
 static bool rows_fwd_ok(const DenseFwdArgs& a) {
   if (!g_rows_enabled) return false;
   if (!(a.K == 64 || a.K == 128 || a.K == 256) || (a.N % 4) || (a.ldy % 4) || !aligned16(a.Y)) return false;
-  if (a.N > 1024) return false;                                  // the all-item logits stay on the tiled kernel
   if (a.b && !aligned16(a.b)) return false;
   if (a.U && ((a.ldu % 4) || !aligned16(a.U))) return false;
   if (a.R && ((a.ldr % 4) || !aligned16(a.R))) return false;
@@ -243,9 +242,10 @@ static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
       done = true;
     }
     DenseBwdArgs args = a;
+    args.nt_z = splits;
     int nb = n_blocks, kb = k_blocks;
     void* kargs[] = {&args, &nb, &kb};
-    if (hipLaunchKernel((const void*)k_dense_dw_rows, dim3(splits * tiles), dim3(DW_NTH), kargs, DW_LDS_BYTES, s) != hipSuccess) return adt_set_error("dense dw rows: launch failed");
+    if (hipLaunchKernel((const void*)k_dense_dw_rows, dim3(xcd_grid(splits, tiles)), dim3(DW_NTH), kargs, DW_LDS_BYTES, s) != hipSuccess) return adt_set_error("dense dw rows: launch failed");
     a.dW = nullptr;
   }
   if (a.dW) {
