@@ -382,6 +382,17 @@ int adt_ce_rows(float* logits, int ld, const int32_t* labels, int M, const int32
                 void* stream) {
   if (M <= 0) return 0;
   CeArgs a{logits, ld, labels, M, V, inv_count, loss64, m_dev};
+  const size_t smem = ((size_t)(V + 3) / 4 * 4 + 16) * sizeof(float);
+  if (smem <= 150 * 1024 && (ld % 4) == 0 && aligned16(logits)) {      // row resident in LDS: one read + one write per element
+    static bool done = false;
+    if (!done) {
+      if (hipFuncSetAttribute((const void*)k_ce_rows_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+        return adt_set_error("ce_rows: hipFuncSetAttribute");
+      done = true;
+    }
+    hipLaunchKernelGGL(k_ce_rows_lds, dim3(M < 1024 ? M : 1024), dim3(CE_NTH), smem, (hipStream_t)stream, a);
+    return check_launch("ce_rows(lds)");
+  }
   hipLaunchKernelGGL(k_ce_rows, dim3(M < 4096 ? M : 4096), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("ce_rows");
 }

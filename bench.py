@@ -74,7 +74,8 @@ def build_model(device, prec):
 
 def cpu_baseline():
     """The numpy oracle (a port of the reference's step, oracle/sasrec_oracle.py) timed on this host's cores on a
-    bounded sample of the same workload: batch 64 of the same shape, 1 warm-up + 2 timed steps."""
+    bounded sample of the same workload: batch 64 of the same shape, 1 warm-up step, then full train steps until about 10 s of
+    CPU work have been timed (at least 2, at most 40 steps)."""
     from oracle import sasrec_oracle as so
     cfg = so.Cfg(CFG["item_num"], CFG["maxlen"], CFG["hidden_units"], CFG["num_heads"], CFG["num_layers"], CFG["dropout"])
     P = so.init_params(cfg, 0)
@@ -83,9 +84,10 @@ def cpu_baseline():
     st = {}
     so.train_step(P, cfg, st, batch, CFG["lambdas1"], CFG["lambdas2"], CFG["weight_decay"], seed=1)
     t0 = time.time()
-    nst = 2
-    for i in range(nst):
-        so.train_step(P, cfg, st, batch, CFG["lambdas1"], CFG["lambdas2"], CFG["weight_decay"], seed=2 + i)
+    nst = 0
+    while nst < 2 or (time.time() - t0 < 10.0 and nst < 40):
+        so.train_step(P, cfg, st, batch, CFG["lambdas1"], CFG["lambdas2"], CFG["weight_decay"], seed=2 + nst)
+        nst += 1
     dt = time.time() - t0
     try:
         from threadpoolctl import threadpool_info

@@ -192,6 +192,27 @@ def test_row_kernels():
     ops.ce_rows(zl[:, :Vv], T_(lab), Vv, inv, loss)
     assert abs(float(loss.sum()) - float(ce.v)) < 1e-5 * abs(float(ce.v))
     assert rel(zl[:, :Vv].cpu().numpy(), vz.g) < 1e-5
+    # long rows: LDS-resident kernel with several sweeps per thread (30,001 items) and the streaming fallback (40,005 > 150 KB)
+    for Vv in (30001, 40005):
+        M = 6
+        z = (2 * r.standard_normal((M, Vv))).astype(np.float32)
+        lab = r.randint(1, Vv, size=M).astype(np.int32)
+        lab[3] = 0
+        z64 = z.astype(np.float64)
+        lse = np.log(np.exp(z64 - z64.max(1, keepdims=True)).sum(1)) + z64.max(1)
+        live = lab != 0
+        want_loss = float((lse[live] - z64[np.arange(M)[live], lab[live]]).sum() / live.sum())
+        want_g = np.exp(z64 - lse[:, None])
+        want_g[np.arange(M), lab] -= 1.0
+        want_g = want_g / live.sum() * live[:, None]
+        ld = (Vv + 3) // 4 * 4
+        zl = torch.zeros(M, ld, device=dev())
+        zl[:, :Vv] = T_(z)
+        loss = torch.zeros(64, device=dev())
+        inv = torch.tensor([1.0 / float(live.sum())], device=dev(), dtype=torch.float32)
+        ops.ce_rows(zl[:, :Vv], T_(lab), Vv, inv, loss)
+        assert abs(float(loss.sum()) - want_loss) < 2e-5 * abs(want_loss)
+        assert rel(zl[:, :Vv].cpu().numpy(), want_g) < 2e-5
 
 
 def test_clip_adam_l2_and_score_bias():
