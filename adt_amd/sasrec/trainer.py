@@ -56,7 +56,7 @@ class FusedTrainer:
         self._host = self._ring[0]
         self._devbuf = torch.empty(n_int, device=m.dev, dtype=torch.int32)
         self._ids = [self._devbuf[i * T:(i + 1) * T].view(B, m.maxlen) for i in range(4)]
-        self._norms_dev = self._devbuf[4 * T:4 * T + 3].view(torch.float32)
+        self._norms_dev = self._devbuf[4 * T:4 * T + 4].view(torch.float32)     # 3 normalisers + a zero pad word
         m.workspace(B)
         self._graph = None
 
@@ -65,7 +65,9 @@ class FusedTrainer:
         m = self.model
         seq, dec, pos, neg = self._ids
         m._seed.add_(-1640531535)   # += 0x9E3779B1 (mod 2^32): a fresh dropout stream every step, on the device
-        m.ws_view(B, WS_NORMS, 0, 3).copy_(self._norms_dev)
+        # a kernel, not tensor.copy_: inside a captured step that would be a memcpy NODE (see DESIGN.md on captured memset nodes)
+        from .. import ops
+        ops.axpy(m.ws_view(B, WS_NORMS, 0, 4), self._norms_dev, 1.0, False)
         m.run_forward(seq, dec, pos, neg, B, True, b_offset)
         m.run_loss_seed(pos, B, self.lambdas1, self.lambdas2)
         m.flat_grad.zero_()
