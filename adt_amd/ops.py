@@ -141,6 +141,29 @@ def logits_bwd(F, E, pos, neg, dpos, dneg, dE):
     return dF
 
 
+def item_scatter(ids, G, rowscale, scale, p, seed, site, row_offset, rep, nrep, rep_stride):
+    """rep[wave % nrep][ids[row]] += rowscale[row] * scale * dropmask * G[row]  (rows with id 0 skipped); see adt_item_scatter."""
+    T, d = G.shape
+    _lib.check(_lib.load().adt_item_scatter(_p(_i32(ids)), _p(_f32(G)), _ld(G), _p(rowscale), T, d, float(scale), float(p), _p(seed), site, row_offset,
+                                            _p(rep), nrep, rep_stride, _stream()), "item_scatter")
+
+
+def replica_reduce(dE, rep, nrep, rep_stride):
+    _lib.check(_lib.load().adt_replica_reduce(_p(dE), _p(rep), dE.numel(), nrep, rep_stride, _stream()), "replica_reduce")
+
+
+def posemb_bwd(ids, dX, L, p, seed, site, row_offset, dP):
+    T, d = dX.shape
+    _lib.check(_lib.load().adt_posemb_bwd(_p(_i32(ids)), _p(_f32(dX)), T, L, d, float(p), _p(seed), site, row_offset, _p(dP), _stream()), "posemb_bwd")
+
+
+def logits_bwd_df(E, pos, neg, dpos, dneg):
+    T, d = pos.numel(), E.shape[1]
+    dF = torch.empty(T, d, device=E.device, dtype=torch.float32)
+    _lib.check(_lib.load().adt_logits_bwd_df(_p(E), _p(_i32(pos)), _p(_i32(neg)), _p(dpos), _p(dneg), T, d, _p(dF), d, _stream()), "logits_bwd_df")
+    return dF
+
+
 def bce_seed(pos_logits, neg_logits, pos, norms, loss2):
     T = pos_logits.numel()
     dpos = torch.empty(T, device=pos_logits.device, dtype=torch.float32)

@@ -28,6 +28,9 @@ def dec_sites(i):
     return {"slf": b, "enc": b + 1, "ffn1": b + 2, "ffn2": b + 3}
 
 
+NREP = 16      # replicas of the item-table gradient (contention relief, as in the fused executor)
+
+
 class SASRecADTWide(FlatModule):
     def __init__(self, user_num, item_num, args):
         super().__init__()
@@ -58,8 +61,14 @@ class SASRecADTWide(FlatModule):
         x = Act(ops.embed_fwd(ids, P("item_emb.weight"), P("pos_emb.weight"), L, p, self._seed, site, tp.row_offset))
 
         def bw():
-            if x.g is not None:
+            if x.g is None:
+                return
+            rep = getattr(tp, "item_rep", None)
+            if rep is None:
                 ops.embed_bwd(ids, x.g, L, p, self._seed, site, G("item_emb.weight"), G("pos_emb.weight"), tp.row_offset)
+            else:      # item rows through the zeroed replicas (popular items: same-address float atomics serialise), positions directly
+                ops.item_scatter(ids, x.g, None, float(self.hidden_units) ** 0.5, p, self._seed, site, tp.row_offset, rep, NREP, self._rep_stride)
+                ops.posemb_bwd(ids, x.g, L, p, self._seed, site, tp.row_offset, G("pos_emb.weight"))
         tp.bw.append(bw)
         return x
 
@@ -194,7 +203,17 @@ class SASRecADTWide(FlatModule):
         E, gE = self.P("item_emb.weight"), self.G("item_emb.weight")
         pl, nlg = ops.logits_fwd(feats.t, E, pos.view(-1), neg.view(-1))
         dpos, dneg = ops.bce_seed(pl, nlg, pos.view(-1), norms, loss_slots[0:2].view(-1))
-        give(feats, ops.logits_bwd(feats.t, E, pos.view(-1), neg.view(-1), dpos, dneg, gE))
+        # item-table gradient through NREP zeroed replicas, reduced once after the backward (as the fused executor does)
+        n_table = gE.numel()
+        if getattr(self, "_rep", None) is None:
+            self._rep_stride = (n_table + 3) // 4 * 4
+            self._rep = torch.zeros(NREP * self._rep_stride, device=self.dev, dtype=torch.float32)
+        else:
+            self._rep.zero_()
+        tp.item_rep = self._rep
+        give(feats, ops.logits_bwd_df(E, pos.view(-1), neg.view(-1), dpos, dneg))
+        ops.item_scatter(pos.view(-1), feats.t, dpos, 1.0, 0.0, None, 0, 0, self._rep, NREP, self._rep_stride)
+        ops.item_scatter(neg.view(-1), feats.t, dneg, 1.0, 0.0, None, 0, 0, self._rep, NREP, self._rep_stride)
         i = 0
         for i in range(nl):
             a, bq = enc_in[i], dec_outs[nl - 1 - i]
@@ -208,6 +227,7 @@ class SASRecADTWide(FlatModule):
                 recs[l].g = torch.empty_like(recs[l].t)
                 ops.nll_seed(recs[l].t, H, lambdas2[i], norms, recs[l].g, loss_slots[2 + nl + l])     # stale index (main.py:169)
         tp.backward()
+        ops.replica_reduce(gE, self._rep, NREP, self._rep_stride)
 
 
 class WideSasrecTrainer:
