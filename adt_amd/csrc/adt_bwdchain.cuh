@@ -34,7 +34,17 @@ ADT_DEVICE_INLINE void acc_zero(f32x4 (&a)[N]) {
   for (int i = 0; i < N; ++i) a[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+ADT_DEVICE_INLINE void bwd_replica(BwdChainArgs& a) {
+  if (a.nrep <= 1) return;
+  const size_t off = (size_t)(blockIdx.x % a.nrep) * a.rep_stride;
+  float** const ptrs[] = {&a.dW0, &a.dW1, &a.dW2, &a.dW3, &a.db0, &a.db1, &a.db2, &a.db3, &a.dgamma, &a.dbeta, &a.dWs, &a.dbs};
+#pragma unroll
+  for (int i = 0; i < 12; ++i)
+    if (*ptrs[i]) *ptrs[i] += off;
+}
+
 #define BWD_PROLOGUE(NWT_)                                                                         \
+  bwd_replica(a);                                                                                  \
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];                         \
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;           \
   BwdLds<PREC, NW, NWT_> lds(smem_raw, w);                                                         \

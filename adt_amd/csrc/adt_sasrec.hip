@@ -11,6 +11,7 @@
 namespace {
 
 constexpr float LN_EPS = 1e-8f;
+constexpr int NREPP = 16;          // replicas of the layer-parameter gradients the backward chains flush into (one per XCD)
 constexpr int NREP = 16;          // replicas of the item-table gradient (contention relief for popular items)   // sasrec/modules.py:638,640,660 ; sasrec/model.py:28
 
 struct Layout {
@@ -61,6 +62,7 @@ struct WS {
   int64_t s1, s2, s3, s4, s5;                                           // backward scratch: Td, Td, 3Td, 2Td, Td
   int64_t loss, norms, scal;
   int64_t rep, rep_stride;                                              // item-table gradient replicas
+  int64_t prep, prep_stride;                                            // replicas of every other parameter gradient
   int64_t total;
 };
 
@@ -94,6 +96,12 @@ void make_ws(const adt_sasrec_cfg* c, int B, WS* w) {
   w->loss = take(64 * (2 + 2 * 16)); w->norms = take(64); w->scal = take(192);
   w->rep_stride = up64((int64_t)(c->item_num + 1) * w->d);
   w->rep = take(NREP * w->rep_stride);
+  {
+    Layout lo;
+    make_layout(c, &lo);
+    w->prep_stride = up64(lo.total - lo.posw());
+    w->prep = take(NREPP * w->prep_stride);
+  }
   w->total = o;
 }
 
@@ -350,6 +358,18 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   const uint32_t ro = b_offset * (uint32_t)L;
   float *s1 = ws + w.s1, *s3 = ws + w.s3, *s4 = ws + w.s4, *s5 = ws + w.s5;
   float* gf = ws + w.g_f;
+  // the backward chains flush their weight / bias / LayerNorm gradients into NREPP zeroed replicas of the non-item parameters
+  // (Gq + lo.xxx() addresses replica 0); each phase folds its range into G at its end
+  float* const Gq = ws + w.prep - lo.posw();
+  auto BA = [&](const int32_t* ids, float pp, const uint32_t* sd) {
+    adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, ids, pp, sd, ro);
+    a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride;
+    return a;
+  };
+  const int64_t dec_begin = lo.dec(0, 0);
+  if (phase == 0 || phase == 1) {
+    if (adt::zero_f32_async(ws + w.prep, (size_t)NREPP * w.prep_stride, (hipStream_t)st)) return adt_set_error("parameter replica zero");
+  }
   const float* f = ws + w.f;
   if (phase == 0 || phase == 1) {
     // d log_feats (overwrites g_f) and item-table rows of pos/neg      (sasrec/model.py:72-76)
@@ -366,19 +386,19 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
             *q2 = base + w.d_q2, *kv2 = base + w.d_kv2, *o2 = base + w.d_o2, *lse2 = base + w.d_lse2, *a2 = base + w.d_a2,
             *u = base + w.d_u;
       const float* einw = P + lo.dec(i, D_EINW);
-      float* geinw = G + lo.dec(i, D_EINW);
-      float* geinb = G + lo.dec(i, D_EINB);
+      float* geinw = Gq + lo.dec(i, D_EINW);
+      float* geinb = Gq + lo.dec(i, D_EINB);
       const float* sinw = P + lo.dec(i, D_SINW);
-      float* gsinw = G + lo.dec(i, D_SINW);
-      float* gsinb = G + lo.dec(i, D_SINB);
+      float* gsinw = Gq + lo.dec(i, D_SINW);
+      float* gsinb = Gq + lo.dec(i, D_SINB);
       const int dd = d * d;
       {  // FFN + mask + enc_attn.out_proj reverse -> dO2 (s1)
-        adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, dec, p, seed, ro);
+        adt::BwdChainArgs a = BA(dec, p, seed);
         a.site1 = dec_site(i, 2); a.site2 = dec_site(i, 3);
         a.gy = gy; a.u = u; a.xin = a2; a.o = o2;
         a.W0 = P + lo.dec(i, D_C2W); a.W1 = P + lo.dec(i, D_C1W); a.W2 = P + lo.dec(i, D_EOW);
-        a.dW0 = G + lo.dec(i, D_C2W); a.dW1 = G + lo.dec(i, D_C1W); a.dW2 = G + lo.dec(i, D_EOW);
-        a.db0 = G + lo.dec(i, D_C2B); a.db1 = G + lo.dec(i, D_C1B); a.db2 = G + lo.dec(i, D_EOB);
+        a.dW0 = Gq + lo.dec(i, D_C2W); a.dW1 = Gq + lo.dec(i, D_C1W); a.dW2 = Gq + lo.dec(i, D_EOW);
+        a.db0 = Gq + lo.dec(i, D_C2B); a.db1 = Gq + lo.dec(i, D_C1B); a.db2 = Gq + lo.dec(i, D_EOB);
         a.out0 = s1;
         CK(adt_launch_bwdchain(prec, 1, a, st));
       }
@@ -386,15 +406,15 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       CK(adt_attn_bwd(prec, q2, d, kv2, 2 * d, kv2 + d, 2 * d, o2, d, lse2, s1, d, B, H, L, hd, 1, p, seed, dec_site(i, 1), b_offset,
                       s5, d, s4, 2 * d, s4 + d, 2 * d, reinterpret_cast<const uint32_t*>(base + w.d_mask2), st));
       {  // q2 = a1 Wq^T, a1 = o1 Wo1^T  -> dO1 (s1)
-        adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, dec, 0.f, nullptr, ro);
+        adt::BwdChainArgs a = BA(dec, 0.f, nullptr);
         a.dqkv = s5; a.lddqkv = d; a.xin = a1; a.o = o1;
         a.W0 = einw; a.W1 = P + lo.dec(i, D_SOW);
-        a.dW0 = geinw; a.dW1 = G + lo.dec(i, D_SOW); a.db0 = geinb; a.db1 = G + lo.dec(i, D_SOB);
+        a.dW0 = geinw; a.dW1 = Gq + lo.dec(i, D_SOW); a.db0 = geinb; a.db1 = Gq + lo.dec(i, D_SOB);
         a.out0 = s1;
         CK(adt_launch_bwdchain(prec, 4, a, st));
       }
       {  // [k2, v2] = f Wkv^T  -> g_f +=
-        adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, dec, 0.f, nullptr, ro);
+        adt::BwdChainArgs a = BA(dec, 0.f, nullptr);
         a.dkv2 = s4; a.f = f;
         a.W0 = einw + dd; a.W1 = einw + 2 * dd;
         a.dW0 = geinw + dd; a.dW1 = geinw + 2 * dd; a.db0 = geinb + d; a.db1 = geinb + 2 * d;
@@ -405,11 +425,11 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
                       dec_site(i, 0), b_offset, s3, 3 * d, s3 + d, 3 * d, s3 + 2 * d, 3 * d,
                       reinterpret_cast<const uint32_t*>(base + w.d_mask1), st));
       {  // layer_norm + packed in_proj reverse: gx (+)= LN'(dqkv Win + gy*mask)
-        adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, dec, 0.f, nullptr, ro);
+        adt::BwdChainArgs a = BA(dec, 0.f, nullptr);
         a.dqkv = s3; a.lddqkv = 3 * d; a.gy = gy; a.xin = x;
         a.W0 = sinw; a.W1 = sinw + dd; a.W2 = sinw + 2 * dd; a.gamma = P + lo.dec(i, D_LNW); a.beta = P + lo.dec(i, D_LNB);
         a.dW0 = gsinw; a.dW1 = gsinw + dd; a.dW2 = gsinw + 2 * dd; a.db0 = gsinb; a.db1 = gsinb + d; a.db2 = gsinb + 2 * d;
-        a.dgamma = G + lo.dec(i, D_LNW); a.dbeta = G + lo.dec(i, D_LNB);
+        a.dgamma = Gq + lo.dec(i, D_LNW); a.dbeta = Gq + lo.dec(i, D_LNB);
         a.out0 = gx; a.acc0 = i > 0 ? 1 : 0;
         CK(adt_launch_bwdchain(prec, 3, a, st));
       }
@@ -417,8 +437,10 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
     // decoder input embedding (sasrec/model.py:53-59)
     CK(adt_posemb_bwd(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), st));
     CK(adt_item_scatter(dec, ws + w.g_dec_x, d, nullptr, T, d, sqrtf((float)d), p, seed, SITE_EMB_DEC, ro, ws + w.rep, NREP, w.rep_stride, st));
-    if (phase == 1)   // two-phase (data-parallel) use: fold what has been scattered so far, the replicas restart at zero
+    if (phase == 1) {  // two-phase (data-parallel) use: fold what has been scattered so far, the replicas restart at zero
       CK(adt_replica_reduce(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, NREP, w.rep_stride, st));
+      CK(adt_replica_reduce(G + dec_begin, Gq + dec_begin, lo.total - dec_begin, NREPP, w.prep_stride, st));
+    }
   }
   if (phase == 0 || phase == 2) {
     // last_layernorm: g_enc_x[nl] = LN'(g_f)
@@ -432,24 +454,24 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       float *qkv = base + w.e_qkv, *o = base + w.e_o, *lse = base + w.e_lse, *h = base + w.e_h, *u = base + w.e_u,
             *rec = base + w.e_rec;
       const float* inw = P + lo.enc(i, E_INW);
-      float* ginw = G + lo.enc(i, E_INW);
-      float* ginb = G + lo.enc(i, E_INB);
+      float* ginw = Gq + lo.enc(i, E_INW);
+      float* ginb = Gq + lo.enc(i, E_INB);
       const int dd = d * d;
       {  // FFN + mask + forward_layernorm + out_proj reverse -> dh (s5), dO (s1)
-        adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, seq, p, seed, ro);
+        adt::BwdChainArgs a = BA(seq, p, seed);
         a.site1 = enc_site(i, 1); a.site2 = enc_site(i, 2);
         a.gy = gy; a.u = u; a.xin = h; a.o = o;
         a.W0 = P + lo.enc(i, E_C2W); a.W1 = P + lo.enc(i, E_C1W); a.W2 = P + lo.enc(i, E_OW);
         a.gamma = P + lo.enc(i, E_LN2W); a.beta = P + lo.enc(i, E_LN2B);
-        a.dW0 = G + lo.enc(i, E_C2W); a.dW1 = G + lo.enc(i, E_C1W); a.dW2 = G + lo.enc(i, E_OW);
-        a.db0 = G + lo.enc(i, E_C2B); a.db1 = G + lo.enc(i, E_C1B); a.db2 = G + lo.enc(i, E_OB);
-        a.dgamma = G + lo.enc(i, E_LN2W); a.dbeta = G + lo.enc(i, E_LN2B);
+        a.dW0 = Gq + lo.enc(i, E_C2W); a.dW1 = Gq + lo.enc(i, E_C1W); a.dW2 = Gq + lo.enc(i, E_OW);
+        a.db0 = Gq + lo.enc(i, E_C2B); a.db1 = Gq + lo.enc(i, E_C1B); a.db2 = Gq + lo.enc(i, E_OB);
+        a.dgamma = Gq + lo.enc(i, E_LN2W); a.dbeta = Gq + lo.enc(i, E_LN2B);
         a.out0 = s5; a.out1 = s1;
         int which = 0;
         if (H > 1 && H <= 4) {   // independence-head classifier reverse, fused (sasrec/modules.py:648-649; main.py:160-169)
           which = H <= 2 ? 6 : 7;
-          a.rec = rec; a.drec = ws + w.g_rec + i * recsz; a.Ws = P + lo.enc(i, E_SW); a.dWs = G + lo.enc(i, E_SW);
-          a.dbs = G + lo.enc(i, E_SB); a.H = H;
+          a.rec = rec; a.drec = ws + w.g_rec + i * recsz; a.Ws = P + lo.enc(i, E_SW); a.dWs = Gq + lo.enc(i, E_SW);
+          a.dbs = Gq + lo.enc(i, E_SB); a.H = H;
         }
         CK(adt_launch_bwdchain(prec, which, a, st));
       }
@@ -460,11 +482,11 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
                       enc_site(i, 0), b_offset, s3, 3 * d, s3 + d, 3 * d, s3 + 2 * d, 3 * d,
                       reinterpret_cast<const uint32_t*>(base + w.e_mask), st));
       {  // attention_layernorm + in_proj reverse: gx += LN'(dq Wq + dh) + dk Wk + dv Wv
-        adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, seq, 0.f, nullptr, ro);
+        adt::BwdChainArgs a = BA(seq, 0.f, nullptr);
         a.dqkv = s3; a.lddqkv = 3 * d; a.dh = s5; a.xin = x;
         a.W0 = inw; a.W1 = inw + dd; a.W2 = inw + 2 * dd; a.gamma = P + lo.enc(i, E_LN1W); a.beta = P + lo.enc(i, E_LN1B);
         a.dW0 = ginw; a.dW1 = ginw + dd; a.dW2 = ginw + 2 * dd; a.db0 = ginb; a.db1 = ginb + d; a.db2 = ginb + 2 * d;
-        a.dgamma = G + lo.enc(i, E_LN1W); a.dbeta = G + lo.enc(i, E_LN1B);
+        a.dgamma = Gq + lo.enc(i, E_LN1W); a.dbeta = Gq + lo.enc(i, E_LN1B);
         a.out0 = gx; a.acc0 = 1;
         CK(adt_launch_bwdchain(prec, 2, a, st));
       }
@@ -473,6 +495,8 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
     CK(adt_posemb_bwd(seq, ws + w.g_enc_x, T, L, d, p, seed, SITE_EMB_SEQ, ro, G + lo.posw(), st));
     CK(adt_item_scatter(seq, ws + w.g_enc_x, d, nullptr, T, d, sqrtf((float)d), p, seed, SITE_EMB_SEQ, ro, ws + w.rep, NREP, w.rep_stride, st));
     CK(adt_replica_reduce(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, NREP, w.rep_stride, st));
+    if (phase == 0) CK(adt_replica_reduce(G + lo.posw(), Gq + lo.posw(), lo.total - lo.posw(), NREPP, w.prep_stride, st));
+    else CK(adt_replica_reduce(G + lo.posw(), Gq + lo.posw(), dec_begin - lo.posw(), NREPP, w.prep_stride, st));
   }
   return 0;
 }
