@@ -114,12 +114,13 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_bwd(BwdChainArgs a) {
   }
 #pragma unroll
   for (int cc = 0; cc < HCM; ++cc) { vacc_zero(dws[cc]); dbs_acc[cc] = 0.f; }
-  RowRegs gy_rows = rows_load(a.gy, 64, tile * 16, a.T, lane);
-  RowRegs h_rows = rows_load(a.xin, 64, tile * 16, a.T, lane);
   for (int rnd = 0; rnd < nrounds; ++rnd, tile += tstride) {
     const int row0 = tile * 16;    // may lie beyond T: a phantom tile of zeros that only takes part in the barriers
+    // every input of the round is requested at its top; carrying the next round's gy / h rows across the round cost 340 B of
+    // scratch per lane (the kernel sits at the 256-register budget of two waves per SIMD)
+    const RowRegs gy_cur = rows_load(a.gy, 64, row0, a.T, lane);
+    const RowRegs h_rows = rows_load(a.xin, 64, row0, a.T, lane);
     const RowRegs u_cur = rows_load(a.u, 64, row0, a.T, lane);    // requested now, consumed later in the round
-    const RowRegs o_rows = rows_load(a.o, 64, row0, a.T, lane);
     // classifier log-probs and their upstream gradient for the 16 tile rows (H*H floats per row, reference row order
     // l*B + b): requested now as one element per lane and step, parked in LDS when needed
     float cls_rec[4], cls_drec[4];
@@ -138,17 +139,13 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_bwd(BwdChainArgs a) {
       }
     }
     const CT h = rows_to_ct(lds.scr, h_rows, lane, c, g);
-    const RowRegs gy_cur = gy_rows;
-    // the next round's first inputs are requested now and consumed one round later
-    const int nrow0 = (tile + tstride) * 16;
-    gy_rows = rows_load(a.gy, 64, nrow0, a.T, lane);
-    h_rows = rows_load(a.xin, 64, nrow0, a.T, lane);
     LnStat st;
     const CT xhat = ln_xhat(h, a.ln_eps, st);
     const CT h2 = ln_apply(xhat, a.gamma, a.beta, c);
     CT gm, dh2;
     ffn_bwd_tile<PREC, NW>(a, lds.scr, coop, lds.w[0], lds.w[1], dW2, dW1, db2, db1, h2, gy_cur, u_cur, key1, key2, row0, lane, c, g,
                            gm, dh2);
+    const RowRegs o_rows = rows_load(a.o, 64, row0, a.T, lane);   // requested after the FFN reverse (register budget), before the store below
     ct_add(dh2, gm);
     const CT dh = ln_bwd_ct(dh2, xhat, st, a.gamma, dgm, dbt, c, g);
     store_ct(lds.scr, a.out0, 64, dh, row0, a.T, lane, c, g);
@@ -248,20 +245,15 @@ __global__ __launch_bounds__(NW * 64) void k_dec_post_bwd(BwdChainArgs a) {
   VAcc db2, db1, dbo;
   acc_zero(dW2); acc_zero(dW1); acc_zero(dWo);
   vacc_zero(db2); vacc_zero(db1); vacc_zero(dbo);
-  RowRegs gy_rows = rows_load(a.gy, 64, tile * 16, a.T, lane);
-  RowRegs u_rows = rows_load(a.u, 64, tile * 16, a.T, lane);
-  RowRegs a2_rows = rows_load(a.xin, 64, tile * 16, a.T, lane);
-  RowRegs o_rows = rows_load(a.o, 64, tile * 16, a.T, lane);
   for (int rnd = 0; rnd < nrounds; ++rnd, tile += tstride) {
     const int row0 = tile * 16;
+    // requested at the top of the round (no carry across rounds: register budget, see k_enc_post_bwd)
+    const RowRegs gy_cur = rows_load(a.gy, 64, row0, a.T, lane);
+    const RowRegs u_cur = rows_load(a.u, 64, row0, a.T, lane);
+    const RowRegs a2_rows = rows_load(a.xin, 64, row0, a.T, lane);
+    const RowRegs o_rows = rows_load(a.o, 64, row0, a.T, lane);
     const CT a2 = rows_to_ct(lds.scr, a2_rows, lane, c, g);
     const CT o = rows_to_ct(lds.scr, o_rows, lane, c, g);
-    const RowRegs gy_cur = gy_rows, u_cur = u_rows;
-    const int nrow0 = (tile + tstride) * 16;
-    gy_rows = rows_load(a.gy, 64, nrow0, a.T, lane);
-    u_rows = rows_load(a.u, 64, nrow0, a.T, lane);
-    a2_rows = rows_load(a.xin, 64, nrow0, a.T, lane);
-    o_rows = rows_load(a.o, 64, nrow0, a.T, lane);
     CT gm, da2;
     ffn_bwd_tile<PREC, NW>(a, lds.scr, coop, lds.w[0], lds.w[1], dW2, dW1, db2, db1, a2, gy_cur, u_cur, key1, key2, row0, lane, c, g,
                            gm, da2);
@@ -294,11 +286,11 @@ __global__ __launch_bounds__(NW * 64) void k_pre_bwd(BwdChainArgs a) {
   acc_zero(dWq); acc_zero(dWk); acc_zero(dWv);
   vacc_zero(dbq); vacc_zero(dbk); vacc_zero(dbv); vacc_zero(dgm); vacc_zero(dbt);
   const float* rsrc = ENC ? a.dh : a.gy;
-  RowRegs dq_rows = rows_load(a.dqkv, a.lddqkv, tile * 16, a.T, lane);
-  RowRegs x_rows = rows_load(a.xin, 64, tile * 16, a.T, lane);
   for (int rnd = 0; rnd < nrounds; ++rnd, tile += tstride) {
     const int row0 = tile * 16;
-    // requested at the top of the round, consumed later in it (not carried across rounds: register budget)
+    // everything is requested at the top of the round: carrying two row sets across rounds cost 224 B of scratch per lane
+    RowRegs dq_rows = rows_load(a.dqkv, a.lddqkv, row0, a.T, lane);
+    RowRegs x_rows = rows_load(a.xin, 64, row0, a.T, lane);
     const RowRegs dk_rows = rows_load(a.dqkv + 64, a.lddqkv, row0, a.T, lane);
     const RowRegs dv_rows = rows_load(a.dqkv + 128, a.lddqkv, row0, a.T, lane);
     const RowRegs r_rows = rows_load(rsrc, 64, row0, a.T, lane);
@@ -310,9 +302,6 @@ __global__ __launch_bounds__(NW * 64) void k_pre_bwd(BwdChainArgs a) {
     {
       const CT dq = rows_to_ct(lds.scr, dq_rows, lane, c, g);
       const AFrags<PREC> aq = scr_to_a<PREC>(lds.scr, c, g);
-      const int nrow0 = (tile + tstride) * 16;
-      dq_rows = rows_load(a.dqkv, a.lddqkv, nrow0, a.T, lane);
-      x_rows = rows_load(a.xin, 64, nrow0, a.T, lane);
       coop.product(dWq, dq, xn);
       colsum_accum(dbq, dq);
       dn = gemm_w<PREC>(aq, lds.w[0], c, g);          // gradient wrt the LN output
