@@ -259,7 +259,10 @@ __global__ __launch_bounds__(NW * 64) void k_dec_post_fwd(FwdChainArgs a) {
 template <int PREC, int NW>
 __global__ __launch_bounds__(NW * 64) void k_final_fwd(FwdChainArgs a) {
   FWD_PROLOGUE(4)
-  for (int j = 0; j < 2 * a.nkv; ++j) stage_wimg<PREC, NW * 64>(lds.w[j], a.W[j], false);
+  // compile-time loop bounds: a runtime index into the argument arrays W[] / b[] puts them into scratch memory
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (j < 2 * a.nkv) stage_wimg<PREC, NW * 64>(lds.w[j], a.W[j], false);
   __syncthreads();
   for (int tile = blockIdx.x * NW + w; tile < ntiles; tile += tstride) {
     const int row0 = tile * 16;
@@ -294,7 +297,9 @@ __global__ __launch_bounds__(NW * 64) void k_final_fwd(FwdChainArgs a) {
     if (a.o0) scr_to_rows(a.o0, a.ld0, lds.scr, row0, a.T, lane);
     if (a.nkv > 0) {
       const AFrags<PREC> af = scr_to_a<PREC>(lds.scr, c, g);
-      for (int j = 0; j < 2 * a.nkv; ++j) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j >= 2 * a.nkv) break;
         CT y = gemm_w<PREC>(af, lds.w[j], c, g);
         ct_add_bias(y, a.b[j], c);
         float* dst = (j < 2 ? a.o2 : a.o3) + 64 * (j & 1);
