@@ -27,12 +27,12 @@ static int grid_for(size_t work_items, int per_block, int cap) {
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // ---- masked attention dispatch ---------------------------------------------------------------------------------
-template <int PREC, int HD, int MAXKT>
+template <int PREC, int HD, int MAXKT, bool CSK = false>
 static int launch_attn_gen(bool bwd, const AttnGenArgs& a, hipStream_t s) {
   constexpr int NW = 8;
   const size_t smem = bwd ? AttnGenLds<PREC, HD, MAXKT>::bwd_bytes : AttnGenLds<PREC, HD, MAXKT>::fwd_bytes;
   if (smem > 160 * 1024) return adt_set_error("masked attention: L=%d hd=%d prec=%d needs %zu B of LDS (> 160 KB)", a.a.L, HD, PREC, smem);
-  const void* fn = bwd ? (const void*)k_attn_gen_bwd<PREC, HD, MAXKT, NW> : (const void*)k_attn_gen_fwd<PREC, HD, MAXKT, NW>;
+  const void* fn = bwd ? (const void*)k_attn_gen_bwd<PREC, HD, MAXKT, NW> : (const void*)k_attn_gen_fwd<PREC, HD, MAXKT, NW, CSK>;
   static bool done[2] = {false, false};
   if (!done[bwd ? 1 : 0]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -57,7 +57,10 @@ static int dispatch_attn_gen_l(bool bwd, const AttnGenArgs& a, hipStream_t s) {
 template <int PREC, int MAXKT, int NCH>
 static int launch_attn_gen_128(bool bwd, const AttnGenArgs& a, hipStream_t s) {
   constexpr int NW = 8, HD = 128;
-  if (!bwd) return launch_attn_gen<PREC, HD, MAXKT>(false, a, s);
+  if (!bwd) {     // causal without key padding (the d = 256 SASRec template): skip the key tiles above the diagonal
+    const bool csk = a.a.causal && a.kid == nullptr && a.fill <= -1e9f;
+    return csk ? launch_attn_gen<PREC, HD, MAXKT, true>(false, a, s) : launch_attn_gen<PREC, HD, MAXKT, false>(false, a, s);
+  }
   const size_t smem = AttnChunkLds<PREC, HD, MAXKT, NCH>::bwd_bytes;
   if (smem > 160 * 1024) return adt_set_error("masked attention bwd: L=%d hd=128 prec=%d needs %zu B of LDS (> 160 KB)", a.a.L, PREC, smem);
   const void* fn = (const void*)k_attn_gen_bwd_chunked<PREC, HD, MAXKT, NCH, NW>;
