@@ -380,13 +380,21 @@ def test_dense_rows_kernels_match_tiled(T, K, N, act):
             ops.dense_bwd(ops.PREC_BF16, dY, X, W, None, None, dX, True, act, U_shared, 0.3, seed, 7, 11, ids, tdev)
             dX2 = torch.empty_like(dX0)
             ops.dense_bwd(ops.PREC_BF16, dY, X, W, None, None, dX2, False)
+            # weight / bias gradient: the 256 x 128-block kernel (from four output blocks on) against the tiled one, with the
+            # fused prologue and the device row count, accumulated into non-zero buffers
+            dW = torch.full((N, K), 0.25, device=dev())
+            db = torch.full((N,), -0.5, device=dev())
+            ops.dense_bwd(ops.PREC_BF16, dY, X, W, dW, db, None, False, act, U_shared, 0.3, seed, 7, 11, ids, tdev)
         finally:
             ops.dense_rows_enable(was)
         n_live = int(tdev.item())
-        outs.append([t[:n_live].cpu().numpy() for t in (Y, U if U is not None else Y, dX, Y2, dX2)])
-    for a, bb, name in zip(outs[0], outs[1], ("Y", "U", "dX", "Y_plain", "dX_plain")):
+        outs.append([t[:n_live].cpu().numpy() for t in (Y, U if U is not None else Y, dX, Y2, dX2)] + [dW.cpu().numpy(), db.cpu().numpy()])
+    for a, bb, name in zip(outs[0], outs[1], ("Y", "U", "dX", "Y_plain", "dX_plain", "dW", "db")):
         assert np.isfinite(bb).all(), name
-        assert np.abs(a - bb).max() <= 2e-5 * max(1.0, np.abs(a).max()), (name, np.abs(a - bb).max(), np.abs(a).max())
+        # dW: sums over T rows in different orders (fp32 atomics).  db: the tiled kernel sums the bf16-ROUNDED tile it has in LDS
+        # (error ~ 2^-9 * sum |g|), the 256 x 128-block kernel sums the fp32 values before rounding, like the reference does
+        tol = {"dW": 1e-4, "db": 1e-2}.get(name, 2e-5)
+        assert np.abs(a - bb).max() <= tol * max(1.0, np.abs(a).max()), (name, np.abs(a - bb).max(), np.abs(a).max())
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
