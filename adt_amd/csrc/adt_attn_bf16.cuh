@@ -156,43 +156,31 @@ __global__ __launch_bounds__(NW * 64) void k_attn_fwd_bf16(AttnArgs a) {
       fq[kb] = pack8(v);
     }
     const int nkt = a.causal ? qt + 1 : nqt;
-    f32x4 s[MAXKT];
-    float m = -INFINITY;
+    // Two sweeps over the key tiles, the scores recomputed in the second (one MFMA per tile at hd = 32) instead of kept: the
+    // 56 registers of a 14-tile score array were what held this kernel at 168 VGPRs = one workgroup per CU; without them two
+    // or three workgroups share a CU and one stages K/V while another multiplies.
+    auto score = [&](int kt, f32x4& sc) {
+      sc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < MAXKT; ++kt) {
-      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (kt < nkt) {
+      for (int kb = 0; kb < KB; ++kb) sc = mfma_bf16(sc, rfrag<HD>(sK, kt * 16 + c, kb, g), fq[kb]);
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) s[kt] = mfma_bf16(s[kt], rfrag<HD>(sK, kt * 16 + c, kb, g), fq[kb]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + 4 * g + r;
-          const bool valid = key < L && (!a.causal || key <= q);
-          s[kt][r] = valid ? s[kt][r] : -INFINITY;
-          m = fmaxf(m, s[kt][r]);
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        const bool valid = key < L && (!a.causal || key <= q);
+        sc[r] = valid ? sc[r] : -INFINITY;
       }
+    };
+    float m = -INFINITY;
+#pragma unroll 1
+    for (int kt = 0; kt < nkt; ++kt) {
+      f32x4 sc;
+      score(kt, sc);
+      m = fmaxf(fmaxf(m, fmaxf(sc[0], sc[1])), fmaxf(sc[2], sc[3]));
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < MAXKT; ++kt) {
-      if (kt < nkt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __expf(s[kt][r] - m);
-          s[kt][r] = e;
-          sum += e;
-        }
-      }
-    }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    if (g == 0 && q < L) a.LSE[(size_t)bh * L + q] = m + __logf(sum);
     const uint32_t idx_q = ((uint32_t)(bh + a.bh_offset) * (uint32_t)L + (uint32_t)q) * (uint32_t)L;
-    const float keep_scale = inv * a.drop.scale;
+    float sum = 0.f;
     uint32_t mw[MAXKT / 2];      // keep bits of this lane's keys: word kp, bit 16*(kt&1) + 4g + r
 #pragma unroll
     for (int i = 0; i < MAXKT / 2; ++i) mw[i] = 0u;
@@ -206,18 +194,18 @@ __global__ __launch_bounds__(NW * 64) void k_attn_fwd_bf16(AttnArgs a) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int kt = 2 * kp + t;
+          f32x4 sc = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+          if (kt < nkt) score(kt, sc);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float p = 0.f;
-            if (kt < nkt) {
-              if (a.drop.thr) {
-                const uint32_t key = kt * 16 + 4 * g + r;
-                const bool keep = adt_keep(key_rng, idx_q + key, a.drop.thr);
-                p = keep ? s[kt][r] * keep_scale : 0.f;
-                mw[kp] |= (keep ? 1u : 0u) << (16 * t + 4 * g + r);
-              } else {
-                p = s[kt][r] * inv;
-              }
+            const float e = __expf(sc[r] - m);        // exp(-inf) = 0 for masked / absent keys
+            sum += e;
+            float p = e;
+            if (a.drop.thr) {
+              const uint32_t key = kt * 16 + 4 * g + r;
+              const bool keep = kt < nkt && adt_keep(key_rng, idx_q + key, a.drop.thr);
+              p = keep ? e * a.drop.scale : 0.f;
+              mw[kp] |= (keep ? 1u : 0u) << (16 * t + 4 * g + r);
             }
             pv[4 * t + r] = p;
           }
@@ -227,6 +215,17 @@ __global__ __launch_bounds__(NW * 64) void k_attn_fwd_bf16(AttnArgs a) {
         for (int nt = 0; nt < NT; ++nt) o[nt] = mfma_bf16(o[nt], fp, tfrag(sVT, LPT, nt * 16 + c, kp * 32, g));
       }
     }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    if (g == 0 && q < L) a.LSE[(size_t)bh * L + q] = m + __logf(sum);
+    // the output rows of this lane are queries 4g + r (accumulator layout), the softmax sums live on lanes c = query: fetch them
+    float inv_r[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) inv_r[r] = 1.0f / __shfl(sum, (lane & 48) | (4 * g + r), 64);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[nt][r] *= inv_r[r];
     if (a.mask && a.drop.thr) {
       // the four g-lanes of a query hold disjoint nibbles: OR them together, lane g == 0 stores the 8 words
       uint32_t ow[8];
