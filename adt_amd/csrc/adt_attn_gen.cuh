@@ -153,69 +153,66 @@ __global__ __launch_bounds__(NW * 64) void k_attn_gen_fwd(AttnGenArgs ga) {
     F fq[KB];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) fq[kb] = gfrag<PREC, HD>(a.Q + row_b * a.ldq + h * HD, a.ldq, q, q < L, kb, g, a.scale);
-    f32x4 s[MAXKT];
-    float m = -INFINITY;
+    // Two sweeps over the key tiles with the scores recomputed in the second, not kept (see k_attn_fwd_bf16): the score array
+    // (56-64 registers) was what limited this kernel to one workgroup per CU at hd = 64 and made it spill at hd = 128.
+    auto score = [&](int kt, f32x4& sc) {
+      sc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < MAXKT; ++kt) {
-      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (kt < nkt) {
+      for (int kb = 0; kb < KB; ++kb) sc = I::mma(sc, rfrag_g<PREC, HD>(sK, kt * 16 + c, kb, g), fq[kb]);
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) s[kt] = I::mma(s[kt], rfrag_g<PREC, HD>(sK, kt * 16 + c, kb, g), fq[kb]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + 4 * g + r;
-          const bool masked = (a.causal && key > q) || !sKv[key];
-          float v = masked ? fill_q : s[kt][r];
-          v = key < L ? v : -INFINITY;
-          s[kt][r] = v;
-          m = fmaxf(m, v);
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        const bool masked = (a.causal && key > q) || !sKv[key];
+        const float v = masked ? fill_q : sc[r];
+        sc[r] = key < L ? v : -INFINITY;
       }
+    };
+    float m = -INFINITY;
+#pragma unroll 1
+    for (int kt = 0; kt < nkt; ++kt) {
+      f32x4 sc;
+      score(kt, sc);
+      m = fmaxf(fmaxf(m, fmaxf(sc[0], sc[1])), fmaxf(sc[2], sc[3]));
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < MAXKT; ++kt) {
-      if (kt < nkt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __expf(s[kt][r] - m);
-          s[kt][r] = e;
-          sum += e;
-        }
-      }
-    }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    if (g == 0 && q < L) a.LSE[(size_t)bh * L + q] = m + __logf(sum);
     const uint32_t idx_q = ((uint32_t)(bh + a.bh_offset) * (uint32_t)L + (uint32_t)q) * (uint32_t)L;
+    float sum = 0.f;
     f32x4 o[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kp = 0; 2 * kp < nkt; ++kp) {
+      float pv[8];
 #pragma unroll
-    for (int kp = 0; kp < MAXKT / 2; ++kp) {
-      if (2 * kp < nkt) {
-        float pv[8];
+      for (int t = 0; t < 2; ++t) {
+        const int kt = 2 * kp + t;
+        f32x4 sc = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (kt < nkt) score(kt, sc);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int kt = 2 * kp + t;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float p = 0.f;
-            if (kt < nkt) {
-              p = s[kt][r] * inv;
-              if (a.drop.thr) p = adt_keep(key_rng, idx_q + (uint32_t)(kt * 16 + 4 * g + r), a.drop.thr) ? p * a.drop.scale : 0.f;
-            }
-            pv[4 * t + r] = p;
-          }
+        for (int r = 0; r < 4; ++r) {
+          const float e = __expf(sc[r] - m);        // exp(-inf) = 0 for absent keys
+          sum += e;
+          float p = e;
+          if (a.drop.thr) p = (kt < nkt && adt_keep(key_rng, idx_q + (uint32_t)(kt * 16 + 4 * g + r), a.drop.thr)) ? e * a.drop.scale : 0.f;
+          pv[4 * t + r] = p;
         }
-        const F fp = I::pack(pv);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) o[nt] = I::mma(o[nt], fp, I::slot8(sVT + (nt * 16 + c) * LPT + kp * 32, g));
       }
+      const F fp = I::pack(pv);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) o[nt] = I::mma(o[nt], fp, I::slot8(sVT + (nt * 16 + c) * LPT + kp * 32, g));
     }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    if (g == 0 && q < L) a.LSE[(size_t)bh * L + q] = m + __logf(sum);
+    // the output rows of this lane are queries 4g + r (accumulator layout), the softmax sums live on lanes c = query: fetch them
+    float inv_r[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) inv_r[r] = 1.0f / __shfl(sum, (lane & 48) | (4 * g + r), 64);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[nt][r] *= inv_r[r];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
