@@ -98,7 +98,9 @@ __global__ __launch_bounds__(NW * 64) void k_pre_fwd(FwdChainArgs a) {
 // ---- encoder post: h = qn + o Wo^T + bo ; h2 = LN2(h) ; u = relu(drop1(h2 W1^T + b1)) ; y = (h2 + drop2(u W2^T + b2)) * mask
 // W0 = out_proj, W1 = conv1, W2 = conv2 ; o0 = h, o1 = u, o2 = y ; optional head classifier on o -> rec
 template <int PREC, int NW, int HC>   // HC: compile-time cap on the number of heads of the fused classifier (0 = none)
-__global__ __launch_bounds__(NW * 64) void k_enc_post_fwd(FwdChainArgs a) {
+// Up to two classifier heads the kernel fits 128 registers (4 waves per SIMD = two workgroups per CU: 32.6 -> 25.7 us); it needed 134
+// without the hint.  Wider classifiers keep the two-waves budget (at 128 they would spill).
+__global__ __launch_bounds__(NW * 64, (HC <= 2 ? 4 : 2)) void k_enc_post_fwd(FwdChainArgs a) {
   constexpr int HCM = HC > 0 ? HC : 1;
   FWD_PROLOGUE(3)
   stage_wimg<PREC, NW * 64>(lds.w[0], a.W[0], false);
