@@ -461,7 +461,7 @@ int adt_mse_seed(const float* A, const float* Bm, int64_t n, float lambda, const
                  int accumulate_a, float* GB, float* loss1, void* stream) {
   if (n % 4) return adt_set_error("mse_seed: n %% 4");
   MseArgs a{A, Bm, (size_t)n, lambda, norms, GA, accumulate_a, GB, loss1};
-  hipLaunchKernelGGL(k_mse_seed, dim3(grid_for((size_t)n / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_mse_seed, dim3(grid_for((size_t)n / 4, 256, 512)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("mse_seed");
 }
 
