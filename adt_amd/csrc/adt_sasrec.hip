@@ -367,13 +367,12 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
     return a;
   };
   const int64_t dec_begin = lo.dec(0, 0);
-  if (phase == 0 || phase == 1) {
-    if (adt::zero_f32_async(ws + w.prep, (size_t)NREPP * w.prep_stride, (hipStream_t)st)) return adt_set_error("parameter replica zero");
-  }
   const float* f = ws + w.f;
   if (phase == 0 || phase == 1) {
     // d log_feats (overwrites g_f) and item-table rows of pos/neg      (sasrec/model.py:72-76)
-    if (adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
+    // item-table replicas and parameter replicas are adjacent in the workspace: one fill
+    if (w.prep != w.rep + NREP * w.rep_stride) return adt_set_error("workspace layout: replica areas not adjacent");
+    if (adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride + (size_t)NREPP * w.prep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
     CK(adt_logits_bwd_df(P + lo.item(), pos, neg, ws + w.g_pos, ws + w.g_neg, T, d, gf, d, st));
     CK(adt_item_scatter(pos, f, d, ws + w.g_pos, T, d, 1.0f, 0.f, nullptr, 0, 0, ws + w.rep, NREP, w.rep_stride, st));
     CK(adt_item_scatter(neg, f, d, ws + w.g_neg, T, d, 1.0f, 0.f, nullptr, 0, 0, ws + w.rep, NREP, w.rep_stride, st));
