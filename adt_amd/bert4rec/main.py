@@ -57,6 +57,10 @@ def parse_args(argv=None):
 
 def main(argv=None):
     args = parse_args(argv)
+    from ..dp import init_from_env, shard_bounds, skip_batch
+    pg, rank, world, local = init_from_env("nccl")     # torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE
+    if pg is not None:
+        args.device = "cuda:%d" % local
     if args.template:
         args = U.set_template(args)
     if args.override:
@@ -69,9 +73,12 @@ def main(argv=None):
     path = os.path.join(args.data_dir, "%s.txt" % args.dataset)
     if not os.path.exists(path) and args.synthetic:
         from ..sasrec import synth
-        os.makedirs(args.data_dir, exist_ok=True)
-        h, _, _ = synth.generate(args.synthetic, 23)
-        synth.write(path, h)
+        if rank == 0:
+            os.makedirs(args.data_dir, exist_ok=True)
+            h, _, _ = synth.generate(args.synthetic, 23)
+            synth.write(path, h)
+        if world > 1:
+            torch.distributed.barrier()
     user_train, user_valid, user_test, usernum, itemnum = D.data_partition(args.dataset, args.data_dir)
     for u in user_train:          # the training sequences include the validation item (bert4rec/trainer.py:165-167)
         user_train[u] = list(user_train[u]) + list(user_valid.get(u, []))
@@ -82,31 +89,42 @@ def main(argv=None):
     test_ds = D.BertEvalDataset(user_train, user_valid, user_test, usernum, itemnum, args.maxlen, sampler, "test", args.eval_set_size)
     torch.manual_seed(23)
     model = BertModel(usernum, itemnum, args)
+    if world > 1:
+        torch.distributed.broadcast(model.flat, 0)
     trainer = FusedBertTrainer(model, lambda1, lambda2, lr=args.lr, betas=(0.9, 0.999), weight_decay=args.weight_decay, clip=args.clip,
-                               use_graph=args.use_graph, seed=23)
+                               process_group=pg, use_graph=args.use_graph, seed=23)
     rng = np.random.RandomState(23)
     best = dict(score=0.0, epoch=0, valid=None, test=None, auc_valid=0.0, auc_test=0.0)
     T, nseq = 0.0, 0
     for epoch in range(args.num_epochs):
         t0 = time.time()
         for src, dec, lab in train_ds.epoch_batches(args.batch_size, rng):
-            if len(src) != args.batch_size:
+            if len(src) != args.batch_size or skip_batch(len(src), world):
                 continue      # keep one captured graph shape (the reference's last partial batch is < 0.5 % of an epoch)
-            trainer.step(src, dec, lab)
+            if pg is None:
+                trainer.step(src, dec, lab)
+            else:             # every rank draws the same global batch (same seed) and trains on its contiguous rows, with the
+                lo, hi = shard_bounds(len(src), rank, world)     # GLOBAL normalisers: label count, B*L*d, B*L*H of the whole batch
+                trainer.step(src[lo:hi], dec[lo:hi], lab[lo:hi], n_valid_global=int(np.count_nonzero(lab)), b_offset=lo,
+                             norms_scale=len(src) / float(hi - lo))
             nseq += len(src)
         torch.cuda.synchronize()
         T += time.time() - t0
         if (epoch + 1) % args.eval_interval == 0 or epoch + 1 == args.num_epochs:
             t_test, auc_test = trainer.evaluate(test_ds.batches(args.eval_batch_size))
             t_valid, auc_valid = trainer.evaluate(val_ds.batches(args.eval_batch_size))
-            for k in (5, 10):
+            for k in (5, 10) if rank == 0 else ():
                 print("epoch: %d, time: %f, valid (NDCG@%d: %.4f, HR@%d: %.4f, AUC: %s), test (NDCG@%d: %.4f, HR@%d: %.4f, AUC: %s)"
                       % (epoch + 1, T, k, t_valid[0][k], k, t_valid[1][k], auc_valid, k, t_test[0][k], k, t_test[1][k], auc_test))
-            print(json.dumps({"epoch": epoch + 1, "train_seconds": T, "sequences_per_sec": nseq / max(T, 1e-9), "loss": float(trainer.loss()),
-                              "valid": {"ndcg10": t_valid[0][10], "hr10": t_valid[1][10], "auc": auc_valid},
-                              "test": {"ndcg10": t_test[0][10], "hr10": t_test[1][10], "auc": auc_test}}), flush=True)
+            loss = float(trainer.loss())      # a collective under data parallelism: every rank calls it
+            if rank == 0:
+                print(json.dumps({"epoch": epoch + 1, "train_seconds": T, "sequences_per_sec": nseq / max(T, 1e-9), "loss": loss,
+                                  "n_gpus": world, "valid": {"ndcg10": t_valid[0][10], "hr10": t_valid[1][10], "auc": auc_valid},
+                                  "test": {"ndcg10": t_test[0][10], "hr10": t_test[1][10], "auc": auc_test}}), flush=True)
             if auc_valid >= best["score"]:
                 best.update(score=auc_valid, epoch=epoch, valid=t_valid, test=t_test, auc_valid=auc_valid, auc_test=auc_test)
+    if pg is not None:
+        torch.distributed.destroy_process_group()
     return best
 
 

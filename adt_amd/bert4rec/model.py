@@ -33,6 +33,14 @@ def dec_sites(i):
     return {"attn": b, "after_multi": b + 1, "src_attn": b + 2, "after_src": b + 3, "final": b + 4}
 
 
+# path components in the order the reference's constructors register them (bert4rec/model/bert.py:20-55, modules.py)
+REF_ORDER = ["mask_bias", "item_emb", "encoder", "decoder", "mask_trans_feat", "mask_layer_norm", "encoder_layers", "decoder_layers",
+             "word_emb", "pos_emb", "sent_emb", "multi_head_attention", "dec_multi_head_attention",
+             "drop_residual_normalize_layer_after_multi", "src_dec_attention", "drop_residual_normalize_layer_after_src_dec", "ffn",
+             "drop_residual_normalize_layer_final", "head_classifier", "layer_norm", "query_transfer", "key_transfer", "value_transfer",
+             "out_transfer", "fc1", "fc2", "weight", "bias"]
+
+
 def param_table(item_num, maxlen, d, H, nl, inner, type_vocab):
     """[(state_dict name, shape)] in flat order.  Within an attention block the three projection weights, then the three
     biases, are consecutive so that q/k/v (or k/v) run as one GEMM."""
@@ -79,7 +87,7 @@ class BertModel(FlatModule):
             raise _lib.AdtError("BertModel (adt_amd): hidden_units must be a multiple of 64 with head size 16/32/64, got d=%d H=%d"
                                 % (self.hidden_units, self.num_heads))
         self._build_flat(param_table(itemnum, args.maxlen, args.hidden_units, args.num_heads, args.num_layers, args.inner_units,
-                                     getattr(args, "type_vocab_size", 2)), args.device)
+                                     getattr(args, "type_vocab_size", 2)), args.device, REF_ORDER)
         # bert4rec/trainer.py:29-37 re-initialises every Linear/Embedding weight N(0.01, initializer_range), LayerNorm 1/0,
         # Linear bias 0; do the same here so that a freshly constructed model is usable
         g = torch.Generator(device="cpu").manual_seed(torch.initial_seed() % (1 << 31))
@@ -190,6 +198,7 @@ class BertModel(FlatModule):
     def _decode(self, tp, dec, src, enc, B):
         """decode + Decoder.forward (bert.py:69-78, modules.py:297-325, 352-358); outputs in layer order (not yet reversed)."""
         x = self._embed(tp, dec, SITE_EMB_DEC)
+        tp.mark_decoder_start()
         outs = []
         for i in range(self.num_layers):
             p = "decoder.decoder_layers.%d" % i

@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from ..dp import GradBuckets, reduce_sum
 
 
 class FusedBertTrainer:
@@ -23,7 +24,11 @@ class FusedBertTrainer:
         self.pg = process_group
         self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
         self.rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
-        self.use_graph = use_graph and self.world == 1
+        self.use_graph = use_graph       # data-parallel steps are captured too (RCCL collectives are graph nodes)
+        # tail bucket: decoder layers + output head (their backward runs first); head bucket: embeddings (word_emb also receives
+        # the all-item-logits gradient) + encoder, reduced at the end
+        self._buckets = GradBuckets(model.flat_grad, model.offset_of("decoder.decoder_layers.0.dec_multi_head_attention.query_transfer.weight"),
+                                    process_group)
         dev = model.dev
         self.m = torch.zeros_like(model.flat)
         self.v = torch.zeros_like(model.flat)
@@ -58,9 +63,9 @@ class FusedBertTrainer:
         self.loss_slots.zero_()
         m.flat_grad.zero_()
         T = st["B"] * m.maxlen
+        m.dp_hook = self._buckets.tail_ready if self._buckets.active else None
         m.loss_forward_backward(st, self.lambda1, self.lambda2, st["norms"], self.loss_slots, b_offset, int(np.ceil(self.mcap_frac * T)))
-        if self.world > 1:
-            torch.distributed.all_reduce(m.flat_grad, group=self.pg)
+        self._buckets.finish()
         ops.clip_adam_l2(m.flat, m.flat_grad, self.m, self.v, self.wd, self.clip, self.lr, self.betas[0], self.betas[1], self.eps, self.scal)
 
     def _copy_stage(self, st):
@@ -96,10 +101,11 @@ class FusedBertTrainer:
 
     def loss(self):
         """Device scalar: the loss of the last step as BertTrainer prints it (trainer.py:139)."""
-        return (self.loss_slots.sum(1) * self._loss_w).sum()
+        return (self.loss_parts() * self._loss_w).sum()
 
     def loss_parts(self):
-        return self.loss_slots.sum(1)
+        slots = self.loss_slots.sum(1)
+        return reduce_sum(slots, self.pg) if self.world > 1 else slots
 
     def grad_norm(self):
         return self.scal[1].sqrt()
@@ -111,16 +117,25 @@ class FusedBertTrainer:
         column 0: rank = number of candidates scored above it, HR@k, NDCG@k, and the AUC with the reference's
         candidates_size = 1 + C."""
         self.model.eval()
-        ranks = []
-        C = None
-        for seq, cand in batches:
+        ks = tuple(ks)
+        # additive statistics [n, sum of AUC terms, per k: hits, sum 1/log2(rank+2)]: under data parallelism rank r scores batches
+        # r, r+W, ... and the statistics are sum-reduced in float64, so every rank ends up with the metrics of the whole user set
+        stats = np.zeros(2 + 2 * len(ks), np.float64)
+        for i, (seq, cand) in enumerate(batches):
+            if i % self.world != self.rank:
+                continue
             _, rank = self.model.predict(None, seq, None, None, cand, want_rank=True)
-            ranks.append(rank.cpu().numpy())
-            C = np.asarray(cand).shape[1]
-        ranks = np.concatenate(ranks).astype(np.int64)
-        n = float(len(ranks))
-        ndcg = {k: float((1.0 / np.log2(ranks[ranks < k] + 2)).sum() / n) for k in ks}
-        hr = {k: float((ranks < k).sum() / n) for k in ks}
-        size = 1 + C
-        auc = float(np.mean((size - (ranks + 1)) / (size - 1)))
-        return (ndcg, hr), auc
+            r = rank.cpu().numpy().astype(np.int64)
+            size = 1 + np.asarray(cand).shape[1]
+            stats[0] += len(r)
+            stats[1] += float(((size - (r + 1)) / (size - 1)).sum())
+            for j, k in enumerate(ks):
+                stats[2 + 2 * j] += float((r < k).sum())
+                stats[3 + 2 * j] += float((1.0 / np.log2(r[r < k] + 2)).sum())
+        if self.world > 1:
+            t = torch.from_numpy(stats).to(self.model.dev)
+            stats = reduce_sum(t, self.pg).cpu().numpy()
+        n = stats[0]
+        ndcg = {k: float(stats[3 + 2 * j] / n) for j, k in enumerate(ks)}
+        hr = {k: float(stats[2 + 2 * j] / n) for j, k in enumerate(ks)}
+        return (ndcg, hr), float(stats[1] / n)

@@ -6,8 +6,9 @@ run restarts Adam from zero moments; this module adds what a resumable (data-par
   buffers, the device-resident step counter and clip scalars, the device dropout seed and the host step count.  Loading on every
   rank (same file) resumes a DP run exactly: the moments are replicated like the weights.
 * to_torch_adam_state / from_torch_adam_state -- the same moments in torch.optim.Adam.state_dict() format, keyed by parameter
-  position in model.parameters() order, so the reference's own `torch.optim.Adam(model.parameters(), ...)` can continue a run
-  started here (optimizer.load_state_dict) and the other way round.  Parameters the reference leaves without gradient (torch
+  position in model.parameters() order.  The mirrors register their parameters in the REFERENCE's constructor order
+  (adt_amd/wide.py:ref_sorted, pinned by tests/golden/param_order.json), not in flat-buffer order, so the reference's own
+  `torch.optim.Adam(model.parameters(), ...)` can continue a run started here (optimizer.load_state_dict) and the other way round.  Parameters the reference leaves without gradient (torch
   Adam creates no state for them) are skipped on export when their moments are identically zero.
 
 Everything is plain device-to-host copies of existing buffers: no arithmetic happens here.
@@ -23,10 +24,12 @@ def _scal_step(tr):
 
 def trainer_state_dict(tr):
     sd = {"format": FORMAT, "trainer": type(tr).__name__, "n_flat": int(tr.model.flat.numel()),
-          "exp_avg": tr.m.detach().cpu().clone(), "exp_avg_sq": tr.v.detach().cpu().clone(), "scal": tr.scal.detach().cpu().clone(),
-          "dropout_seed": tr.model._seed.detach().cpu().clone(), "nstep": int(tr.nstep),
+          "exp_avg": tr.m.detach().cpu().clone(), "exp_avg_sq": tr.v.detach().cpu().clone(),
+          "dropout_seed": tr.model._seed.detach().cpu().clone(), "nstep": int(getattr(tr, "nstep", 0)),
           "hyper": {"lr": tr.lr, "betas": tuple(tr.betas), "eps": tr.eps}}
-    if hasattr(tr, "steps"):       # supernet: one Adam step count per trained parameter range
+    if hasattr(tr, "scal"):        # fused trainers: adt_clip_adam's device scalars (step count, norms)
+        sd["scal"] = tr.scal.detach().cpu().clone()
+    if hasattr(tr, "steps"):       # supernet (SuperTrainer): one Adam step count per trained parameter range, host side
         sd["range_steps"] = {"%d:%d" % k: int(v) for k, v in tr.steps.items()}
     return sd
 
@@ -39,9 +42,11 @@ def load_trainer_state_dict(tr, sd):
                          % (sd["trainer"], sd["n_flat"], type(tr).__name__, tr.model.flat.numel()))
     tr.m.copy_(sd["exp_avg"])
     tr.v.copy_(sd["exp_avg_sq"])
-    tr.scal.copy_(sd["scal"])
+    if hasattr(tr, "scal"):
+        tr.scal.copy_(sd["scal"])
     tr.model._seed.copy_(sd["dropout_seed"])
-    tr.nstep = int(sd["nstep"])
+    if hasattr(tr, "nstep"):
+        tr.nstep = int(sd["nstep"])
     if hasattr(tr, "steps"):
         tr.steps = {tuple(int(x) for x in k.split(":")): int(v) for k, v in sd.get("range_steps", {}).items()}
 

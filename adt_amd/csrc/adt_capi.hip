@@ -5,7 +5,6 @@
 
 #include "adt_attn.cuh"
 #include "adt_attn_bf16.cuh"
-#include "adt_chain.cuh"
 #include "adt_bwdchain.cuh"
 #include "adt_fwdchain.cuh"
 #include "adt_misc.cuh"
@@ -140,21 +139,6 @@ static int dispatch_attn(int prec, bool bwd, int hd, const AttnArgs& a, hipStrea
   if ((a.ldq % 4) || (a.ldk % 4) || (a.ldv % 4) || (a.ldo % 4)) return adt_set_error("attention: ld %% 4");
   if (prec == ADT_PREC_F32) return dispatch_attn_hd<PREC_F32>(bwd, hd, a, s);
   return dispatch_attn_hd<PREC_BF16>(bwd, hd, a, s);
-}
-
-int adt_launch_rowchain_fwd(int prec, const ChainArgs& a, void* stream) {
-  const size_t smem = (size_t)(CH_NBUF + 1) * CH_TILE * sizeof(float);
-  static bool done = false;
-  if (!done) {
-    if (hipFuncSetAttribute((const void*)k_rowchain_fwd<PREC_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_rowchain_fwd<PREC_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-      return adt_set_error("rowchain_fwd: hipFuncSetAttribute");
-    done = true;
-  }
-  const int grid = grid_for(a.T, 64, 512);
-  if (prec == ADT_PREC_F32) hipLaunchKernelGGL(k_rowchain_fwd<PREC_F32>, dim3(grid), dim3(CH_THREADS), smem, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(k_rowchain_fwd<PREC_BF16>, dim3(grid), dim3(CH_THREADS), smem, (hipStream_t)stream, a);
-  return check_launch("rowchain_fwd");
 }
 
 template <int PREC, int NW>

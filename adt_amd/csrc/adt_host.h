@@ -17,10 +17,6 @@ enum { SITE_EMB_SEQ = 1, SITE_EMB_DEC = 2 };
 static inline uint32_t enc_site(int layer, int which) { return 16u + 8u * (uint32_t)layer + (uint32_t)which; }   // 0 attn 1 ffn1 2 ffn2
 static inline uint32_t dec_site(int layer, int which) { return 128u + 8u * (uint32_t)layer + (uint32_t)which; }  // 0 slf 1 enc 2 ffn1 3 ffn2
 
-// fused forward chain (adt_chain.cuh); defined in adt_capi.hip
-namespace adt { struct ChainArgs; }
-int adt_launch_rowchain_fwd(int prec, const adt::ChainArgs& a, void* stream);
-
 // fused backward chains (adt_bwdchain.cuh); defined in adt_capi.hip.  which: 0 enc_post, 1 dec_post, 2 enc_pre, 3 dec_pre, 4 dec_mid
 namespace adt { struct BwdChainArgs; }
 int adt_launch_bwdchain(int prec, int which, const adt::BwdChainArgs& a, void* stream);

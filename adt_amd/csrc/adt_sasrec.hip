@@ -4,7 +4,6 @@
 // enqueues kernels (via the per-stage C ABI) on the caller's stream.
 #include "adt_host.h"
 #include <string.h>
-#include "adt_chain_args.h"
 #include "adt_bwdchain_args.h"
 #include "adt_fwdchain_args.h"
 
@@ -117,8 +116,6 @@ int check_cfg(const adt_sasrec_cfg* c) {
   return 0;
 }
 
-using adt::ChainArgs;
-using adt::ChainStep;
 
 adt::FwdChainArgs fwd_args(int T, int L, int B, int H, const int32_t* ids, float p, const uint32_t* seed, uint32_t row_offset) {
   adt::FwdChainArgs a;
@@ -133,34 +130,6 @@ adt::BwdChainArgs bwd_args(int T, int L, int B, const int32_t* ids, float p, con
   a.T = T; a.L = L; a.B = B; a.ids = ids; a.drop = adt_make_drop(p, seed, 0); a.row_offset = row_offset; a.ln_eps = LN_EPS;
   return a;
 }
-
-// ---- fused-chain program builders (adt_chain.cuh) ------------------------------------------------
-struct Prog {
-  ChainArgs a;
-  int n = 0;
-  Prog(int T, int L, int B, const int32_t* ids, float p, const uint32_t* seed, uint32_t row_offset) {
-    memset(&a, 0, sizeof(a));
-    a.T = T; a.L = L; a.B = B; a.ids = ids; a.drop = adt_make_drop(p, seed, 0); a.row_offset = row_offset; a.ln_eps = LN_EPS;
-  }
-  ChainStep& add(int op, int src, int dst) {
-    ChainStep& s = a.steps[n++];
-    s.op = op; s.src = src; s.dst = dst; s.add_buf = -1;
-    return s;
-  }
-  void load(int dst, const float* g, int ld) { ChainStep& s = add(adt::ST_LOAD, 0, dst); s.in_g = g; s.ld_in = ld; }
-  void gather(int dst, const float* E, const float* P, float scale, uint32_t site, float* out, int ld) {
-    ChainStep& s = add(adt::ST_GATHER, 0, dst); s.site = site; s.out_g = out; s.ld_out = ld;
-    a.E = E; a.P = P; a.emb_scale = scale;
-  }
-  void ln(int src, int dst, const float* gm, const float* bt, float* out, int ld) {
-    ChainStep& s = add(adt::ST_LN, src, dst); s.W = gm; s.b = bt; s.out_g = out; s.ld_out = ld;
-  }
-  ChainStep& gemm(int src, int dst, const float* W, const float* b, float* out, int ld, int flags = 0, uint32_t site = 0) {
-    ChainStep& s = add(adt::ST_GEMM, src, dst); s.W = W; s.b = b; s.out_g = out; s.ld_out = ld; s.flags = flags; s.site = site;
-    return s;
-  }
-  int run(int prec, void* st) { return adt_launch_rowchain_fwd(prec, a, st); }
-};
 
 // encoder stack forward (gathers the input embedding inside the first chain) + last LayerNorm (+ logits and the
 // cross-attention k/v projections of every decoder layer when training_outputs)

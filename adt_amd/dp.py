@@ -1,20 +1,59 @@
-"""Data-parallel step logic shared by the HIP trainer (adt_amd/sasrec/trainer.py, RCCL over xGMI) and the CPU
-gloo tests.  The path shards by user sequence and has exactly one exchange step: a sum all-reduce of the flat
-fp32 gradient buffer.  Exactness rules that make N ranks reproduce the 1-rank step on the same
-global batch:
+"""Data-parallel layer shared by every fused trainer (sasrec/trainer.py, sasrec/model_wide.py, bert4rec/trainer.py,
+stosa/trainer.py) and the three entry points.  One process per GPU, torch.distributed backend "nccl" (= RCCL over xGMI on
+ROCm); the same code runs on "gloo" in the CPU / shared-GPU tests.
+
+The path shards by user sequence and has exactly one exchange step: a sum all-reduce of the flat fp32 gradient buffer
+(SURVEY.md 8e).  Exactness rules that make N ranks reproduce the 1-rank step on the same global batch:
   1. loss normalisers are GLOBAL (count of pos != 0, B*L*d, B*L*H of the whole batch), never per-rank means;
   2. dropout masks are indexed by GLOBAL sequence index (b_offset), so sharding does not change them;
   3. the weight-decay term wd*||E||_F, gradient clipping and Adam run AFTER the all-reduce, identically on every
      rank, on the reduced buffer.
+
+xGMI is point-to-point (7 links per GPU), so a ring all-reduce of a small buffer is latency bound: the gradient goes out in
+TWO buckets, not many.  The flat layout puts embeddings and encoder first and the decoder (and, for BERT, the output head) last;
+the backward pass finishes the decoder's parameters first, so the tail bucket's all-reduce runs on RCCL's stream while the
+encoder's backward and the embedding scatter still execute (`GradBuckets.tail_ready()`), and the head bucket goes out at the
+end (`GradBuckets.finish()`).  Both collectives are captured into the step's HIP graph together with the kernels.
 """
+import os
+
 import numpy as np
 
 
+def init_from_env(backend="nccl"):
+    """Process-group set-up of an entry point launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
+    Returns (process_group or None, rank, world, local_rank); with ADT_FORCE_DP=1 a single process still gets a 1-rank group
+    so that the data-parallel code path (bucketed all-reduce on RCCL's stream) is the one that runs."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    force = os.environ.get("ADT_FORCE_DP", "0") == "1"
+    if world == 1 and not force:
+        return None, 0, 1, local
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 2000))
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return dist.group.WORLD, rank, world, local
+
+
 def shard_bounds(B, rank, world):
-    """Contiguous rows [lo, hi) of a global batch of B sequences owned by `rank`."""
-    per = (B + world - 1) // world
-    lo = min(B, rank * per)
-    return lo, min(B, lo + per)
+    """Contiguous rows [lo, hi) of a global batch of B sequences owned by `rank`: balanced, the first B % world ranks get one
+    more row, so a rank is empty only when B < world (callers skip such a trailing batch: `skip_batch`)."""
+    base, rem = divmod(B, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def skip_batch(B, world):
+    """A trailing batch with fewer sequences than ranks would leave a rank without rows (zero-sized launches on that rank
+    while the others wait in the all-reduce): every rank drops it (identically, so nobody hangs)."""
+    return B < world
 
 
 def global_norms(pos, hidden, num_heads):
@@ -24,37 +63,45 @@ def global_norms(pos, hidden, num_heads):
     return float(np.count_nonzero(pos)), float(pos.size * hidden), float(pos.size * num_heads)
 
 
-def allreduce_buckets(flat, boundaries, group=None, async_op=True):
-    """Sum-all-reduce `flat` in the buckets delimited by `boundaries` (offsets, ascending, within (0, len)).
-    Returns the list of work handles (empty when torch.distributed is not initialised: single process)."""
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return []
-    edges = [0] + [int(b) for b in boundaries] + [flat.numel()]
-    handles = []
-    for lo, hi in zip(edges[:-1], edges[1:]):
-        if hi > lo:
-            handles.append(dist.all_reduce(flat[lo:hi], group=group, async_op=async_op))
-    return [h for h in handles if h is not None]
+class GradBuckets:
+    """The gradient exchange of one step: flat[boundary:n) as soon as the decoder's backward is done, flat[0:boundary) at the
+    end.  With no process group (single GPU) both calls are no-ops.  torch.distributed issues each collective on the
+    backend's own stream behind an event of the current stream, and `wait()` makes the current stream wait for it: under HIP
+    graph capture both become cross-stream edges of the captured graph."""
+
+    def __init__(self, flat_grad, boundary, group=None, n=None):
+        n = flat_grad.numel() if n is None else int(n)
+        boundary = max(0, min(int(boundary), n))
+        self.group = group
+        self.tail = flat_grad[boundary:n] if boundary < n else None
+        self.head = flat_grad[:boundary] if boundary > 0 else None
+        self._h = []
+
+    @property
+    def active(self):
+        return self.group is not None
+
+    def tail_ready(self):
+        if self.group is None or self.tail is None:
+            return
+        import torch.distributed as dist
+        self._h.append(dist.all_reduce(self.tail, group=self.group, async_op=True))
+
+    def finish(self):
+        if self.group is None:
+            return
+        import torch.distributed as dist
+        if self.head is not None:
+            self._h.append(dist.all_reduce(self.head, group=self.group, async_op=True))
+        for h in self._h:
+            if h is not None:
+                h.wait()
+        self._h = []
 
 
-class DPStep:
-    """Engine-agnostic data-parallel optimisation step.  `engine` provides
-         forward_backward(shard_batch, norms, b_offset) -> flat gradient tensor of THIS shard's contribution
-                                                           (no weight-decay term), to be summed over ranks
-         apply(flat_gradient)                           -> weight-decay term + clip + Adam on the reduced buffer
-    """
-
-    def __init__(self, engine, hidden, num_heads, rank=0, world=1, group=None, bucket_boundaries=()):
-        self.engine, self.hidden, self.num_heads = engine, hidden, num_heads
-        self.rank, self.world, self.group, self.boundaries = rank, world, group, list(bucket_boundaries)
-
-    def step(self, seq, dec, pos, neg):
-        B = len(seq)
-        lo, hi = shard_bounds(B, self.rank, self.world)
-        norms = global_norms(pos, self.hidden, self.num_heads)
-        flat = self.engine.forward_backward((seq[lo:hi], dec[lo:hi], pos[lo:hi], neg[lo:hi]), norms, lo)
-        for h in allreduce_buckets(flat, self.boundaries, self.group, async_op=True):
-            h.wait()
-        self.engine.apply(flat)
-        return flat
+def reduce_sum(t, group=None):
+    """Sum a small device tensor (loss partial sums, normaliser counts) over the ranks, in place; no-op without a group."""
+    if group is not None:
+        import torch.distributed as dist
+        dist.all_reduce(t, group=group)
+    return t

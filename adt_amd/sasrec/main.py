@@ -80,16 +80,8 @@ def set_rng_seed(seed):
 
 def main(argv=None):
     args = parse_args(argv)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    pg = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        pg = dist.group.WORLD
+    from ..dp import global_norms, init_from_env, shard_bounds, skip_batch
+    pg, rank, world, local = init_from_env("nccl")     # torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE
     if args.device == "cuda":
         args.device = "cuda:%d" % local
     out_dir = args.dataset + "_" + args.train_dir
@@ -148,6 +140,8 @@ def main(argv=None):
         trainer = FusedTrainer(model, lambdas1, lambdas2, lr=args.lr, betas=(0.9, 0.98), weight_decay=args.weight_decay, clip=args.clip,
                                process_group=pg, use_graph=args.use_graph, seed=23)
     else:
+        if pg is not None:
+            raise SystemExit("--loop reference is the single-process loop of sasrec/main.py; data-parallel runs use --loop fused")
         bce = torch.nn.BCEWithLogitsLoss()
         opt = torch.optim.Adam(model.parameters(), lr=args.lr, betas=(0.9, 0.98))
     best = dict(score=0.0, epoch=0, valid=None, test=None, auc_valid=0.0, auc_test=0.0)
@@ -157,8 +151,9 @@ def main(argv=None):
         if args.inference_only:
             break
         for u, seq, dec, pos, neg in warp.epoch_batches(args.batch_size, rng):
-            if world > 1:   # contiguous shard of the global batch (every rank draws the same batch: same seed)
-                from ..dp import shard_bounds, global_norms
+            if pg is not None:   # contiguous shard of the global batch (every rank draws the same batch: same seed)
+                if skip_batch(len(u), world):
+                    continue        # a trailing batch with fewer sequences than ranks: dropped on every rank alike
                 lo, hi = shard_bounds(len(u), rank, world)
                 norms = global_norms(pos, args.hidden_units, args.num_heads)
                 trainer.step(seq[lo:hi], dec[lo:hi], pos[lo:hi], neg[lo:hi], norms=norms, b_offset=lo)
@@ -216,7 +211,7 @@ def main(argv=None):
                      best["test"][1][k], best["auc_test"]))
     if logf:
         logf.close()
-    if world > 1:
+    if pg is not None:
         torch.distributed.destroy_process_group()
     return best
 

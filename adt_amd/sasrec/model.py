@@ -28,6 +28,12 @@ _DEC_SLOTS = ["layer_norm.weight", "layer_norm.bias", "slf_attn.in_proj_weight",
               "enc_attn.out_proj.weight", "enc_attn.out_proj.bias", "pos_ffn.conv1.weight", "pos_ffn.conv1.bias",
               "pos_ffn.conv2.weight", "pos_ffn.conv2.bias", "pos_ffn_layernorm.weight", "pos_ffn_layernorm.bias"]
 
+# path components in the order the reference's constructors register them (sasrec/model.py:18-28, modules.py:636-665)
+REF_ORDER = ["item_emb", "pos_emb", "encoder", "decoder", "last_layernorm", "encoder_layers", "decoder_layers",
+             "attention_layernorm", "attention_layer", "forward_layernorm", "forward_layer", "sparse",
+             "layer_norm", "slf_attn", "enc_attn", "pos_ffn", "pos_ffn_layernorm",
+             "in_proj_weight", "in_proj_bias", "out_proj", "conv1", "conv2", "weight", "bias"]
+
 WS_ENC_X, WS_DEC_X, WS_REC, WS_POS_LOGITS, WS_NEG_LOGITS, WS_F = 0, 1, 2, 3, 4, 5
 WS_G_ENC_X, WS_G_DEC_X, WS_G_REC, WS_G_POS, WS_G_NEG, WS_LOSS, WS_NORMS, WS_SCAL = 6, 7, 8, 9, 10, 11, 12, 13
 
@@ -102,11 +108,12 @@ class SASRecADT(torch.nn.Module):
                 fan_out, fan_in = shape[0], shape[1] * (shape[2] if len(shape) > 2 else 1)
                 bound = (1.0 / max(fan_in, 1)) ** 0.5
                 view.copy_((torch.rand(shape, generator=g) * 2 - 1) * bound)
-            prm = torch.nn.Parameter(view, requires_grad=True)
-            _set_nested(self, name, prm)
             self._views[name] = (off, n, shape)
-        self._ws = None
-        self._ws_B = -1
+        from ..wide import ref_sorted
+        for name in ref_sorted([n for n, _ in self.table], REF_ORDER):   # registration order = the reference's (Adam-state interop)
+            off, n, shape = self._views[name]
+            _set_nested(self, name, torch.nn.Parameter(self.flat[off:off + n].view(shape), requires_grad=True))
+        self._ws_cache = {}   # one arena per batch size, never freed: a captured HIP graph holds raw pointers into it
         self._seed = torch.zeros(1, device=self.dev, dtype=torch.int32)   # uint32 bits, device resident
         self._step_seed = 0
 
@@ -124,11 +131,14 @@ class SASRecADT(torch.nn.Module):
         return self.flat_grad[off:off + n].view(shape)
 
     def workspace(self, B):
-        if self._ws is None or self._ws_B != B:
+        """The arena for batch size B.  Arenas are cached per B for the life of the model (train batch, trailing partial
+        batch and eval batch each get their own), so predict() at another B can never free or move a buffer that a captured
+        training graph still points into."""
+        ws = self._ws_cache.get(B)
+        if ws is None:
             n = self.lib.adt_sasrec_workspace_floats(ctypes.byref(self.cfg), B)
-            self._ws = torch.empty(int(n), device=self.dev, dtype=torch.float32)
-            self._ws_B = B
-        return self._ws
+            ws = self._ws_cache[B] = torch.empty(int(n), device=self.dev, dtype=torch.float32)
+        return ws
 
     def ws_view(self, B, what, layer, numel):
         off = self.lib.adt_sasrec_ws_offset(ctypes.byref(self.cfg), B, what, layer)

@@ -11,8 +11,9 @@ import numpy as np
 import torch
 
 from .. import _lib, ops
+from ..dp import GradBuckets, reduce_sum
 from ..wide import Act, FlatModule, Tape, give
-from .model import param_table
+from .model import REF_ORDER, param_table
 
 LN_EPS = 1e-8
 SITE_EMB_SEQ, SITE_EMB_DEC = 1, 2
@@ -28,7 +29,15 @@ def dec_sites(i):
     return {"slf": b, "enc": b + 1, "ffn1": b + 2, "ffn2": b + 3}
 
 
-NREP = 16      # replicas of the item-table gradient (contention relief, as in the fused executor)
+NREP_MAX = 16             # replicas of the item-table gradient (contention relief, as in the fused executor)
+REP_BUDGET = 64 << 20     # bytes of zero-fill + reduce per step we are willing to spend on them
+
+
+def n_replicas(table_floats):
+    """Replica count for a (V+1, d) item table: 16 for ml-1m (3.5 MB at d=256), fewer as the table grows, 1 (scatter straight into
+    the gradient, no replica traffic at all) from 32 MB up -- Amazon-Beauty's 54,542 x 256 table is 56 MB, and its ids are spread
+    over 16x more rows, so the same-address atomic chains the replicas exist to break are short anyway."""
+    return int(max(1, min(NREP_MAX, REP_BUDGET // (4 * int(table_floats)))))
 
 
 class SASRecADTWide(FlatModule):
@@ -43,7 +52,7 @@ class SASRecADTWide(FlatModule):
         if d % 64 or d > 256 or (d // H) not in (16, 32, 64, 128) or self.maxlen > 256:
             raise _lib.AdtError("SASRecADT (adt_amd, wide path): hidden_units in {64,128,192,256}, head size 16..128, maxlen <= 256; got d=%d H=%d L=%d"
                                 % (d, H, self.maxlen))
-        self._build_flat(param_table(item_num, args.maxlen, d, H, args.num_layers), args.device)   # item table first: adt_clip_adam's wd term
+        self._build_flat(param_table(item_num, args.maxlen, d, H, args.num_layers), args.device, REF_ORDER)   # item table first: adt_clip_adam's wd term
         g = torch.Generator(device="cpu").manual_seed(torch.initial_seed() % (1 << 31))
         for name, shape in self.table:
             v = self.P(name)
@@ -67,7 +76,7 @@ class SASRecADTWide(FlatModule):
             if rep is None:
                 ops.embed_bwd(ids, x.g, L, p, self._seed, site, G("item_emb.weight"), G("pos_emb.weight"), tp.row_offset)
             else:      # item rows through the zeroed replicas (popular items: same-address float atomics serialise), positions directly
-                ops.item_scatter(ids, x.g, None, float(self.hidden_units) ** 0.5, p, self._seed, site, tp.row_offset, rep, NREP, self._rep_stride)
+                ops.item_scatter(ids, x.g, None, float(self.hidden_units) ** 0.5, p, self._seed, site, tp.row_offset, rep, self._nrep, self._rep_stride)
                 ops.posemb_bwd(ids, x.g, L, p, self._seed, site, tp.row_offset, G("pos_emb.weight"))
         tp.bw.append(bw)
         return x
@@ -149,6 +158,7 @@ class SASRecADTWide(FlatModule):
 
     def _decode(self, tp, dec, feats, B):
         y = self._embed(tp, dec, SITE_EMB_DEC)
+        tp.mark_decoder_start()
         outs = []
         for i in range(self.num_layers):
             y = self._dec_layer(tp, "decoder.decoder_layers.%d" % i, y, feats, dec, B, dec_sites(i))
@@ -206,14 +216,15 @@ class SASRecADTWide(FlatModule):
         # item-table gradient through NREP zeroed replicas, reduced once after the backward (as the fused executor does)
         n_table = gE.numel()
         if getattr(self, "_rep", None) is None:
+            self._nrep = n_replicas(n_table)
             self._rep_stride = (n_table + 3) // 4 * 4
-            self._rep = torch.zeros(NREP * self._rep_stride, device=self.dev, dtype=torch.float32)
-        else:
+            self._rep = gE.view(-1) if self._nrep == 1 else torch.zeros(self._nrep * self._rep_stride, device=self.dev, dtype=torch.float32)
+        elif self._nrep > 1:
             self._rep.zero_()
         tp.item_rep = self._rep
         give(feats, ops.logits_bwd_df(E, pos.view(-1), neg.view(-1), dpos, dneg))
-        ops.item_scatter(pos.view(-1), feats.t, dpos, 1.0, 0.0, None, 0, 0, self._rep, NREP, self._rep_stride)
-        ops.item_scatter(neg.view(-1), feats.t, dneg, 1.0, 0.0, None, 0, 0, self._rep, NREP, self._rep_stride)
+        ops.item_scatter(pos.view(-1), feats.t, dpos, 1.0, 0.0, None, 0, 0, self._rep, self._nrep, self._rep_stride)
+        ops.item_scatter(neg.view(-1), feats.t, dneg, 1.0, 0.0, None, 0, 0, self._rep, self._nrep, self._rep_stride)
         i = 0
         for i in range(nl):
             a, bq = enc_in[i], dec_outs[nl - 1 - i]
@@ -227,7 +238,8 @@ class SASRecADTWide(FlatModule):
                 recs[l].g = torch.empty_like(recs[l].t)
                 ops.nll_seed(recs[l].t, H, lambdas2[i], norms, recs[l].g, loss_slots[2 + nl + l])     # stale index (main.py:169)
         tp.backward()
-        ops.replica_reduce(gE, self._rep, NREP, self._rep_stride)
+        if self._nrep > 1:
+            ops.replica_reduce(gE, self._rep, self._nrep, self._rep_stride)
 
 
 class WideSasrecTrainer:
@@ -238,8 +250,9 @@ class WideSasrecTrainer:
         self.lr, self.betas, self.eps, self.wd, self.clip = lr, betas, eps, weight_decay, clip
         self.pg = process_group
         self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
-        self.use_graph = use_graph and self.world == 1
+        self.use_graph = use_graph       # data-parallel steps are captured too (RCCL collectives are graph nodes)
         dev = model.dev
+        self._buckets = GradBuckets(model.flat_grad, model.offset_of("decoder.decoder_layers.0.layer_norm.weight"), process_group)
         self.m, self.v = torch.zeros_like(model.flat), torch.zeros_like(model.flat)
         self.scal = torch.zeros(192, device=dev, dtype=torch.float32)
         nl = model.num_layers
@@ -248,6 +261,7 @@ class WideSasrecTrainer:
         self._loss_w = torch.tensor(w, device=dev, dtype=torch.float32)
         model.set_seed(seed * 1000003 + 12345)
         self._graph, self._st = None, None
+        self.nstep = 0
 
     def stage(self, seq, dec, pos, neg, norms=None):
         m = self.model
@@ -262,14 +276,15 @@ class WideSasrecTrainer:
         m._seed.add_(-1640531535)
         self.loss_slots.zero_()
         m.flat_grad.zero_()
+        m.dp_hook = self._buckets.tail_ready if self._buckets.active else None
         m.loss_forward_backward((st["seq"], st["dec"], st["pos"], st["neg"]), self.lambdas1, self.lambdas2, st["norms"], self.loss_slots, b_offset)
-        if self.world > 1:
-            torch.distributed.all_reduce(m.flat_grad, group=self.pg)
+        self._buckets.finish()
         ops.clip_adam(m.flat, m.flat_grad, self.m, self.v, (m.item_num + 1) * m.hidden_units, self.wd, self.clip, self.lr, self.betas[0],
                       self.betas[1], self.eps, self.scal)
 
     def step(self, seq, dec, pos, neg, norms=None, b_offset=0):
         self.model.train()
+        self.nstep += 1
         st = self.stage(seq, dec, pos, neg, norms)
         if self._st is None or self._st["B"] != st["B"]:
             self._st = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in st.items()}
@@ -290,7 +305,10 @@ class WideSasrecTrainer:
         self._graph.replay()
 
     def loss(self):
-        return (self.loss_slots.sum(1) * self._loss_w).sum() + self.scal[3]
+        slots = self.loss_slots.sum(1)
+        if self.world > 1:
+            slots = reduce_sum(slots, self.pg)
+        return (slots * self._loss_w).sum() + self.scal[3]
 
     def grad_norm(self):
         return self.scal[1].sqrt()

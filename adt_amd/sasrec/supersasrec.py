@@ -19,6 +19,7 @@ import torch
 
 from .. import _lib, ops
 from ..wide import Act, FlatModule, Tape, give
+from .model import REF_ORDER
 
 LN_EPS = 1e-8
 SITE_EMB_SEQ, SITE_EMB_DEC = 1, 2
@@ -89,7 +90,7 @@ class SuperSASRecModel(FlatModule):
         for i in range(self.num_layers):
             for c in range(self.block):
                 table += [("decoder.decoder_layers.%d.%d.%s" % (i, c, n), s) for n, s in zip(_DEC, ds)]
-        self._build_flat(table, args.device)
+        self._build_flat(table, args.device, REF_ORDER)
         g = torch.Generator(device="cpu").manual_seed(torch.initial_seed() % (1 << 31))
         for name, shape in self.table:     # evolution.py:103-107: xavier_normal_ on >= 2-D tensors; 1-D keep torch defaults
             v = self.P(name)

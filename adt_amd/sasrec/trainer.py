@@ -13,7 +13,8 @@ import ctypes
 import numpy as np
 import torch
 
-from .. import _lib
+from .. import _lib, ops
+from ..dp import GradBuckets, reduce_sum
 from .model import WS_LOSS, WS_NORMS
 
 
@@ -27,7 +28,7 @@ class FusedTrainer:
         self.pg = process_group
         self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
         self.rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
-        self.use_graph = use_graph and self.world == 1
+        self.use_graph = use_graph       # the data-parallel step is captured too: RCCL collectives are graph nodes
         dev = model.dev
         self.m = torch.zeros_like(model.flat)
         self.v = torch.zeros_like(model.flat)
@@ -35,30 +36,38 @@ class FusedTrainer:
         self.base_seed = seed
         self.nstep = 0
         self._B = -1
-        self._graph = None
+        self._bstate = {}
         nl, H = model.num_layers, model.num_heads
         w = [1.0, 1.0] + self.lambdas1 + [self.lambdas2[nl - 1] if H > 1 else 0.0] * nl   # stale-index NLL weight
         self._loss_w = torch.tensor(w, device=dev, dtype=torch.float32)
         # bucket boundary for the overlapped all-reduce: decoder parameters start at this flat offset
         self._dec_off = model.offsets[4 + 14 * nl]
+        self._buckets = GradBuckets(model.flat_grad, self._dec_off, process_group)
 
     # ------------------------------------------------------------------------------------------
     def _alloc(self, B):
+        """Per-batch-size state (id staging ring, device id buffer, captured graph), cached: the trailing partial batch of an
+        epoch and the regular batch each keep theirs, so switching B neither re-captures nor invalidates a live graph."""
         m = self.model
-        T = B * m.maxlen
-        self._B, self._T = B, T
-        n_int = 4 * T + 4   # seq, dec, pos, neg, 3 normalisers (float bits), pad
+        st = self._bstate.get(B)
+        if st is None:
+            T = B * m.maxlen
+            n_int = 4 * T + 4   # seq, dec, pos, neg, 3 normalisers (float bits), pad
+            st = {"T": T, "ring": [torch.empty(n_int, dtype=torch.int32).pin_memory() for _ in range(3)], "ring_ev": [None] * 3,
+                  "devbuf": torch.empty(n_int, device=m.dev, dtype=torch.int32), "graph": None}
+            self._bstate[B] = st
+            m.workspace(B)
         # Pinned staging ring: the H2D copy of step n is asynchronous, so the host may only refill a buffer once the copy that
         # last read it has executed (its event).  Three buffers keep the host two steps ahead of the device without waiting.
-        self._ring = [torch.empty(n_int, dtype=torch.int32).pin_memory() for _ in range(3)]
-        self._ring_ev = [None] * 3
+        self._B, self._T = B, st["T"]
+        self._ring, self._ring_ev = st["ring"], st["ring_ev"]
         self._ring_i = 0
         self._host = self._ring[0]
-        self._devbuf = torch.empty(n_int, device=m.dev, dtype=torch.int32)
+        self._devbuf = st["devbuf"]
+        T = self._T
         self._ids = [self._devbuf[i * T:(i + 1) * T].view(B, m.maxlen) for i in range(4)]
         self._norms_dev = self._devbuf[4 * T:4 * T + 4].view(torch.float32)     # 3 normalisers + a zero pad word
-        m.workspace(B)
-        self._graph = None
+        self._st = st
 
     def _launch(self, B, b_offset):
         """Everything after the H2D copy; capturable."""
@@ -66,24 +75,20 @@ class FusedTrainer:
         seq, dec, pos, neg = self._ids
         m._seed.add_(-1640531535)   # += 0x9E3779B1 (mod 2^32): a fresh dropout stream every step, on the device
         # a kernel, not tensor.copy_: inside a captured step that would be a memcpy NODE (see DESIGN.md on captured memset nodes)
-        from .. import ops
         ops.axpy(m.ws_view(B, WS_NORMS, 0, 4), self._norms_dev, 1.0, False)
         m.run_forward(seq, dec, pos, neg, B, True, b_offset)
         m.run_loss_seed(pos, B, self.lambdas1, self.lambdas2)
         m.flat_grad.zero_()
-        if self.world == 1:
+        if not self._buckets.active:
             m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=0)
         else:
             # two buckets: the decoder bucket's all-reduce (RCCL, its own stream) overlaps the encoder's backward.
             # NOTE: phase 1 also scatters the decoder-input embedding rows, which live in the encoder bucket
             # (item/pos tables at flat offset 0) -- that bucket is reduced after phase 2, so nothing is lost.
             m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=1)
-            h1 = torch.distributed.all_reduce(m.flat_grad[self._dec_off:], group=self.pg, async_op=True)
+            self._buckets.tail_ready()
             m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=2)
-            h2 = torch.distributed.all_reduce(m.flat_grad[:self._dec_off], group=self.pg, async_op=True)
-            h1.wait()
-            h2.wait()
-        from .. import ops
+            self._buckets.finish()
         ops.clip_adam(m.flat, m.flat_grad, self.m, self.v, (m.item_num + 1) * m.hidden_units, self.wd, self.clip, self.lr,
                       self.betas[0], self.betas[1], self.eps, self.scal)
 
@@ -116,7 +121,7 @@ class FusedTrainer:
         hn[4 * T + 3] = 0
         return B
 
-    def stage(self, batch, norms=None, **_):
+    def stage(self, batch, norms=None):
         """Upload one id batch (+ normalisers) to HBM ahead of time; returns the device buffer for step_staged."""
         self._fill_host(*batch, norms)
         buf = torch.empty_like(self._devbuf)
@@ -146,21 +151,25 @@ class FusedTrainer:
         if not self.use_graph:
             self._launch(B, b_offset)
             return
-        if self._graph is None:
+        st = self._st
+        if st["graph"] is None or st["b_offset"] != b_offset:
             # warm up once eagerly (hipFuncSetAttribute etc. are not capturable), then capture
             self._launch(B, b_offset)
             torch.cuda.synchronize()
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
                 self._launch(B, b_offset)
+            st["graph"], st["b_offset"] = g, b_offset
             return
-        self._graph.replay()
+        st["graph"].replay()
 
     def loss(self):
         """Device scalar: the loss of the last step as the reference prints it (sasrec/main.py:174)."""
         m = self.model
         n = 2 + 2 * m.num_layers
         slots = m.ws_view(self._B, WS_LOSS, 0, 64 * n).view(n, 64).sum(1)   # 64 sub-slots per loss term
+        if self.world > 1:          # every rank holds its shard's partial sums (already over the global normalisers)
+            slots = reduce_sum(slots.clone(), self.pg)
         return (slots * self._loss_w).sum() + self.scal[3]
 
     def grad_norm(self):

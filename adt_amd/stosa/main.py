@@ -67,15 +67,24 @@ def _write_synthetic(path, users=22363, items=12101, seed=42):
 
 
 def _evaluate(trainer, ds, matrix, batch_size):
+    """Full-sort scores of the whole user set on every rank: under data parallelism rank r sorts batches r, r+W, ... on its GPU
+    and the (N, 40) id lists are gathered (a few hundred KB)."""
     def gen():
-        for users, inp, dec, pos, neg, ans in ds.epoch_batches(batch_size, shuffle=False):
-            yield inp, matrix[users], ans
+        for i, (users, inp, dec, pos, neg, ans) in enumerate(ds.epoch_batches(batch_size, shuffle=False)):
+            if i % trainer.world == trainer.rank:
+                yield inp, matrix[users], ans
     pred, answers = trainer.full_sort(gen())
+    if trainer.world > 1:
+        parts = [None] * trainer.world
+        torch.distributed.all_gather_object(parts, (pred, answers), group=trainer.pg)
+        pred, answers = np.concatenate([p for p, _ in parts]), np.concatenate([a for _, a in parts])
     return get_full_sort_score(answers, pred)
 
 
 def main(argv=None):
     args = parse_args(argv)
+    from ..dp import init_from_env, shard_bounds, skip_batch
+    pg, rank, world, local = init_from_env("nccl")     # torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE
     args = U.set_template(args)
     if args.override:
         for k, v in json.loads(args.override).items():
@@ -84,9 +93,14 @@ def main(argv=None):
     torch.manual_seed(args.seed)
     os.makedirs(args.output_dir, exist_ok=True)
     data_file = os.path.join(args.data_dir, args.dataset + ".txt")
+    if pg is not None:
+        args.device = "cuda:%d" % local
     if not os.path.exists(data_file) and args.synthetic:
-        os.makedirs(args.data_dir, exist_ok=True)
-        _write_synthetic(data_file)
+        if rank == 0:
+            os.makedirs(args.data_dir, exist_ok=True)
+            _write_synthetic(data_file)
+        if world > 1:
+            torch.distributed.barrier()
     user_seq, max_item, valid_matrix, test_matrix, num_users = get_user_seqs(data_file)
     args.item_size, args.num_users, args.mask_id = max_item + 2, num_users, max_item + 1
     lambda1, lambda2 = U.get_lambdas(args.dataset, args.topk)
@@ -95,35 +109,49 @@ def main(argv=None):
     valid_ds = DisenDataset(args, user_seq, "valid", args.eval_set, seed=args.seed + 1)
     test_ds = DisenDataset(args, user_seq, "test", args.eval_set, seed=args.seed + 2)
     model = DisenDistSAModel(args)
+    if world > 1:
+        torch.distributed.broadcast(model.flat, 0)
     trainer = FusedStosaTrainer(model, lambda1, lambda2, lr=args.lr, betas=(args.adam_beta1, args.adam_beta2), weight_decay=args.weight_decay,
-                                use_graph=args.use_graph, seed=args.seed)
+                                process_group=pg, use_graph=args.use_graph, seed=args.seed)
     ckpt = os.path.join(args.output_dir, "adt-%s-%d-%d-%d.pt" % (args.dataset, args.hidden_units, args.num_layers, args.num_heads))
     best, wait, T, nseq = None, 0, 0.0, 0
     for epoch in range(args.epochs):
         t0 = time.time()
         for users, inp, dec, pos, neg, _ in train_ds.epoch_batches(args.batch_size):
-            if len(users) != args.batch_size:
+            if len(users) != args.batch_size or skip_batch(len(users), world):
                 continue          # one captured graph shape
-            trainer.step(inp, dec, pos, neg)
+            if pg is None:
+                trainer.step(inp, dec, pos, neg)
+            else:                 # same global batch on every rank (same seed); each trains on its rows with the GLOBAL normalisers
+                lo, hi = shard_bounds(len(users), rank, world)
+                trainer.step(inp[lo:hi], dec[lo:hi], pos[lo:hi], neg[lo:hi], n_target_global=int((np.asarray(pos) > 0).sum()), b_offset=lo,
+                             norms_scale=len(users) / float(hi - lo))
             nseq += len(users)
         torch.cuda.synchronize()
         T += time.time() - t0
         scores = _evaluate(trainer, valid_ds, valid_matrix, args.eval_batch_size)
-        parts = trainer.loss_parts().cpu().numpy()
-        print(json.dumps({"epoch": epoch, "train_seconds": T, "sequences_per_sec": nseq / max(T, 1e-9), "rec_cur_loss": float(trainer.loss()),
-                          "auc": float(parts[2]), "pvn_loss": float(parts[1]), "valid_HIT@10": scores[4], "valid_NDCG@10": scores[5], "valid_MRR": scores[-1]}),
-              flush=True)
+        parts = trainer.loss_parts().cpu().numpy()      # a collective under data parallelism: every rank calls it
+        if rank == 0:
+            print(json.dumps({"epoch": epoch, "train_seconds": T, "sequences_per_sec": nseq / max(T, 1e-9), "n_gpus": world,
+                              "rec_cur_loss": float((trainer._loss_w.cpu().numpy() * parts).sum()), "auc": float(parts[2]), "pvn_loss": float(parts[1]),
+                              "valid_HIT@10": scores[4], "valid_NDCG@10": scores[5], "valid_MRR": scores[-1]}), flush=True)
         if best is None or scores[-1] > best:       # EarlyStopping on MRR (stosa/main.py:122-126, utils.py:38-86)
             best, wait = scores[-1], 0
-            torch.save(model.state_dict(), ckpt)
+            if rank == 0:
+                torch.save(model.state_dict(), ckpt)
         else:
             wait += 1
             if wait >= args.patience:
                 break
+    if world > 1:
+        torch.distributed.barrier()
     model.load_state_dict(torch.load(ckpt))
     valid_scores = _evaluate(trainer, valid_ds, valid_matrix, args.eval_batch_size)
     scores = _evaluate(trainer, test_ds, test_matrix, args.eval_batch_size)
-    print("(%s, %s, %s, %s, %s, %s, %s, %s)" % (valid_scores[0], valid_scores[2], valid_scores[3], valid_scores[-1], scores[0], scores[2], scores[3], scores[-1]))
+    if rank == 0:
+        print("(%s, %s, %s, %s, %s, %s, %s, %s)" % (valid_scores[0], valid_scores[2], valid_scores[3], valid_scores[-1], scores[0], scores[2], scores[3], scores[-1]))
+    if pg is not None:
+        torch.distributed.destroy_process_group()
     return valid_scores, scores
 
 

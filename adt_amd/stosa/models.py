@@ -28,6 +28,13 @@ def dec_sites(i):
     return {"attn": b, "out_mean": b + 1, "out_cov": b + 2, "ffn_mean": b + 3, "ffn_cov": b + 4}
 
 
+# path components in the order the reference's constructors register them (stosa/models.py:169-178, modules.py)
+REF_ORDER = ["item_mean_embeddings", "item_cov_embeddings", "position_mean_embeddings", "position_cov_embeddings", "user_margins",
+             "item_encoder", "item_decoder", "layer", "attention", "dec_attention", "enc_attention", "mean_intermediate", "cov_intermediate",
+             "mean_independence_layer", "cov_independence_layer", "mean_query", "cov_query", "mean_key", "cov_key", "mean_value",
+             "cov_value", "mean_dense", "cov_dense", "dense_1", "dense_2", "LayerNorm", "decLayerNorm", "weight", "bias"]
+
+
 def param_table(item_size, maxlen, d, H, nl, num_users):
     """([(state_dict name, shape)] in flat order, index of the first parameter outside the loss graph).  Within an
     attention block the mean q/k/v weights (then biases), and the covariance ones, are consecutive so that each triple
@@ -80,7 +87,7 @@ class DisenDistSAModel(FlatModule):
         if getattr(args, "distance_metric", "wasserstein") != "wasserstein":
             raise _lib.AdtError("DisenDistSAModel (adt_amd): only distance_metric='wasserstein' is built")
         table, n_trained = param_table(args.item_size, args.maxlen, d, H, args.num_layers, args.num_users)
-        self._build_flat(table, getattr(args, "device", "cuda:0"))
+        self._build_flat(table, getattr(args, "device", "cuda:0"), REF_ORDER)
         self.n_trained_floats = self._views[table[n_trained][0]][0]     # optimizer prefix (flat floats)
         # init_weights (stosa/models.py:262-272): N(0.01, initializer_range) on Linear/Embedding weights, LayerNorm 1/0, biases 0
         g = torch.Generator(device="cpu").manual_seed(torch.initial_seed() % (1 << 31))
@@ -192,6 +199,7 @@ class DisenDistSAModel(FlatModule):
             enc_recs.append((rm, rc))
             m = self._intermediate(tp, p + ".mean_intermediate", hm, st["ffn_mean"], False)
             c = self._intermediate(tp, p + ".cov_intermediate", hc, st["ffn_cov"], True)
+        tp.mark_decoder_start()
         for i in range(self.num_layers):
             p = "item_decoder.layer.%d" % i
             st = dec_sites(i)

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from ..dp import GradBuckets, reduce_sum
 
 
 class FusedStosaTrainer:
@@ -25,7 +26,9 @@ class FusedStosaTrainer:
         self.pg = process_group
         self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
         self.rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
-        self.use_graph = use_graph and self.world == 1
+        self.use_graph = use_graph       # data-parallel steps are captured too (RCCL collectives are graph nodes)
+        self._buckets = GradBuckets(model.flat_grad, model.offset_of("item_decoder.layer.0.enc_attention.mean_query.weight"), process_group,
+                                    n=model.n_trained_floats)
         dev = model.dev
         self.m = torch.zeros_like(model.flat)
         self.v = torch.zeros_like(model.flat)
@@ -55,10 +58,10 @@ class FusedStosaTrainer:
         m._seed.add_(-1640531535)    # += 0x9E3779B1 (mod 2^32): a fresh dropout stream every step, on the device
         self.loss_slots.zero_()
         m.flat_grad.zero_()
+        m.dp_hook = self._buckets.tail_ready if self._buckets.active else None
         m.loss_forward_backward(st, self.lambda1, self.lambda2, st["norms"], self.loss_slots, b_offset)
+        self._buckets.finish()
         n = m.n_trained_floats
-        if self.world > 1:
-            torch.distributed.all_reduce(m.flat_grad[:n], group=self.pg)
         # no clip_grad_norm_ in the reference (trainer.py:557-559): clip = inf
         ops.clip_adam_l2(m.flat, m.flat_grad, self.m, self.v, self.wd, 1e30, self.lr, self.betas[0], self.betas[1], self.eps, self.scal, n=n)
 
@@ -94,11 +97,12 @@ class FusedStosaTrainer:
 
     def loss(self):
         """Device scalar: the loss of the last step as the reference accumulates it (trainer.py:561)."""
-        return (self.loss_slots.sum(1) * self._loss_w).sum()
+        return (self.loss_parts() * self._loss_w).sum()
 
     def loss_parts(self):
-        """{bpr, pvn (weighted), auc, mse.., nll..} of the last step."""
-        return self.loss_slots.sum(1)
+        """{bpr, pvn (weighted), auc, mse.., nll..} of the last step (summed over the ranks: each holds its shard's partial sums)."""
+        slots = self.loss_slots.sum(1)
+        return reduce_sum(slots, self.pg) if self.world > 1 else slots
 
     def grad_norm(self):
         return self.scal[1].sqrt()

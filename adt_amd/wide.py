@@ -25,13 +25,25 @@ def _set_nested(root, dotted, param):
     m.register_parameter(parts[-1], param)
 
 
+def ref_sorted(names, order):
+    """`names` (dotted parameter names) in the order the reference's nn.Module tree registers them, which is the order of
+    model.parameters() and therefore the key order of torch.optim.Adam.state_dict().  `order` lists path components in the
+    order the reference's constructors create them (siblings only are ever compared); numeric components sort as integers.
+    Pinned by tests/golden/param_order.json (tests/test_utils_cpu.py)."""
+    rank = {c: i for i, c in enumerate(order)}
+
+    def key(n):
+        return tuple((0, int(c)) if c.isdigit() else (1, rank[c]) for c in n.split("."))
+    return sorted(names, key=key)
+
+
 class FlatModule(torch.nn.Module):
     """nn.Module whose parameters are views into ONE flat fp32 GPU buffer (`flat`), with an identically laid-out
     gradient buffer (`flat_grad`): the optimizer and the gradient all-reduce see one array.  Tensors start on 16-byte
     boundaries; tensors listed consecutively with sizes that are multiples of 4 floats are contiguous, which is what
     lets q/k/v projections run as one GEMM over a (3d, d) view."""
 
-    def _build_flat(self, table, device):
+    def _build_flat(self, table, device, ref_order=None):
         self.lib = _lib.load()   # raises when the HIP library is missing: no fallback
         self.dev = torch.device(device)
         if self.dev.type != "cuda":
@@ -46,11 +58,19 @@ class FlatModule(torch.nn.Module):
         self.n_flat = off
         self.flat = torch.zeros(off, device=self.dev, dtype=torch.float32)
         self.flat_grad = torch.zeros_like(self.flat)
-        for name, shape in self.table:
-            o, n, _ = self._views[name]
+        # The flat layout follows `table` (what the kernels want: q/k/v consecutive, never-trained tensors last); the nn.Module
+        # registration follows the reference's constructor order so that parameters() lines up with the reference's optimizer.
+        names = [n for n, _ in self.table]
+        for name in (ref_sorted(names, ref_order) if ref_order else names):
+            o, n, shape = self._views[name]
             _set_nested(self, name, torch.nn.Parameter(self.flat[o:o + n].view(shape), requires_grad=True))
         self._seed = torch.zeros(1, device=self.dev, dtype=torch.int32)   # uint32 bits of the dropout seed, device resident
         self._step_seed = 0
+        self.dp_hook = None       # see Tape.mark_decoder_start
+
+    def offset_of(self, name):
+        """Flat offset (floats) of a parameter: bucket boundaries of the gradient all-reduce."""
+        return self._views[name][0]
 
     def _apply(self, fn, recurse=True):
         probe = fn(self.flat)
@@ -124,14 +144,27 @@ class Tape:
         self.seed = model._seed
         self.row_offset, self.b_offset = row_offset, b_offset
         self.bw = []
+        self.marks = {}
 
     def p_eff(self, p):
         return float(p) if self.training else 0.0
 
+    def mark_decoder_start(self):
+        """Called by a model's forward where its decoder stack begins: every closure recorded from here on belongs to the decoder
+        (and the output head after it), whose parameters sit at the END of the flat buffer.  In the backward, `model.dp_hook`
+        (the data-parallel trainers set it to GradBuckets.tail_ready) fires as soon as those closures have run, so that bucket's
+        all-reduce overlaps the encoder's backward and the embedding scatter."""
+        hook = getattr(self.m, "dp_hook", None)
+        if hook is not None:
+            self.marks[len(self.bw)] = hook
+
     def backward(self):
-        for f in reversed(self.bw):
-            f()
-        self.bw = []
+        for i in range(len(self.bw) - 1, -1, -1):
+            self.bw[i]()
+            hook = self.marks.get(i)
+            if hook is not None:
+                hook()
+        self.bw, self.marks = [], {}
 
     # ---- Linear (+ activation, dropout, residual) -------------------------------------------------------------------
     def dense(self, x, W, b, gW, gb, act=ops.ACT_NONE, p=0.0, site=0, R=None, t_dev=None, ldy=None, R2=None, mask_ids=None):

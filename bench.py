@@ -8,7 +8,9 @@ gradient all-reduce (N > 1), clip_grad_norm_ and Adam -- nothing skipped, dropou
 ml-1m-shaped id batches) are resident in HBM before the timed region.  One JSON line on stdout (rank 0).
 
     python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus 8 ...          # launches its own 8 ranks (torch.distributed.run, 127.0.0.1) when WORLD_SIZE is unset
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
+    python bench.py --force-dp            # one rank, but through the data-parallel path (1-rank RCCL group, bucketed all-reduce)
 """
 import argparse
 import json
@@ -134,6 +136,19 @@ def roofline_probe(model, trainer, B):
             "algorithmic_bytes_per_launch": alg_bytes}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) with torch.distributed.run on 127.0.0.1 and
+    pass their output through.  Runs BEFORE anything in this process touches the GPU; the parent only waits."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,30 +157,42 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dp", action="store_true", help="run the data-parallel code path even on one rank (1-rank RCCL group)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import torch
+        have = torch.cuda.device_count()      # counting devices does not initialise the GPU
+        if have < args.gpus:
+            sys.exit("bench.py: --gpus %d but this node shows %d GPU(s)" % (args.gpus, have))
+        sys.exit(self_launch(args.gpus))
+    if args.force_dp:
+        os.environ["ADT_FORCE_DP"] = "1"
 
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if args.gpus != world and rank == 0 and world > 1:
+    from adt_amd.dp import init_from_env
+    pg, rank, world, local = init_from_env("nccl")
+    if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     device = "cuda:%d" % local
     torch.cuda.set_device(local)
     from adt_amd.sasrec.trainer import FusedTrainer
     B = CFG["batch"]
     model = build_model(device, args.precision)
+    if world > 1:
+        dist.broadcast(model.flat, 0)
     tr = FusedTrainer(model, CFG["lambdas1"], CFG["lambdas2"], lr=CFG["lr"], weight_decay=CFG["weight_decay"], clip=CFG["clip"],
-                      process_group=dist.group.WORLD if world > 1 else None, use_graph=not args.no_graph, seed=23)
-    # weak scaling: every rank gets its own 256-sequence shard of a global batch of 256*N
+                      process_group=pg, use_graph=not args.no_graph, seed=23)
+    # weak scaling: every rank gets its own 256-sequence shard of a global batch of 256*N; loss normalisers are those of the
+    # GLOBAL batch (n_bce summed over ranks, B*L*d and B*L*H times N), dropout indices are global (b_offset)
     nb = 4
-    batches = synth_batches(nb, B, CFG["maxlen"], CFG["item_num"], seed=100 + rank)
-    staged = [tr.stage(b, norms_scale=world, b_offset=rank * B) for b in batches]
+    L, d, H = CFG["maxlen"], CFG["hidden_units"], CFG["num_heads"]
+    batches = synth_batches(nb, B, L, CFG["item_num"], seed=100 + rank)
+    nbce = torch.tensor([float(np.count_nonzero(b[2])) for b in batches], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(nbce)
+    norms = [(float(nbce[i]), float(world * B * L * d), float(world * B * L * H)) for i in range(nb)]
+    staged = [tr.stage(b, norms=norms[i]) for i, b in enumerate(batches)]
     torch.cuda.synchronize()
 
     def run(k0, k):
@@ -189,6 +216,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     loss = float(tr.loss())
+    # the same steps through trainer.step(): host int arrays -> pinned ring -> one async H2D copy per step -> the same launch
+    # sequence (SURVEY 8d counts the H2D of the ids in a step; `value` stays the HBM-resident rate, this one is reported beside it)
+    for i in range(3):
+        tr.step(*batches[i % nb], norms=norms[i % nb], b_offset=rank * B)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        tr.step(*batches[i % nb], norms=norms[i % nb], b_offset=rank * B)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt_h2d = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([dt_h2d], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_h2d = float(t)
     if rank == 0:
         res = {"metric": "train sequences/sec, SASRec-ADT ml-1m (seq_len=200, d=64, 2 blocks)", "value": round(world * B * args.steps / dt, 1),
                "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -196,14 +241,15 @@ def main():
                "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
                "config": {"workload": "SASRec-ADT ml-1m shape, 2 blocks d=64 H=2 seq_len=200, batch 256/GPU, dropout 0.5, "
                                       "full train step (fwd+loss+bwd+clip+Adam), ids resident in HBM",
-                          "global_batch": world * B, "seq_len": CFG["maxlen"], "parallelism": "dp%d" % world,
-                          "hip_graph": not args.no_graph and world == 1},
-               "loss_last_step": round(loss, 5)}
+                          "global_batch": world * B, "seq_len": CFG["maxlen"],
+                          "parallelism": "dp%d%s" % (world, "-rccl" if pg is not None else ""), "hip_graph": not args.no_graph},
+               "loss_last_step": round(loss, 5),
+               "value_incl_h2d": round(world * B * args.steps / dt_h2d, 1), "ms_per_step_incl_h2d": round(dt_h2d / args.steps * 1e3, 4)}
         res["roofline"] = roofline_probe(model, tr, B)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.force_dp:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if pg is not None:
         dist.barrier()
         dist.destroy_process_group()
 

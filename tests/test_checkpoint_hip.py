@@ -94,7 +94,34 @@ def _stosa(seed):
     return m, tr, batches
 
 
-MAKERS = {"sasrec": _sasrec, "bert": _bert, "stosa": _stosa}
+def _wide(seed):
+    """SASRec-ADT on the general (template-width) path: what adt_amd/sasrec/main.py picks for hidden_units != 64."""
+    from adt_amd.sasrec.model_wide import SASRecADTWide, WideSasrecTrainer
+    a = Args()
+    a.device, a.num_heads, a.maxlen, a.num_layers, a.hidden_units, a.dropout, a.precision = "cuda:0", 2, 24, 1, 128, 0.3, "f32"
+    torch.manual_seed(seed)
+    m = SASRecADTWide(1, 300, a)
+    for _, p in m.named_parameters():
+        if p.dim() >= 2:
+            torch.nn.init.xavier_normal_(p.data)
+    m.train()
+    tr = WideSasrecTrainer(m, [0.1], [0.1], lr=LR, weight_decay=1e-3, clip=5.0, use_graph=False, seed=5)
+    return m, tr, _sasrec_batches(24)
+
+
+def _sasrec_batches(L, n=4, B=16, V=300):
+    r = np.random.RandomState(1)
+    batches = []
+    for _ in range(n):
+        seq = r.randint(1, V + 1, size=(B, L)); seq[:, :7] = 0
+        dec = np.roll(seq, 1, 1); dec[:, 0] = 0
+        pos = r.randint(1, V + 1, size=(B, L)) * (seq > 0)
+        neg = r.randint(1, V + 1, size=(B, L)) * (seq > 0)
+        batches.append((seq, dec, pos, neg))
+    return batches
+
+
+MAKERS = {"sasrec": _sasrec, "bert": _bert, "stosa": _stosa, "wide": _wide}
 
 
 def _far(a, b):
@@ -102,7 +129,7 @@ def _far(a, b):
     return float((d > 1e-5).float().mean()), float(d.max())
 
 
-@pytest.mark.parametrize("kind", ["sasrec", "bert", "stosa"])
+@pytest.mark.parametrize("kind", ["sasrec", "bert", "stosa", "wide"])
 def test_resume_equals_uninterrupted(kind, tmp_path):
     from adt_amd import checkpoint as ck
     m, tr, batches = MAKERS[kind](11)
@@ -133,7 +160,7 @@ def test_resume_equals_uninterrupted(kind, tmp_path):
     assert frac3 > 0.2, frac3
 
 
-@pytest.mark.parametrize("kind", ["sasrec", "bert", "stosa"])
+@pytest.mark.parametrize("kind", ["sasrec", "bert", "stosa", "wide"])
 def test_torch_adam_interop(kind):
     from adt_amd import checkpoint as ck, ops
     m, tr, batches = MAKERS[kind](11)
@@ -179,3 +206,76 @@ def test_torch_adam_interop(kind):
         assert torch.equal(tr2.m[off:off + p.numel()], m0[o1:o1 + p.numel()])
         assert torch.equal(tr2.v[off:off + p.numel()], v0[o1:o1 + p.numel()])
     assert float(tr2.scal[2]) == 3.0 and tr2.nstep == 3
+
+
+def _super(seed):
+    from adt_amd.sasrec.supersasrec import SuperSASRecModel, SuperTrainer
+    a = Args()
+    a.device, a.num_heads, a.maxlen, a.num_layers, a.hidden_units, a.dropout, a.precision = "cuda:0", 2, 24, 1, 64, 0.2, "f32"
+    torch.manual_seed(seed)
+    m = SuperSASRecModel(1, 300, [0.0, 0.5, 1.0], [0.0, 0.5, 1.0], a)
+    tr = SuperTrainer(m, lr=LR, weight_decay=1e-4, seed=5)
+    return m, tr, _sasrec_batches(24)
+
+
+def test_supernet_resume_equals_uninterrupted(tmp_path):
+    """SuperTrainer keeps one Adam step count per candidate range on the host and has no `scal`: the checkpoint must carry both."""
+    from adt_amd import checkpoint as ck
+    cands = [[0.2, 0.7], [0.9, 0.1], [0.2, 0.7], [0.55, 0.45]]
+    m, tr, batches = _super(11)
+    for c, b in zip(cands, batches):
+        tr.set_choice(c)
+        tr.step(*b)
+    want = m.flat.clone()
+    m1, tr1, _ = _super(11)
+    for c, b in zip(cands[:2], batches[:2]):
+        tr1.set_choice(c)
+        tr1.step(*b)
+    path = os.path.join(tmp_path, "ck.pt")
+    ck.save(path, m1, tr1)
+    m2, tr2, _ = _super(99)
+    ck.load(path, m2, tr2)
+    assert tr2.steps == tr1.steps and len(tr2.steps) > 0
+    for c, b in zip(cands[2:], batches[2:]):
+        tr2.set_choice(c)
+        tr2.step(*b)
+    frac, worst = _far(m2.flat, want)
+    assert frac < 1e-3 and worst <= 4 * LR, (frac, worst)
+
+
+def test_adam_state_lands_on_the_references_parameter_positions():
+    """Position i of the exported optimizer state is the reference's i-th parameter (tests/golden/param_order.json): the third
+    parameter of the reference SASRecADT is the first encoder LayerNorm weight, not last_layernorm (which sits third in OUR flat buffer)."""
+    import json
+    from adt_amd import checkpoint as ck
+    m, tr, batches = _sasrec(11)
+    tr.step(*batches[0])
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "param_order.json")))["sasrec_nl2"]
+    names = [n for n, _ in m.named_parameters()]
+    assert names == want
+    osd = ck.to_torch_adam_state(tr, skip_untrained=False)
+    for i, n in enumerate(names):
+        off, cnt, shape = m._views[n]
+        assert torch.equal(osd["state"][i]["exp_avg"], tr.m[off:off + cnt].view(shape)), n
+
+
+def test_graph_step_survives_predict_at_another_batch_size():
+    """a captured training graph holds raw pointers into the model workspace; predict() at another B used to reallocate
+    that one buffer.  graph step -> predict_rank(B') -> graph step must equal the same two steps without the predict."""
+    outs = []
+    for with_predict in (False, True):
+        m, tr, batches = _sasrec(11)
+        tr.use_graph = True
+        tr.step(*batches[0])       # eager warm-up + capture
+        tr.step(*batches[1])       # replay
+        if with_predict:
+            r = np.random.RandomState(5)
+            m.eval()
+            m.predict_rank(r.randint(1, 301, size=(37, 40)), r.randint(1, 301, size=(37, 11)))
+            m.train()
+        tr.step(*batches[2])       # replay again: same workspace as captured?
+        torch.cuda.synchronize()
+        outs.append((m.flat.clone(), float(tr.loss())))
+    frac, worst = _far(outs[0][0], outs[1][0])
+    assert frac < 1e-3 and worst <= 4 * LR, (frac, worst)
+    assert abs(outs[0][1] - outs[1][1]) < 1e-4 * abs(outs[0][1])

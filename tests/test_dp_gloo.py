@@ -1,7 +1,8 @@
-"""CPU, world_size 2, gloo: the data-parallel step (adt_amd/dp.py) reproduces the single-process step on the same
-global batch -- with dropout ON (global mask indices), an uneven split (5 sequences over 2 ranks) and bucketed
-all-reduce.  The compute engine here is the numpy oracle (test infrastructure standing in for the HIP engine, which
-needs a GPU); the HIP trainer uses the same sharding / normaliser / bucket code."""
+"""CPU, world_size 2, gloo: the data-parallel layer every fused trainer uses (adt_amd/dp.py: shard_bounds, global_norms,
+GradBuckets) reproduces the single-process step on the same global batch -- with dropout ON (global mask indices), an uneven
+split (5 sequences over 2 ranks) and the two-bucket all-reduce with the tail bucket issued before the backward has finished.
+The compute engine here is the numpy oracle (test infrastructure standing in for the HIP engine, which needs a GPU); the
+same GradBuckets object drives RCCL in the HIP trainers (tests/test_dp_gpu.py, tests/test_dp_nccl.py)."""
 import os
 import sys
 
@@ -58,16 +59,30 @@ class OracleEngine:
         so.clip_adam(self.P, G, self.state, lr=1e-3, clip=5.0)
 
 
+def dp_step(eng, cfg, batch, rank, world, group):
+    """What each fused trainer's _launch does, with the oracle as the engine: own shard with global normalisers -> gradient ->
+    tail bucket out, head bucket out, wait -> weight-decay term + clip + Adam on the reduced buffer."""
+    from adt_amd.dp import GradBuckets, global_norms, shard_bounds
+    seq, dec, pos, neg = batch
+    lo, hi = shard_bounds(len(seq), rank, world)
+    flat = eng.forward_backward((seq[lo:hi], dec[lo:hi], pos[lo:hi], neg[lo:hi]), global_norms(pos, cfg.hidden_units, cfg.num_heads), lo)
+    buckets = GradBuckets(flat, flat.numel() // 3, group)
+    buckets.tail_ready()
+    buckets.finish()
+    eng.apply(flat)
+    return flat
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from adt_amd.dp import DPStep
+    os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = str(rank), str(world), str(rank)
+    from adt_amd.dp import init_from_env
+    pg, r, w, _ = init_from_env("gloo")
+    assert (r, w) == (rank, world) and pg is not None
     so, cfg, P, batch = _setup()
     eng = OracleEngine(so, cfg, P, seed=77)
-    n = sum(eng.sizes)
-    dp = DPStep(eng, cfg.hidden_units, cfg.num_heads, rank, world, None, bucket_boundaries=[n // 3, n // 2])
     for _ in range(2):
-        flat = dp.step(*batch)
+        flat = dp_step(eng, cfg, batch, rank, world, pg)
     if rank == 0:
         q.put(({k: v.copy() for k, v in P.items()}, flat.numpy().copy()))
     dist.barrier()
@@ -76,14 +91,17 @@ def _worker(rank, world, port, q):
 
 def test_two_ranks_reproduce_single_process_step():
     so, cfg, P, batch = _setup()
-    from adt_amd.dp import DPStep, shard_bounds, global_norms
+    from adt_amd.dp import shard_bounds, global_norms, skip_batch
     assert [shard_bounds(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
     assert [shard_bounds(256, r, 8) for r in range(8)][-1] == (224, 256)
+    # the 34-row trailing batch of Amazon-Beauty (40,226 % 256) over 8 ranks: balanced, nobody empty, rows covered once
+    b34 = [shard_bounds(34, r, 8) for r in range(8)]
+    assert b34[0] == (0, 5) and b34[-1] == (30, 34) and all(hi > lo for lo, hi in b34) and all(b34[i][1] == b34[i + 1][0] for i in range(7))
+    assert skip_batch(5, 8) and not skip_batch(8, 8)
     assert global_norms(batch[2], 32, 2)[1:] == (5 * 12 * 32.0, 5 * 12 * 2.0)
     eng = OracleEngine(so, cfg, P, seed=77)
-    single = DPStep(eng, cfg.hidden_units, cfg.num_heads)
     for _ in range(2):
-        flat1 = single.step(*batch)
+        flat1 = dp_step(eng, cfg, batch, 0, 1, None)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
