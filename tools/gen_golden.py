@@ -298,6 +298,11 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["beauty"]:
+        # BASELINE configs[3]: SASRec-ADT at the Amazon-Beauty template shape (sasrec/templates/beauty.json: d=256, H=2, L=50,
+        # wd 1e-4; sasrec/data/beauty.txt has 54,542 items; get_lambdas("beauty")), B=8
+        case_sampled("sasrec_cfg4_beauty", V=54542, L=50, d=256, H=2, nl=2, B=8, seed=31, lam1=[0.0124, 0.122], lam2=[0.0001, 0.0], wd=1e-4)
+        sys.exit(0)
     case_small("sasrec_small", B=4, L=16, d=32, H=2, nl=2, V=50, seed=11,
                lam1=[0.104292, 0.065892], lam2=[0.100833, 0.000607], wd=1e-3)
     case_small("sasrec_small_h1", B=3, L=12, d=16, H=1, nl=1, V=30, seed=13, lam1=[0.05], lam2=[0.02], wd=1e-4)

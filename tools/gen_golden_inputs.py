@@ -22,3 +22,36 @@ def make_batch(r, B, L, V, max_pad_frac=0.9):
 
 def sample_idx(n, k=256):
     return (np.arange(min(k, n), dtype=np.int64) * 7919) % n
+
+
+def compact(out, keep=(), k=1024, thresh=8192):
+    """Fixtures at the BASELINE configurations' own shapes would be hundreds of MB: every float array larger than `thresh` elements
+    becomes its Frobenius norm (`key@norm`) plus `k` strided samples (`key@sample`, indices sample_idx(size, k))."""
+    res = {}
+    for key, v in out.items():
+        a = np.asarray(v)
+        if key in keep or a.dtype.kind != "f" or a.size <= thresh:
+            res[key] = v
+            continue
+        t = a.reshape(-1)
+        res[key + "@norm"] = np.float64(np.sqrt((t.astype(np.float64) ** 2).sum()))
+        res[key + "@sample"] = t[sample_idx(t.size, k)].copy()
+    return res
+
+
+def golden_err(got, g, key, k=1024):
+    """Relative error of `got` against fixture entry `key`, stored whole or compacted (see compact()): max |diff| over the stored
+    entries relative to the reference's magnitude, and -- for compacted entries -- also the relative error of the norm."""
+    got = np.asarray(got, np.float64)
+    if key in g.files:
+        want = np.asarray(g[key], np.float64)
+        assert got.shape == want.shape, (key, got.shape, want.shape)
+        return np.abs(got - want).max() / max(np.abs(want).max(), 1e-6)
+    want = np.asarray(g[key + "@sample"], np.float64)
+    norm = float(g[key + "@norm"])
+    t = got.reshape(-1)
+    s = t[sample_idx(t.size, k)]
+    scale = max(np.abs(want).max(), norm / np.sqrt(max(t.size, 1)), 1e-9)
+    e_s = np.abs(s - want).max() / scale
+    e_n = abs(np.sqrt((t ** 2).sum()) - norm) / max(norm, 1e-9)
+    return max(e_s, e_n)

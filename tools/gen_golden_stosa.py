@@ -40,7 +40,7 @@ def stosa_batch(r, B, L, V):
     return inp, dec, pos, neg
 
 
-def gen_stosa(tag, cfg_kw, B, seed, lam1, lam2, lr=1e-3, keep_w3=True):
+def gen_stosa(tag, cfg_kw, B, seed, lam1, lam2, lr=1e-3, keep_w3=True, compact=False, steps=3):
     from tools.gen_golden_wide import _import_from
     from oracle import stosa_oracle as so
     models = _import_from("/root/reference/stosa", "models")
@@ -78,7 +78,7 @@ def gen_stosa(tag, cfg_kw, B, seed, lam1, lam2, lr=1e-3, keep_w3=True):
     m.train()
     opt = torch.optim.Adam(m.parameters(), lr=lr, betas=(0.9, 0.999), weight_decay=0.0)
     wd = modules.wasserstein_distance
-    for step in range(3):
+    for step in range(steps):
         mo, co, att, margins, enc_in, enc_rec, dec_out = m.finetune(t[0], t[1], uid)
         # bpr_optimization (trainer.py:358-391)
         act = nn.ELU()
@@ -121,6 +121,9 @@ def gen_stosa(tag, cfg_kw, B, seed, lam1, lam2, lr=1e-3, keep_w3=True):
             for k, p in m.named_parameters():
                 out["w%d." % (step + 1) + k] = p.detach().numpy().copy()
     path = os.path.join(OUT, "stosa_%s.npz" % tag)
+    if compact:
+        from tools.gen_golden_inputs import compact as _compact
+        out = _compact(out)
     np.savez_compressed(path, **out)
     print("wrote", path, "loss", out["loss"], "none-grads", len(out["grad_none"]), "%.1f KB" % (os.path.getsize(path) / 1024))
 
@@ -132,6 +135,13 @@ def main():
               lam1=[0.25, 0.1], lam2=[0.15, 0.05], keep_w3=False)
     gen_stosa("h1", dict(item_size=28, maxlen=9, hidden_units=64, num_heads=1, num_layers=1, num_users=2, pvn_weight=0.05), B=2, seed=23,
               lam1=[0.1], lam2=[0.05], keep_w3=False)
+
+
+def main_cfg5():
+    """BASELINE configs[4]: STOSA-ADT at the Amazon-Beauty template shape (stosa/templates/Beauty.json: d=64, H=4, 1 layer, L=100,
+    pvn_weight 0.005; stosa/data/Beauty.txt has 12,101 items => item_size 12,103; 22,363 users), B=8; get_lambdas("Beauty")[:1]."""
+    gen_stosa("cfg5_beauty", dict(item_size=12103, maxlen=100, hidden_units=64, num_heads=4, num_layers=1, num_users=22363, pvn_weight=0.005), B=8,
+              seed=33, lam1=[0.0021], lam2=[0.0009], keep_w3=False, compact=True, steps=1)
 
 
 if __name__ == "__main__":

@@ -60,7 +60,7 @@ def bert_batch(r, B, L, V, mask_prob=0.3):
     return src, dec, lab
 
 
-def gen_bert(tag, cfg_kw, B, seed, lam1, lam2, wd=1e-4, lr=1e-3, clip=5.0, keep_w3=True):
+def gen_bert(tag, cfg_kw, B, seed, lam1, lam2, wd=1e-4, lr=1e-3, clip=5.0, keep_w3=True, compact=False, steps=3):
     from oracle import bert_oracle as bo
     bert = _import_from("/root/reference/bert4rec", "model.bert")
     cfg = bo.Cfg(**cfg_kw)
@@ -95,7 +95,7 @@ def gen_bert(tag, cfg_kw, B, seed, lam1, lam2, wd=1e-4, lr=1e-3, clip=5.0, keep_
     opt = torch.optim.Adam(m.parameters(), lr=lr, betas=(0.9, 0.999), weight_decay=wd)
     ce = torch.nn.CrossEntropyLoss(ignore_index=0)
     labels = torch.from_numpy(lab)
-    for step in range(3):
+    for step in range(steps):
         opt.zero_grad()
         logits, enc_in, dec_out, rec = m(tsrc, tdec, pos, sent, pos, sent)
         loss = ce(logits.view(-1, logits.size(-1)), labels.view(-1))
@@ -122,6 +122,9 @@ def gen_bert(tag, cfg_kw, B, seed, lam1, lam2, wd=1e-4, lr=1e-3, clip=5.0, keep_
             for k, p in m.named_parameters():
                 out["w%d." % (step + 1) + k] = p.detach().numpy().copy()
     path = os.path.join(OUT, "bert_%s.npz" % tag)
+    if compact:
+        from tools.gen_golden_inputs import compact as _compact
+        out = _compact(out)
     np.savez_compressed(path, **out)
     print("wrote", path, "loss", out["loss"], "grad_norm", out["grad_norm"], "%.1f KB" % (os.path.getsize(path) / 1024))
 
@@ -137,9 +140,18 @@ def main():
                  lam1=[0.25], lam2=[0.15])
         gen_bert("hd64", dict(item_num=25, maxlen=9, hidden_units=128, num_heads=2, num_layers=1, inner_units=64), B=2, seed=13,
                  lam1=[0.1], lam2=[0.05], keep_w3=False)
+    if "bert_cfg3" in which:
+        # BASELINE configs[2]: BERT4Rec-ADT at the ml-20m shape (26,744 items => vocabulary 26,844; d=256, H=4, inner=1024, L=200,
+        # 2 layers, get_lambda("ml-20m")), B=4: the reference's (4, 200, 26,844) logits are 86 MB; stored as norms + samples
+        gen_bert("cfg3_ml20m", dict(item_num=26744, maxlen=200, hidden_units=256, num_heads=4, num_layers=2, inner_units=1024), B=4, seed=31,
+                 lam1=[0.005435293808249262, 0.0019764407654292064], lam2=[0.0007068258408279514, 0.0013811031763964325], wd=1e-3,
+                 keep_w3=False, compact=True, steps=1)
     if "stosa" in which:
         from tools import gen_golden_stosa
         gen_golden_stosa.main()
+    if "stosa_cfg5" in which:
+        from tools import gen_golden_stosa
+        gen_golden_stosa.main_cfg5()
 
 
 if __name__ == "__main__":
