@@ -173,3 +173,39 @@ def test_supernet_matches_reference(tag):
         _adam_close(Pw[k], g["w1." + k], float(g["lr"]), 1, k, g["grad." + k])
     for k in none:
         assert np.array_equal(Pw[k], P[k])      # grad None: untouched, not even by the weight decay
+
+
+# ---- the oracles at the BASELINE configurations' own shapes (compacted fixtures: norms + strided samples) ------------------
+from tools.gen_golden_inputs import golden_err  # noqa: E402
+
+
+def test_stosa_oracle_at_beauty_shape():
+    """configs[4]: item_size 12,103, L=100, H=4, d=64, 1 layer, B=8 (tests/golden/stosa_cfg5_beauty.npz)."""
+    g, cfg, P = _stosa_case("cfg5_beauty")
+    m, c, enc_in, enc_rec, dec_out = so.finetune(P, cfg, g["input_ids"], g["dec_ids"], training=False)
+    assert golden_err(m, g, "mean_out") < 2e-5 and golden_err(c, g, "cov_out") < 2e-5
+    assert golden_err(dec_out[0][0], g, "dec_out_mean_0") < 2e-5 and golden_err(enc_rec[0][1], g, "rec_cov_0") < 2e-5
+    assert golden_err(so.predict_full(P, cfg, g["input_ids"], g["dec_ids"]), g, "full_dist") < 2e-5
+    lam1, lam2 = list(g["lambda1"]), list(g["lambda2"])
+    loss, parts, G = so.loss_and_grads(P, cfg, g["input_ids"], g["dec_ids"], g["pos_ids"], g["neg_ids"], lam1, lam2, training=True, seed=0)
+    assert abs(loss - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))
+    assert sorted(k for k in P if G[k] is None) == sorted(str(x) for x in g["grad_none"])
+    for k in P:
+        if G[k] is not None:
+            assert golden_err(G[k], g, "grad." + k) < 2e-4, k
+
+
+def test_bert_oracle_at_ml20m_shape():
+    """configs[2]: vocabulary 26,844, d=256, H=4, inner=1024, L=200, 2 layers (tests/golden/bert_cfg3_ml20m.npz); the first
+    two sequences of the recorded batch (the oracle is numpy: the full B=4 backward takes minutes)."""
+    g, cfg, P = _bert_case("cfg3_ml20m")
+    logits, enc_in, dec_out, rec = bo.forward(P, cfg, g["src"][:1], g["dec"][:1], training=False)
+    # batch rows are independent in eval mode: row 0 of the recorded tensors is every sample with flat index < row size
+    for got, key in ((logits, "logits"), (enc_in[1], "enc_in_1"), (dec_out[0], "dec_out_0"), (rec[1], "rec_1")):
+        n_total = 4 * got.size
+        idx = (np.arange(1024, dtype=np.int64) * 7919) % n_total
+        keep = idx < got.size
+        assert keep.sum() > 100, key
+        want = g[key + "@sample"][keep].astype(np.float64)
+        err = np.abs(got.reshape(-1)[idx[keep]].astype(np.float64) - want).max() / max(np.abs(want).max(), 1e-6)
+        assert err < 5e-5, (key, err)

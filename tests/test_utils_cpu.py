@@ -120,3 +120,26 @@ def test_parameter_registration_order_is_the_references(golden_dir):
     # and the golden state_dict of a recorded reference model lists its weights in that same order
     z = np.load(os.path.join(golden_dir, "sasrec_small.npz"))
     assert [k[2:] for k in z.keys() if k.startswith("w.")] == want["sasrec_nl2"]
+
+
+def test_synthetic_presets_have_the_baseline_configs_shapes(tmp_path):
+    """ml20m / beauty / beauty-stosa presets (BASELINE configs[2..4]): user and item counts exact, mean history near the
+    public figure, file in the reference's "<user> <item>" line format and readable by data_partition."""
+    from adt_amd.sasrec import synth
+    assert (synth.PRESETS["ml20m"]["users"], synth.PRESETS["ml20m"]["items"]) == (138493, 26744)
+    h, U, V = synth.generate("beauty", 23)
+    n = sum(len(v) for v in h.values())
+    assert (U, V) == (40226, 54542) and 8.0 < n / U < 10.0
+    assert max(max(v) for v in h.values()) <= V and min(min(v) for v in h.values()) >= 1
+    assert all(len(set(v)) == len(v) for v in list(h.values())[:2000])          # no repeated item inside a history
+    h2, _, _ = synth.generate("beauty", 23)
+    assert h2[17] == h[17] and h2[40226] == h[40226]                             # seeded
+    os.makedirs(tmp_path / "data")
+    small = {u: h[u] for u in range(1, 301)}
+    synth.write(str(tmp_path / "data" / "b.txt"), small)
+    tr, va, te, usernum, itemnum = U_data_partition("b", str(tmp_path / "data"))
+    assert usernum == 300 and all((len(small[u]) < 3) == (len(va[u]) == 0) for u in small)
+
+
+def U_data_partition(name, d):
+    return U.data_partition(name, d)
