@@ -45,24 +45,13 @@ static int launch_attn_gen(bool bwd, const AttnGenArgs& a, hipStream_t s) {
   return check_launch(bwd ? "attn_masked_bwd" : "attn_masked_fwd");
 }
 
-template <int PREC, int HD>
-static int dispatch_attn_gen_l(bool bwd, const AttnGenArgs& a, hipStream_t s) {
-  if (a.a.L <= 64) return launch_attn_gen<PREC, HD, 4>(bwd, a, s);
-  if (a.a.L <= 128) return launch_attn_gen<PREC, HD, 8>(bwd, a, s);
-  if (a.a.L <= 224) return launch_attn_gen<PREC, HD, 14>(bwd, a, s);
-  return adt_set_error("masked attention: L=%d > 224 unsupported", a.a.L);
-}
-
-// hd = 128 (sasrec d = 256, H = 2): forward with the whole (b, h) resident, backward staged in NCH chunks
-template <int PREC, int MAXKT, int NCH>
-static int launch_attn_gen_128(bool bwd, const AttnGenArgs& a, hipStream_t s) {
-  constexpr int NW = 8, HD = 128;
-  if (!bwd) {     // causal without key padding (the d = 256 SASRec template): skip the key tiles above the diagonal
-    const bool csk = a.a.causal && a.kid == nullptr && a.fill <= -1e9f;
-    return csk ? launch_attn_gen<PREC, HD, MAXKT, true>(false, a, s) : launch_attn_gen<PREC, HD, MAXKT, false>(false, a, s);
-  }
+// backward staged in NCH chunks of the sequence (k_attn_gen_bwd_chunked): hd = 128 always, and hd = 64 in the exact-fp32 mode at
+// L > 128, whose whole-(b, h) images (fp32: 248 KB at L = 200) do not fit the 160 KB of LDS
+template <int PREC, int HD, int MAXKT, int NCH>
+static int launch_attn_gen_bwd_chunked(const AttnGenArgs& a, hipStream_t s) {
+  constexpr int NW = 8;
   const size_t smem = AttnChunkLds<PREC, HD, MAXKT, NCH>::bwd_bytes;
-  if (smem > 160 * 1024) return adt_set_error("masked attention bwd: L=%d hd=128 prec=%d needs %zu B of LDS (> 160 KB)", a.a.L, PREC, smem);
+  if (smem > 160 * 1024) return adt_set_error("masked attention bwd: L=%d hd=%d prec=%d needs %zu B of LDS (> 160 KB)", a.a.L, HD, PREC, smem);
   const void* fn = (const void*)k_attn_gen_bwd_chunked<PREC, HD, MAXKT, NCH, NW>;
   static bool done = false;
   if (!done) {
@@ -72,7 +61,31 @@ static int launch_attn_gen_128(bool bwd, const AttnGenArgs& a, hipStream_t s) {
   AttnGenArgs args = a;
   void* kargs[] = {&args};
   if (hipLaunchKernel(fn, dim3(a.a.B * a.a.H), dim3(NW * 64), kargs, smem, s) != hipSuccess) return adt_set_error("masked attention: launch failed");
-  return check_launch("attn_masked_bwd(hd128)");
+  return check_launch("attn_masked_bwd(chunked)");
+}
+
+template <int PREC, int HD>
+static int dispatch_attn_gen_l(bool bwd, const AttnGenArgs& a, hipStream_t s) {
+  if (a.a.L <= 64) return launch_attn_gen<PREC, HD, 4>(bwd, a, s);
+  if (a.a.L <= 128) return launch_attn_gen<PREC, HD, 8>(bwd, a, s);
+  if (a.a.L <= 224) {
+    if constexpr (PREC == PREC_F32 && HD == 64) {
+      if (bwd) return launch_attn_gen_bwd_chunked<PREC, HD, 16, 2>(a, s);
+    }
+    return launch_attn_gen<PREC, HD, 14>(bwd, a, s);
+  }
+  return adt_set_error("masked attention: L=%d > 224 unsupported", a.a.L);
+}
+
+// hd = 128 (sasrec d = 256, H = 2): forward with the whole (b, h) resident, backward staged in NCH chunks
+template <int PREC, int MAXKT, int NCH>
+static int launch_attn_gen_128(bool bwd, const AttnGenArgs& a, hipStream_t s) {
+  constexpr int HD = 128;
+  if (!bwd) {     // causal without key padding (the d = 256 SASRec template): skip the key tiles above the diagonal
+    const bool csk = a.a.causal && a.kid == nullptr && a.fill <= -1e9f;
+    return csk ? launch_attn_gen<PREC, HD, MAXKT, true>(false, a, s) : launch_attn_gen<PREC, HD, MAXKT, false>(false, a, s);
+  }
+  return launch_attn_gen_bwd_chunked<PREC, HD, MAXKT, NCH>(a, s);
 }
 
 template <int PREC>

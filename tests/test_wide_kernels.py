@@ -116,11 +116,11 @@ def attn_oracle(q, k, v, B, H, L, key_valid, causal, fill, p, seed, site, b_off,
 
 @pytest.mark.parametrize("prec", [0, 1])
 @pytest.mark.parametrize("B,H,L,hd,causal,p", [(3, 2, 50, 32, False, 0.0), (2, 4, 100, 16, False, 0.3), (2, 2, 37, 64, False, 0.2),
-                                              (2, 2, 200, 64, False, 0.0), (3, 2, 20, 32, True, 0.1), (2, 1, 128, 64, False, 0.0)])
+                                              (2, 2, 200, 64, False, 0.0), (3, 2, 20, 32, True, 0.1), (2, 1, 128, 64, False, 0.0),
+                                              (3, 4, 200, 64, False, 0.2), (2, 2, 160, 64, True, 0.1)])
 def test_masked_attention(prec, B, H, L, hd, causal, p):
     from adt_amd import ops
-    if prec == 0 and hd == 64 and L > 128:
-        pytest.skip("fp32 images of hd=64, L=200 exceed the LDS (the exact mode is a small-shape parity aid)")
+    # (fp32, hd=64, L=200): the whole-(b, h) fp32 images of the backward (248 KB) exceed the LDS; it runs chunked (adt_wide.hip)
     r = np.random.RandomState(B * 1000 + L + hd)
     d = H * hd
     qkv = r.standard_normal((B * L, 3 * d)).astype(np.float32)
