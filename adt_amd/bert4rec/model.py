@@ -14,7 +14,7 @@ coupled weight decay on the device; it is HIP-graph capturable (masked-row count
 import numpy as np
 import torch
 
-from .. import _lib, ops
+from .. import _lib, custom_ops, ops
 from ..wide import Act, FlatModule, Tape, give
 
 LN_EPS = 1e-5
@@ -218,24 +218,44 @@ class BertModel(FlatModule):
         return tp.layernorm(h, P("mask_layer_norm.weight"), P("mask_layer_norm.bias"), G("mask_layer_norm.weight"), G("mask_layer_norm.bias"), LN_EPS)
 
     # ------------------------------------------------------------------------------------------------------------------
-    @torch.no_grad()
     def forward(self, src_ids, dec_ids, seq_pos_ids=None, seq_sent_ids=None, deq_pos_ids=None, deq_sent_ids=None):
         """bert.py:92-108.  Position ids are always 0..L-1 and sentence ids 0 in the reference's callers (trainer.py:104-107);
         they are accepted for signature compatibility.  Returns (logits (B, L, V+100), enc_inputs, dec_outputs reversed,
-        ind_outputs) as plain tensors; training goes through train_step()."""
-        src, dec = self.ids(src_ids), self.ids(dec_ids)
+        ind_outputs).  Under autograd the tensors are wired into it (adt_amd::model_forward), so the reference's loop body
+        (bert4rec/trainer.py:100-138: CrossEntropyLoss over all items, loss.backward(), clip, Adam) runs on them unchanged -- with the
+        reference's (B, L, V+100) logits materialised; FusedBertTrainer.step (masked rows only) is the fast way to train."""
+        ids = [self.ids(src_ids), self.ids(dec_ids)]
+        if custom_ops.wants_grad(self):
+            outs = custom_ops.forward_with_grad(self, ids)
+        else:
+            with torch.no_grad():
+                outs, _ = self._op_forward(ids, self.training)
+        nl = self.num_layers
+        return outs[0], list(outs[1:1 + nl]), list(outs[1 + nl:1 + 2 * nl]), list(outs[1 + 2 * nl:1 + 3 * nl])
+
+    def _op_forward(self, ids, training):
+        src, dec = ids
         B, L = src.shape
         d, H = self.hidden_units, self.num_heads
-        if self.training:
+        if training:
             self.next_seed()
-        tp = Tape(self, self.prec, self.training)
+        tp = Tape(self, self.prec, training)
         enc, enc_inputs, recs = self._encode(tp, src.view(-1), B)
         dec_outs = self._decode(tp, dec.view(-1), src.view(-1), enc, B)
         h = self._head(tp, enc)
-        logits, _ = ops.dense_fwd(self.prec, h.t, self.P("item_emb.word_emb.weight"), self.P("mask_bias"))
+        logits = tp.dense(h, self.P("item_emb.word_emb.weight"), self.P("mask_bias"), self.G("item_emb.word_emb.weight"), self.G("mask_bias"))
         dec_outs.reverse()
-        return (logits.view(B, L, self.vocab), [a.t.view(B, L, d) for a in enc_inputs], [a.t.view(B, L, d) for a in dec_outs],
-                [r.t.view(B, L, H, H) for r in recs])
+        outs = [logits.t.view(B, L, self.vocab)] + [a.t.view(B, L, d) for a in enc_inputs] + [a.t.view(B, L, d) for a in dec_outs] + \
+               [r.t.view(B, L, H, H) for r in recs]
+        return outs, {"tp": tp, "acts": [logits] + list(enc_inputs) + list(dec_outs) + list(recs)}
+
+    def _op_backward(self, st, grads):
+        self.flat_grad.zero_()
+        for a, g in zip(st["acts"], grads):
+            give(a, custom_ops.take_grad(g, tuple(a.t.shape)))
+        st["tp"].backward()
+        self.G("item_emb.pos_emb.weight")[0].zero_()   # padding_idx = 0 of the position table (modules.py:24-28)
+        return custom_ops.param_grads(self)
 
     @torch.no_grad()
     def predict(self, user_ids, seqs, seq_pos_ids=None, seq_sent_ids=None, candidates=None, want_rank=False):

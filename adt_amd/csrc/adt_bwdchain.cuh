@@ -53,7 +53,8 @@ ADT_DEVICE_INLINE void bwd_replica(BwdChainArgs& a) {
   const int ntiles = (a.T + 15) / 16;                                                              \
   const int tstride = gridDim.x * NW;                                                              \
   const int nrounds = (ntiles + tstride - 1) / tstride;   /* identical for every wave: barriers inside */ \
-  int tile = blockIdx.x * NW + w;
+  int tile = blockIdx.x * NW + w;                                                                   \
+  const WPack wpk{a.wp_base, reinterpret_cast<const __bf16*>(a.wp_img)};
 
 // FFN reverse shared by encoder and decoder:  y = mask(R + drop2(conv2 relu(drop1(conv1 xin)))).
 // Returns g = masked upstream gradient and dxin = gradient reaching xin through the FFN.
@@ -88,9 +89,11 @@ template <int PREC, int NW, int HC>   // HC: compile-time cap on the number of h
 __global__ __launch_bounds__(NW * 64) void k_enc_post_bwd(BwdChainArgs a) {
   constexpr int HCM = HC > 0 ? HC : 1;
   BWD_PROLOGUE(3)
-  stage_wimg<PREC, NW * 64>(lds.w[0], a.W0, true);
-  stage_wimg<PREC, NW * 64>(lds.w[1], a.W1, true);
-  stage_wimg<PREC, NW * 64>(lds.w[2], a.W2, true);
+  {
+    typename WImg<PREC>::T* const im[3] = {lds.w[0], lds.w[1], lds.w[2]};
+    const float* const wsrc[3] = {a.W0, a.W1, a.W2};
+    stage_w_set<PREC, NW * 64, 3>(im, wsrc, true, wpk);
+  }
   __syncthreads();
   const uint32_t seedv = a.drop.thr ? *a.drop.seed : 0u;
   const uint32_t key1 = adt_site_key(seedv, a.site1), key2 = adt_site_key(seedv, a.site2);
@@ -235,9 +238,11 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_bwd(BwdChainArgs a) {
 template <int PREC, int NW>
 __global__ __launch_bounds__(NW * 64) void k_dec_post_bwd(BwdChainArgs a) {
   BWD_PROLOGUE(3)
-  stage_wimg<PREC, NW * 64>(lds.w[0], a.W0, true);
-  stage_wimg<PREC, NW * 64>(lds.w[1], a.W1, true);
-  stage_wimg<PREC, NW * 64>(lds.w[2], a.W2, true);
+  {
+    typename WImg<PREC>::T* const im[3] = {lds.w[0], lds.w[1], lds.w[2]};
+    const float* const wsrc[3] = {a.W0, a.W1, a.W2};
+    stage_w_set<PREC, NW * 64, 3>(im, wsrc, true, wpk);
+  }
   __syncthreads();
   const uint32_t seedv = a.drop.thr ? *a.drop.seed : 0u;
   const uint32_t key1 = adt_site_key(seedv, a.site1), key2 = adt_site_key(seedv, a.site2);
@@ -277,9 +282,11 @@ __global__ __launch_bounds__(NW * 64) void k_dec_post_bwd(BwdChainArgs a) {
 template <int PREC, int NW, bool ENC>
 __global__ __launch_bounds__(NW * 64) void k_pre_bwd(BwdChainArgs a) {
   BWD_PROLOGUE(3)
-  stage_wimg<PREC, NW * 64>(lds.w[0], a.W0, true);
-  stage_wimg<PREC, NW * 64>(lds.w[1], a.W1, true);
-  stage_wimg<PREC, NW * 64>(lds.w[2], a.W2, true);
+  {
+    typename WImg<PREC>::T* const im[3] = {lds.w[0], lds.w[1], lds.w[2]};
+    const float* const wsrc[3] = {a.W0, a.W1, a.W2};
+    stage_w_set<PREC, NW * 64, 3>(im, wsrc, true, wpk);
+  }
   __syncthreads();
   f32x4 dWq[NOWN], dWk[NOWN], dWv[NOWN];
   VAcc dbq, dbk, dbv, dgm, dbt;
@@ -350,8 +357,11 @@ __global__ __launch_bounds__(NW * 64) void k_pre_bwd(BwdChainArgs a) {
 template <int PREC, int NW>
 __global__ __launch_bounds__(NW * 64) void k_dec_mid_bwd(BwdChainArgs a) {
   BWD_PROLOGUE(2)
-  stage_wimg<PREC, NW * 64>(lds.w[0], a.W0, true);
-  stage_wimg<PREC, NW * 64>(lds.w[1], a.W1, true);
+  {
+    typename WImg<PREC>::T* const im[2] = {lds.w[0], lds.w[1]};
+    const float* const wsrc[2] = {a.W0, a.W1};
+    stage_w_set<PREC, NW * 64, 2>(im, wsrc, true, wpk);
+  }
   __syncthreads();
   f32x4 dWq[NOWN], dWo[NOWN];
   VAcc dbq, dbo;
@@ -390,8 +400,11 @@ __global__ __launch_bounds__(NW * 64) void k_dec_mid_bwd(BwdChainArgs a) {
 template <int PREC, int NW>
 __global__ __launch_bounds__(NW * 64) void k_kv_bwd(BwdChainArgs a) {
   BWD_PROLOGUE(2)
-  stage_wimg<PREC, NW * 64>(lds.w[0], a.W0, true);
-  stage_wimg<PREC, NW * 64>(lds.w[1], a.W1, true);
+  {
+    typename WImg<PREC>::T* const im[2] = {lds.w[0], lds.w[1]};
+    const float* const wsrc[2] = {a.W0, a.W1};
+    stage_w_set<PREC, NW * 64, 2>(im, wsrc, true, wpk);
+  }
   __syncthreads();
   f32x4 dWk[NOWN], dWv[NOWN];
   VAcc dbk, dbv;

@@ -36,6 +36,7 @@ struct BwdChainArgs {
   // 256-deep chain of same-address float atomics (10.5 us per million adds measured, 5.7 us with 8 replicas, 4.5 us private);
   // the executor sums the replicas into the gradient buffer afterwards (adt_replica_reduce).
   int nrep; size_t rep_stride;
+  const float* wp_base; const void* wp_img;      // pre-packed bf16 weight images (adt_wave.cuh: WPack); wp_img == nullptr: none
 };
 
 }  // namespace adt

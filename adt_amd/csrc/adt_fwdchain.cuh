@@ -22,15 +22,6 @@ struct FwdLds {
   }
 };
 
-ADT_DEVICE_INLINE void ct_add_bias(CT& t, const float* b, int c) {
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const float bv = b[16 * nt + c];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) t.v[nt][r] += bv;
-  }
-}
-
 #define FWD_PROLOGUE(NWT_)                                                                          \
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];                          \
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;            \

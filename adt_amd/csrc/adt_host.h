@@ -24,3 +24,11 @@ int adt_launch_bwdchain(int prec, int which, const adt::BwdChainArgs& a, void* s
 // wave-local forward chains (adt_fwdchain.cuh); which: 0 enc_pre, 1 dec_pre, 2 enc_post, 3 dec_mid, 4 dec_post, 5 final
 namespace adt { struct FwdChainArgs; }
 int adt_launch_fwdchain(int prec, int which, const adt::FwdChainArgs& a, void* stream);
+
+// per-sequence fused layer kernels (adt_seqfwd.cuh); defined in adt_seq.hip
+namespace adt { struct SeqFwdArgs; }
+int adt_seq_supported(int prec, int L, int d, int hd);      // bf16 mode, d = 64, L <= 224; ADT_SEQ=0 in the environment turns them off
+int adt_launch_seq_enc_fwd(int hd, const adt::SeqFwdArgs& a, void* stream);
+int adt_launch_seq_dec_fwd(int hd, const adt::SeqFwdArgs& a, void* stream);
+// pre-packed bf16 weight images of n 64 x 64 blocks at base + offs[i] -> img + 6 * offs[i] (bf16 elements); defined in adt_seq.hip
+int adt_pack_wimg(const float* base, void* img, const int* offs, int n, void* stream);

@@ -6,6 +6,7 @@
 #include <string.h>
 #include "adt_bwdchain_args.h"
 #include "adt_fwdchain_args.h"
+#include "adt_seq_args.h"
 
 namespace {
 
@@ -62,6 +63,7 @@ struct WS {
   int64_t loss, norms, scal;
   int64_t rep, rep_stride;                                              // item-table gradient replicas
   int64_t prep, prep_stride;                                            // replicas of every other parameter gradient
+  int64_t wpack;                                                        // pre-packed bf16 weight images (3 floats per parameter float)
   int64_t total;
 };
 
@@ -100,6 +102,7 @@ void make_ws(const adt_sasrec_cfg* c, int B, WS* w) {
     make_layout(c, &lo);
     w->prep_stride = up64(lo.total - lo.posw());
     w->prep = take(NREPP * w->prep_stride);
+    w->wpack = take(3 * w->prep_stride);
   }
   w->total = o;
 }
@@ -131,6 +134,33 @@ adt::BwdChainArgs bwd_args(int T, int L, int B, const int32_t* ids, float p, con
   return a;
 }
 
+// bf16 mode: both LDS images of every 64 x 64 layer weight, written once per forward (the weights do not change until the
+// optimizer step that follows the backward), so that every kernel's weight staging is a plain copy
+int pack_weights(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const float* P, float* ws, void* st) {
+  if (c->prec != ADT_PREC_BF16) return 0;
+  int offs[256];
+  int n = 0;
+  const int64_t base = lo.posw();
+  const int dd = c->hidden * c->hidden;
+  for (int i = 0; i < c->num_layers; ++i) {
+    for (int j = 0; j < 3; ++j) offs[n++] = (int)(lo.enc(i, E_INW) + j * dd - base);
+    offs[n++] = (int)(lo.enc(i, E_OW) - base); offs[n++] = (int)(lo.enc(i, E_C1W) - base); offs[n++] = (int)(lo.enc(i, E_C2W) - base);
+    for (int j = 0; j < 3; ++j) offs[n++] = (int)(lo.dec(i, D_SINW) + j * dd - base);
+    for (int j = 0; j < 3; ++j) offs[n++] = (int)(lo.dec(i, D_EINW) + j * dd - base);
+    offs[n++] = (int)(lo.dec(i, D_SOW) - base); offs[n++] = (int)(lo.dec(i, D_EOW) - base);
+    offs[n++] = (int)(lo.dec(i, D_C1W) - base); offs[n++] = (int)(lo.dec(i, D_C2W) - base);
+  }
+  return adt_pack_wimg(P + base, ws + w.wpack, offs, n, st);
+}
+
+adt::SeqFwdArgs seq_args(int L, int B, int H, const int32_t* ids, float p, const uint32_t* seed, uint32_t b_offset, int hd) {
+  adt::SeqFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.L = L; a.B = B; a.H = H; a.ids = ids; a.drop = adt_make_drop(p, seed, 0); a.b_offset = b_offset; a.ln_eps = LN_EPS;
+  a.scale = 1.0f / sqrtf((float)hd);
+  return a;
+}
+
 // encoder stack forward (gathers the input embedding inside the first chain) + last LayerNorm (+ logits and the
 // cross-attention k/v projections of every decoder layer when training_outputs)
 int encoder_forward(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const float* P, float* ws,
@@ -140,6 +170,10 @@ int encoder_forward(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, cons
   const int64_t Td = up64(w.T * w.d);
   const uint32_t ro = b_offset * (uint32_t)L;
   const int dd = d * d;
+  const bool use_seq = adt_seq_supported(prec, L, d, hd) != 0;
+  CK(pack_weights(c, lo, w, P, ws, st));
+  const float* wp_base = P + lo.posw();
+  const void* wp_img = prec == ADT_PREC_BF16 ? (const void*)(ws + w.wpack) : nullptr;
   for (int i = 0; i < nl; ++i) {
     float* x = ws + w.enc_x + i * Td;
     float* y = ws + w.enc_x + (i + 1) * Td;
@@ -148,6 +182,19 @@ int encoder_forward(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, cons
           *u = base + w.e_u, *rec = base + w.e_rec;
     const float* inw = P + lo.enc(i, E_INW);
     const float* inb = P + lo.enc(i, E_INB);
+    if (use_seq) {   // the whole layer in one launch, one workgroup per sequence (adt_seqfwd.cuh)
+      adt::SeqFwdArgs a = seq_args(L, B, H, seq, p, seed, b_offset, hd);
+      a.x = i == 0 ? nullptr : x; a.E = P + lo.item(); a.P = P + lo.posw(); a.emb_scale = sqrtf((float)d); a.site_emb = SITE_EMB_SEQ;
+      a.site_attn = enc_site(i, 0); a.site1 = enc_site(i, 1); a.site2 = enc_site(i, 2);
+      a.gamma = P + lo.enc(i, E_LN1W); a.beta = P + lo.enc(i, E_LN1B); a.Win = inw; a.bin = inb;
+      a.Wo = P + lo.enc(i, E_OW); a.bo = P + lo.enc(i, E_OB); a.gamma2 = P + lo.enc(i, E_LN2W); a.beta2 = P + lo.enc(i, E_LN2B);
+      a.W1 = P + lo.enc(i, E_C1W); a.b1 = P + lo.enc(i, E_C1B); a.W2 = P + lo.enc(i, E_C2W); a.b2 = P + lo.enc(i, E_C2B);
+      a.x_out = x; a.xn = qn; a.qkv = qkv; a.o = o; a.lse = lse; a.mask = reinterpret_cast<uint32_t*>(base + w.e_mask); a.h = h; a.u = u; a.y = y;
+      if (training_outputs && H > 1) { a.rec = rec; a.Ws = P + lo.enc(i, E_SW); a.bs = P + lo.enc(i, E_SB); }
+      a.wp_base = wp_base; a.wp_img = wp_img;
+      CK(adt_launch_seq_enc_fwd(hd, a, st));
+      continue;
+    }
     {  // [gather] ; Q = LN1(x) ; q = Q Wq^T + bq ; k, v = x Wk^T, x Wv^T     (sasrec/model.py:34-41, modules.py:646-647)
       adt::FwdChainArgs a = fwd_args(T, L, B, H, seq, p, seed, ro);
       a.x = i == 0 ? nullptr : x; a.E = P + lo.item(); a.P = P + lo.posw(); a.emb_scale = sqrtf((float)d); a.site0 = SITE_EMB_SEQ;
@@ -175,13 +222,13 @@ int encoder_forward(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, cons
     }
   }
   // log_feats = last_layernorm(encoder out); pos/neg logits; [k2, v2] of every decoder layer   (model.py:48, :72-76)
-  for (int j0 = 0; j0 == 0 || (training_outputs && j0 < nl); j0 += 2) {
+  for (int j0 = 0; j0 == 0 || (training_outputs && !use_seq && j0 < nl); j0 += 2) {
     adt::FwdChainArgs a = fwd_args(T, L, B, H, seq, 0.f, nullptr, ro);
     a.x = ws + w.enc_x + nl * Td; a.gamma = P + lo.lnl_w(); a.beta = P + lo.lnl_b();
     if (j0 == 0) { a.o0 = ws + w.f; a.ld0 = d; }
     if (training_outputs) {
       if (j0 == 0) { a.E = P + lo.item(); a.pos = pos; a.neg = neg; a.pos_logits = ws + w.posl; a.neg_logits = ws + w.negl; }
-      a.nkv = nl - j0 >= 2 ? 2 : 1;
+      a.nkv = use_seq ? 0 : (nl - j0 >= 2 ? 2 : 1);       // the fused decoder layer projects its own cross keys / values
       for (int k = 0; k < a.nkv; ++k) {
         const float* einw = P + lo.dec(j0 + k, D_EINW);
         const float* einb = P + lo.dec(j0 + k, D_EINB);
@@ -263,6 +310,21 @@ int adt_sasrec_forward(const adt_sasrec_cfg* c, const float* P, float* ws, const
     const float* sinb = P + lo.dec(i, D_SINB);
     const float* einw = P + lo.dec(i, D_EINW);
     const float* einb = P + lo.dec(i, D_EINB);
+    if (adt_seq_supported(prec, L, d, hd)) {   // the whole layer in one launch, one workgroup per sequence (adt_seqfwd.cuh)
+      adt::SeqFwdArgs a = seq_args(L, B_, H, dec, p, seed, b_offset, hd);
+      a.x = i == 0 ? nullptr : x; a.E = P + lo.item(); a.P = P + lo.posw(); a.emb_scale = sqrtf((float)d); a.site_emb = SITE_EMB_DEC;
+      a.site_attn = dec_site(i, 0); a.site_attn2 = dec_site(i, 1); a.site1 = dec_site(i, 2); a.site2 = dec_site(i, 3);
+      a.gamma = P + lo.dec(i, D_LNW); a.beta = P + lo.dec(i, D_LNB); a.Win = sinw; a.bin = sinb;
+      a.Wo = P + lo.dec(i, D_SOW); a.bo = P + lo.dec(i, D_SOB); a.f = f; a.Win2 = einw; a.bin2 = einb;
+      a.Wo2 = P + lo.dec(i, D_EOW); a.bo2 = P + lo.dec(i, D_EOB);
+      a.W1 = P + lo.dec(i, D_C1W); a.b1 = P + lo.dec(i, D_C1B); a.W2 = P + lo.dec(i, D_C2W); a.b2 = P + lo.dec(i, D_C2B);
+      a.x_out = x; a.xn = dn; a.qkv = qkv; a.o = o1; a.lse = lse1; a.mask = reinterpret_cast<uint32_t*>(base + w.d_mask1);
+      a.a1 = a1; a.q2 = q2; a.kv2 = kv2; a.o2 = o2; a.lse2 = lse2; a.mask2 = reinterpret_cast<uint32_t*>(base + w.d_mask2);
+      a.h = a2; a.u = u; a.y = y;
+      a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack;
+      CK(adt_launch_seq_dec_fwd(hd, a, st));
+      continue;
+    }
     {  // [gather] ; D = LN(x) ; qkv = D Win^T + b                          (sasrec/model.py:53-59, modules.py:668-670)
       adt::FwdChainArgs a = fwd_args(T, L, B_, H, dec, p, seed, ro);
       a.x = i == 0 ? nullptr : x; a.E = P + lo.item(); a.P = P + lo.posw(); a.emb_scale = sqrtf((float)d); a.site0 = SITE_EMB_DEC;
@@ -333,6 +395,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   auto BA = [&](const int32_t* ids, float pp, const uint32_t* sd) {
     adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, ids, pp, sd, ro);
     a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride;
+    a.wp_base = P + lo.posw(); a.wp_img = prec == ADT_PREC_BF16 ? (const void*)(ws + w.wpack) : nullptr;   // packed by the forward of this step
     return a;
   };
   const int64_t dec_begin = lo.dec(0, 0);

@@ -80,6 +80,39 @@ ADT_DEVICE_INLINE void stage_wimg(typename WImg<PREC>::T* img, const float* W, b
   }
 }
 
+// Pre-packed weight images (bf16 mode): adt_pack_wimg writes, once per step, both LDS images of every 64 x 64 weight block of the
+// flat parameter buffer -- plain and transposed, [64][RS = 72] bf16 each, exactly the bytes stage_wimg would produce -- so a
+// kernel's staging is a straight 16-byte copy instead of 1,024 float4 loads, 4,096 conversions and 4,096 two-byte LDS stores per
+// image (14,000 cycles for the six images of an encoder layer, measured with s_memtime stamps).  The block whose fp32 weights
+// start at `base + off` keeps its images at img + 6 * off (bf16 elements): plain first, transposed WPACK_IMG elements later.
+constexpr int WPACK_IMG = 64 * 72;
+struct WPack {
+  const float* base;       // start of the packed parameter range (the positional table: everything after the item table)
+  const __bf16* img;       // nullptr: not packed (fp32-exact mode, or a caller that did not pack)
+};
+
+template <int PREC, int NTHREADS>
+ADT_DEVICE_INLINE void stage_w(typename WImg<PREC>::T* img, const float* W, bool transposed, const WPack& wp) {
+  if constexpr (PREC == PREC_BF16) {
+    if (wp.img) {
+      const uint4* src = reinterpret_cast<const uint4*>(wp.img + 6 * (W - wp.base) + (transposed ? WPACK_IMG : 0));
+      uint4* dst = reinterpret_cast<uint4*>(img);
+      for (int i = threadIdx.x; i < WPACK_IMG * 2 / 16; i += NTHREADS) dst[i] = src[i];
+      return;
+    }
+  }
+  stage_wimg<PREC, NTHREADS>(img, W, transposed);
+}
+
+// N images.  (Issuing every global load of the set before the first LDS store -- 42 x 16 B in flight per thread for six images --
+// was measured SLOWER than image after image: 18,700 against 10,300 cycles for an encoder layer's six images with all 256
+// workgroups staging at once; converting from fp32 in the kernel took 14,000.)
+template <int PREC, int NTHREADS, int N>
+ADT_DEVICE_INLINE void stage_w_set(typename WImg<PREC>::T* const (&img)[N], const float* const (&W)[N], bool transposed, const WPack& wp) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) stage_w<PREC, NTHREADS>(img[k], W[k], transposed, wp);
+}
+
 template <int PREC>
 ADT_DEVICE_INLINE OpFrag<PREC> wfrag(const typename WImg<PREC>::T* img, int nt, int kb, int c, int g) {
   constexpr int RS = WImg<PREC>::RS;
@@ -508,6 +541,15 @@ ADT_DEVICE_INLINE void ct_dropmask(CT& t, uint32_t key, const DropCfg& d, uint32
       const uint32_t idx = (row_base + (uint32_t)(4 * g + r)) * 64u + (uint32_t)(16 * nt + c);
       t.v[nt][r] = adt_keep(key, idx, d.thr) ? t.v[nt][r] * d.scale : 0.f;
     }
+}
+
+ADT_DEVICE_INLINE void ct_add_bias(CT& t, const float* b, int c) {
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const float bv = b[16 * nt + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t.v[nt][r] += bv;
+  }
 }
 
 ADT_DEVICE_INLINE void ct_add(CT& a, const CT& b) {

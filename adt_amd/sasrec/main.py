@@ -114,7 +114,6 @@ def main(argv=None):
     if wide:
         from .model_wide import SASRecADTWide, WideSasrecTrainer
         model = SASRecADTWide(usernum, itemnum, args)
-        args.loop = "fused"
     else:
         model = SASRecADT(usernum, itemnum, args).to(args.device)
     for _, prm in model.named_parameters():       # sasrec/main.py:95-99
@@ -133,7 +132,7 @@ def main(argv=None):
     ks = [5, 10]
     logf = open(os.path.join(out_dir, "log.txt"), "w") if rank == 0 else None
     trainer = None
-    if wide:
+    if wide and args.loop == "fused":
         trainer = WideSasrecTrainer(model, lambdas1, lambdas2, lr=args.lr, betas=(0.9, 0.98), weight_decay=args.weight_decay, clip=args.clip,
                                     process_group=pg, use_graph=args.use_graph, seed=23)
     elif args.loop == "fused":

@@ -10,7 +10,7 @@ import math
 import numpy as np
 import torch
 
-from .. import _lib, ops
+from .. import _lib, custom_ops, ops
 from ..dp import GradBuckets, reduce_sum
 from ..wide import Act, FlatModule, Tape, give
 from .model import REF_ORDER, param_table
@@ -166,22 +166,47 @@ class SASRecADTWide(FlatModule):
         return outs
 
     # ---- reference API -----------------------------------------------------------------------------------------------------
-    @torch.no_grad()
     def forward(self, user_ids, log_seqs, dec_seqs, pos_seqs, neg_seqs):
         """sasrec/model.py:67-81 -> (pos_logits, neg_logits, encoder_layer_input, decoder_layer_output [reversed], rec_layer_ind
-        [natural (b, l) row order]) as plain tensors; training goes through WideSasrecTrainer.step()."""
-        seq, dec, pos, neg = (self.ids(a) for a in (log_seqs, dec_seqs, pos_seqs, neg_seqs))
+        [natural (b, l) row order]).  Under autograd (grad mode on, parameters requiring grad) the tensors are wired into it through
+        the adt_amd::model_forward custom operator, so the reference's loop body (sasrec/main.py:146-173) runs on them unchanged;
+        WideSasrecTrainer.step() is the fused, faster way to train."""
+        ids = [self.ids(a) for a in (log_seqs, dec_seqs, pos_seqs, neg_seqs)]
+        if custom_ops.wants_grad(self):
+            outs = custom_ops.forward_with_grad(self, ids)
+        else:
+            with torch.no_grad():
+                outs, _ = self._op_forward(ids, self.training)
+        nl = self.num_layers
+        return outs[0], outs[1], list(outs[2:2 + nl]), list(outs[2 + nl:2 + 2 * nl]), list(outs[2 + 2 * nl:2 + 3 * nl])
+
+    def _op_forward(self, ids, training):
+        seq, dec, pos, neg = ids
         B, L = seq.shape
         d, H = self.hidden_units, self.num_heads
-        if self.training:
+        if training:
             self.next_seed()
-        tp = Tape(self, self.prec, self.training)
+        tp = Tape(self, self.prec, training)
         feats, enc_in, recs = self._encode(tp, seq.view(-1), B)
         dec_outs = self._decode(tp, dec.view(-1), feats, B)
         pl, nl = ops.logits_fwd(feats.t, self.P("item_emb.weight"), pos.view(-1), neg.view(-1))
         dec_outs.reverse()
-        return (pl.view(B, L), nl.view(B, L), [a.t.view(B, L, d) for a in enc_in], [a.t.view(B, L, d) for a in dec_outs],
-                [r.t.view(B, L, H, H) for r in recs])
+        outs = [pl.view(B, L), nl.view(B, L)] + [a.t.view(B, L, d) for a in enc_in] + [a.t.view(B, L, d) for a in dec_outs] + \
+               [r.t.view(B, L, H, H) for r in recs]
+        return outs, {"tp": tp, "feats": feats, "acts": list(enc_in) + list(dec_outs) + list(recs), "pos": pos, "neg": neg}
+
+    def _op_backward(self, st, grads):
+        """Reverse of _op_forward for the output gradients autograd hands over; returns one gradient per parameter."""
+        tp, feats, pos, neg = st["tp"], st["feats"], st["pos"].view(-1), st["neg"].view(-1)
+        self.flat_grad.zero_()
+        tp.item_rep = None          # embedding rows straight into the table gradient (no replicas on this path)
+        dpos, dneg = (custom_ops.take_grad(g, (pos.numel(),)) for g in grads[:2])
+        give(feats, ops.logits_bwd(feats.t, self.P("item_emb.weight"), pos, neg, dpos, dneg, self.G("item_emb.weight")))
+        for a, g in zip(st["acts"], grads[2:]):
+            give(a, custom_ops.take_grad(g, tuple(a.t.shape)))
+        tp.backward()
+        H = self.num_heads
+        return custom_ops.param_grads(self, lambda n: "pos_ffn_layernorm" in n or (H == 1 and ".sparse." in n))
 
     @torch.no_grad()
     def predict_rank(self, log_seqs, item_indices, want_rank=True):

@@ -17,7 +17,7 @@ import math
 import numpy as np
 import torch
 
-from .. import _lib, ops
+from .. import _lib, custom_ops, ops
 from ..wide import Act, FlatModule, Tape, give
 from .model import REF_ORDER
 
@@ -223,22 +223,43 @@ class SuperSASRecModel(FlatModule):
             outs.append(y)
         return outs
 
-    @torch.no_grad()
     def forward(self, user_ids, log_seqs, dec_seqs, pos_seqs, neg_seqs):
-        """supersasrec.py:81-94 -> (pos_logits, neg_logits, encoder_layer_input, decoder_layer_output [reversed], rec_layer_ind)
-        as plain tensors (training goes through SuperTrainer.step)."""
-        seq, dec, pos, neg = (self.ids(a) for a in (log_seqs, dec_seqs, pos_seqs, neg_seqs))
+        """supersasrec.py:81-94 -> (pos_logits, neg_logits, encoder_layer_input, decoder_layer_output [reversed], rec_layer_ind).
+        Under autograd the tensors are wired into it (adt_amd::model_forward), so the reference's warm-up loop body
+        (sasrec/evolution.py:296-316) runs on them unchanged; SuperTrainer.step is the fused way."""
+        ids = [self.ids(a) for a in (log_seqs, dec_seqs, pos_seqs, neg_seqs)]
+        if custom_ops.wants_grad(self):
+            outs = custom_ops.forward_with_grad(self, ids)
+        else:
+            with torch.no_grad():
+                outs, _ = self._op_forward(ids, self.training)
+        nl = self.num_layers
+        return outs[0], outs[1], list(outs[2:2 + nl]), list(outs[2 + nl:2 + 2 * nl]), list(outs[2 + 2 * nl:2 + 3 * nl])
+
+    def _op_forward(self, ids, training):
+        seq, dec, pos, neg = ids
         B, L = seq.shape
         d, H = self.hidden_units, self.num_heads
-        if self.training:
+        if training:
             self.next_seed()
-        tp = Tape(self, self.prec, self.training)
+        tp = Tape(self, self.prec, training)
         feats, enc_in, recs = self._encode(tp, seq.view(-1), B)
         dec_outs = self._decode(tp, dec.view(-1), feats, B)
         pl, nl = ops.logits_fwd(feats.t, self.P("item_emb.weight"), pos.view(-1), neg.view(-1))
         dec_outs.reverse()
-        return (pl.view(B, L), nl.view(B, L), [a.t.view(B, L, d) for a in enc_in], [a.t.view(B, L, d) for a in dec_outs],
-                [r.t.view(B, L, H, H) for r in recs])
+        outs = [pl.view(B, L), nl.view(B, L)] + [a.t.view(B, L, d) for a in enc_in] + [a.t.view(B, L, d) for a in dec_outs] + \
+               [r.t.view(B, L, H, H) for r in recs]
+        return outs, {"tp": tp, "feats": feats, "acts": list(enc_in) + list(dec_outs) + list(recs), "pos": pos, "neg": neg}
+
+    def _op_backward(self, st, grads):
+        tp, feats, pos, neg = st["tp"], st["feats"], st["pos"].view(-1), st["neg"].view(-1)
+        self.flat_grad.zero_()
+        dpos, dneg = (custom_ops.take_grad(g, (pos.numel(),)) for g in grads[:2])
+        give(feats, ops.logits_bwd(feats.t, self.P("item_emb.weight"), pos, neg, dpos, dneg, self.G("item_emb.weight")))
+        for a, g in zip(st["acts"], grads[2:]):
+            give(a, custom_ops.take_grad(g, tuple(a.t.shape)))
+        tp.backward()
+        return custom_ops.param_grads(self)
 
     @torch.no_grad()
     def predict(self, user_ids, log_seqs, item_indices, full=False, want_rank=False):

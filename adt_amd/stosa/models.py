@@ -11,7 +11,7 @@ reductions), LayerNorm / dropout / ELU row kernels.
 import numpy as np
 import torch
 
-from .. import _lib, ops
+from .. import _lib, custom_ops, ops
 from ..wide import Act, FlatModule, Tape, give
 
 LN_EPS = 1e-12
@@ -211,23 +211,47 @@ class DisenDistSAModel(FlatModule):
             dec_outs.append((dm, dc))
         return m, c, enc_inputs, enc_recs, dec_outs
 
-    @torch.no_grad()
     def finetune(self, input_ids, dec_ids, user_ids=None):
         """stosa/models.py:212-260 -> (mean_out, cov_out, att_scores=None, margins, enc_inputs, enc_recs, dec_outputs).  The
-        (B, H, L, L) attention probabilities are never materialised (no caller reads them: trainer.py:534,585)."""
-        inp, dec = self.ids(input_ids), self.ids(dec_ids)
+        (B, H, L, L) attention probabilities are never materialised (no caller reads them: trainer.py:534,585).  Under autograd the
+        tensors are wired into it (adt_amd::model_forward) and `item_mean_embeddings` / `item_cov_embeddings` / `user_margins` are
+        callable like the reference's nn.Embedding modules, so the reference's loop body (stosa/trainer.py:534-559 with
+        bpr_optimization :358-391) runs unchanged; FusedStosaTrainer.step is the fast way to train."""
+        ids = [self.ids(input_ids), self.ids(dec_ids)]
+        B, L = ids[0].shape
+        if custom_ops.wants_grad(self):
+            outs = custom_ops.forward_with_grad(self, ids)
+        else:
+            with torch.no_grad():
+                outs, _ = self._op_forward(ids, self.training)
+        nl = self.num_layers
+        margins = None if user_ids is None else self.user_margins(user_ids)
+        pairs = [[outs[2 + 2 * i], outs[3 + 2 * i]] for i in range(3 * nl)]
+        return outs[0], outs[1], None, margins, pairs[:nl], pairs[nl:2 * nl], pairs[2 * nl:]
+
+    def _op_forward(self, ids, training):
+        inp, dec = ids
         B, L = inp.shape
         d, H = self.hidden_units, self.num_heads
-        if self.training:
+        if training:
             self.next_seed()
-        tp = Tape(self, self.prec, self.training)
+        tp = Tape(self, self.prec, training)
         m, c, enc_inputs, enc_recs, dec_outs = self._finetune(tp, inp.view(-1), dec.view(-1), B)
+        acts = [m, c] + [x for pr in enc_inputs for x in pr] + [x for pr in enc_recs for x in pr] + [x for pr in dec_outs for x in pr]
+        nl = self.num_layers
+        outs = []
+        for k, a in enumerate(acts):
+            is_rec = 2 + 2 * nl <= k < 2 + 4 * nl
+            outs.append(a.t.view(B, L, H, H) if is_rec else a.t.view(B, L, d))
+        return outs, {"tp": tp, "acts": acts}
 
-        def v3(a):
-            return a.t.view(B, L, d)
-        margins = None if user_ids is None else self.P("user_margins.weight")[self.ids(user_ids).long().view(-1)]
-        return (v3(m), v3(c), None, margins, [[v3(a), v3(b)] for a, b in enc_inputs],
-                [[a.t.view(B, L, H, H), b.t.view(B, L, H, H)] for a, b in enc_recs], [[v3(a), v3(b)] for a, b in dec_outs])
+    def _op_backward(self, st, grads):
+        self.flat_grad.zero_()
+        for a, g in zip(st["acts"], grads):
+            give(a, custom_ops.take_grad(g, tuple(a.t.shape)))
+        st["tp"].backward()
+        base = self.n_trained_floats
+        return custom_ops.param_grads(self, lambda n: self._views[n][0] >= base)     # the reference leaves these at grad None
 
     @torch.no_grad()
     def predict_full(self, input_ids, dec_ids=None):

@@ -12,7 +12,16 @@ from . import _lib, ops
 
 
 class _Holder(torch.nn.Module):
-    """Plain container so that named_parameters()/state_dict() reproduce the reference's dotted names."""
+    """Plain container so that named_parameters()/state_dict() reproduce the reference's dotted names.  A holder of exactly one
+    2-D `weight` (an embedding table) is callable like the reference's nn.Embedding: the reference's trainers look item / user
+    rows up through the module (stosa/trainer.py:361-364, stosa/models.py:236), a plain torch gather outside the hot path."""
+
+    def forward(self, ids):
+        w = self._parameters.get("weight")
+        if w is None or w.dim() != 2:
+            raise TypeError("this container holds parameters only; it is not a layer")
+        ids = ids if isinstance(ids, torch.Tensor) else torch.as_tensor(np.asarray(ids))
+        return torch.nn.functional.embedding(ids.to(device=w.device, dtype=torch.long), w)
 
 
 def _set_nested(root, dotted, param):

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Timing aid: s_memtime stamps of workgroup 0 of the fused encoder-layer forward (ADT_SEQ_STAMPS=1), per wave, in cycles since the
+kernel's first stamp.  Phases: 1 weights staged, 2/3 in-projection of slot 0/1, 4 barrier, 5/8 attention of slot 0/1, 6/9 out_proj +
+residual, 7/10 FFN + store."""
+import ctypes
+import os
+import sys
+
+os.environ["ADT_SEQ_STAMPS"] = "1"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from adt_amd import _lib  # noqa: E402
+
+m = bench.build_model("cuda:0", "bf16")
+batch = bench.synth_batches(1, 256, 200, 3416, 7)[0]
+ids = [m._ids(a) for a in batch]
+for _ in range(3):
+    m.run_forward(*ids, 256, True)
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 128)()
+rc = _lib.load().adt_seq_stamps_read(buf, 128)
+t = np.array(list(buf), dtype=np.int64).reshape(8, 16)
+print("rc", rc)
+t0 = t[:, 0].min()
+names = ["start", "staged", "pre0", "pre1", "barrier", "attn0", "oproj0", "ffn0", "attn1", "oproj1", "ffn1"]
+print("wave " + " ".join("%8s" % n for n in names))
+for w in range(8):
+    print("%4d " % w + " ".join("%8d" % (t[w, k] - t0 if t[w, k] else -1) for k in range(11)))
