@@ -76,18 +76,18 @@ def build_model(device, prec):
 
 def cpu_baseline():
     """The numpy oracle (a port of the reference's step, oracle/sasrec_oracle.py) timed on this host's cores on a
-    bounded sample of the same workload: batch 64 of the same shape, 1 warm-up step, then full train steps until about 10 s of
-    CPU work have been timed (at least 2, at most 40 steps)."""
+    bounded sample of the same workload: the bench's own batch of 256 sequences, 1 warm-up step, then full train steps until about
+    15 s of CPU work have been timed (at least 2, at most 12 steps).  `cores` = the BLAS thread count numpy actually ran with."""
     from oracle import sasrec_oracle as so
     cfg = so.Cfg(CFG["item_num"], CFG["maxlen"], CFG["hidden_units"], CFG["num_heads"], CFG["num_layers"], CFG["dropout"])
     P = so.init_params(cfg, 0)
-    B = 64
+    B = CFG["batch"]
     batch = synth_batches(1, B, CFG["maxlen"], CFG["item_num"], 5)[0]
     st = {}
     so.train_step(P, cfg, st, batch, CFG["lambdas1"], CFG["lambdas2"], CFG["weight_decay"], seed=1)
     t0 = time.time()
     nst = 0
-    while nst < 2 or (time.time() - t0 < 10.0 and nst < 40):
+    while nst < 2 or (time.time() - t0 < 15.0 and nst < 12):
         so.train_step(P, cfg, st, batch, CFG["lambdas1"], CFG["lambdas2"], CFG["weight_decay"], seed=2 + nst)
         nst += 1
     dt = time.time() - t0
@@ -100,40 +100,73 @@ def cpu_baseline():
             "sample": "numpy oracle, %d full train steps at batch %d (same L=200, d=64, 2 blocks, dropout 0.5) after 1 warm-up" % (nst, B)}
 
 
-def roofline_probe(model, trainer, B):
-    """Average launch duration of the dominant kernel (attention backward, causal, hd=32: see profiles/) measured
-    live with HIP events on the launch stream, on the buffers of the last step; algorithmic bytes per launch =
-    B*H (b,h) units x 8 tensors (q, k, v, o, dO in; dQ, dK, dV out) x L*hd*4 B (fp32 activations) -- DESIGN.md."""
+MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
+
+
+def _time_us(fn, reps=20, warm=3):
+    """Average duration of fn() in microseconds, HIP events on the launch stream (torch's current stream = the C ABI's stream)."""
+    import torch
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def roofline_probe(model, trainer, B, seq_per_s):
+    """`roofline` of the bench line.  The object itself describes the DOMINANT kernel of the step (attention backward, causal,
+    hd = 32: profiles/): algorithmic bytes per launch = B*H (b,h) units x 8 tensors (q, k, v, o, dO in; dQ, dK, dV out) x L*hd*4 B
+    (fp32 activations as stored today) / its average launch duration, measured live with HIP events on the launch stream on
+    step-shaped buffers.  `kernels` adds what north_star asks for by name: achieved HBM GB/s of the embedding gather and MFMA
+    utilisation of the attention kernels (causal-aware FLOPs, SURVEY 8d: 4*L(L+1)/2*hd per (b,h) forward, 2.5x that backward);
+    `step` is SURVEY 8d's step-level figure, sequences/s x 2.4 MB of ideal fused-step traffic against the HBM peak."""
     import torch
     from adt_amd import ops
     L, d, H = CFG["maxlen"], CFG["hidden_units"], CFG["num_heads"]
+    hd = d // H
     T = B * L
     dev = model.dev
+    prec, p, sd = model.cfg.prec, CFG["dropout"], model._seed
     qkv = torch.randn(T, 3 * d, device=dev)
+    q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
     mask = torch.zeros(B * H * L * 8, device=dev, dtype=torch.int32)   # dropout keep bits, as inside the step
-    O, LSE = ops.attn_fwd(model.cfg.prec, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, L, True, CFG["dropout"], model._seed, 16, 0, mask)
+    O, LSE = ops.attn_fwd(prec, q, k, v, B, H, L, True, p, sd, 16, 0, mask)
     dO = torch.randn(T, d, device=dev)
-    for _ in range(3):
-        ops.attn_bwd(model.cfg.prec, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], O, LSE, dO, B, H, L, True, CFG["dropout"], model._seed, 16, 0, mask)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    R = 20
-    e0.record()
-    for _ in range(R):
-        ops.attn_bwd(model.cfg.prec, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], O, LSE, dO, B, H, L, True, CFG["dropout"], model._seed, 16, 0, mask)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / R
-    alg_bytes = B * H * 8 * L * (d // H) * 4
-    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    us_bwd = _time_us(lambda: ops.attn_bwd(prec, q, k, v, O, LSE, dO, B, H, L, True, p, sd, 16, 0, mask))
+    us_fwd = _time_us(lambda: ops.attn_fwd(prec, q, k, v, B, H, L, True, p, sd, 16, 0, mask))
+    ids = torch.randint(1, CFG["item_num"] + 1, (T,), device=dev, dtype=torch.int32)
+    E, Pt = model.flat[:(CFG["item_num"] + 1) * d].view(-1, d), model.flat[model.offsets[1]:model.offsets[1] + L * d].view(L, d)
+    us_emb = _time_us(lambda: ops.embed_fwd(ids, E, Pt, L, p, sd, 1, 0))
+    alg_bytes = B * H * 8 * L * hd * 4
+    achieved = alg_bytes / (us_bwd * 1e-6) / 1e9
+    fl_fwd = B * H * 4 * (L * (L + 1) // 2) * hd           # QK^T and PV, causal half
+    emb_bytes = T * (4 + d * 4 + d * 4)                     # id + fp32 table row + fp32 output row (positional table stays in cache)
     # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes of this same command,
     # corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py): a profiler measurement, committed under profiles/
     traffic = None
     pmc = os.path.join(REPO, "profiles", "r01_attn_bwd_pmc.json")
     if os.path.exists(pmc):
         traffic = round(json.load(open(pmc))["traffic_bytes"])
+    step_bytes = 2.4e6
     return {"bound": "hbm", "kernel": "k_attn_bwd", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_us": round(ms * 1e3, 2),
-            "algorithmic_bytes_per_launch": alg_bytes}
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_us": round(us_bwd, 2),
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "kernels": [
+                {"kernel": "k_embed_fwd (item + positional gather, dropout, pad mask)", "bound": "hbm", "avg_launch_us": round(us_emb, 2),
+                 "algorithmic_bytes_per_launch": emb_bytes, "achieved_GBps": round(emb_bytes / (us_emb * 1e-6) / 1e9, 1),
+                 "frac": round(emb_bytes / (us_emb * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                {"kernel": "k_attn_fwd", "bound": "mfma", "avg_launch_us": round(us_fwd, 2), "flops_per_launch": fl_fwd,
+                 "achieved_TFLOPs": round(fl_fwd / (us_fwd * 1e-6) / 1e12, 2), "mfma_util": round(fl_fwd / (us_fwd * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+                {"kernel": "k_attn_bwd", "bound": "mfma", "avg_launch_us": round(us_bwd, 2), "flops_per_launch": int(2.5 * fl_fwd),
+                 "achieved_TFLOPs": round(2.5 * fl_fwd / (us_bwd * 1e-6) / 1e12, 2),
+                 "mfma_util": round(2.5 * fl_fwd / (us_bwd * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)}],
+            "step": {"bytes_per_sequence_ideal": step_bytes, "achieved_GBps": round(seq_per_s * step_bytes / 1e9, 1),
+                     "frac": round(seq_per_s * step_bytes / 1e9 / HBM_PEAK_GBS, 4),
+                     "mfma_util": round(seq_per_s * 250e6 / 1e12 / MFMA_PEAK_TFLOPS, 4)}}
 
 
 def self_launch(n):
@@ -245,7 +278,7 @@ def main():
                           "parallelism": "dp%d%s" % (world, "-rccl" if pg is not None else ""), "hip_graph": not args.no_graph},
                "loss_last_step": round(loss, 5),
                "value_incl_h2d": round(world * B * args.steps / dt_h2d, 1), "ms_per_step_incl_h2d": round(dt_h2d / args.steps * 1e3, 4)}
-        res["roofline"] = roofline_probe(model, tr, B)
+        res["roofline"] = roofline_probe(model, tr, B, B * args.steps / dt)
         if world == 1 and not args.no_cpu_baseline and not args.force_dp:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -39,3 +39,21 @@ def test_stosa_ranking_matches_reference(golden_dir):
             assert abs(eo[mode]["mrr"] - er[mode]["mrr"]) <= 0.03, (eo["epoch"], mode, eo[mode], er[mode])
     assert abs(ours["loss"][-1] - ref["loss"][-1]) <= 0.05 * ref["loss"][-1]
     assert ours["evals"][-1]["test"]["ndcg10"] > 0.1               # full-sort over 800 items: random is ~0.006
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_stosa_deterministic_training_matches_reference(golden_dir, precision):
+    """The same 20 epochs with dropout 0 from the SAME initial weights (oracle.stosa_oracle.init_params, seed 42) as the reference run
+    recorded in ref_ndcg_stosa_small_det.json: nothing random is left, so the comparison is as tight as north_star states -- NDCG@10
+    and HIT@10 within +-0.01 absolute on validation and test at epochs 10 and 20, the epoch-mean loss within 1 % throughout.  (Round 1's
+    stochastic runs sat ~0.009 below the mean of three reference seeds whose own spread is 0.0087: this run shows the two
+    implementations train to the same point when the dropout streams and the initialisation are taken out.)"""
+    from tools.gpu_wide_ndcg_run import run_stosa
+    ref = json.load(open(os.path.join(golden_dir, "ref_ndcg_stosa_small_det.json")))
+    ours = run_stosa(seed=42, precision=precision, deterministic=True)
+    for lo, lr in zip(ours["loss"], ref["loss"]):
+        assert abs(lo - lr) <= 0.01 * lr, (ours["loss"], ref["loss"])
+    for eo, er in zip(ours["evals"], ref["evals"]):
+        for mode in ("val", "test"):
+            for k in ("ndcg10", "hit10", "mrr"):
+                assert abs(eo[mode][k] - er[mode][k]) <= 0.01, (precision, eo["epoch"], mode, k, eo[mode], er[mode])

@@ -55,12 +55,16 @@ def run_bert(seed=23, precision="bf16", use_graph=True, data=None):
     return log
 
 
-def run_stosa(seed=42, precision="bf16", use_graph=True, data=None):
+def run_stosa(seed=42, precision="bf16", use_graph=True, data=None, deterministic=False):
+    """deterministic: dropout 0 and the numpy initial weights oracle.stosa_oracle.init_params(cfg, seed) -- exactly what
+    tools/ref_train_wide.py stosa_det gave the reference, so the two runs differ by floating-point rounding only."""
     import torch
     from adt_amd.stosa.main import _evaluate
     from adt_amd.stosa.models import DisenDistSAModel
     from adt_amd.stosa.trainer import FusedStosaTrainer
-    cfg = C.STOSA
+    cfg = dict(C.STOSA)
+    if deterministic:
+        cfg["dropout"] = cfg["attention_dropout"] = 0.0
     train, valid, test, vm, tm, max_item, nu = data or C.stosa_data()
     a = _A()
     a.item_size, a.hidden_units, a.maxlen, a.num_users, a.dropout, a.attention_dropout = max_item + 2, cfg["hidden_units"], cfg["maxlen"], nu, cfg["dropout"], cfg["attention_dropout"]
@@ -68,6 +72,10 @@ def run_stosa(seed=42, precision="bf16", use_graph=True, data=None):
     a.cuda_condition, a.pvn_weight, a.device, a.precision = True, cfg["pvn_weight"], "cuda:0", precision
     torch.manual_seed(seed)
     m = DisenDistSAModel(a)
+    if deterministic:
+        from oracle import stosa_oracle as so
+        ocfg = so.Cfg(a.item_size, a.maxlen, a.hidden_units, a.num_heads, a.num_layers, num_users=nu, pvn_weight=cfg["pvn_weight"])
+        m.load_numpy(so.init_params(ocfg, seed))
     tr = FusedStosaTrainer(m, cfg["lambda1"], cfg["lambda2"], lr=cfg["lr"], betas=(0.9, 0.999), weight_decay=0.0, use_graph=use_graph, seed=seed)
     log = {"seed": seed, "evals": [], "loss": []}
     t0 = time.time()

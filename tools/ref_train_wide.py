@@ -97,8 +97,12 @@ def run_bert(seed=23, suffix=""):
     json.dump(log, open(os.path.join(OUT, "ref_ndcg_bert_small%s.json" % suffix), "w"), indent=1)
 
 
-def run_stosa(seed=42, suffix=""):
-    cfg = C.STOSA
+def run_stosa(seed=42, suffix="", deterministic=False):
+    """deterministic: dropout 0 and the numpy initial weights of oracle.stosa_oracle.init_params(cfg, seed) -- the HIP path starts from
+    the same weights (tests/test_ndcg_parity_wide.py), so the two training runs differ by floating-point rounding only."""
+    cfg = dict(C.STOSA)
+    if deterministic:
+        cfg["dropout"] = cfg["attention_dropout"] = 0.0
     models = _import_from("/root/reference/stosa", "models")
     modules = sys.modules["modules"]
     train, valid, test, vm, tm, max_item, nu = C.stosa_data()
@@ -108,6 +112,10 @@ def run_stosa(seed=42, suffix=""):
     a.cuda_condition, a.pvn_weight = False, cfg["pvn_weight"]
     torch.manual_seed(seed)
     m = models.DisenDistSAModel(a)
+    if deterministic:
+        from oracle import stosa_oracle as so
+        ocfg = so.Cfg(a.item_size, a.maxlen, a.hidden_units, a.num_heads, a.num_layers, num_users=nu, pvn_weight=cfg["pvn_weight"])
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in so.init_params(ocfg, seed).items()}, strict=True)
     opt = torch.optim.Adam(m.parameters(), lr=cfg["lr"], betas=(0.9, 0.999), weight_decay=0.0)
     wd = modules.wasserstein_distance
     d, L, H = cfg["hidden_units"], cfg["maxlen"], cfg["num_heads"]
@@ -170,6 +178,9 @@ def run_stosa(seed=42, suffix=""):
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if sys.argv[1] == "stosa_det":      # deterministic run: dropout 0, shared numpy init -> ref_ndcg_stosa_small_det.json
+        run_stosa(int(sys.argv[2]) if len(sys.argv) > 2 else 42, "_det", deterministic=True)
+        sys.exit(0)
     fn = {"bert": run_bert, "stosa": run_stosa}[sys.argv[1]]
     if len(sys.argv) > 2:          # extra model-init seeds (reference seed spread): ... <mode> <seed> -> *_small_s<seed>.json
         fn(int(sys.argv[2]), "_s%s" % sys.argv[2])
