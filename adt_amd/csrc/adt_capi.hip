@@ -32,10 +32,10 @@ DropCfg adt_make_drop(float p, const uint32_t* seed, uint32_t site) {
   DropCfg d;
   d.seed = seed;
   d.site = site;
-  if (p > 0.f && seed != nullptr) {
-    double t = (double)p * 4294967296.0;
-    d.thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
-    d.scale = 1.0f / (1.0f - p);
+  const int t8 = p > 0.f ? (int)((double)p * 256.0 + 0.5) : 0;      // oracle/rng.py: threshold(p)
+  if (t8 > 0 && seed != nullptr) {
+    d.thr = (uint32_t)(t8 > 255 ? 255 : t8);
+    d.scale = (float)(1.0 / (1.0 - (double)d.thr / 256.0));
   } else {
     d.thr = 0;
     d.scale = 1.0f;

@@ -85,15 +85,24 @@ __host__ __device__ __forceinline__ uint32_t adt_hash32(uint32_t x) {
 __host__ __device__ __forceinline__ uint32_t adt_site_key(uint32_t seed, uint32_t site) {
   return adt_hash32(seed ^ (site * 0x9E3779B9u));
 }
+// One 32-bit hash serves the four elements 4k .. 4k+3, one byte each: element idx reads byte (idx & 3) of hash32((idx >> 2) ^ key)
+// and is dropped iff that byte < thr (an 8-bit threshold, round(p * 256)).  A lane that holds four consecutive elements -- an MFMA
+// accumulator register quad -- hashes once per quad (adt_keep4) instead of four times; identical to oracle/rng.py.
 __host__ __device__ __forceinline__ bool adt_keep(uint32_t key, uint32_t idx, uint32_t thr) {
-  return adt_hash32(idx ^ key) >= thr;
+  return ((adt_hash32((idx >> 2) ^ key) >> (8u * (idx & 3u))) & 0xFFu) >= thr;
+}
+// the four keep decisions of elements idx4 .. idx4 + 3 (idx4 % 4 == 0) from one hash: bit r of the result = keep(idx4 + r)
+__host__ __device__ __forceinline__ uint32_t adt_keep4(uint32_t key, uint32_t idx4, uint32_t thr) {
+  const uint32_t h = adt_hash32((idx4 >> 2) ^ key);
+  return ((h & 0xFFu) >= thr ? 1u : 0u) | (((h >> 8) & 0xFFu) >= thr ? 2u : 0u) | (((h >> 16) & 0xFFu) >= thr ? 4u : 0u) |
+         ((h >> 24) >= thr ? 8u : 0u);
 }
 
 struct DropCfg {
   const uint32_t* seed;  // device scalar (changes every step; lives in device memory so a captured graph replays)
   uint32_t site;
-  uint32_t thr;    // drop iff hash < thr ; 0 = dropout off
-  float scale;     // 1/(1-p)
+  uint32_t thr;    // 8-bit threshold round(p * 256): drop iff the element's random byte < thr ; 0 = dropout off
+  float scale;     // 1 / (1 - thr / 256): unbiased at the quantised rate
 };
 
 __device__ __forceinline__ uint32_t drop_key(const DropCfg& d) { return d.thr ? adt_site_key(*d.seed, d.site) : 0u; }

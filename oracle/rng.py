@@ -37,15 +37,25 @@ def site_key(seed, site):
 
 
 def threshold(p):
-    """Drop iff hash < threshold(p); threshold = floor(p * 2^32) clipped to uint32."""
-    t = int(float(p) * 4294967296.0)
-    return np.uint32(min(max(t, 0), 0xFFFFFFFF))
+    """8-bit drop threshold: an element is dropped iff its random byte < threshold(p) = round(p * 256), at most 255."""
+    t = int(float(p) * 256.0 + 0.5)
+    return np.uint32(min(max(t, 0), 255))
+
+
+def drop_prob(p):
+    """The drop probability actually applied, threshold(p) / 256 (0.5 -> 0.5, 0.2 -> 0.19922, 0.3 -> 0.30078): survivors are
+    scaled by 1 / (1 - drop_prob(p)), so the mask stays unbiased at the quantised rate."""
+    return float(threshold(p)) / 256.0
 
 
 def keep_mask(seed, site, idx, p):
-    """Boolean keep mask for element indices `idx` (any shape, values < 2^32)."""
+    """Boolean keep mask for element indices `idx` (any shape, values < 2^32).  One 32-bit hash serves the four elements
+    4k .. 4k+3, one byte each (element idx reads byte idx & 3 of hash32((idx >> 2) ^ key)): a kernel whose lane holds four
+    consecutive elements -- an MFMA accumulator register quad -- hashes once per quad instead of four times."""
     idx = np.asarray(idx)
     assert idx.size == 0 or int(idx.max()) < (1 << 32)
     key = site_key(seed, site)
-    r = hash32(idx.astype(np.uint32) ^ key)
-    return r >= threshold(p)
+    idx = idx.astype(np.uint32)
+    r = hash32((idx >> np.uint32(2)) ^ key)
+    byte = (r >> (np.uint32(8) * (idx & np.uint32(3)))) & np.uint32(0xFF)
+    return byte >= threshold(p)

@@ -108,11 +108,11 @@ def init_params(cfg, seed=0, dtype=np.float32):
 # ----------------------------------------------------------------------------------------------
 # primitives
 def _dropout(x, p, seed, site, idx):
-    """y = x * keep / (1-p); keep from the shared hash RNG (oracle/rng.py)."""
+    """y = x * keep / (1 - drop_prob(p)); keep from the shared hash RNG (oracle/rng.py: 8-bit thresholds)."""
     if p <= 0.0:
         return x, None
     keep = rng.keep_mask(seed, site, idx, p)
-    scale = x.dtype.type(1.0 / (1.0 - p))
+    scale = x.dtype.type(1.0 / (1.0 - rng.drop_prob(p)))
     return x * keep * scale, keep
 
 
@@ -202,7 +202,7 @@ def attention_bwd(do, cache, H):
     dvh = pd.transpose(0, 1, 3, 2) @ doh
     dpd = doh @ vh.transpose(0, 1, 3, 2)
     if keep is not None:
-        dpr = dpd * keep * pr.dtype.type(1.0 / (1.0 - p))
+        dpr = dpd * keep * pr.dtype.type(1.0 / (1.0 - rng.drop_prob(p)))
     else:
         dpr = dpd
     ds = pr * (dpr - (dpr * pr).sum(-1, keepdims=True))
@@ -227,7 +227,7 @@ def ffn(x, w1, b1, w2, b2, p, seed, s1, s2, b_offset=0):
 
 def ffn_bwd(df, cache, w1, w2):
     x, u, k1, k2, p = cache
-    sc = x.dtype.type(1.0 / (1.0 - p)) if p > 0 else x.dtype.type(1.0)
+    sc = x.dtype.type(1.0 / (1.0 - rng.drop_prob(p))) if p > 0 else x.dtype.type(1.0)
     if k2 is not None:
         df = df * k2 * sc
     du, dw2, db2 = linear_bwd(df, u, w2)
@@ -485,7 +485,7 @@ def backward(P, cfg, cache, seeds, weight_decay=0.0, add_wd=True):
         keep, m = c
         g = g * m
         if keep is not None:
-            g = g * keep * g.dtype.type(1.0 / (1.0 - cache["p"]))
+            g = g * keep * g.dtype.type(1.0 / (1.0 - rng.drop_prob(cache["p"])))
         dP[: g.shape[1]] += g.sum(0)
         np.add.at(dE, ids, g * E.dtype.type(E.shape[1] ** 0.5))
     if add_wd and weight_decay != 0.0:

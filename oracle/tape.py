@@ -344,7 +344,7 @@ def dropout(a, p, seed, site, idx, training=True):
     if not training or p <= 0.0:
         return a
     keep = rng.keep_mask(seed, site, idx, p)
-    return mul_mask(a, keep.astype(F32) * F32(1.0 / (1.0 - p)))
+    return mul_mask(a, keep.astype(F32) * F32(1.0 / (1.0 - rng.drop_prob(p))))
 
 
 def idx_rows(T, N, row_offset=0):

@@ -166,4 +166,8 @@ def test_dropout_rng_is_deterministic_and_calibrated():
     assert [int(x) for x in rng.hash32(np.array([0, 1, 2, 0xDEADBEEF], np.uint32))] == \
         [0, 1753845952, 3507691905, 3861431939]
     assert int(rng.site_key(7, 17)) == 88319467
-    assert list(rng.keep_mask(7, 17, np.arange(16), 0.5).astype(int)) == [1, 1, 1, 0, 1, 1, 1, 0, 1, 0, 1, 0, 1, 1, 1, 1]
+    assert list(rng.keep_mask(7, 17, np.arange(16), 0.5).astype(int)) == [1, 0, 1, 1, 0, 1, 0, 1, 1, 1, 0, 1, 1, 0, 1, 0]
+    # one hash word serves four consecutive elements, one byte each; the applied rate is round(256 p) / 256
+    assert rng.drop_prob(0.5) == 0.5 and rng.drop_prob(0.2) == 51 / 256 and rng.drop_prob(0.3) == 77 / 256
+    h = rng.hash32(np.array([5], np.uint32) ^ rng.site_key(7, 17))[0]
+    assert [bool(b) for b in rng.keep_mask(7, 17, np.arange(20, 24), 0.5)] == [((int(h) >> (8 * r)) & 255) >= 128 for r in range(4)]

@@ -15,7 +15,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 
-def run(preset, epochs, eval_every, seed, precision, hidden=64, maxlen=200, data=None):
+def run(preset, epochs, eval_every, seed, precision, hidden=64, maxlen=200, data=None, deterministic=False):
+    """deterministic: dropout 0, the numpy initial weights oracle.sasrec_oracle.init_params(cfg, 23) and the seeded batches of
+    WarpDataset.epoch_batches(256, RandomState(1000 + epoch)) -- what tools/ref_train_ndcg.py --deterministic gave the reference."""
     import torch
     from adt_amd.sasrec import synth, utils as U
     from adt_amd.sasrec.model import SASRecADT
@@ -28,7 +30,7 @@ def run(preset, epochs, eval_every, seed, precision, hidden=64, maxlen=200, data
     class A:
         pass
     a = A()
-    a.device, a.num_heads, a.maxlen, a.num_layers, a.hidden_units, a.dropout, a.precision = "cuda:0", 2, maxlen, 2, hidden, 0.5, precision
+    a.device, a.num_heads, a.maxlen, a.num_layers, a.hidden_units, a.dropout, a.precision = "cuda:0", 2, maxlen, 2, hidden, (0.0 if deterministic else 0.5), precision
     torch.manual_seed(seed)
     np.random.seed(seed)
     if hidden != 64:       # the template width (d = 256) runs on the general kernels, as adt_amd/sasrec/main.py routes it
@@ -41,6 +43,10 @@ def run(preset, epochs, eval_every, seed, precision, hidden=64, maxlen=200, data
             torch.nn.init.xavier_normal_(p.data)
         except Exception:
             pass
+    if deterministic:
+        from oracle import sasrec_oracle as so
+        ocfg = so.Cfg(itemnum, maxlen, hidden, 2, 2, dropout=0.0)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in so.init_params(ocfg, seed=23).items()})
     model.train()
     lam1, lam2 = U.get_lambdas("ml-1m")
     Trainer = FusedTrainer if hidden == 64 else WideSasrecTrainer
@@ -56,12 +62,15 @@ def run(preset, epochs, eval_every, seed, precision, hidden=64, maxlen=200, data
     for epoch in range(epochs):
         t0 = time.time()
         losses = []
-        for u, seq, dec, pos, neg in warp.epoch_batches(256, rng):
+        ep_loss = []
+        for u, seq, dec, pos, neg in warp.epoch_batches(256, np.random.RandomState(1000 + epoch) if deterministic else rng):
             tr.step(seq, dec, pos, neg)
             nseq += len(u)
+            if deterministic:
+                ep_loss.append(tr.loss())
         torch.cuda.synchronize()
         t_train += time.time() - t0
-        log["loss"].append(float(tr.loss()))
+        log["loss"].append(float(torch.stack(ep_loss).mean()) if ep_loss else float(tr.loss()))
         if (epoch + 1) % eval_every == 0 or epoch + 1 == epochs:
             model.eval()
             rec = {"epoch": epoch + 1}

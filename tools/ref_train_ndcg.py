@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--eval_every", type=int, default=10)
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--maxlen", type=int, default=200)
+    ap.add_argument("--deterministic", action="store_true",
+                    help="dropout 0, numpy initial weights oracle.sasrec_oracle.init_params(cfg, 23) and seeded batches from "
+                         "adt_amd.sasrec.utils.WarpDataset.epoch_batches: the HIP run (tools/gpu_ndcg_run.py --deterministic) sees the same")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     torch.set_num_threads(8)
@@ -57,7 +60,7 @@ def main():
     os.chdir(cwd)
     args = Args()
     args.device, args.num_heads, args.maxlen, args.num_layers, args.hidden_units = "cpu", 2, a.maxlen, 2, a.hidden
-    args.dropout, args.weight_decay, args.lr, args.clip, args.batch_size = 0.5, 1e-3, 1e-3, 5.0, 256
+    args.dropout, args.weight_decay, args.lr, args.clip, args.batch_size = (0.0 if a.deterministic else 0.5), 1e-3, 1e-3, 5.0, 256
     lambdas1, lambdas2 = ref_utils.get_lambdas("ml-1m")
 
     # reference's seeding (sasrec/main.py:60-66, :71)
@@ -69,11 +72,20 @@ def main():
             torch.nn.init.xavier_normal_(p.data)
         except Exception:
             pass
+    if a.deterministic:
+        from oracle import sasrec_oracle as so
+        ocfg = so.Cfg(itemnum, args.maxlen, args.hidden_units, args.num_heads, args.num_layers, dropout=0.0)
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in so.init_params(ocfg, seed=23).items()}, strict=True)
     model.train()
     bce = torch.nn.BCEWithLogitsLoss()
     opt = torch.optim.Adam(model.parameters(), lr=args.lr, betas=(0.9, 0.98))
     ds = ref_utils.WarpDataset(user_train, usernum, itemnum, args.maxlen)
     loader = DataLoader(ds, batch_size=args.batch_size, num_workers=4, shuffle=True)
+    our_warp = our_utils.WarpDataset(user_train, usernum, itemnum, args.maxlen)
+
+    def det_batches(epoch):
+        for u, seq, dec, pos, neg in our_warp.epoch_batches(args.batch_size, np.random.RandomState(1000 + epoch)):
+            yield [u, seq, dec, pos, neg], None
 
     sampler = our_utils.PopularSampler(user_train, user_valid, user_test, usernum, itemnum, 100)
     evals = {}
@@ -82,11 +94,11 @@ def main():
         evals[mode] = [((torch.from_numpy(u), torch.from_numpy(s), torch.from_numpy(c.astype(np.int64))), torch.from_numpy(l))
                        for (u, s, c), l in ed.batches(512)]
 
-    log = {"preset": a.preset, "users": usernum, "items": itemnum, "hidden": a.hidden, "maxlen": a.maxlen, "evals": [], "loss": []}
+    log = {"deterministic": bool(a.deterministic), "preset": a.preset, "users": usernum, "items": itemnum, "hidden": a.hidden, "maxlen": a.maxlen, "evals": [], "loss": []}
     t0 = time.time()
     for epoch in range(a.epochs):
         tot, nb = 0.0, 0
-        for batch, _ in loader:
+        for batch, _ in (det_batches(epoch) if a.deterministic else loader):
             u, seq, dec, pos, neg = [np.array(x) for x in batch]
             pos_logits, neg_logits, enc_in, dec_out, rec_ind = model(u, seq, dec, pos, neg)
             pos_labels, neg_labels = torch.ones(pos_logits.shape), torch.zeros(neg_logits.shape)
