@@ -386,6 +386,10 @@ int adt_attn_bwd(int prec, const float* Q, int ldq, const float* K, int ldk, con
   a.drop = adt_make_drop(p, seed, site); a.bh_offset = b_offset * (uint32_t)H;
   a.dO = dO; a.lddo = lddo; a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv;
   if ((lddo % 4) || (lddq % 4) || (lddk % 4) || (lddv % 4)) return adt_set_error("attn_bwd: ld %% 4");
+  if (prec == ADT_PREC_BF16) {      // d = 64: one workgroup per sequence, one natural-order image per tensor (adt_seqattn.cuh)
+    const int rc = adt_launch_seq_attn_bwd(hd, a, stream);
+    if (rc <= 0) return rc;
+  }
   return dispatch_attn(prec, true, hd, a, (hipStream_t)stream);
 }
 

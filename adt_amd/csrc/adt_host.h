@@ -32,3 +32,5 @@ int adt_launch_seq_enc_fwd(int hd, const adt::SeqFwdArgs& a, void* stream);
 int adt_launch_seq_dec_fwd(int hd, const adt::SeqFwdArgs& a, void* stream);
 // pre-packed bf16 weight images of n 64 x 64 blocks at base + offs[i] -> img + 6 * offs[i] (bf16 elements); defined in adt_seq.hip
 int adt_pack_wimg(const float* base, void* img, const int* offs, int n, void* stream);
+namespace adt { struct AttnArgs; }
+int adt_launch_seq_attn_bwd(int hd, const adt::AttnArgs& a, void* stream);     // 0 launched, 1 shape not covered, < 0 error

@@ -2,6 +2,8 @@
 #include "adt_host.h"
 #include <stdlib.h>
 #include "adt_seqfwd.cuh"
+#include "adt_seqfwd_tt.cuh"
+#include "adt_seqattn.cuh"
 
 using namespace adt;
 
@@ -35,14 +37,21 @@ __global__ __launch_bounds__(256) void k_pack_wimg(PackArgs a) {
   const float* W = a.base + off;
   __bf16* plain = a.img + 6 * (size_t)off;
   __bf16* trans = plain + WPACK_IMG;
+  __bf16* splain = plain + 2 * WPACK_IMG;       // slot-ordered forms for the transposed chains (adt_tt.cuh): column 32 kb + 4 g' + q + 16 s
+  __bf16* strans = plain + 3 * WPACK_IMG;       // of a row sits at 32 kb + 8 g' + 4 s + q
   for (int i = threadIdx.x; i < 64 * 16; i += 256) {
     const int n = i >> 4, k4 = (i & 15) * 4;
     const float4 v = *reinterpret_cast<const float4*>(W + n * 64 + k4);
     const float x[4] = {v.x, v.y, v.z, v.w};
+    const int ns = (n & 32) + 8 * ((n >> 2) & 3) + 4 * ((n >> 4) & 1) + (n & 3);      // slot position of column n in a transposed row
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      plain[n * 72 + k4 + j] = (__bf16)x[j];
-      trans[(k4 + j) * 72 + n] = (__bf16)x[j];
+      const int k = k4 + j;
+      const int ks = (k & 32) + 8 * ((k >> 2) & 3) + 4 * ((k >> 4) & 1) + (k & 3);
+      plain[n * 72 + k] = (__bf16)x[j];
+      trans[k * 72 + n] = (__bf16)x[j];
+      splain[n * 72 + ks] = (__bf16)x[j];
+      strans[k * 72 + ns] = (__bf16)x[j];
     }
   }
 }
@@ -84,12 +93,25 @@ static void seq_ablate(SeqFwdArgs& a) {
   if (ab & 1) { a.qkv = nullptr; a.o = nullptr; a.h = nullptr; a.u = nullptr; a.a1 = nullptr; a.q2 = nullptr; a.kv2 = nullptr; a.o2 = nullptr; a.mask = nullptr; a.mask2 = nullptr; }
 }
 
+static bool seq_use_tt(const SeqFwdArgs& a) {     // register-resident transposed chains (adt_seqfwd_tt.cuh); ADT_SEQ_TT=0: the row-major fused form
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("ADT_SEQ_TT"); on = (e && atoi(e) == 0) ? 0 : 1; }
+  return on && a.wp_img != nullptr;
+}
+
 int adt_launch_seq_enc_fwd(int hd, const SeqFwdArgs& a, void* stream) {
   static bool done[3] = {false, false, false};
+  static bool done_tt[3] = {false, false, false};
   SeqFwdArgs args = a;
   seq_ablate(args);
-  const size_t smem = SeqFwdLds<6>::bytes;
   hipStream_t s = (hipStream_t)stream;
+  if (seq_use_tt(args)) {
+    const size_t smem_tt = SeqTtLds<6>::bytes;
+    if (hd == 64) return seq_launch((const void*)k_seqtt_enc_fwd<64>, smem_tt, done_tt[0], a.B, &args, s, "seqtt_enc_fwd<64>");
+    if (hd == 32) return seq_launch((const void*)k_seqtt_enc_fwd<32>, smem_tt, done_tt[1], a.B, &args, s, "seqtt_enc_fwd<32>");
+    if (hd == 16) return seq_launch((const void*)k_seqtt_enc_fwd<16>, smem_tt, done_tt[2], a.B, &args, s, "seqtt_enc_fwd<16>");
+  }
+  const size_t smem = SeqFwdLds<6>::bytes;
   if (hd == 64) return seq_launch((const void*)k_seq_enc_fwd<64, 2>, smem, done[0], a.B, &args, s, "seq_enc_fwd<64>");
   if (hd == 32) return seq_launch((const void*)k_seq_enc_fwd<32, 2>, smem, done[1], a.B, &args, s, "seq_enc_fwd<32>");
   if (hd == 16) return seq_launch((const void*)k_seq_enc_fwd<16, 4>, smem, done[2], a.B, &args, s, "seq_enc_fwd<16>");
@@ -98,12 +120,41 @@ int adt_launch_seq_enc_fwd(int hd, const SeqFwdArgs& a, void* stream) {
 
 int adt_launch_seq_dec_fwd(int hd, const SeqFwdArgs& a, void* stream) {
   static bool done[3] = {false, false, false};
+  static bool done_tt[3] = {false, false, false};
   SeqFwdArgs args = a;
   seq_ablate(args);
-  const size_t smem = SeqFwdLds<5>::bytes;
   hipStream_t s = (hipStream_t)stream;
+  if (seq_use_tt(args)) {
+    const size_t smem_tt = SeqTtLds<5>::bytes;
+    if (hd == 64) return seq_launch((const void*)k_seqtt_dec_fwd<64>, smem_tt, done_tt[0], a.B, &args, s, "seqtt_dec_fwd<64>");
+    if (hd == 32) return seq_launch((const void*)k_seqtt_dec_fwd<32>, smem_tt, done_tt[1], a.B, &args, s, "seqtt_dec_fwd<32>");
+    if (hd == 16) return seq_launch((const void*)k_seqtt_dec_fwd<16>, smem_tt, done_tt[2], a.B, &args, s, "seqtt_dec_fwd<16>");
+  }
+  const size_t smem = SeqFwdLds<5>::bytes;
   if (hd == 64) return seq_launch((const void*)k_seq_dec_fwd<64>, smem, done[0], a.B, &args, s, "seq_dec_fwd<64>");
   if (hd == 32) return seq_launch((const void*)k_seq_dec_fwd<32>, smem, done[1], a.B, &args, s, "seq_dec_fwd<32>");
   if (hd == 16) return seq_launch((const void*)k_seq_dec_fwd<16>, smem, done[2], a.B, &args, s, "seq_dec_fwd<16>");
   return adt_set_error("seq_dec_fwd: head size %d", hd);
+}
+
+// causal attention backward, one workgroup per sequence (adt_seqattn.cuh); returns 1 when the shape is not covered (caller falls back)
+int adt_launch_seq_attn_bwd(int hd, const AttnArgs& a, void* stream) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("ADT_SEQ_ATTN_BWD"); on = (e && atoi(e) == 0) ? 0 : 1; }
+  if (!on || !a.causal || a.H * hd != 64 || a.L > 224) return 1;
+  if ((a.ldq % 4) || (a.ldk % 4) || (a.ldv % 4) || (a.ldo % 4)) return 1;
+  const size_t smem = sab_lds_bytes(a.L, a.H);
+  if (smem > 160 * 1024) return 1;
+  static bool done[3] = {false, false, false};
+  const void* fn = hd == 64 ? (const void*)k_seq_attn_bwd<64> : hd == 32 ? (const void*)k_seq_attn_bwd<32> : hd == 16 ? (const void*)k_seq_attn_bwd<16> : nullptr;
+  if (!fn) return 1;
+  const int slot = hd == 64 ? 0 : hd == 32 ? 1 : 2;
+  if (!done[slot]) {      // the attribute is the maximum this kernel may ask for, not this launch's size
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return adt_set_error("seq_attn_bwd: hipFuncSetAttribute");
+    done[slot] = true;
+  }
+  AttnArgs args = a;
+  void* kargs[] = {&args};
+  if (hipLaunchKernel(fn, dim3(a.B), dim3(SAB_NW * 64), kargs, smem, (hipStream_t)stream) != hipSuccess) return adt_set_error("seq_attn_bwd: launch failed");
+  return seq_check("seq_attn_bwd");
 }

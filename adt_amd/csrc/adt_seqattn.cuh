@@ -1,0 +1,247 @@
+// Causal attention BACKWARD, one workgroup per sequence (all heads), bf16 MFMA operands -- replaces k_attn_bwd_bf16 (one workgroup
+// per (b, h), four row images + three TRANSPOSED images per head, written with two-byte LDS stores) for d = H * hd = 64.
+//
+// LDS holds ONE natural-order row image [token][64] (bf16, stride 72) each of Q (pre-scaled by log2(e)/sqrt(hd)), K, V and dO for
+// the whole sequence and all heads.  Operands that contract over FEATURES read a row of an image in slot order (two 8-byte reads:
+// columns 4g .. 4g+3 and 16 + 4g .. of the head's 32-feature block); operands that contract over TOKENS (K^T for dQ, dO^T for dV,
+// Q^T for dK) come from the SAME images through ds_read_b64_tr_b16 (adt_tt.cuh: tt_trfrag) -- no transposed copies, staging is
+// plain 16-byte stores.  Algorithm as before (adt_attn.cuh): P is recomputed from the saved log-sum-exp, pass A (a wave owns a
+// query tile) accumulates dQ, pass B (a wave owns a key tile) accumulates dK and dV, no cross-wave sums => bitwise reproducible.
+// All gradients come out as TRANSPOSED tiles (feature on the accumulator row, token on the lane): 16-byte global stores.
+#pragma once
+#include "adt_attn.cuh"
+#include "adt_tt.cuh"
+
+namespace adt {
+
+constexpr int SAB_NW = 8;
+
+__host__ __device__ inline int sab_rows(int L) { return (L + 31) / 32 * 32; }       // image rows: whole tile pairs
+__host__ __device__ inline size_t sab_lds_bytes(int L, int H) {
+  const size_t R = (size_t)((L + 31) / 32 * 32);
+  return 4 * R * TT_RS * 2 + (size_t)H * R * 8 * 4 + 2 * (size_t)H * R * 4;
+}
+
+// 8 features of image row `row` in slot order for head h (block kb of the head): {4g .. 4g+3} and {16 + 4g ..} of the 32-feature block;
+// a 16-wide head fills the low four slots only (the high four are zero in BOTH operands of its products)
+template <int HD>
+ADT_DEVICE_INLINE bf16x8 sab_rowfrag(const __bf16* img, int row, int h, int kb, int g) {
+  const __bf16* p = img + row * TT_RS + h * HD + 32 * kb + 4 * g;
+  const bf16x4 lo = *reinterpret_cast<const bf16x4*>(p);
+  bf16x4 hi;
+  if constexpr (HD == 16) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) hi[j] = (__bf16)0.f;
+  } else {
+    hi = *reinterpret_cast<const bf16x4*>(p + 16);
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { o[j] = lo[j]; o[4 + j] = hi[j]; }
+  return o;
+}
+
+template <int HD>
+__global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
+  constexpr int H = 64 / HD, NT = HD / 16, KB = (HD + 31) / 32, MAXKT = 14, NW = SAB_NW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int L = a.L, R = sab_rows(L);
+  __bf16* sQ = reinterpret_cast<__bf16*>(smem_raw);
+  __bf16* sK = sQ + R * TT_RS;
+  __bf16* sV = sK + R * TT_RS;
+  __bf16* sdO = sV + R * TT_RS;
+  uint32_t* sM = reinterpret_cast<uint32_t*>(sdO + R * TT_RS);     // [H][R][8] dropout keep bits of the forward, 0 beyond L
+  float* sLse = reinterpret_cast<float*>(sM + (size_t)H * R * 8);   // [H][R] log2-domain log-sum-exp (+inf beyond L)
+  float* sDelta = sLse + H * R;                                     // [H][R] rowsum(dO * O) per head
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const size_t row_b = (size_t)b * L;
+  const bool use_bits = a.mask != nullptr && a.drop.thr != 0;
+  const float qmul = a.scale * 1.4426950408889634f;
+  if (use_bits) {
+    for (int i = threadIdx.x; i < H * R * 2; i += NW * 64) {
+      const int hr = i >> 1, h = hr / R, r = hr - h * R;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (r < L) v = reinterpret_cast<const uint4*>(a.mask + ((size_t)(b * H + h) * L + r) * 8)[i & 1];
+      reinterpret_cast<uint4*>(sM + (size_t)hr * 8)[i & 1] = v;
+    }
+  }
+  for (int i = threadIdx.x; i < H * R; i += NW * 64) {
+    const int h = i / R, r = i - h * R;
+    sLse[i] = r < L ? a.LSE[(size_t)(b * H + h) * L + r] * 1.4426950408889634f : INFINITY;
+  }
+  // images: 8 features per thread and step; delta from the same dO / O chunks (the chunks of a head are adjacent lanes)
+  for (int i = threadIdx.x; i < R * 8; i += NW * 64) {
+    const int r = i >> 3, c8 = (i & 7) * 8;
+    float q[8], k[8], v[8], d[8], o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = k[j] = v[j] = d[j] = o[j] = 0.f;
+    if (r < L) {
+      *reinterpret_cast<float4*>(q) = *reinterpret_cast<const float4*>(a.Q + (row_b + r) * a.ldq + c8);
+      *reinterpret_cast<float4*>(q + 4) = *reinterpret_cast<const float4*>(a.Q + (row_b + r) * a.ldq + c8 + 4);
+      *reinterpret_cast<float4*>(k) = *reinterpret_cast<const float4*>(a.K + (row_b + r) * a.ldk + c8);
+      *reinterpret_cast<float4*>(k + 4) = *reinterpret_cast<const float4*>(a.K + (row_b + r) * a.ldk + c8 + 4);
+      *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(a.V + (row_b + r) * a.ldv + c8);
+      *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(a.V + (row_b + r) * a.ldv + c8 + 4);
+      *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(a.dO + (row_b + r) * a.lddo + c8);
+      *reinterpret_cast<float4*>(d + 4) = *reinterpret_cast<const float4*>(a.dO + (row_b + r) * a.lddo + c8 + 4);
+      *reinterpret_cast<float4*>(o) = *reinterpret_cast<const float4*>(a.O + (row_b + r) * a.ldo + c8);
+      *reinterpret_cast<float4*>(o + 4) = *reinterpret_cast<const float4*>(a.O + (row_b + r) * a.ldo + c8 + 4);
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { part += d[j] * o[j]; q[j] *= qmul; }
+    *reinterpret_cast<bf16x8*>(sQ + r * TT_RS + c8) = pack8(q);
+    *reinterpret_cast<bf16x8*>(sK + r * TT_RS + c8) = pack8(k);
+    *reinterpret_cast<bf16x8*>(sV + r * TT_RS + c8) = pack8(v);
+    *reinterpret_cast<bf16x8*>(sdO + r * TT_RS + c8) = pack8(d);
+#pragma unroll
+    for (int off = HD / 16; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);      // HD/8 adjacent lanes hold one head's chunks
+    if (((i & 7) % (HD / 8)) == 0) sDelta[((i & 7) / (HD / 8)) * R + r] = part;
+  }
+  __syncthreads();
+  const uint32_t key_rng = drop_key(a.drop);
+  const int nqt = (L + 15) / 16;
+  const float ln2 = 0.6931471805599453f;
+
+  // ---- pass A: dQ (a wave owns query tile qt, keys on the accumulator rows) -----------------------------------------------------
+  for (int rnd = 0; rnd * NW < nqt; ++rnd) {
+    const int tix = rnd * NW + ((rnd & 1) ? NW - 1 - w : w);       // snake order, heaviest causal tile first
+    if (tix >= nqt) continue;
+    const int qt = nqt - 1 - tix;
+    const int q = qt * 16 + c;
+    const int nkt = qt + 1;
+#pragma unroll 1
+    for (int h = 0; h < H; ++h) {
+      const float lse_q = sLse[h * R + q], delta_q = sDelta[h * R + q];
+      bf16x8 fq[KB], fdo[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        fq[kb] = sab_rowfrag<HD>(sQ, q, h, kb, g);
+        fdo[kb] = sab_rowfrag<HD>(sdO, q, h, kb, g);
+      }
+      f32x4 dq[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) dq[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const uint32_t bh_rng = (uint32_t)(b * H + h) + a.bh_offset;
+      const uint32_t idx_q = (bh_rng * (uint32_t)L + (uint32_t)q) * (uint32_t)L;
+#pragma unroll 1
+      for (int kp = 0; 2 * kp < nkt; ++kp) {
+        f32x4 s[2], dp[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int kt = 2 * kp + t;
+          s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[t] = s[t];
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb) {          // rows beyond the causal range are zero-filled or masked below
+            s[t] = mfma_bf16(s[t], sab_rowfrag<HD>(sK, kt * 16 + c, h, kb, g), fq[kb]);
+            dp[t] = mfma_bf16(dp[t], sab_rowfrag<HD>(sV, kt * 16 + c, h, kb, g), fdo[kb]);
+          }
+        }
+        const uint32_t mword = use_bits ? (sM[((size_t)h * R + q) * 8 + kp] >> (4 * g)) : 0u;
+        f32x4 ds[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int kt = 2 * kp + t;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + 4 * g + r;
+            float p = __builtin_amdgcn_exp2f(s[t][r] - lse_q);
+            if (kt >= qt) p = (kt < nkt && key <= q) ? p : 0.f;       // diagonal tile and the unused half of the last pair
+            float d = dp[t][r];
+            if (use_bits) d = ((mword >> (16 * t + r)) & 1u) ? d * a.drop.scale : 0.f;
+            else if (a.drop.thr) d = adt_keep(key_rng, idx_q + (uint32_t)key, a.drop.thr) ? d * a.drop.scale : 0.f;
+            ds[t][r] = p * (d - delta_q);
+          }
+        }
+        const bf16x8 fds = tt_pack(ds[0], ds[1]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) dq[nt] = mfma_bf16(dq[nt], tt_trfrag(sK, kp * 32, h * HD + nt * 16, c, g), fds);
+      }
+      if (q < L) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          *reinterpret_cast<float4*>(a.dQ + (row_b + q) * a.lddq + h * HD + nt * 16 + 4 * g) =
+              make_float4(dq[nt][0] * a.scale, dq[nt][1] * a.scale, dq[nt][2] * a.scale, dq[nt][3] * a.scale);
+      }
+    }
+  }
+
+  // ---- pass B: dK, dV (a wave owns key tile kt, queries on the accumulator rows) ---------------------------------------------
+  for (int rnd = 0; rnd * NW < nqt; ++rnd) {
+    const int kt = rnd * NW + ((rnd & 1) ? NW - 1 - w : w);        // key tile 0 is the heaviest under the causal mask
+    if (kt >= nqt) continue;
+    const int key = kt * 16 + c;
+#pragma unroll 1
+    for (int h = 0; h < H; ++h) {
+      bf16x8 fk[KB], fv[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        fk[kb] = sab_rowfrag<HD>(sK, key, h, kb, g);
+        fv[kb] = sab_rowfrag<HD>(sV, key, h, kb, g);
+      }
+      f32x4 dk[NT], dv[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        dk[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      const uint32_t bh_rng = (uint32_t)(b * H + h) + a.bh_offset;
+      const float* lse_h = sLse + h * R;
+      const float* del_h = sDelta + h * R;
+#pragma unroll 1
+      for (int qp = kt / 2; 2 * qp < nqt; ++qp) {
+        f32x4 s[2], dp[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int qt = 2 * qp + t;
+          s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[t] = s[t];
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb) {
+            s[t] = mfma_bf16(s[t], sab_rowfrag<HD>(sQ, qt * 16 + c, h, kb, g), fk[kb]);
+            dp[t] = mfma_bf16(dp[t], sab_rowfrag<HD>(sdO, qt * 16 + c, h, kb, g), fv[kb]);
+          }
+        }
+        f32x4 pv[2], ds[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int qt = 2 * qp + t;
+          const float4 lse4 = *reinterpret_cast<const float4*>(lse_h + qt * 16 + 4 * g);      // +inf for padded queries -> p = 0
+          const float4 del4 = *reinterpret_cast<const float4*>(del_h + qt * 16 + 4 * g);
+          const float lq[4] = {lse4.x, lse4.y, lse4.z, lse4.w}, dq4[4] = {del4.x, del4.y, del4.z, del4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qq = qt * 16 + 4 * g + r;
+            float p = __builtin_amdgcn_exp2f(s[t][r] - lq[r]);
+            if (qt <= kt) p = (qt == kt && key <= qq) ? p : 0.f;       // the diagonal tile, and the tile below it in the first pair
+            float ks = 1.0f;
+            if (use_bits) ks = ((sM[((size_t)h * R + qq) * 8 + (kt >> 1)] >> (16 * (kt & 1) + c)) & 1u) ? a.drop.scale : 0.f;
+            else if (a.drop.thr) ks = adt_keep(key_rng, (bh_rng * (uint32_t)L + (uint32_t)qq) * (uint32_t)L + (uint32_t)key, a.drop.thr) ? a.drop.scale : 0.f;
+            pv[t][r] = p * ks;
+            ds[t][r] = p * (dp[t][r] * ks - dq4[r]);
+          }
+        }
+        const bf16x8 fp = tt_pack(pv[0], pv[1]), fds = tt_pack(ds[0], ds[1]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          dv[nt] = mfma_bf16(dv[nt], tt_trfrag(sdO, qp * 32, h * HD + nt * 16, c, g), fp);
+          dk[nt] = mfma_bf16(dk[nt], tt_trfrag(sQ, qp * 32, h * HD + nt * 16, c, g), fds);
+        }
+      }
+      if (key < L) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          // the Q image carries the factor log2(e) / sqrt(hd): dK = dS^T Q / sqrt(hd)
+          *reinterpret_cast<float4*>(a.dK + (row_b + key) * a.lddk + h * HD + nt * 16 + 4 * g) =
+              make_float4(dk[nt][0] * ln2, dk[nt][1] * ln2, dk[nt][2] * ln2, dk[nt][3] * ln2);
+          *reinterpret_cast<float4*>(a.dV + (row_b + key) * a.lddv + h * HD + nt * 16 + 4 * g) =
+              make_float4(dv[nt][0], dv[nt][1], dv[nt][2], dv[nt][3]);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace adt

@@ -1,0 +1,308 @@
+// Per-sequence fused layer forward on the register-resident transposed chains of adt_tt.cuh (bf16 MFMA operands).
+// Same contract and argument block as adt_seqfwd.cuh (one workgroup = one sequence = one EncoderLayer / DecoderLayer forward,
+// sasrec/modules.py:644-655, :666-677; the same tensors reach HBM), different data path: activations never touch LDS -- the only
+// LDS traffic is the read-only weight images and the key / value images of the attention (both row-major [token][64], bf16).
+#pragma once
+#include "adt_seq_args.h"
+#include "adt_tt.cuh"
+
+namespace adt {
+
+#define TQ_STAMP(k) do { if (a.stamps && blockIdx.x == 0 && lane == 0) a.stamps[w * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+
+constexpr int TQ_NW = 8;                       // waves per workgroup
+constexpr int TQ_MAXKT = 14;                   // 16-token tiles per sequence: L <= 224
+constexpr int TQ_LP = TQ_MAXKT * 16;
+
+template <int NWT>
+struct SeqTtLds {
+  static constexpr size_t wbytes = (size_t)NWT * TT_WIMG * 2, ibytes = (size_t)TQ_LP * TT_RS * 2;
+  static constexpr size_t bytes = wbytes + 2 * ibytes;
+  __bf16* w[NWT]; __bf16* sK; __bf16* sV;
+  __device__ SeqTtLds(unsigned char* base) {
+    __bf16* pw = reinterpret_cast<__bf16*>(base);
+    for (int i = 0; i < NWT; ++i) w[i] = pw + i * TT_WIMG;
+    sK = reinterpret_cast<__bf16*>(base + wbytes);
+    sV = reinterpret_cast<__bf16*>(base + wbytes + ibytes);
+  }
+};
+
+ADT_DEVICE_INLINE int tq_tile(int s, int w, int ntiles) {        // heaviest causal tile paired with the lightest (adt_seqfwd.cuh)
+  if (s == 0) return ntiles - 1 - w;
+  return w < ntiles - TQ_NW ? w : -1;
+}
+
+// slot-ordered packed image of the 64 x 64 block at W (adt_seq.hip: k_pack_wimg writes it at + 2 images, transposed at + 3)
+template <int NTHREADS>
+ADT_DEVICE_INLINE void tq_stage(__bf16* img, const float* W, bool transposed, const SeqFwdArgs& a) {
+  const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.wp_img) + 6 * (W - a.wp_base) + (transposed ? 3 : 2) * WPACK_IMG);
+  uint4* dst = reinterpret_cast<uint4*>(img);
+  for (int i = threadIdx.x; i < TT_WIMG * 2 / 16; i += NTHREADS) dst[i] = src[i];
+}
+
+ADT_DEVICE_INLINE void tq_zero(__bf16* p, size_t nbytes) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  for (int i = threadIdx.x; i < (int)(nbytes / 16); i += TQ_NW * 64) q[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// layer input of this lane's token: a load, or the embedding gather x = dropout(E[id] * sqrt(d) + P[l]) * (id != 0)   (model.py:34-41)
+ADT_DEVICE_INLINE TT tq_load_x(const SeqFwdArgs& a, int row, int l, bool valid, uint32_t key0, int g) {
+  if (a.x) return tt_load(a.x + (size_t)row * 64, valid, g);
+  TT x = tt_zero();
+  const int id = valid ? a.ids[row] : 0;
+  if (id != 0) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const float4 e = *reinterpret_cast<const float4*>(a.E + (size_t)id * 64 + 16 * nt + 4 * g);
+      const float4 p = *reinterpret_cast<const float4*>(a.P + (size_t)l * 64 + 16 * nt + 4 * g);
+      x.v[nt] = f32x4{e.x * a.emb_scale + p.x, e.y * a.emb_scale + p.y, e.z * a.emb_scale + p.z, e.w * a.emb_scale + p.w};
+    }
+    tt_dropout(x, key0, a.drop, (uint32_t)row + a.b_offset * (uint32_t)a.L, g);
+  }
+  if (a.x_out) tt_store(a.x_out + (size_t)row * 64, x, valid, g);
+  return x;
+}
+
+// LayerNorm + packed in-projection of one tile: query operands to registers, k / v into the LDS images (and to HBM for the backward)
+template <int HD, bool ENC>
+ADT_DEVICE_INLINE void tq_pre_tile(const SeqFwdArgs& a, const __bf16* wq, const __bf16* wk, const __bf16* wv, __bf16* sK, __bf16* sV,
+                                   int tile, int b, uint32_t key0, float qmul, int c, int g,
+                                   bf16x8 (&fq)[(64 / HD) * ((HD + 31) / 32)], TT& xn_out) {
+  const int l = tile * 16 + c, row = b * a.L + l;
+  const bool valid = l < a.L;
+  const TT x = tq_load_x(a, row, l, valid, key0, g);
+  const TT xn = tt_layernorm(x, a.gamma, a.beta, a.ln_eps, g);
+  if (a.xn) tt_store(a.xn + (size_t)row * 64, xn, valid, g);
+  xn_out = xn;
+  const TTB bn = tt_bfrags(xn);
+  TTB bx;
+  if (ENC) bx = tt_bfrags(x);
+  {
+    TT q = tt_gemm(bn, wq, c, g);
+    tt_add_vec(q, a.bin, g);
+    if (a.qkv && valid) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<float4*>(a.qkv + (size_t)row * 192 + 16 * nt + 4 * g) = make_float4(q.v[nt][0], q.v[nt][1], q.v[nt][2], q.v[nt][3]);
+    }
+    tt_qfrags<HD>(q, qmul, fq);
+  }
+  {
+    TT k = tt_gemm(ENC ? bx : bn, wk, c, g);
+    tt_add_vec(k, a.bin + 64, g);
+    if (a.qkv && valid) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<float4*>(a.qkv + (size_t)row * 192 + 64 + 16 * nt + 4 * g) = make_float4(k.v[nt][0], k.v[nt][1], k.v[nt][2], k.v[nt][3]);
+    }
+    tt_put_slot(sK, l, k, valid, g);
+  }
+  {
+    TT v = tt_gemm(ENC ? bx : bn, wv, c, g);
+    tt_add_vec(v, a.bin + 128, g);
+    if (a.qkv && valid) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<float4*>(a.qkv + (size_t)row * 192 + 128 + 16 * nt + 4 * g) = make_float4(v.v[nt][0], v.v[nt][1], v.v[nt][2], v.v[nt][3]);
+    }
+    tt_put_rows(sV, l, v, valid, g);
+  }
+}
+
+// u = relu(dropout1(xin W1^T + b1)) -> stored ; returns dropout2(u W2^T + b2)           (PointWiseFeedForward, modules.py:629-633)
+ADT_DEVICE_INLINE TT tq_ffn(const SeqFwdArgs& a, const __bf16* w1, const __bf16* w2, const TT& xin, uint32_t key1, uint32_t key2, int row,
+                            bool valid, int c, int g) {
+  const uint32_t rg = (uint32_t)row + a.b_offset * (uint32_t)a.L;
+  TT u = tt_gemm(tt_bfrags(xin), w1, c, g);
+  tt_add_vec(u, a.b1, g);
+  tt_dropout(u, key1, a.drop, rg, g);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u.v[nt][r] = fmaxf(u.v[nt][r], 0.f);
+  if (a.u) tt_store(a.u + (size_t)row * 64, u, valid, g);
+  TT y = tt_gemm(tt_bfrags(u), w2, c, g);
+  tt_add_vec(y, a.b2, g);
+  tt_dropout(y, key2, a.drop, rg, g);
+  return y;
+}
+
+// ---- encoder layer: weight images 0 Wq, 1 Wk, 2 Wv, 3 out_proj, 4 conv1, 5 conv2 ------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
+  constexpr int H = 64 / HD, KB = (HD + 31) / 32, NF = H * KB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  SeqTtLds<6> lds(smem_raw);
+  const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16;
+  const uint32_t seedv = a.drop.thr ? *a.drop.seed : 0u;
+  TQ_STAMP(0);
+  tq_stage<TQ_NW * 64>(lds.w[0], a.Win, false, a);
+  tq_stage<TQ_NW * 64>(lds.w[1], a.Win + 4096, false, a);
+  tq_stage<TQ_NW * 64>(lds.w[2], a.Win + 8192, false, a);
+  tq_stage<TQ_NW * 64>(lds.w[3], a.Wo, false, a);
+  tq_stage<TQ_NW * 64>(lds.w[4], a.W1, false, a);
+  tq_stage<TQ_NW * 64>(lds.w[5], a.W2, false, a);
+  tq_zero(lds.sK, 2 * SeqTtLds<6>::ibytes);
+  __syncthreads();
+  TQ_STAMP(1);
+  const uint32_t key0 = adt_site_key(seedv, a.site_emb), key1 = adt_site_key(seedv, a.site1), key2 = adt_site_key(seedv, a.site2);
+  const float qmul = a.scale * 1.4426950408889634f;          // scores in log2 units: the softmax is exp2
+  bf16x8 fq[2][NF];
+  TT xn[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile >= 0) tq_pre_tile<HD, true>(a, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[s], xn[s]);
+    TQ_STAMP(2 + s);
+  }
+  __syncthreads();
+  TQ_STAMP(4);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = l < L;
+    const TT o = tt_attn_heads<HD, TQ_MAXKT>(lds.sK, lds.sV, fq[s], tile, L, b, a.b_offset, a.drop, a.site_attn, seedv, a.lse, a.mask, lane, c, g);
+    TQ_STAMP(5 + 3 * s);
+    if (a.o) tt_store(a.o + (size_t)row * 64, o, valid, g);
+    if (a.rec) {
+      // head classifier (sasrec/modules.py:648-649): z[h][cc] = sum_j o[h hd + j] Ws[cc][j] + bs[cc]; log-softmax over cc.  The features of
+      // a token are spread over this lane's 16 registers and the 4 lanes g: in-lane products, two cross-lane steps per class.
+      constexpr int NT = HD / 16;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float z[H];
+#pragma unroll
+        for (int cc = 0; cc < H; ++cc) {
+          float acc = 0.f;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const float4 ws = *reinterpret_cast<const float4*>(a.Ws + cc * HD + 16 * nt + 4 * g);
+            const f32x4& ov = o.v[h * NT + nt];
+            acc += ov[0] * ws.x + ov[1] * ws.y + ov[2] * ws.z + ov[3] * ws.w;
+          }
+          z[cc] = tt_colsum(acc) + a.bs[cc];
+        }
+        float m = z[0];
+#pragma unroll
+        for (int cc = 1; cc < H; ++cc) m = fmaxf(m, z[cc]);
+        float se = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < H; ++cc) se += __expf(z[cc] - m);
+        const float lz = m + __logf(se);
+        if (g == 0 && valid) {
+          float* dst = a.rec + ((size_t)(l * a.B + b) * H + h) * H;
+#pragma unroll
+          for (int cc = 0; cc < H; ++cc) dst[cc] = z[cc] - lz;
+        }
+      }
+    }
+    TT hh = tt_gemm(tt_bfrags(o), lds.w[3], c, g);
+    tt_add_vec(hh, a.bo, g);
+    tt_add(hh, xn[s]);                                        // the residual adds LN1(x)                         (modules.py:651)
+    TQ_STAMP(6 + 3 * s);
+    if (a.h) tt_store(a.h + (size_t)row * 64, hh, valid, g);
+    const TT h2 = tt_layernorm(hh, a.gamma2, a.beta2, a.ln_eps, g);
+    TT y = tq_ffn(a, lds.w[4], lds.w[5], h2, key1, key2, row, valid, c, g);
+    tt_add(y, h2);
+    if (!valid || a.ids[row] == 0) y = tt_zero();
+    tt_store(a.y + (size_t)row * 64, y, valid, g);
+    TQ_STAMP(7 + 3 * s);
+  }
+}
+
+// ---- decoder layer: set A: 0 Wq, 1 Wk, 2 Wv (slf_attn), 3 slf out_proj, 4 enc_attn Wq ; set B: 0 enc_attn Wk, 1 Wv, 2 enc_attn out_proj,
+// 3 conv1, 4 conv2 -------------------------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
+  constexpr int H = 64 / HD, KB = (HD + 31) / 32, NF = H * KB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  SeqTtLds<5> lds(smem_raw);
+  const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16;
+  const uint32_t seedv = a.drop.thr ? *a.drop.seed : 0u;
+  tq_stage<TQ_NW * 64>(lds.w[0], a.Win, false, a);
+  tq_stage<TQ_NW * 64>(lds.w[1], a.Win + 4096, false, a);
+  tq_stage<TQ_NW * 64>(lds.w[2], a.Win + 8192, false, a);
+  tq_stage<TQ_NW * 64>(lds.w[3], a.Wo, false, a);
+  tq_stage<TQ_NW * 64>(lds.w[4], a.Win2, false, a);
+  tq_zero(lds.sK, 2 * SeqTtLds<5>::ibytes);
+  __syncthreads();
+  const uint32_t key0 = adt_site_key(seedv, a.site_emb), key1 = adt_site_key(seedv, a.site1), key2 = adt_site_key(seedv, a.site2);
+  const float qmul = a.scale * 1.4426950408889634f;
+  bf16x8 fq[2][NF];
+  TT dn[2];
+  // self attention: D = LN(x); q, k, v = D Win^T + b                                                    (sasrec/modules.py:668-670)
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile >= 0) tq_pre_tile<HD, false>(a, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[s], dn[s]);
+  }
+  __syncthreads();
+  // a1 = out_proj(o1) ; q2 = a1 Wq2^T + b : the cross attention's queries replace the self attention's in the registers
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = l < L;
+    const TT o1 = tt_attn_heads<HD, TQ_MAXKT>(lds.sK, lds.sV, fq[s], tile, L, b, a.b_offset, a.drop, a.site_attn, seedv, a.lse, a.mask, lane, c, g);
+    if (a.o) tt_store(a.o + (size_t)row * 64, o1, valid, g);
+    TT a1 = tt_gemm(tt_bfrags(o1), lds.w[3], c, g);
+    tt_add_vec(a1, a.bo, g);
+    if (a.a1) tt_store(a.a1 + (size_t)row * 64, a1, valid, g);
+    TT q2 = tt_gemm(tt_bfrags(a1), lds.w[4], c, g);
+    tt_add_vec(q2, a.bin2, g);
+    if (a.q2) tt_store(a.q2 + (size_t)row * 64, q2, valid, g);
+    tt_qfrags<HD>(q2, qmul, fq[s]);
+  }
+  __syncthreads();                      // every wave is done with the self-attention images and with weight set A
+  tq_stage<TQ_NW * 64>(lds.w[0], a.Win2 + 4096, false, a);
+  tq_stage<TQ_NW * 64>(lds.w[1], a.Win2 + 8192, false, a);
+  tq_stage<TQ_NW * 64>(lds.w[2], a.Wo2, false, a);
+  tq_stage<TQ_NW * 64>(lds.w[3], a.W1, false, a);
+  tq_stage<TQ_NW * 64>(lds.w[4], a.W2, false, a);
+  __syncthreads();
+  // cross attention keys / values from the encoder's log_feats: [k2, v2] = f Wkv^T + b              (memory = log_feats, model.py:69-70)
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = l < L;
+    const TTB bf = tt_bfrags(tt_load(a.f + (size_t)row * 64, valid, g));
+    TT k2 = tt_gemm(bf, lds.w[0], c, g);
+    tt_add_vec(k2, a.bin2 + 64, g);
+    TT v2 = tt_gemm(bf, lds.w[1], c, g);
+    tt_add_vec(v2, a.bin2 + 128, g);
+    if (a.kv2 && valid) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        *reinterpret_cast<float4*>(a.kv2 + (size_t)row * 128 + 16 * nt + 4 * g) = make_float4(k2.v[nt][0], k2.v[nt][1], k2.v[nt][2], k2.v[nt][3]);
+        *reinterpret_cast<float4*>(a.kv2 + (size_t)row * 128 + 64 + 16 * nt + 4 * g) = make_float4(v2.v[nt][0], v2.v[nt][1], v2.v[nt][2], v2.v[nt][3]);
+      }
+    }
+    tt_put_slot(lds.sK, l, k2, valid, g);
+    tt_put_rows(lds.sV, l, v2, valid, g);
+  }
+  __syncthreads();
+  // a2 = out_proj(o2) ; y = (D + a2 + FFN(a2)) * mask                                                (sasrec/modules.py:673-676)
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = l < L;
+    const TT o2 = tt_attn_heads<HD, TQ_MAXKT>(lds.sK, lds.sV, fq[s], tile, L, b, a.b_offset, a.drop, a.site_attn2, seedv, a.lse2, a.mask2, lane, c, g);
+    if (a.o2) tt_store(a.o2 + (size_t)row * 64, o2, valid, g);
+    TT a2 = tt_gemm(tt_bfrags(o2), lds.w[2], c, g);
+    tt_add_vec(a2, a.bo2, g);
+    if (a.h) tt_store(a.h + (size_t)row * 64, a2, valid, g);
+    TT y = tq_ffn(a, lds.w[3], lds.w[4], a2, key1, key2, row, valid, c, g);
+    tt_add(y, a2);
+    tt_add(y, dn[s]);
+    if (!valid || a.ids[row] == 0) y = tt_zero();
+    tt_store(a.y + (size_t)row * 64, y, valid, g);
+  }
+}
+
+}  // namespace adt

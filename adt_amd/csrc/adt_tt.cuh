@@ -1,0 +1,309 @@
+// Register-resident TRANSPOSED row chains (bf16 MFMA operands, d == 64).
+//
+// A wave keeps its 16-token tile as X^T: `TT.v[nt][r]` = element (feature 16 nt + 4 g + r, token c) -- the MFMA C layout with the
+// FEATURE on the accumulator rows and the token on the lane.  Every product of the layer then is Y^T = W X^T:
+//   * the A operand is the weight (row n, 8 contraction slots per lane) -- one ds_read_b128 from a pre-packed, slot-ordered LDS image;
+//   * the B operand is X^T itself, taken straight from the accumulator registers of the previous product (accumulator-as-operand:
+//     slot (g, j) of a 32-feature block is feature 4g + (j & 3) + 16 (j >> 2), i.e. registers r = j & 3 of tiles 2 kb + (j >> 2));
+//   * the result lands in the same layout.
+// So a whole chain LayerNorm -> in-projection -> ... -> FFN runs with NO layout change and NO LDS traffic for activations (the
+// row-major chains of adt_wave.cuh cross a per-wave LDS scratch twice per product: 57 % of the fused forward's wave cycles were
+// s_waitcnt stalls, profiles/r02_*).  Feature reductions (LayerNorm, classifier) are 16 in-lane adds + 2 cross-lane steps; bias,
+// gamma and beta are 16 per-lane constants; four consecutive features per register quad mean one dropout hash per quad
+// (adt_keep4) and 8- / 16-byte global and LDS accesses.
+//
+// Attention in this layout: S^T = K Q^T with the key on the accumulator rows (A = a row of the slot-ordered K image, B = the q
+// registers), softmax statistics per lane column, P^T as the B operand of O^T = V^T P^T whose A operand (4 consecutive keys of
+// one feature) comes from the ROW-major V image through ds_read_b64_tr_b16 -- the output is again a TT tile, ready for out_proj.
+#pragma once
+#include "adt_attn_bf16.cuh"
+#include "adt_wave.cuh"
+
+namespace adt {
+
+struct TT { f32x4 v[4]; };
+
+constexpr int TT_RS = 72;                      // bf16 row stride of every [row][64] LDS image (weights, K, V, ...)
+constexpr int TT_WIMG = 64 * TT_RS;
+
+ADT_DEVICE_INLINE bf16x8 tt_pack(const f32x4& lo, const f32x4& hi, float mul = 1.0f) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { o[j] = (__bf16)(lo[j] * mul); o[4 + j] = (__bf16)(hi[j] * mul); }
+  return o;
+}
+
+struct TTB { bf16x8 kb[2]; };                  // X^T as the B operands of the two 32-feature contraction blocks
+
+ADT_DEVICE_INLINE TTB tt_bfrags(const TT& x, float mul = 1.0f) {
+  TTB b;
+  b.kb[0] = tt_pack(x.v[0], x.v[1], mul);
+  b.kb[1] = tt_pack(x.v[2], x.v[3], mul);
+  return b;
+}
+
+// Y^T = W X^T ; img: slot-ordered image of W ([n][32 kb + 8 g + j] = W[n][32 kb + 4 g + (j & 3) + 16 (j >> 2)])
+ADT_DEVICE_INLINE TT tt_gemm(const TTB& b, const __bf16* img, int c, int g) {
+  int opaque_zero = 0;                         // keep the (loop-invariant) image reads inside the tile loop: see gemm_w
+  asm volatile("" : "+v"(opaque_zero));
+  img += opaque_zero;
+  TT y;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+      acc = mfma_bf16(acc, *reinterpret_cast<const bf16x8*>(img + (16 * nt + c) * TT_RS + 32 * kb + 8 * g), b.kb[kb]);
+    y.v[nt] = acc;
+  }
+  return y;
+}
+
+// 16 per-lane constants of a 64-vector (bias, gamma, beta): element (nt, r) = p[16 nt + 4 g + r]
+struct TTV { f32x4 v[4]; };
+ADT_DEVICE_INLINE TTV tt_vec(const float* p, int g) {
+  TTV t;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const float4 x = *reinterpret_cast<const float4*>(p + 16 * nt + 4 * g);
+    t.v[nt] = f32x4{x.x, x.y, x.z, x.w};
+  }
+  return t;
+}
+ADT_DEVICE_INLINE void tt_add_vec(TT& t, const float* p, int g) {
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const float4 x = *reinterpret_cast<const float4*>(p + 16 * nt + 4 * g);
+    t.v[nt] += f32x4{x.x, x.y, x.z, x.w};
+  }
+}
+ADT_DEVICE_INLINE void tt_add(TT& a, const TT& b) {
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) a.v[nt] += b.v[nt];
+}
+ADT_DEVICE_INLINE TT tt_zero() {
+  TT t;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) t.v[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  return t;
+}
+
+// global fp32 rows <-> TT: `row` points at this lane's token row (64 floats); lanes whose token is absent pass valid = false
+ADT_DEVICE_INLINE TT tt_load(const float* row, bool valid, int g) {
+  TT t;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) x = *reinterpret_cast<const float4*>(row + 16 * nt + 4 * g);
+    t.v[nt] = f32x4{x.x, x.y, x.z, x.w};
+  }
+  return t;
+}
+ADT_DEVICE_INLINE void tt_store(float* row, const TT& t, bool valid, int g) {
+  if (!valid) return;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<float4*>(row + 16 * nt + 4 * g) = make_float4(t.v[nt][0], t.v[nt][1], t.v[nt][2], t.v[nt][3]);
+}
+
+// feature reductions: every lane of a token column ends up with the column's total
+ADT_DEVICE_INLINE float tt_colsum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// LayerNorm over the 64 features of each token (eps inside the square root, as torch.nn.LayerNorm); returns gamma * xhat + beta
+ADT_DEVICE_INLINE TT tt_layernorm(const TT& x, const float* gamma, const float* beta, float eps, int g) {
+  float s = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) s += (x.v[nt][0] + x.v[nt][1]) + (x.v[nt][2] + x.v[nt][3]);
+  const float mu = tt_colsum(s) * (1.0f / 64);
+  TT d;
+  float q = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float t = x.v[nt][r] - mu; d.v[nt][r] = t; q += t * t; }
+  const float rstd = 1.0f / sqrtf(tt_colsum(q) * (1.0f / 64) + eps);
+  const TTV gm = tt_vec(gamma, g), bt = tt_vec(beta, g);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d.v[nt][r] = d.v[nt][r] * rstd * gm.v[nt][r] + bt.v[nt][r];
+  return d;
+}
+
+// inverted dropout on a (rows x 64) tensor: element (token row, feature f) has index row * 64 + f; one hash per register quad
+ADT_DEVICE_INLINE void tt_dropout(TT& t, uint32_t key, const DropCfg& d, uint32_t row_global, int g) {
+  if (!d.thr) return;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const uint32_t bits = adt_keep4(key, row_global * 64u + (uint32_t)(16 * nt + 4 * g), d.thr);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t.v[nt][r] = ((bits >> r) & 1u) ? t.v[nt][r] * d.scale : 0.f;
+  }
+}
+
+// ---- LDS images written from TT tiles ---------------------------------------------------------------------------------------
+// slot-ordered [token][64] image (the A operand of products that contract over FEATURES, e.g. the keys of S^T = K Q^T):
+// feature 16 nt + 4 g + r sits at 32 (nt >> 1) + 8 g + 4 (nt & 1) + r, so one ds_read_b128 at [row][32 kb + 8 g] is a whole fragment
+ADT_DEVICE_INLINE void tt_put_slot(__bf16* img, int token, const TT& t, bool valid, int g) {
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    bf16x4 b;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b[r] = (__bf16)(valid ? t.v[nt][r] : 0.f);
+    *reinterpret_cast<bf16x4*>(img + token * TT_RS + 32 * (nt >> 1) + 8 * g + 4 * (nt & 1)) = b;
+  }
+}
+// natural-order [token][64] image (read through ds_read_b64_tr_b16 by products that contract over TOKENS)
+ADT_DEVICE_INLINE void tt_put_rows(__bf16* img, int token, const TT& t, bool valid, int g) {
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    bf16x4 b;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b[r] = (__bf16)(valid ? t.v[nt][r] : 0.f);
+    *reinterpret_cast<bf16x4*>(img + token * TT_RS + 16 * nt + 4 * g) = b;
+  }
+}
+
+// A-operand fragment with the FEATURE on the lane and 8 TOKENS in slot order (rows row0 + 4g .. +3 and row0 + 16 + 4g .. +3) from a
+// natural-order [token][64] image: two hardware-transposed reads.  Lane 4q + p of a 16-lane group addresses row q, columns 4p .. 4p+3
+// of its group's 4 x 16 block and receives column (c) of the four rows.  EXEC must be full (no divergence around this call).
+typedef short tt_s4 __attribute__((ext_vector_type(4)));
+ADT_DEVICE_INLINE bf16x8 tt_trfrag(const __bf16* img, int row0, int col0, int c, int g) {
+  const __bf16* p = img + (row0 + 4 * g + (c >> 2)) * TT_RS + col0 + 4 * (c & 3);
+  const tt_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tt_s4 __attribute__((address_space(3)))*)(p));
+  const tt_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tt_s4 __attribute__((address_space(3)))*)(p + 16 * TT_RS));
+  union { struct { tt_s4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+// ---- causal attention of one query tile, one head ----------------------------------------------------------------------------
+// sK: slot-ordered key image, sV: natural-order value image (both [LP][TT_RS], rows >= L zero).  fq: the head's query operand(s),
+// pre-multiplied by log2(e) / sqrt(hd).  One sweep: all score tiles stay in registers (the workgroup owns a CU: 256 VGPRs per wave),
+// so the MFMAs of the sweep are independent and issue back to back, and the exponentials form one long independent stream.
+// Output: o[nt] = O^T rows (features 16 nt + 4g + r of this head), column = query c; log-sum-exp and dropout keep bits to HBM.
+template <int HD, int MAXKT>
+ADT_DEVICE_INLINE void tt_attn_tile(const __bf16* sK, const __bf16* sV, const bf16x8* fq, int kcol, int vcol, int qt, int L, int bh,
+                                    uint32_t bh_rng, const DropCfg& drop, uint32_t key_rng, float* lse, uint32_t* mask, int lane,
+                                    int c, int g, f32x4 (&o)[HD / 16]) {
+  constexpr int NT = HD / 16, KB = (HD + 31) / 32;
+  const int q = qt * 16 + c;
+  const int nkt = qt + 1;
+  f32x4 s[MAXKT];
+#pragma unroll
+  for (int kt = 0; kt < MAXKT; ++kt) {
+    s[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (kt < nkt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+        acc = mfma_bf16(acc, *reinterpret_cast<const bf16x8*>(sK + (kt * 16 + c) * TT_RS + kcol + 32 * kb + 8 * g), fq[kb]);
+      if (kt == qt) {              // the diagonal tile is the only one the causal mask cuts (every other key < every query of the tile)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = (4 * g + r <= c) ? acc[r] : -INFINITY;
+      }
+      s[kt] = acc;
+    }
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < MAXKT; ++kt) m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  const uint32_t idx_q = (bh_rng * (uint32_t)L + (uint32_t)q) * (uint32_t)L;
+  const bool quad = (L & 3) == 0;           // then idx_q is a multiple of 4 and a register quad of keys shares one hash word
+  float sum = 0.f;
+  uint32_t mw[MAXKT / 2];
+#pragma unroll
+  for (int i = 0; i < MAXKT / 2; ++i) mw[i] = 0u;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kp = 0; kp < MAXKT / 2; ++kp) {
+    if (2 * kp < nkt) {
+      f32x4 pv[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int kt = 2 * kp + t;
+        uint32_t bits = 15u;
+        if (drop.thr && kt < nkt) {
+          const uint32_t i4 = idx_q + (uint32_t)(16 * kt + 4 * g);
+          if (quad) bits = adt_keep4(key_rng, i4, drop.thr);
+          else bits = (adt_keep(key_rng, i4, drop.thr) ? 1u : 0u) | (adt_keep(key_rng, i4 + 1, drop.thr) ? 2u : 0u) |
+                      (adt_keep(key_rng, i4 + 2, drop.thr) ? 4u : 0u) | (adt_keep(key_rng, i4 + 3, drop.thr) ? 8u : 0u);
+          mw[kp] |= bits << (16 * t + 4 * g);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(s[kt][r] - m);      // exp2(-inf) = 0 for masked / absent keys
+          sum += e;
+          pv[t][r] = ((bits >> r) & 1u) ? e * drop.scale : 0.f;
+        }
+      }
+      const bf16x8 fp = tt_pack(pv[0], pv[1]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) o[nt] = mfma_bf16(o[nt], tt_trfrag(sV, kp * 32, vcol + nt * 16, c, g), fp);
+    }
+  }
+  sum = tt_colsum(sum);
+  if (g == 0 && q < L) lse[(size_t)bh * L + q] = (m + __builtin_amdgcn_logf(sum)) * 0.6931471805599453f;   // natural log of sum exp(score)
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) o[nt] *= inv;
+  if (mask && drop.thr) {
+    uint32_t ow[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      uint32_t v = i < MAXKT / 2 ? mw[i] : 0u;
+      v |= (uint32_t)__shfl_xor((int)v, 16, 64);
+      v |= (uint32_t)__shfl_xor((int)v, 32, 64);
+      ow[i] = v;
+    }
+    if (g == 0 && q < L) {
+      uint4* dst = reinterpret_cast<uint4*>(mask + ((size_t)bh * L + q) * 8);
+      dst[0] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+      dst[1] = make_uint4(ow[4], ow[5], ow[6], ow[7]);
+    }
+  }
+}
+
+// query operands of every head from a TT q tile (scaled): fq[h * KB + kb]
+template <int HD>
+ADT_DEVICE_INLINE void tt_qfrags(const TT& q, float mul, bf16x8 (&fq)[(64 / HD) * ((HD + 31) / 32)]) {
+  if constexpr (HD == 64) {
+    fq[0] = tt_pack(q.v[0], q.v[1], mul);
+    fq[1] = tt_pack(q.v[2], q.v[3], mul);
+  } else if constexpr (HD == 32) {
+    fq[0] = tt_pack(q.v[0], q.v[1], mul);
+    fq[1] = tt_pack(q.v[2], q.v[3], mul);
+  } else {          // HD == 16: head h is tile h; it occupies the low (even h) or high (odd h) four slots of its 32-feature block
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 4; ++h) fq[h] = (h & 1) ? tt_pack(z, q.v[h], mul) : tt_pack(q.v[h], z, mul);
+  }
+}
+
+// attention of every head for one query tile -> a TT tile (features x queries)
+template <int HD, int MAXKT>
+ADT_DEVICE_INLINE TT tt_attn_heads(const __bf16* sK, const __bf16* sV, const bf16x8* fq, int tile, int L, int b, uint32_t b_offset,
+                                   DropCfg drop, uint32_t site, uint32_t seedv, float* lse, uint32_t* mask, int lane, int c, int g) {
+  constexpr int H = 64 / HD, NT = HD / 16, KB = (HD + 31) / 32;
+  const uint32_t key_rng = drop.thr ? adt_site_key(seedv, site) : 0u;
+  TT o;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    f32x4 oh[NT];
+    const int bh = b * H + h;
+    const int kcol = HD == 16 ? 32 * (h >> 1) : h * HD;      // start of the 32-feature slot block(s) that hold this head's keys
+    tt_attn_tile<HD, MAXKT>(sK, sV, fq + h * KB, kcol, h * HD, tile, L, bh, (uint32_t)bh + b_offset * (uint32_t)H, drop, key_rng, lse, mask,
+                            lane, c, g, oh);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) o.v[h * NT + nt] = oh[nt];
+  }
+  return o;
+}
+
+}  // namespace adt
