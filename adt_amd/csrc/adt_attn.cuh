@@ -32,6 +32,7 @@ struct AttnArgs {
   float* dK; int lddk;
   float* dV; int lddv;
   uint32_t* mask;             // optional (B*H*L x 8 words): dropout keep bits written by the bf16 forward, read by its backward
+  unsigned long long* stamps; // timing experiments only (ADT_SEQ_STAMPS): s_memtime per wave of workgroup 0
 };
 
 template <int HD>

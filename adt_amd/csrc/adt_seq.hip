@@ -79,14 +79,18 @@ extern "C" int adt_seq_stamps_read(unsigned long long* out, int n) {      // deb
   return hipMemcpy(out, g_stamps, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }
 
-static void seq_ablate(SeqFwdArgs& a) {
+static unsigned long long* seq_stamp_buffer(bool for_attention) {      // ADT_SEQ_STAMPS=1: forward kernels; =2: the attention backward
   static int st = -1;
   if (st < 0) {
     const char* e = getenv("ADT_SEQ_STAMPS");
-    st = (e && atoi(e)) ? 1 : 0;
+    st = e ? atoi(e) : 0;
     if (st && hipMalloc(&g_stamps, 8 * 16 * sizeof(unsigned long long)) != hipSuccess) st = 0;
   }
-  a.stamps = st ? g_stamps : nullptr;
+  return (st == (for_attention ? 2 : 1)) ? g_stamps : nullptr;
+}
+
+static void seq_ablate(SeqFwdArgs& a) {
+  a.stamps = seq_stamp_buffer(false);
   static int ab = -1;
   if (ab < 0) { const char* e = getenv("ADT_SEQ_ABLATE"); ab = e ? atoi(e) : 0; }
   a.ablate = ab;
@@ -145,15 +149,20 @@ int adt_launch_seq_attn_bwd(int hd, const AttnArgs& a, void* stream) {
   if ((a.ldq % 4) || (a.ldk % 4) || (a.ldv % 4) || (a.ldo % 4)) return 1;
   const size_t smem = sab_lds_bytes(a.L, a.H);
   if (smem > 160 * 1024) return 1;
-  static bool done[3] = {false, false, false};
-  const void* fn = hd == 64 ? (const void*)k_seq_attn_bwd<64> : hd == 32 ? (const void*)k_seq_attn_bwd<32> : hd == 16 ? (const void*)k_seq_attn_bwd<16> : nullptr;
-  if (!fn) return 1;
-  const int slot = hd == 64 ? 0 : hd == 32 ? 1 : 2;
+  const int mode = a.drop.thr == 0 ? 0 : (a.mask != nullptr ? 1 : 2);
+  static bool done[9] = {false, false, false, false, false, false, false, false, false};
+  const void* fns[9] = {(const void*)k_seq_attn_bwd<64, 0>, (const void*)k_seq_attn_bwd<64, 1>, (const void*)k_seq_attn_bwd<64, 2>,
+                        (const void*)k_seq_attn_bwd<32, 0>, (const void*)k_seq_attn_bwd<32, 1>, (const void*)k_seq_attn_bwd<32, 2>,
+                        (const void*)k_seq_attn_bwd<16, 0>, (const void*)k_seq_attn_bwd<16, 1>, (const void*)k_seq_attn_bwd<16, 2>};
+  if (hd != 64 && hd != 32 && hd != 16) return 1;
+  const int slot = (hd == 64 ? 0 : hd == 32 ? 3 : 6) + mode;
+  const void* fn = fns[slot];
   if (!done[slot]) {      // the attribute is the maximum this kernel may ask for, not this launch's size
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return adt_set_error("seq_attn_bwd: hipFuncSetAttribute");
     done[slot] = true;
   }
   AttnArgs args = a;
+  args.stamps = seq_stamp_buffer(true);
   void* kargs[] = {&args};
   if (hipLaunchKernel(fn, dim3(a.B), dim3(SAB_NW * 64), kargs, smem, (hipStream_t)stream) != hipSuccess) return adt_set_error("seq_attn_bwd: launch failed");
   return seq_check("seq_attn_bwd");

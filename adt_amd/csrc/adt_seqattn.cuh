@@ -41,7 +41,9 @@ ADT_DEVICE_INLINE bf16x8 sab_rowfrag(const __bf16* img, int row, int h, int kb, 
   return o;
 }
 
-template <int HD>
+// MODE: 0 no dropout, 1 keep bits saved by the forward (a.mask), 2 keep decisions recomputed from the hash RNG -- a compile-time
+// choice: as run-time branches inside the element loops the three variants cost ~100 branch instructions per key-tile pair
+template <int HD, int MODE>
 __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
   constexpr int H = 64 / HD, NT = HD / 16, KB = (HD + 31) / 32, MAXKT = 14, NW = SAB_NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -56,9 +58,11 @@ __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const size_t row_b = (size_t)b * L;
-  const bool use_bits = a.mask != nullptr && a.drop.thr != 0;
+  constexpr bool use_bits = MODE == 1;
   const float qmul = a.scale * 1.4426950408889634f;
-  if (use_bits) {
+#define SAB_STAMP(k) do { if (a.stamps && blockIdx.x == 0 && lane == 0) a.stamps[w * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+  SAB_STAMP(0);
+  if constexpr (MODE == 1) {
     for (int i = threadIdx.x; i < H * R * 2; i += NW * 64) {
       const int hr = i >> 1, h = hr / R, r = hr - h * R;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -99,7 +103,9 @@ __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
     for (int off = HD / 16; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);      // HD/8 adjacent lanes hold one head's chunks
     if (((i & 7) % (HD / 8)) == 0) sDelta[((i & 7) / (HD / 8)) * R + r] = part;
   }
+  SAB_STAMP(1);
   __syncthreads();
+  SAB_STAMP(2);
   const uint32_t key_rng = drop_key(a.drop);
   const int nqt = (L + 15) / 16;
   const float ln2 = 0.6931471805599453f;
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
       for (int nt = 0; nt < NT; ++nt) dq[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
       const uint32_t bh_rng = (uint32_t)(b * H + h) + a.bh_offset;
       const uint32_t idx_q = (bh_rng * (uint32_t)L + (uint32_t)q) * (uint32_t)L;
-#pragma unroll 1
+#pragma unroll 2
       for (int kp = 0; 2 * kp < nkt; ++kp) {
         f32x4 s[2], dp[2];
 #pragma unroll
@@ -139,19 +145,20 @@ __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
             dp[t] = mfma_bf16(dp[t], sab_rowfrag<HD>(sV, kt * 16 + c, h, kb, g), fdo[kb]);
           }
         }
-        const uint32_t mword = use_bits ? (sM[((size_t)h * R + q) * 8 + kp] >> (4 * g)) : 0u;
+        uint32_t mword = 0u;
+        if constexpr (MODE == 1) mword = sM[((size_t)h * R + q) * 8 + kp] >> (4 * g);
         f32x4 ds[2];
+        const bool edge = 2 * kp + 1 >= qt;          // the pair touches the diagonal tile (or lies beyond it): per-element mask
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int kt = 2 * kp + t;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int key = kt * 16 + 4 * g + r;
             float p = __builtin_amdgcn_exp2f(s[t][r] - lse_q);
-            if (kt >= qt) p = (kt < nkt && key <= q) ? p : 0.f;       // diagonal tile and the unused half of the last pair
+            if (edge) p = (kt < qt || (kt == qt && 4 * g + r <= c)) ? p : 0.f;
             float d = dp[t][r];
-            if (use_bits) d = ((mword >> (16 * t + r)) & 1u) ? d * a.drop.scale : 0.f;
-            else if (a.drop.thr) d = adt_keep(key_rng, idx_q + (uint32_t)key, a.drop.thr) ? d * a.drop.scale : 0.f;
+            if constexpr (MODE == 1) d = ((mword >> (16 * t + r)) & 1u) ? d * a.drop.scale : 0.f;
+            if constexpr (MODE == 2) d = adt_keep(key_rng, idx_q + (uint32_t)(kt * 16 + 4 * g + r), a.drop.thr) ? d * a.drop.scale : 0.f;
             ds[t][r] = p * (d - delta_q);
           }
         }
@@ -168,6 +175,7 @@ __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
     }
   }
 
+  SAB_STAMP(3);
   // ---- pass B: dK, dV (a wave owns key tile kt, queries on the accumulator rows) ---------------------------------------------
   for (int rnd = 0; rnd * NW < nqt; ++rnd) {
     const int kt = rnd * NW + ((rnd & 1) ? NW - 1 - w : w);        // key tile 0 is the heaviest under the causal mask
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
       const uint32_t bh_rng = (uint32_t)(b * H + h) + a.bh_offset;
       const float* lse_h = sLse + h * R;
       const float* del_h = sDelta + h * R;
-#pragma unroll 1
+#pragma unroll 2
       for (int qp = kt / 2; 2 * qp < nqt; ++qp) {
         f32x4 s[2], dp[2];
 #pragma unroll
@@ -205,6 +213,7 @@ __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
           }
         }
         f32x4 pv[2], ds[2];
+        const bool edge = 2 * qp <= kt;               // the pair holds the diagonal tile (and, for odd kt, the tile below it)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int qt = 2 * qp + t;
@@ -215,10 +224,10 @@ __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
           for (int r = 0; r < 4; ++r) {
             const int qq = qt * 16 + 4 * g + r;
             float p = __builtin_amdgcn_exp2f(s[t][r] - lq[r]);
-            if (qt <= kt) p = (qt == kt && key <= qq) ? p : 0.f;       // the diagonal tile, and the tile below it in the first pair
+            if (edge) p = (qt > kt || (qt == kt && c <= 4 * g + r)) ? p : 0.f;
             float ks = 1.0f;
-            if (use_bits) ks = ((sM[((size_t)h * R + qq) * 8 + (kt >> 1)] >> (16 * (kt & 1) + c)) & 1u) ? a.drop.scale : 0.f;
-            else if (a.drop.thr) ks = adt_keep(key_rng, (bh_rng * (uint32_t)L + (uint32_t)qq) * (uint32_t)L + (uint32_t)key, a.drop.thr) ? a.drop.scale : 0.f;
+            if constexpr (MODE == 1) ks = ((sM[((size_t)h * R + qq) * 8 + (kt >> 1)] >> (16 * (kt & 1) + c)) & 1u) ? a.drop.scale : 0.f;
+            if constexpr (MODE == 2) ks = adt_keep(key_rng, (bh_rng * (uint32_t)L + (uint32_t)qq) * (uint32_t)L + (uint32_t)key, a.drop.thr) ? a.drop.scale : 0.f;
             pv[t][r] = p * ks;
             ds[t][r] = p * (dp[t][r] * ks - dq4[r]);
           }
@@ -242,6 +251,7 @@ __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
       }
     }
   }
+  SAB_STAMP(4);
 }
 
 }  // namespace adt

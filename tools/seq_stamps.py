@@ -6,7 +6,8 @@ import ctypes
 import os
 import sys
 
-os.environ["ADT_SEQ_STAMPS"] = "1"
+MODE = sys.argv[1] if len(sys.argv) > 1 else "fwd"          # fwd: fused encoder forward ; attn: per-sequence attention backward
+os.environ["ADT_SEQ_STAMPS"] = "2" if MODE == "attn" else "1"
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import numpy as np  # noqa: E402
@@ -18,8 +19,13 @@ from adt_amd import _lib  # noqa: E402
 m = bench.build_model("cuda:0", "bf16")
 batch = bench.synth_batches(1, 256, 200, 3416, 7)[0]
 ids = [m._ids(a) for a in batch]
+from adt_amd.sasrec.trainer import FusedTrainer  # noqa: E402
+tr = FusedTrainer(m, bench.CFG["lambdas1"], bench.CFG["lambdas2"], weight_decay=1e-3, seed=3)
 for _ in range(3):
-    m.run_forward(*ids, 256, True)
+    if MODE == "attn":
+        tr.step(*batch)
+    else:
+        m.run_forward(*ids, 256, True)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 128)()
 rc = _lib.load().adt_seq_stamps_read(buf, 128)
@@ -27,6 +33,8 @@ t = np.array(list(buf), dtype=np.int64).reshape(8, 16)
 print("rc", rc)
 t0 = t[:, 0].min()
 names = ["start", "staged", "pre0", "pre1", "barrier", "attn0", "oproj0", "ffn0", "attn1", "oproj1", "ffn1"]
+if MODE == "attn":
+    names = ["start", "staged", "barrier", "passA", "passB"]
 print("wave " + " ".join("%8s" % n for n in names))
 for w in range(8):
-    print("%4d " % w + " ".join("%8d" % (t[w, k] - t0 if t[w, k] else -1) for k in range(11)))
+    print("%4d " % w + " ".join("%8d" % (t[w, k] - t0 if t[w, k] else -1) for k in range(len(names))))
