@@ -34,3 +34,5 @@ int adt_launch_seq_dec_fwd(int hd, const adt::SeqFwdArgs& a, void* stream);
 int adt_pack_wimg(const float* base, void* img, const int* offs, int n, void* stream);
 namespace adt { struct AttnArgs; }
 int adt_launch_seq_attn_bwd(int hd, const adt::AttnArgs& a, void* stream);     // 0 launched, 1 shape not covered, < 0 error
+namespace adt { struct SeqBwdArgs; }
+int adt_launch_seq_attn_pre_bwd(int hd, int dec, const adt::SeqBwdArgs& a, void* stream);     // 0 launched, 1 not covered, < 0 error

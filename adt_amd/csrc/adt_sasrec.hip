@@ -7,6 +7,7 @@
 #include "adt_bwdchain_args.h"
 #include "adt_fwdchain_args.h"
 #include "adt_seq_args.h"
+#include "adt_seqbwd_args.h"
 
 namespace {
 
@@ -151,6 +152,14 @@ int pack_weights(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const f
     offs[n++] = (int)(lo.dec(i, D_C1W) - base); offs[n++] = (int)(lo.dec(i, D_C2W) - base);
   }
   return adt_pack_wimg(P + base, ws + w.wpack, offs, n, st);
+}
+
+adt::SeqBwdArgs seq_bwd_args(int L, int B, int H, const int32_t* ids, float p, const uint32_t* seed, uint32_t site, uint32_t b_offset, int hd) {
+  adt::SeqBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.L = L; a.B = B; a.H = H; a.ids = ids; a.drop = adt_make_drop(p, seed, site); a.b_offset = b_offset; a.ln_eps = LN_EPS;
+  a.scale = 1.0f / sqrtf((float)hd);
+  return a;
 }
 
 adt::SeqFwdArgs seq_args(int L, int B, int H, const int32_t* ids, float p, const uint32_t* seed, uint32_t b_offset, int hd) {
@@ -400,6 +409,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   };
   const int64_t dec_begin = lo.dec(0, 0);
   const float* f = ws + w.f;
+  const bool use_seq = adt_seq_supported(prec, L, d, hd) != 0;
   if (phase == 0 || phase == 1) {
     // d log_feats (overwrites g_f) and item-table rows of pos/neg      (sasrec/model.py:72-76)
     // item-table replicas and parameter replicas are adjacent in the workspace: one fill
@@ -452,17 +462,30 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.out0 = gf; a.acc0 = 1;
         CK(adt_launch_bwdchain(prec, 5, a, st));
       }
-      CK(adt_attn_bwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, o1, d, lse1, s1, d, B, H, L, hd, 1, p, seed,
-                      dec_site(i, 0), b_offset, s3, 3 * d, s3 + d, 3 * d, s3 + 2 * d, 3 * d,
-                      reinterpret_cast<const uint32_t*>(base + w.d_mask1), st));
-      {  // layer_norm + packed in_proj reverse: gx (+)= LN'(dqkv Win + gy*mask)
-        adt::BwdChainArgs a = BA(dec, 0.f, nullptr);
-        a.dqkv = s3; a.lddqkv = 3 * d; a.gy = gy; a.xin = x;
-        a.W0 = sinw; a.W1 = sinw + dd; a.W2 = sinw + 2 * dd; a.gamma = P + lo.dec(i, D_LNW); a.beta = P + lo.dec(i, D_LNB);
-        a.dW0 = gsinw; a.dW1 = gsinw + dd; a.dW2 = gsinw + 2 * dd; a.db0 = gsinb; a.db1 = gsinb + d; a.db2 = gsinb + 2 * d;
-        a.dgamma = Gq + lo.dec(i, D_LNW); a.dbeta = Gq + lo.dec(i, D_LNB);
-        a.out0 = gx; a.acc0 = i > 0 ? 1 : 0;
-        CK(adt_launch_bwdchain(prec, 3, a, st));
+      bool fused_blk = false;
+      if (adt_seq_supported(prec, L, d, hd)) {   // self-attention backward + layer_norm / in-projection backward in one launch per sequence
+        adt::SeqBwdArgs a = seq_bwd_args(L, (int)w.B, H, dec, p, seed, dec_site(i, 0), b_offset, hd);
+        a.x = x; a.gamma = P + lo.dec(i, D_LNW); a.beta = P + lo.dec(i, D_LNB); a.Win = sinw; a.bin = P + lo.dec(i, D_SINB);
+        a.dO = s1; a.o = o1; a.lse = lse1; a.mask = reinterpret_cast<const uint32_t*>(base + w.d_mask1); a.dres = gy;
+        a.gx = gx; a.acc = i > 0 ? 1 : 0; a.dWin = gsinw; a.dbin = gsinb; a.dgamma = Gq + lo.dec(i, D_LNW); a.dbeta = Gq + lo.dec(i, D_LNB);
+        a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride; a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack;
+        const int rc = adt_launch_seq_attn_pre_bwd(hd, 1, a, st);
+        if (rc < 0) return rc;
+        fused_blk = rc == 0;
+      }
+      if (!fused_blk) {
+        CK(adt_attn_bwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, o1, d, lse1, s1, d, B, H, L, hd, 1, p, seed,
+                        dec_site(i, 0), b_offset, s3, 3 * d, s3 + d, 3 * d, s3 + 2 * d, 3 * d,
+                        reinterpret_cast<const uint32_t*>(base + w.d_mask1), st));
+        {  // layer_norm + packed in_proj reverse: gx (+)= LN'(dqkv Win + gy*mask)
+          adt::BwdChainArgs a = BA(dec, 0.f, nullptr);
+          a.dqkv = s3; a.lddqkv = 3 * d; a.gy = gy; a.xin = x;
+          a.W0 = sinw; a.W1 = sinw + dd; a.W2 = sinw + 2 * dd; a.gamma = P + lo.dec(i, D_LNW); a.beta = P + lo.dec(i, D_LNB);
+          a.dW0 = gsinw; a.dW1 = gsinw + dd; a.dW2 = gsinw + 2 * dd; a.db0 = gsinb; a.db1 = gsinb + d; a.db2 = gsinb + 2 * d;
+          a.dgamma = Gq + lo.dec(i, D_LNW); a.dbeta = Gq + lo.dec(i, D_LNB);
+          a.out0 = gx; a.acc0 = i > 0 ? 1 : 0;
+          CK(adt_launch_bwdchain(prec, 3, a, st));
+        }
       }
     }
     // decoder input embedding (sasrec/model.py:53-59)
@@ -509,17 +532,30 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       if (H > 4)   // wider classifiers: separate kernel
         CK(adt_headcls_bwd(o, d, P + lo.enc(i, E_SW), rec, ws + w.g_rec + i * recsz, (int)w.B, L, H, hd, s1, d, G + lo.enc(i, E_SW),
                            G + lo.enc(i, E_SB), st));
-      CK(adt_attn_bwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, o, d, lse, s1, d, (int)w.B, H, L, hd, 1, p, seed,
-                      enc_site(i, 0), b_offset, s3, 3 * d, s3 + d, 3 * d, s3 + 2 * d, 3 * d,
-                      reinterpret_cast<const uint32_t*>(base + w.e_mask), st));
-      {  // attention_layernorm + in_proj reverse: gx += LN'(dq Wq + dh) + dk Wk + dv Wv
-        adt::BwdChainArgs a = BA(seq, 0.f, nullptr);
-        a.dqkv = s3; a.lddqkv = 3 * d; a.dh = s5; a.xin = x;
-        a.W0 = inw; a.W1 = inw + dd; a.W2 = inw + 2 * dd; a.gamma = P + lo.enc(i, E_LN1W); a.beta = P + lo.enc(i, E_LN1B);
-        a.dW0 = ginw; a.dW1 = ginw + dd; a.dW2 = ginw + 2 * dd; a.db0 = ginb; a.db1 = ginb + d; a.db2 = ginb + 2 * d;
-        a.dgamma = Gq + lo.enc(i, E_LN1W); a.dbeta = Gq + lo.enc(i, E_LN1B);
-        a.out0 = gx; a.acc0 = 1;
-        CK(adt_launch_bwdchain(prec, 2, a, st));
+      bool fused_blk = false;
+      if (use_seq) {   // attention backward + LayerNorm / in-projection backward in one launch per sequence (adt_seqbwd_tt.cuh)
+        adt::SeqBwdArgs a = seq_bwd_args(L, (int)w.B, H, seq, p, seed, enc_site(i, 0), b_offset, hd);
+        a.x = x; a.gamma = P + lo.enc(i, E_LN1W); a.beta = P + lo.enc(i, E_LN1B); a.Win = inw; a.bin = P + lo.enc(i, E_INB);
+        a.dO = s1; a.o = o; a.lse = lse; a.mask = reinterpret_cast<const uint32_t*>(base + w.e_mask); a.dres = s5;
+        a.gx = gx; a.acc = 1; a.dWin = ginw; a.dbin = ginb; a.dgamma = Gq + lo.enc(i, E_LN1W); a.dbeta = Gq + lo.enc(i, E_LN1B);
+        a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride; a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack;
+        const int rc = adt_launch_seq_attn_pre_bwd(hd, 0, a, st);
+        if (rc < 0) return rc;
+        fused_blk = rc == 0;
+      }
+      if (!fused_blk) {
+        CK(adt_attn_bwd(prec, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, o, d, lse, s1, d, (int)w.B, H, L, hd, 1, p, seed,
+                        enc_site(i, 0), b_offset, s3, 3 * d, s3 + d, 3 * d, s3 + 2 * d, 3 * d,
+                        reinterpret_cast<const uint32_t*>(base + w.e_mask), st));
+        {  // attention_layernorm + in_proj reverse: gx += LN'(dq Wq + dh) + dk Wk + dv Wv
+          adt::BwdChainArgs a = BA(seq, 0.f, nullptr);
+          a.dqkv = s3; a.lddqkv = 3 * d; a.dh = s5; a.xin = x;
+          a.W0 = inw; a.W1 = inw + dd; a.W2 = inw + 2 * dd; a.gamma = P + lo.enc(i, E_LN1W); a.beta = P + lo.enc(i, E_LN1B);
+          a.dW0 = ginw; a.dW1 = ginw + dd; a.dW2 = ginw + 2 * dd; a.db0 = ginb; a.db1 = ginb + d; a.db2 = ginb + 2 * d;
+          a.dgamma = Gq + lo.enc(i, E_LN1W); a.dbeta = Gq + lo.enc(i, E_LN1B);
+          a.out0 = gx; a.acc0 = 1;
+          CK(adt_launch_bwdchain(prec, 2, a, st));
+        }
       }
     }
     if (phase == 2 && adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride, (hipStream_t)st)) return adt_set_error("replica zero");

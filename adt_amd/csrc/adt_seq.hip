@@ -4,6 +4,7 @@
 #include "adt_seqfwd.cuh"
 #include "adt_seqfwd_tt.cuh"
 #include "adt_seqattn.cuh"
+#include "adt_seqbwd_tt.cuh"
 
 using namespace adt;
 
@@ -100,7 +101,7 @@ static void seq_ablate(SeqFwdArgs& a) {
 static bool seq_use_tt(const SeqFwdArgs& a) {     // register-resident transposed chains (adt_seqfwd_tt.cuh); ADT_SEQ_TT=0: the row-major fused form
   static int on = -1;
   if (on < 0) { const char* e = getenv("ADT_SEQ_TT"); on = (e && atoi(e) == 0) ? 0 : 1; }
-  return on && a.wp_img != nullptr;
+  return on && a.wp_img != nullptr && (a.L & 3) == 0;      // L % 4 == 0: a quad of attention keys shares one dropout hash word
 }
 
 int adt_launch_seq_enc_fwd(int hd, const SeqFwdArgs& a, void* stream) {
@@ -166,4 +167,30 @@ int adt_launch_seq_attn_bwd(int hd, const AttnArgs& a, void* stream) {
   void* kargs[] = {&args};
   if (hipLaunchKernel(fn, dim3(a.B), dim3(SAB_NW * 64), kargs, smem, (hipStream_t)stream) != hipSuccess) return adt_set_error("seq_attn_bwd: launch failed");
   return seq_check("seq_attn_bwd");
+}
+
+// fused backward of one attention block (adt_seqbwd_tt.cuh); dec = 0: encoder block, 1: decoder self-attention block.
+// Returns 1 when the shape is not covered (the caller runs the staged kernels).
+template <int HD, bool DEC>
+static int seq_attn_pre_bwd_t(int mode, const SeqBwdArgs& a, hipStream_t s) {
+  constexpr int H = 64 / HD;
+  const size_t smem = SeqBwdLds<H>::bytes;
+  static bool done[3] = {false, false, false};
+  const void* fns[3] = {(const void*)k_seqtt_attn_pre_bwd<HD, 0, DEC>, (const void*)k_seqtt_attn_pre_bwd<HD, 1, DEC>,
+                        (const void*)k_seqtt_attn_pre_bwd<HD, 2, DEC>};
+  SeqBwdArgs args = a;
+  args.stamps = seq_stamp_buffer(true);
+  return seq_launch(fns[mode], smem, done[mode], a.B, &args, s, "seqtt_attn_pre_bwd");
+}
+
+int adt_launch_seq_attn_pre_bwd(int hd, int dec, const SeqBwdArgs& a, void* stream) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("ADT_SEQ_BWD"); on = (e && atoi(e) == 0) ? 0 : 1; }
+  if (!on || a.wp_img == nullptr || a.L > SB_R || (a.L & 3) || a.H * hd != 64) return 1;
+  const int mode = a.drop.thr == 0 ? 0 : (a.mask != nullptr ? 1 : 2);
+  hipStream_t s = (hipStream_t)stream;
+  if (hd == 32) return dec ? seq_attn_pre_bwd_t<32, true>(mode, a, s) : seq_attn_pre_bwd_t<32, false>(mode, a, s);
+  if (hd == 64) return dec ? seq_attn_pre_bwd_t<64, true>(mode, a, s) : seq_attn_pre_bwd_t<64, false>(mode, a, s);
+  if (hd == 16) return dec ? seq_attn_pre_bwd_t<16, true>(mode, a, s) : seq_attn_pre_bwd_t<16, false>(mode, a, s);
+  return 1;
 }

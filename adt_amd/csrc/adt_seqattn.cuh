@@ -41,8 +41,115 @@ ADT_DEVICE_INLINE bf16x8 sab_rowfrag(const __bf16* img, int row, int h, int kb, 
   return o;
 }
 
-// MODE: 0 no dropout, 1 keep bits saved by the forward (a.mask), 2 keep decisions recomputed from the hash RNG -- a compile-time
-// choice: as run-time branches inside the element loops the three variants cost ~100 branch instructions per key-tile pair
+// ---- the two passes over one (tile, head), shared by the stand-alone kernel below and the fused layer backward (adt_seqbwd_tt.cuh) ----
+// MODE: 0 no dropout, 1 keep bits saved by the forward, 2 keep decisions recomputed from the hash RNG -- a compile-time choice: as
+// run-time branches inside the element loops the three variants cost ~100 branch instructions per key-tile pair.
+//
+// pass A: query tile qt on the lane (q = 16 qt + c), keys on the accumulator rows.  fq / fdo: this lane's query and dO rows of head h in
+// slot order (fq pre-scaled by log2(e)/sqrt(hd)); lse_q in the log2 domain; mrow: the 8 keep-bit words of query q (MODE 1).
+// Result: dq[nt] = rows (features 16 nt + 4g + r of the head) x column (query c) of dS K, NOT yet multiplied by 1/sqrt(hd).
+template <int HD, int MODE>
+ADT_DEVICE_INLINE void sab_pass_a(const __bf16* sK, const __bf16* sV, const bf16x8* fq, const bf16x8* fdo, float lse_q, float delta_q,
+                                  const uint32_t* mrow, int qt, int h, const DropCfg& drop, uint32_t key_rng, uint32_t idx_q, int c, int g,
+                                  f32x4 (&dq)[HD / 16]) {
+  constexpr int NT = HD / 16, KB = (HD + 31) / 32;
+  const int nkt = qt + 1;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) dq[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int kp = 0; 2 * kp < nkt; ++kp) {
+    f32x4 s[2], dp[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int kt = 2 * kp + t;
+      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dp[t] = s[t];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {          // rows beyond the causal range are zero-filled or masked below
+        s[t] = mfma_bf16(s[t], sab_rowfrag<HD>(sK, kt * 16 + c, h, kb, g), fq[kb]);
+        dp[t] = mfma_bf16(dp[t], sab_rowfrag<HD>(sV, kt * 16 + c, h, kb, g), fdo[kb]);
+      }
+    }
+    uint32_t mword = 0u;
+    if constexpr (MODE == 1) mword = mrow[kp] >> (4 * g);
+    f32x4 ds[2];
+    const bool edge = 2 * kp + 1 >= qt;          // the pair touches the diagonal tile (or lies beyond it): per-element mask
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int kt = 2 * kp + t;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = __builtin_amdgcn_exp2f(s[t][r] - lse_q);
+        if (edge) p = (kt < qt || (kt == qt && 4 * g + r <= c)) ? p : 0.f;
+        float d = dp[t][r];
+        if constexpr (MODE == 1) d = ((mword >> (16 * t + r)) & 1u) ? d * drop.scale : 0.f;
+        if constexpr (MODE == 2) d = adt_keep(key_rng, idx_q + (uint32_t)(kt * 16 + 4 * g + r), drop.thr) ? d * drop.scale : 0.f;
+        ds[t][r] = p * (d - delta_q);
+      }
+    }
+    const bf16x8 fds = tt_pack(ds[0], ds[1]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dq[nt] = mfma_bf16(dq[nt], tt_trfrag(sK, kp * 32, h * HD + nt * 16, c, g), fds);
+  }
+}
+
+// pass B: key tile kt on the lane (key = 16 kt + c), queries on the accumulator rows.  fk / fv: this lane's key and value rows of head h;
+// lse_h / del_h: the head's per-query log2-domain log-sum-exp (+inf for padded queries) and delta; sM_h: [rows][8] keep bits (MODE 1).
+// Results: dk = dS^T Q (carries the Q image's factor log2(e)/sqrt(hd)), dv = P'^T dO; rows = features, column = key c.
+template <int HD, int MODE>
+ADT_DEVICE_INLINE void sab_pass_b(const __bf16* sQ, const __bf16* sdO, const bf16x8* fk, const bf16x8* fv, const float* lse_h, const float* del_h,
+                                  const uint32_t* sM_h, int kt, int nqt, int h, const DropCfg& drop, uint32_t key_rng, uint32_t idx_bh, int L,
+                                  int c, int g, f32x4 (&dk)[HD / 16], f32x4 (&dv)[HD / 16]) {
+  constexpr int NT = HD / 16, KB = (HD + 31) / 32;
+  const int key = kt * 16 + c;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    dk[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll 2
+  for (int qp = kt / 2; 2 * qp < nqt; ++qp) {
+    f32x4 s[2], dp[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int qt = 2 * qp + t;
+      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dp[t] = s[t];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        s[t] = mfma_bf16(s[t], sab_rowfrag<HD>(sQ, qt * 16 + c, h, kb, g), fk[kb]);
+        dp[t] = mfma_bf16(dp[t], sab_rowfrag<HD>(sdO, qt * 16 + c, h, kb, g), fv[kb]);
+      }
+    }
+    f32x4 pv[2], ds[2];
+    const bool edge = 2 * qp <= kt;               // the pair holds the diagonal tile (and, for odd kt, the tile below it)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int qt = 2 * qp + t;
+      const float4 lse4 = *reinterpret_cast<const float4*>(lse_h + qt * 16 + 4 * g);      // +inf for padded queries -> p = 0
+      const float4 del4 = *reinterpret_cast<const float4*>(del_h + qt * 16 + 4 * g);
+      const float lq[4] = {lse4.x, lse4.y, lse4.z, lse4.w}, dq4[4] = {del4.x, del4.y, del4.z, del4.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qq = qt * 16 + 4 * g + r;
+        float p = __builtin_amdgcn_exp2f(s[t][r] - lq[r]);
+        if (edge) p = (qt > kt || (qt == kt && c <= 4 * g + r)) ? p : 0.f;
+        float ks = 1.0f;
+        if constexpr (MODE == 1) ks = ((sM_h[(size_t)qq * 8 + (kt >> 1)] >> (16 * (kt & 1) + c)) & 1u) ? drop.scale : 0.f;
+        if constexpr (MODE == 2) ks = adt_keep(key_rng, (idx_bh + (uint32_t)qq) * (uint32_t)L + (uint32_t)key, drop.thr) ? drop.scale : 0.f;
+        pv[t][r] = p * ks;
+        ds[t][r] = p * (dp[t][r] * ks - dq4[r]);
+      }
+    }
+    const bf16x8 fp = tt_pack(pv[0], pv[1]), fds = tt_pack(ds[0], ds[1]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      dv[nt] = mfma_bf16(dv[nt], tt_trfrag(sdO, qp * 32, h * HD + nt * 16, c, g), fp);
+      dk[nt] = mfma_bf16(dk[nt], tt_trfrag(sQ, qp * 32, h * HD + nt * 16, c, g), fds);
+    }
+  }
+}
+
 template <int HD, int MODE>
 __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
   constexpr int H = 64 / HD, NT = HD / 16, KB = (HD + 31) / 32, MAXKT = 14, NW = SAB_NW;
@@ -127,45 +234,9 @@ __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
         fdo[kb] = sab_rowfrag<HD>(sdO, q, h, kb, g);
       }
       f32x4 dq[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) dq[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
       const uint32_t bh_rng = (uint32_t)(b * H + h) + a.bh_offset;
       const uint32_t idx_q = (bh_rng * (uint32_t)L + (uint32_t)q) * (uint32_t)L;
-#pragma unroll 2
-      for (int kp = 0; 2 * kp < nkt; ++kp) {
-        f32x4 s[2], dp[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int kt = 2 * kp + t;
-          s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-          dp[t] = s[t];
-#pragma unroll
-          for (int kb = 0; kb < KB; ++kb) {          // rows beyond the causal range are zero-filled or masked below
-            s[t] = mfma_bf16(s[t], sab_rowfrag<HD>(sK, kt * 16 + c, h, kb, g), fq[kb]);
-            dp[t] = mfma_bf16(dp[t], sab_rowfrag<HD>(sV, kt * 16 + c, h, kb, g), fdo[kb]);
-          }
-        }
-        uint32_t mword = 0u;
-        if constexpr (MODE == 1) mword = sM[((size_t)h * R + q) * 8 + kp] >> (4 * g);
-        f32x4 ds[2];
-        const bool edge = 2 * kp + 1 >= qt;          // the pair touches the diagonal tile (or lies beyond it): per-element mask
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int kt = 2 * kp + t;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float p = __builtin_amdgcn_exp2f(s[t][r] - lse_q);
-            if (edge) p = (kt < qt || (kt == qt && 4 * g + r <= c)) ? p : 0.f;
-            float d = dp[t][r];
-            if constexpr (MODE == 1) d = ((mword >> (16 * t + r)) & 1u) ? d * a.drop.scale : 0.f;
-            if constexpr (MODE == 2) d = adt_keep(key_rng, idx_q + (uint32_t)(kt * 16 + 4 * g + r), a.drop.thr) ? d * a.drop.scale : 0.f;
-            ds[t][r] = p * (d - delta_q);
-          }
-        }
-        const bf16x8 fds = tt_pack(ds[0], ds[1]);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) dq[nt] = mfma_bf16(dq[nt], tt_trfrag(sK, kp * 32, h * HD + nt * 16, c, g), fds);
-      }
+      sab_pass_a<HD, MODE>(sK, sV, fq, fdo, lse_q, delta_q, sM + ((size_t)h * R + q) * 8, qt, h, a.drop, key_rng, idx_q, c, g, dq);
       if (q < L) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -190,55 +261,9 @@ __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
         fv[kb] = sab_rowfrag<HD>(sV, key, h, kb, g);
       }
       f32x4 dk[NT], dv[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        dk[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
       const uint32_t bh_rng = (uint32_t)(b * H + h) + a.bh_offset;
-      const float* lse_h = sLse + h * R;
-      const float* del_h = sDelta + h * R;
-#pragma unroll 2
-      for (int qp = kt / 2; 2 * qp < nqt; ++qp) {
-        f32x4 s[2], dp[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int qt = 2 * qp + t;
-          s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-          dp[t] = s[t];
-#pragma unroll
-          for (int kb = 0; kb < KB; ++kb) {
-            s[t] = mfma_bf16(s[t], sab_rowfrag<HD>(sQ, qt * 16 + c, h, kb, g), fk[kb]);
-            dp[t] = mfma_bf16(dp[t], sab_rowfrag<HD>(sdO, qt * 16 + c, h, kb, g), fv[kb]);
-          }
-        }
-        f32x4 pv[2], ds[2];
-        const bool edge = 2 * qp <= kt;               // the pair holds the diagonal tile (and, for odd kt, the tile below it)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int qt = 2 * qp + t;
-          const float4 lse4 = *reinterpret_cast<const float4*>(lse_h + qt * 16 + 4 * g);      // +inf for padded queries -> p = 0
-          const float4 del4 = *reinterpret_cast<const float4*>(del_h + qt * 16 + 4 * g);
-          const float lq[4] = {lse4.x, lse4.y, lse4.z, lse4.w}, dq4[4] = {del4.x, del4.y, del4.z, del4.w};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int qq = qt * 16 + 4 * g + r;
-            float p = __builtin_amdgcn_exp2f(s[t][r] - lq[r]);
-            if (edge) p = (qt > kt || (qt == kt && c <= 4 * g + r)) ? p : 0.f;
-            float ks = 1.0f;
-            if constexpr (MODE == 1) ks = ((sM[((size_t)h * R + qq) * 8 + (kt >> 1)] >> (16 * (kt & 1) + c)) & 1u) ? a.drop.scale : 0.f;
-            if constexpr (MODE == 2) ks = adt_keep(key_rng, (bh_rng * (uint32_t)L + (uint32_t)qq) * (uint32_t)L + (uint32_t)key, a.drop.thr) ? a.drop.scale : 0.f;
-            pv[t][r] = p * ks;
-            ds[t][r] = p * (dp[t][r] * ks - dq4[r]);
-          }
-        }
-        const bf16x8 fp = tt_pack(pv[0], pv[1]), fds = tt_pack(ds[0], ds[1]);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          dv[nt] = mfma_bf16(dv[nt], tt_trfrag(sdO, qp * 32, h * HD + nt * 16, c, g), fp);
-          dk[nt] = mfma_bf16(dk[nt], tt_trfrag(sQ, qp * 32, h * HD + nt * 16, c, g), fds);
-        }
-      }
+      sab_pass_b<HD, MODE>(sQ, sdO, fk, fv, sLse + h * R, sDelta + h * R, sM + (size_t)h * R * 8, kt, nqt, h, a.drop, key_rng, bh_rng * (uint32_t)L, L, c,
+                           g, dk, dv);
       if (key < L) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {

@@ -1,0 +1,25 @@
+// Argument block of the per-sequence fused attention-block backward (adt_seqbwd_tt.cuh); shared with the host executor.
+#pragma once
+#include "adt_common.cuh"
+
+namespace adt {
+
+struct SeqBwdArgs {
+  int L, B, H;
+  const int* ids;                     // (B*L) padding mask of this stack
+  DropCfg drop; uint32_t b_offset;    // attention dropout (site set by the host), global index of this shard's first sequence
+  float ln_eps, scale;
+  const float* x;                     // block input (B*L x 64): the encoder / decoder layer input
+  const float* gamma; const float* beta;           // LayerNorm in front of the in-projection
+  const float* Win; const float* bin;              // packed in-projection (3 x 64 x 64, 3 x 64)
+  const float* dO; const float* o;                 // gradient wrt the attention output ; the forward's attention output
+  const float* lse; const uint32_t* mask;          // (B*H*L) log-sum-exp ; (B*H*L x 8) dropout keep bits
+  const float* dres;                  // encoder: gradient wrt LN(x) from the residual path ; decoder: gradient wrt the layer output (masked here)
+  float* gx; int acc;                 // gradient wrt x (acc: add to what is there)
+  float* dWin; float* dbin; float* dgamma; float* dbeta;     // accumulators (global float atomics)
+  int nrep; size_t rep_stride;        // parameter-gradient replicas (adt_bwdchain_args.h): workgroup b adds into replica b % nrep
+  const float* wp_base; const void* wp_img;        // pre-packed weight images (slot-ordered: + 2 plain, + 3 transposed)
+  unsigned long long* stamps;
+};
+
+}  // namespace adt

@@ -1,0 +1,370 @@
+// Per-sequence fused BACKWARD of one attention block on the transposed chains of adt_tt.cuh (bf16 MFMA operands):
+//   LayerNorm + packed in-projection (recomputed) -> causal attention backward -> in-projection weight gradients -> gradient of the
+//   block input.  One workgroup = one user sequence, replacing per (layer, block) the staged k_attn_bwd / k_seq_attn_bwd + k_pre_bwd pair
+//   (sasrec/modules.py:644-647, :666-670 and their autograd) and the trip of q, k, v, dq, dk, dv through HBM between them.
+//
+// q, k, v are not read back: the layer input x is (fp32, 256 B per token), LayerNorm and the three 64x64 products are recomputed into
+// registers (24 MFMAs per 16-token tile), and k, v go straight into the LDS row images the attention sweeps.  dO / O come from the
+// out_proj backward.  The two passes of adt_seqattn.cuh run on two image slots: K, V for pass A (the wave's own q and dO rows are
+// MFMA operands in registers), then Q, dO for pass B (own k, v rows in registers).  dq, dk, dv stay in registers as transposed tiles:
+//   * weight gradients dW = G^T X contract over ALL tokens of the sequence: G and X rows go to the two image slots and every wave
+//     computes its share of the 16 + 4 output tiles through ds_read_b64_tr_b16 fragments (column 64 of the X image holds 1 for real
+//     tokens, so the fifth tile column IS the bias gradient);
+//   * the input gradient is two / three more transposed-chain products and the LayerNorm backward, all in registers.
+#pragma once
+#include "adt_seqattn.cuh"
+#include "adt_seqbwd_args.h"
+#include "adt_seqfwd_tt.cuh"
+#include "adt_tt.cuh"
+
+namespace adt {
+
+constexpr int SB_NW = 8;
+constexpr int SB_R = 224;                          // image rows: L <= 224
+
+template <int H>
+struct SeqBwdLds {
+  static constexpr size_t wbytes = 6 * (size_t)TT_WIMG * 2, ibytes = (size_t)SB_R * TT_RS * 2;
+  static constexpr size_t mbytes = (size_t)H * SB_R * 8 * 4, sbytes = 2 * (size_t)H * SB_R * 4, rbytes = (2 * 64 + 320) * 4;
+  static constexpr size_t bytes = wbytes + 2 * ibytes + 64 /* spill of the last row's ones-column read */ + mbytes + sbytes + rbytes;
+};
+
+// operands of every head from a transposed tile, in the slot order sab_rowfrag reads image rows in: f[h * KB + kb]
+template <int HD>
+ADT_DEVICE_INLINE void sb_frags(const TT& t, float mul, bf16x8 (&f)[(64 / HD) * ((HD + 31) / 32)]) {
+  if constexpr (HD >= 32) {
+    f[0] = tt_pack(t.v[0], t.v[1], mul);
+    f[1] = tt_pack(t.v[2], t.v[3], mul);
+  } else {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 4; ++h) f[h] = tt_pack(t.v[h], z, mul);
+  }
+}
+
+// rows of a natural-order image from such operands (the inverse of sab_rowfrag)
+template <int HD>
+ADT_DEVICE_INLINE void sb_put_frags(__bf16* img, int token, const bf16x8 (&f)[(64 / HD) * ((HD + 31) / 32)], bool valid, int g) {
+  constexpr int NF = (64 / HD) * ((HD + 31) / 32);
+#pragma unroll
+  for (int i = 0; i < NF; ++i) {
+    bf16x4 lo, hi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { lo[j] = valid ? f[i][j] : (__bf16)0.f; hi[j] = valid ? f[i][4 + j] : (__bf16)0.f; }
+    if constexpr (HD >= 32) {
+      *reinterpret_cast<bf16x4*>(img + token * TT_RS + 32 * i + 4 * g) = lo;
+      *reinterpret_cast<bf16x4*>(img + token * TT_RS + 32 * i + 16 + 4 * g) = hi;
+    } else {
+      *reinterpret_cast<bf16x4*>(img + token * TT_RS + 16 * i + 4 * g) = lo;
+    }
+  }
+}
+
+// LayerNorm of a transposed tile, keeping what its backward needs
+struct TTLn { TT xhat; float rstd; };
+ADT_DEVICE_INLINE TTLn tt_ln_stats(const TT& x, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) s += (x.v[nt][0] + x.v[nt][1]) + (x.v[nt][2] + x.v[nt][3]);
+  const float mu = tt_colsum(s) * (1.0f / 64);
+  TTLn o;
+  float q = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float t = x.v[nt][r] - mu; o.xhat.v[nt][r] = t; q += t * t; }
+  o.rstd = 1.0f / sqrtf(tt_colsum(q) * (1.0f / 64) + eps);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) o.xhat.v[nt] *= o.rstd;
+  return o;
+}
+ADT_DEVICE_INLINE TT tt_ln_apply(const TT& xhat, const float* gamma, const float* beta, int g) {
+  const TTV gm = tt_vec(gamma, g), bt = tt_vec(beta, g);
+  TT y;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y.v[nt][r] = xhat.v[nt][r] * gm.v[nt][r] + bt.v[nt][r];
+  return y;
+}
+// dx = rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat)), dxh = dy * gamma ; dgamma += dy * xhat, dbeta += dy (per-lane partials)
+ADT_DEVICE_INLINE TT tt_ln_bwd(const TT& dy, const TTLn& st, const float* gamma, TT& dgm, TT& dbt, int g) {
+  const TTV gm = tt_vec(gamma, g);
+  TT dx;
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dgm.v[nt][r] += dy.v[nt][r] * st.xhat.v[nt][r];
+      dbt.v[nt][r] += dy.v[nt][r];
+      const float dxh = dy.v[nt][r] * gm.v[nt][r];
+      dx.v[nt][r] = dxh;
+      m1 += dxh;
+      m2 += dxh * st.xhat.v[nt][r];
+    }
+  m1 = tt_colsum(m1) * (1.0f / 64);
+  m2 = tt_colsum(m2) * (1.0f / 64);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dx.v[nt][r] = st.rstd * (dx.v[nt][r] - m1 - st.xhat.v[nt][r] * m2);
+  return dx;
+}
+
+// one weight-gradient product over all tokens of the sequence: dW[n][k] += sum_t G[t][n] X[t][k] (k = 64: the ones column -> db[n]).
+// 20 output tiles (4 n-tiles x (4 k-tiles + the bias column)) dealt round-robin over the waves; every wave calls (no barrier inside).
+ADT_DEVICE_INLINE void sb_dw_product(const __bf16* sG, const __bf16* sX, int npair, float* dW, float* db, int w, int c, int g) {
+#pragma unroll 1
+  for (int id = w; id < 20; id += SB_NW) {
+    const int nt = id / 5, kt = id - 5 * nt;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kp = 0; kp < npair; ++kp) acc = mfma_bf16(acc, tt_trfrag(sG, kp * 32, 16 * nt, c, g), tt_trfrag(sX, kp * 32, 16 * kt, c, g));
+    if (kt < 4) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(dW + (16 * nt + 4 * g + r) * 64 + 16 * kt + c, acc[r]);
+    } else if (c == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(db + 16 * nt + 4 * g + r, acc[r]);
+    }
+  }
+}
+
+// rows of the X image of a weight-gradient product, with the ones column
+ADT_DEVICE_INLINE void sb_put_x(__bf16* img, int token, const TT& t, bool valid, int g) {
+  tt_put_rows(img, token, t, valid, g);
+  if (g == 0) img[token * TT_RS + 64] = (__bf16)(valid ? 1.0f : 0.0f);
+}
+
+#define SB_STAMP(k) do { if (a.stamps && blockIdx.x == 0 && lane == 0) a.stamps[w * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+
+// DEC = false: encoder block (q from LN(x), k / v from the raw x; the residual gradient joins at the LayerNorm output);
+// DEC = true : decoder self-attention block (q, k, v from LN(x); the masked layer-output gradient joins at the LayerNorm output).
+template <int HD, int MODE, bool DEC>
+__global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a) {
+  constexpr int H = 64 / HD, NT = HD / 16, KB = (HD + 31) / 32, NF = H * KB, NW = SB_NW, R = SB_R;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  typedef SeqBwdLds<H> Lds;
+  __bf16* wimg = reinterpret_cast<__bf16*>(smem_raw);                       // 0..2 Wq, Wk, Wv (plain) ; 3..5 transposed
+  __bf16* img0 = reinterpret_cast<__bf16*>(smem_raw + Lds::wbytes);
+  __bf16* img1 = reinterpret_cast<__bf16*>(smem_raw + Lds::wbytes + Lds::ibytes);
+  uint32_t* sM = reinterpret_cast<uint32_t*>(smem_raw + Lds::wbytes + 2 * Lds::ibytes + 64);
+  float* sLse = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(sM) + Lds::mbytes);
+  float* sDelta = sLse + H * R;
+  float* sRed = sDelta + H * R;                                              // [2][64] dgamma, dbeta of this workgroup
+  float* sVec = sRed + 128;                                                  // gamma, beta, packed in-projection bias (LDS copies)
+  const float *vgamma = sVec, *vbeta = sVec + 64, *vbin = sVec + 128;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16, npair = (L + 31) / 32;
+  if (a.nrep > 1) {
+    const size_t off = (size_t)(blockIdx.x % a.nrep) * a.rep_stride;
+    a.dWin += off; a.dbin += off; a.dgamma += off; a.dbeta += off;
+  }
+  SB_STAMP(0);
+  // ---- P0: weight images, zeroed token images, keep bits, statistics -------------------------------------------------------------
+  {
+    const __bf16* src = reinterpret_cast<const __bf16*>(a.wp_img) + 6 * (a.Win - a.wp_base);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const uint4* p2 = reinterpret_cast<const uint4*>(src + 6 * 4096 * j + 2 * WPACK_IMG);
+      const uint4* p3 = reinterpret_cast<const uint4*>(src + 6 * 4096 * j + 3 * WPACK_IMG);
+      uint4* d2 = reinterpret_cast<uint4*>(wimg + j * TT_WIMG);
+      uint4* d3 = reinterpret_cast<uint4*>(wimg + (3 + j) * TT_WIMG);
+      for (int i = threadIdx.x; i < TT_WIMG * 2 / 16; i += NW * 64) { d2[i] = p2[i]; d3[i] = p3[i]; }
+    }
+    uint4* z = reinterpret_cast<uint4*>(img0);
+    for (int i = threadIdx.x; i < (int)((2 * Lds::ibytes + 64) / 16); i += NW * 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (MODE == 1) {
+      for (int i = threadIdx.x; i < H * R * 2; i += NW * 64) {
+        const int hr = i >> 1, h = hr / R, r = hr - h * R;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (r < L) v = reinterpret_cast<const uint4*>(a.mask + ((size_t)(b * H + h) * L + r) * 8)[i & 1];
+        reinterpret_cast<uint4*>(sM + (size_t)hr * 8)[i & 1] = v;
+      }
+    }
+    for (int i = threadIdx.x; i < H * R; i += NW * 64) {
+      const int h = i / R, r = i - h * R;
+      sLse[i] = r < L ? a.lse[(size_t)(b * H + h) * L + r] * 1.4426950408889634f : INFINITY;
+      sDelta[i] = 0.f;
+    }
+    if (threadIdx.x < 128) sRed[threadIdx.x] = 0.f;
+    tt_stage_vec<NW * 64>(sVec, a.gamma, 64); tt_stage_vec<NW * 64>(sVec + 64, a.beta, 64); tt_stage_vec<NW * 64>(sVec + 128, a.bin, 192);
+  }
+  __syncthreads();
+  SB_STAMP(1);
+  const float qmul = a.scale * 1.4426950408889634f;
+  const uint32_t key_rng = drop_key(a.drop);
+  // ---- P1: recompute LN + in-projection; operands to registers, K / V images ------------------------------------------------------
+  bf16x8 fq[2][NF], fdo[2][NF], fk[2][NF], fv[2][NF];
+  float delta[2][H];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = l < L;
+    const TT x = tt_load(a.x + (size_t)row * 64, valid, g);
+    const TT xn = tt_ln_apply(tt_ln_stats(x, a.ln_eps).xhat, vgamma, vbeta, g);
+    const TTB bn = tt_bfrags(xn);
+    TTB bx;
+    if (!DEC) bx = tt_bfrags(x);
+    TT q = tt_gemm(bn, wimg, c, g);
+    tt_add_vec(q, vbin, g);
+    sb_frags<HD>(q, qmul, fq[s]);
+    TT k = tt_gemm(DEC ? bn : bx, wimg + TT_WIMG, c, g);
+    tt_add_vec(k, vbin + 64, g);
+    sb_frags<HD>(k, 1.0f, fk[s]);
+    tt_put_rows(img0, l, k, valid, g);
+    TT v = tt_gemm(DEC ? bn : bx, wimg + 2 * TT_WIMG, c, g);
+    tt_add_vec(v, vbin + 128, g);
+    sb_frags<HD>(v, 1.0f, fv[s]);
+    tt_put_rows(img1, l, v, valid, g);
+    const TT dO = tt_load(a.dO + (size_t)row * 64, valid, g);
+    const TT o = tt_load(a.o + (size_t)row * 64, valid, g);
+    sb_frags<HD>(dO, 1.0f, fdo[s]);
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float part = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part += dO.v[h * NT + nt][r] * o.v[h * NT + nt][r];
+      delta[s][h] = tt_colsum(part);
+      if (g == 0 && valid) sDelta[h * R + l] = delta[s][h];
+    }
+  }
+  __syncthreads();
+  SB_STAMP(2);
+  // ---- P2: pass A (dQ): keys / values from the images, own query and dO rows from registers ----------------------------------------
+  TT dq[2], dk[2], dv[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+    const int q = tile * 16 + c;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      f32x4 t[NT];
+      const uint32_t bh_rng = (uint32_t)(b * H + h) + a.b_offset * (uint32_t)H;
+      sab_pass_a<HD, MODE>(img0, img1, fq[s] + h * KB, fdo[s] + h * KB, sLse[h * R + q], delta[s][h], sM + ((size_t)h * R + q) * 8, tile, h, a.drop,
+                           key_rng, (bh_rng * (uint32_t)L + (uint32_t)q) * (uint32_t)L, c, g, t);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) dq[s].v[h * NT + nt] = t[nt] * a.scale;
+    }
+  }
+  __syncthreads();
+  SB_STAMP(3);
+  // ---- P3: Q / dO images, then pass B (dK, dV) with own key and value rows from registers ----------------------------------------------
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+    const int l = tile * 16 + c;
+    sb_put_frags<HD>(img0, l, fq[s], l < L, g);
+    sb_put_frags<HD>(img1, l, fdo[s], l < L, g);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      f32x4 tk[NT], tv[NT];
+      const uint32_t bh_rng = (uint32_t)(b * H + h) + a.b_offset * (uint32_t)H;
+      sab_pass_b<HD, MODE>(img0, img1, fk[s] + h * KB, fv[s] + h * KB, sLse + h * R, sDelta + h * R, sM + (size_t)h * R * 8, tile, ntiles, h, a.drop,
+                           key_rng, bh_rng * (uint32_t)L, L, c, g, tk, tv);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        dk[s].v[h * NT + nt] = tk[nt] * 0.6931471805599453f;        // the Q image carries log2(e) / sqrt(hd)
+        dv[s].v[h * NT + nt] = tv[nt];
+      }
+    }
+  }
+  __syncthreads();
+  SB_STAMP(4);
+  // ---- P4: in-projection weight / bias gradients: three products over all tokens ------------------------------------------------------
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = l < L;
+    const TT x = tt_load(a.x + (size_t)row * 64, valid, g);
+    tt_put_rows(img0, l, dq[s], valid, g);
+    sb_put_x(img1, l, tt_ln_apply(tt_ln_stats(x, a.ln_eps).xhat, vgamma, vbeta, g), valid, g);     // q always reads LN(x)
+  }
+  __syncthreads();
+  sb_dw_product(img0, img1, npair, a.dWin, a.dbin, w, c, g);
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = l < L;
+    tt_put_rows(img0, l, dk[s], valid, g);
+    if (!DEC) sb_put_x(img1, l, tt_load(a.x + (size_t)row * 64, valid, g), valid, g);                  // encoder: k, v read the raw x
+  }
+  __syncthreads();
+  sb_dw_product(img0, img1, npair, a.dWin + 4096, a.dbin + 64, w, c, g);
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+    const int l = tile * 16 + c;
+    tt_put_rows(img0, l, dv[s], l < L, g);
+  }
+  __syncthreads();
+  sb_dw_product(img0, img1, npair, a.dWin + 8192, a.dbin + 128, w, c, g);
+  SB_STAMP(5);
+  // ---- P5: gradient of the block input ----------------------------------------------------------------------------------------
+  TT dgm = tt_zero(), dbt = tt_zero();
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = l < L;
+    const TT x = tt_load(a.x + (size_t)row * 64, valid, g);
+    const TTLn st = tt_ln_stats(x, a.ln_eps);
+    TT dn = tt_gemm(tt_bfrags(dq[s]), wimg + 3 * TT_WIMG, c, g);
+    TT dkv = tt_gemm(tt_bfrags(dk[s]), wimg + 4 * TT_WIMG, c, g);
+    tt_add(dkv, tt_gemm(tt_bfrags(dv[s]), wimg + 5 * TT_WIMG, c, g));
+    TT res = tt_load(a.dres + (size_t)row * 64, valid, g);
+    if (DEC && (!valid || a.ids[row] == 0)) res = tt_zero();
+    tt_add(dn, res);
+    TT dx;
+    if (!DEC) {
+      dx = tt_ln_bwd(dn, st, vgamma, dgm, dbt, g);
+      tt_add(dx, dkv);                                  // k, v read the raw x (sasrec/modules.py:647)
+    } else {
+      tt_add(dn, dkv);
+      dx = tt_ln_bwd(dn, st, vgamma, dgm, dbt, g);
+    }
+    if (valid) {
+      float* dst = a.gx + (size_t)row * 64;
+      if (a.acc) tt_add(dx, tt_load(dst, true, g));
+      tt_store(dst, dx, true, g);
+    }
+  }
+  // LayerNorm gamma / beta gradients: per-lane partials over this wave's tokens -> workgroup sums in LDS -> one atomic per feature
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float sg = tt_rowsum16(dgm.v[nt][r]), sb = tt_rowsum16(dbt.v[nt][r]);      // over the 16 tokens on this row of lanes
+      if (c == 0) {
+        atomicAdd(sRed + 16 * nt + 4 * g + r, sg);
+        atomicAdd(sRed + 64 + 16 * nt + 4 * g + r, sb);
+      }
+    }
+  __syncthreads();
+  if (threadIdx.x < 64) atomicAdd(a.dgamma + threadIdx.x, sRed[threadIdx.x]);
+  else if (threadIdx.x < 128) atomicAdd(a.dbeta + threadIdx.x - 64, sRed[threadIdx.x]);
+  SB_STAMP(6);
+}
+
+}  // namespace adt

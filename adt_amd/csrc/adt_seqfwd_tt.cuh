@@ -17,15 +17,59 @@ constexpr int TQ_LP = TQ_MAXKT * 16;
 template <int NWT>
 struct SeqTtLds {
   static constexpr size_t wbytes = (size_t)NWT * TT_WIMG * 2, ibytes = (size_t)TQ_LP * TT_RS * 2;
-  static constexpr size_t bytes = wbytes + 2 * ibytes;
-  __bf16* w[NWT]; __bf16* sK; __bf16* sV;
+  static constexpr size_t vbytes = 1024 * sizeof(float);            // per-feature vectors (SeqVec offsets)
+  static constexpr size_t bytes = wbytes + 2 * ibytes + vbytes;
+  __bf16* w[NWT]; __bf16* sK; __bf16* sV; float* vec;
   __device__ SeqTtLds(unsigned char* base) {
     __bf16* pw = reinterpret_cast<__bf16*>(base);
     for (int i = 0; i < NWT; ++i) w[i] = pw + i * TT_WIMG;
     sK = reinterpret_cast<__bf16*>(base + wbytes);
     sV = reinterpret_cast<__bf16*>(base + wbytes + ibytes);
+    vec = reinterpret_cast<float*>(base + wbytes + 2 * ibytes);
   }
 };
+
+// offsets (floats) of the per-feature vectors in the LDS vector area
+enum SeqVec { SV_GAMMA = 0, SV_BETA = 64, SV_BIN = 128, SV_BO = 320, SV_GAMMA2 = 384, SV_BETA2 = 448, SV_B1 = 512, SV_B2 = 576, SV_BIN2 = 640,
+              SV_BO2 = 832, SV_WS = 896, SV_BS = 960 };
+
+// all vectors in one pass: element i of the 1,024-float area comes from segment i >> 6.  Split into the global loads (issued together
+// with the weight-image loads at kernel entry) and the LDS stores (after the zero-fill), so the prologue pays ONE global round trip.
+struct TqVecRegs { float v[2]; };
+template <int NTHREADS>
+ADT_DEVICE_INLINE TqVecRegs tq_vec_load(const SeqFwdArgs& a, int H, int HD) {
+  TqVecRegs r;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = threadIdx.x + it * NTHREADS;
+    const int seg = i >> 6, j = i & 63;
+    const float* src = nullptr;
+    switch (seg) {
+      case 0: src = a.gamma; break;
+      case 1: src = a.beta; break;
+      case 2: case 3: case 4: src = a.bin ? a.bin + 64 * (seg - 2) : nullptr; break;
+      case 5: src = a.bo; break;
+      case 6: src = a.gamma2; break;
+      case 7: src = a.beta2; break;
+      case 8: src = a.b1; break;
+      case 9: src = a.b2; break;
+      case 10: case 11: case 12: src = a.bin2 ? a.bin2 + 64 * (seg - 10) : nullptr; break;
+      case 13: src = a.bo2; break;
+      case 14: src = (a.rec && j < H * HD) ? a.Ws : nullptr; break;
+      case 15: src = (a.rec && j < H) ? a.bs : nullptr; break;
+    }
+    r.v[it] = (i < 1024 && src) ? src[j] : 0.f;
+  }
+  return r;
+}
+template <int NTHREADS>
+ADT_DEVICE_INLINE void tq_vec_store(float* vec, const TqVecRegs& r) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = threadIdx.x + it * NTHREADS;
+    if (i < 1024) vec[i] = r.v[it];
+  }
+}
 
 ADT_DEVICE_INLINE int tq_tile(int s, int w, int ntiles) {        // heaviest causal tile paired with the lightest (adt_seqfwd.cuh)
   if (s == 0) return ntiles - 1 - w;
@@ -38,6 +82,33 @@ ADT_DEVICE_INLINE void tq_stage(__bf16* img, const float* W, bool transposed, co
   const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.wp_img) + 6 * (W - a.wp_base) + (transposed ? 3 : 2) * WPACK_IMG);
   uint4* dst = reinterpret_cast<uint4*>(img);
   for (int i = threadIdx.x; i < TT_WIMG * 2 / 16; i += NTHREADS) dst[i] = src[i];
+}
+
+// N weight images: all global loads first (2 x 16 B per thread and image), the LDS stores later
+template <int N> struct TqImgRegs { uint4 r0[N], r1[N]; };
+template <int NTHREADS, int N>
+ADT_DEVICE_INLINE TqImgRegs<N> tq_img_load(const float* const (&W)[N], bool transposed, const SeqFwdArgs& a) {
+  constexpr int CH = TT_WIMG * 2 / 16;            // 576 chunks of 16 bytes
+  TqImgRegs<N> t;
+  const int i1 = threadIdx.x + NTHREADS;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.wp_img) + 6 * (W[k] - a.wp_base) + (transposed ? 3 : 2) * WPACK_IMG);
+    t.r0[k] = src[threadIdx.x];
+    t.r1[k] = src[i1 < CH ? i1 : 0];
+  }
+  return t;
+}
+template <int NTHREADS, int N>
+ADT_DEVICE_INLINE void tq_img_store(__bf16* const (&img)[N], const TqImgRegs<N>& t) {
+  constexpr int CH = TT_WIMG * 2 / 16;
+  const int i1 = threadIdx.x + NTHREADS;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    uint4* dst = reinterpret_cast<uint4*>(img[k]);
+    dst[threadIdx.x] = t.r0[k];
+    if (i1 < CH) dst[i1] = t.r1[k];
+  }
 }
 
 ADT_DEVICE_INLINE void tq_zero(__bf16* p, size_t nbytes) {
@@ -65,13 +136,13 @@ ADT_DEVICE_INLINE TT tq_load_x(const SeqFwdArgs& a, int row, int l, bool valid, 
 
 // LayerNorm + packed in-projection of one tile: query operands to registers, k / v into the LDS images (and to HBM for the backward)
 template <int HD, bool ENC>
-ADT_DEVICE_INLINE void tq_pre_tile(const SeqFwdArgs& a, const __bf16* wq, const __bf16* wk, const __bf16* wv, __bf16* sK, __bf16* sV,
+ADT_DEVICE_INLINE void tq_pre_tile(const SeqFwdArgs& a, const float* vec, const __bf16* wq, const __bf16* wk, const __bf16* wv, __bf16* sK, __bf16* sV,
                                    int tile, int b, uint32_t key0, float qmul, int c, int g,
                                    bf16x8 (&fq)[(64 / HD) * ((HD + 31) / 32)], TT& xn_out) {
   const int l = tile * 16 + c, row = b * a.L + l;
   const bool valid = l < a.L;
   const TT x = tq_load_x(a, row, l, valid, key0, g);
-  const TT xn = tt_layernorm(x, a.gamma, a.beta, a.ln_eps, g);
+  const TT xn = tt_layernorm(x, vec + SV_GAMMA, vec + SV_BETA, a.ln_eps, g);
   if (a.xn) tt_store(a.xn + (size_t)row * 64, xn, valid, g);
   xn_out = xn;
   const TTB bn = tt_bfrags(xn);
@@ -79,7 +150,7 @@ ADT_DEVICE_INLINE void tq_pre_tile(const SeqFwdArgs& a, const __bf16* wq, const 
   if (ENC) bx = tt_bfrags(x);
   {
     TT q = tt_gemm(bn, wq, c, g);
-    tt_add_vec(q, a.bin, g);
+    tt_add_vec(q, vec + SV_BIN, g);
     if (a.qkv && valid) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<float4*>(a.qkv + (size_t)row * 192 + 16 * nt + 4 * g) = make_float4(q.v[nt][0], q.v[nt][1], q.v[nt][2], q.v[nt][3]);
@@ -88,7 +159,7 @@ ADT_DEVICE_INLINE void tq_pre_tile(const SeqFwdArgs& a, const __bf16* wq, const 
   }
   {
     TT k = tt_gemm(ENC ? bx : bn, wk, c, g);
-    tt_add_vec(k, a.bin + 64, g);
+    tt_add_vec(k, vec + SV_BIN + 64, g);
     if (a.qkv && valid) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<float4*>(a.qkv + (size_t)row * 192 + 64 + 16 * nt + 4 * g) = make_float4(k.v[nt][0], k.v[nt][1], k.v[nt][2], k.v[nt][3]);
@@ -97,7 +168,7 @@ ADT_DEVICE_INLINE void tq_pre_tile(const SeqFwdArgs& a, const __bf16* wq, const 
   }
   {
     TT v = tt_gemm(ENC ? bx : bn, wv, c, g);
-    tt_add_vec(v, a.bin + 128, g);
+    tt_add_vec(v, vec + SV_BIN + 128, g);
     if (a.qkv && valid) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<float4*>(a.qkv + (size_t)row * 192 + 128 + 16 * nt + 4 * g) = make_float4(v.v[nt][0], v.v[nt][1], v.v[nt][2], v.v[nt][3]);
@@ -107,11 +178,11 @@ ADT_DEVICE_INLINE void tq_pre_tile(const SeqFwdArgs& a, const __bf16* wq, const 
 }
 
 // u = relu(dropout1(xin W1^T + b1)) -> stored ; returns dropout2(u W2^T + b2)           (PointWiseFeedForward, modules.py:629-633)
-ADT_DEVICE_INLINE TT tq_ffn(const SeqFwdArgs& a, const __bf16* w1, const __bf16* w2, const TT& xin, uint32_t key1, uint32_t key2, int row,
+ADT_DEVICE_INLINE TT tq_ffn(const SeqFwdArgs& a, const float* vec, const __bf16* w1, const __bf16* w2, const TT& xin, uint32_t key1, uint32_t key2, int row,
                             bool valid, int c, int g) {
   const uint32_t rg = (uint32_t)row + a.b_offset * (uint32_t)a.L;
   TT u = tt_gemm(tt_bfrags(xin), w1, c, g);
-  tt_add_vec(u, a.b1, g);
+  tt_add_vec(u, vec + SV_B1, g);
   tt_dropout(u, key1, a.drop, rg, g);
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
@@ -119,7 +190,7 @@ ADT_DEVICE_INLINE TT tq_ffn(const SeqFwdArgs& a, const __bf16* w1, const __bf16*
     for (int r = 0; r < 4; ++r) u.v[nt][r] = fmaxf(u.v[nt][r], 0.f);
   if (a.u) tt_store(a.u + (size_t)row * 64, u, valid, g);
   TT y = tt_gemm(tt_bfrags(u), w2, c, g);
-  tt_add_vec(y, a.b2, g);
+  tt_add_vec(y, vec + SV_B2, g);
   tt_dropout(y, key2, a.drop, rg, g);
   return y;
 }
@@ -134,13 +205,19 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
   const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16;
   const uint32_t seedv = a.drop.thr ? *a.drop.seed : 0u;
   TQ_STAMP(0);
-  tq_stage<TQ_NW * 64>(lds.w[0], a.Win, false, a);
-  tq_stage<TQ_NW * 64>(lds.w[1], a.Win + 4096, false, a);
-  tq_stage<TQ_NW * 64>(lds.w[2], a.Win + 8192, false, a);
-  tq_stage<TQ_NW * 64>(lds.w[3], a.Wo, false, a);
-  tq_stage<TQ_NW * 64>(lds.w[4], a.W1, false, a);
-  tq_stage<TQ_NW * 64>(lds.w[5], a.W2, false, a);
-  tq_zero(lds.sK, 2 * SeqTtLds<6>::ibytes);
+  {
+    __bf16* const im[6] = {lds.w[0], lds.w[1], lds.w[2], lds.w[3], lds.w[4], lds.w[5]};
+    const float* const ws6[6] = {a.Win, a.Win + 4096, a.Win + 8192, a.Wo, a.W1, a.W2};
+    const TqImgRegs<6> wr = tq_img_load<TQ_NW * 64, 6>(ws6, false, a);
+    const TqVecRegs vr = tq_vec_load<TQ_NW * 64>(a, H, HD);
+    TQ_STAMP(11);
+    tq_zero(lds.sK, 2 * SeqTtLds<6>::ibytes);
+    TQ_STAMP(12);
+    tq_img_store<TQ_NW * 64, 6>(im, wr);
+    TQ_STAMP(13);
+    tq_vec_store<TQ_NW * 64>(lds.vec, vr);
+    TQ_STAMP(14);
+  }
   __syncthreads();
   TQ_STAMP(1);
   const uint32_t key0 = adt_site_key(seedv, a.site_emb), key1 = adt_site_key(seedv, a.site1), key2 = adt_site_key(seedv, a.site2);
@@ -150,7 +227,7 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile(s, w, ntiles);
-    if (tile >= 0) tq_pre_tile<HD, true>(a, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[s], xn[s]);
+    if (tile >= 0) tq_pre_tile<HD, true>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[s], xn[s]);
     TQ_STAMP(2 + s);
   }
   __syncthreads();
@@ -176,11 +253,11 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
           float acc = 0.f;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            const float4 ws = *reinterpret_cast<const float4*>(a.Ws + cc * HD + 16 * nt + 4 * g);
+            const float4 ws = *reinterpret_cast<const float4*>(lds.vec + SV_WS + cc * HD + 16 * nt + 4 * g);
             const f32x4& ov = o.v[h * NT + nt];
             acc += ov[0] * ws.x + ov[1] * ws.y + ov[2] * ws.z + ov[3] * ws.w;
           }
-          z[cc] = tt_colsum(acc) + a.bs[cc];
+          z[cc] = tt_colsum(acc) + lds.vec[SV_BS + cc];
         }
         float m = z[0];
 #pragma unroll
@@ -197,12 +274,12 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
       }
     }
     TT hh = tt_gemm(tt_bfrags(o), lds.w[3], c, g);
-    tt_add_vec(hh, a.bo, g);
+    tt_add_vec(hh, lds.vec + SV_BO, g);
     tt_add(hh, xn[s]);                                        // the residual adds LN1(x)                         (modules.py:651)
     TQ_STAMP(6 + 3 * s);
     if (a.h) tt_store(a.h + (size_t)row * 64, hh, valid, g);
-    const TT h2 = tt_layernorm(hh, a.gamma2, a.beta2, a.ln_eps, g);
-    TT y = tq_ffn(a, lds.w[4], lds.w[5], h2, key1, key2, row, valid, c, g);
+    const TT h2 = tt_layernorm(hh, lds.vec + SV_GAMMA2, lds.vec + SV_BETA2, a.ln_eps, g);
+    TT y = tq_ffn(a, lds.vec, lds.w[4], lds.w[5], h2, key1, key2, row, valid, c, g);
     tt_add(y, h2);
     if (!valid || a.ids[row] == 0) y = tt_zero();
     tt_store(a.y + (size_t)row * 64, y, valid, g);
@@ -220,12 +297,15 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
   SeqTtLds<5> lds(smem_raw);
   const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16;
   const uint32_t seedv = a.drop.thr ? *a.drop.seed : 0u;
-  tq_stage<TQ_NW * 64>(lds.w[0], a.Win, false, a);
-  tq_stage<TQ_NW * 64>(lds.w[1], a.Win + 4096, false, a);
-  tq_stage<TQ_NW * 64>(lds.w[2], a.Win + 8192, false, a);
-  tq_stage<TQ_NW * 64>(lds.w[3], a.Wo, false, a);
-  tq_stage<TQ_NW * 64>(lds.w[4], a.Win2, false, a);
-  tq_zero(lds.sK, 2 * SeqTtLds<5>::ibytes);
+  __bf16* const im5[5] = {lds.w[0], lds.w[1], lds.w[2], lds.w[3], lds.w[4]};
+  {
+    const float* const wsA[5] = {a.Win, a.Win + 4096, a.Win + 8192, a.Wo, a.Win2};
+    const TqImgRegs<5> wr = tq_img_load<TQ_NW * 64, 5>(wsA, false, a);
+    const TqVecRegs vr = tq_vec_load<TQ_NW * 64>(a, H, HD);
+    tq_zero(lds.sK, 2 * SeqTtLds<5>::ibytes);
+    tq_img_store<TQ_NW * 64, 5>(im5, wr);
+    tq_vec_store<TQ_NW * 64>(lds.vec, vr);
+  }
   __syncthreads();
   const uint32_t key0 = adt_site_key(seedv, a.site_emb), key1 = adt_site_key(seedv, a.site1), key2 = adt_site_key(seedv, a.site2);
   const float qmul = a.scale * 1.4426950408889634f;
@@ -235,7 +315,7 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile(s, w, ntiles);
-    if (tile >= 0) tq_pre_tile<HD, false>(a, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[s], dn[s]);
+    if (tile >= 0) tq_pre_tile<HD, false>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[s], dn[s]);
   }
   __syncthreads();
   // a1 = out_proj(o1) ; q2 = a1 Wq2^T + b : the cross attention's queries replace the self attention's in the registers
@@ -248,19 +328,17 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
     const TT o1 = tt_attn_heads<HD, TQ_MAXKT>(lds.sK, lds.sV, fq[s], tile, L, b, a.b_offset, a.drop, a.site_attn, seedv, a.lse, a.mask, lane, c, g);
     if (a.o) tt_store(a.o + (size_t)row * 64, o1, valid, g);
     TT a1 = tt_gemm(tt_bfrags(o1), lds.w[3], c, g);
-    tt_add_vec(a1, a.bo, g);
+    tt_add_vec(a1, lds.vec + SV_BO, g);
     if (a.a1) tt_store(a.a1 + (size_t)row * 64, a1, valid, g);
     TT q2 = tt_gemm(tt_bfrags(a1), lds.w[4], c, g);
-    tt_add_vec(q2, a.bin2, g);
+    tt_add_vec(q2, lds.vec + SV_BIN2, g);
     if (a.q2) tt_store(a.q2 + (size_t)row * 64, q2, valid, g);
     tt_qfrags<HD>(q2, qmul, fq[s]);
   }
+  const float* const wsB[5] = {a.Win2 + 4096, a.Win2 + 8192, a.Wo2, a.W1, a.W2};
+  const TqImgRegs<5> wrB = tq_img_load<TQ_NW * 64, 5>(wsB, false, a);      // weight set B is requested before the barrier ...
   __syncthreads();                      // every wave is done with the self-attention images and with weight set A
-  tq_stage<TQ_NW * 64>(lds.w[0], a.Win2 + 4096, false, a);
-  tq_stage<TQ_NW * 64>(lds.w[1], a.Win2 + 8192, false, a);
-  tq_stage<TQ_NW * 64>(lds.w[2], a.Wo2, false, a);
-  tq_stage<TQ_NW * 64>(lds.w[3], a.W1, false, a);
-  tq_stage<TQ_NW * 64>(lds.w[4], a.W2, false, a);
+  tq_img_store<TQ_NW * 64, 5>(im5, wrB);                                   // ... and lands after it
   __syncthreads();
   // cross attention keys / values from the encoder's log_feats: [k2, v2] = f Wkv^T + b              (memory = log_feats, model.py:69-70)
 #pragma unroll
@@ -271,9 +349,9 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
     const bool valid = l < L;
     const TTB bf = tt_bfrags(tt_load(a.f + (size_t)row * 64, valid, g));
     TT k2 = tt_gemm(bf, lds.w[0], c, g);
-    tt_add_vec(k2, a.bin2 + 64, g);
+    tt_add_vec(k2, lds.vec + SV_BIN2 + 64, g);
     TT v2 = tt_gemm(bf, lds.w[1], c, g);
-    tt_add_vec(v2, a.bin2 + 128, g);
+    tt_add_vec(v2, lds.vec + SV_BIN2 + 128, g);
     if (a.kv2 && valid) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
@@ -295,9 +373,9 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
     const TT o2 = tt_attn_heads<HD, TQ_MAXKT>(lds.sK, lds.sV, fq[s], tile, L, b, a.b_offset, a.drop, a.site_attn2, seedv, a.lse2, a.mask2, lane, c, g);
     if (a.o2) tt_store(a.o2 + (size_t)row * 64, o2, valid, g);
     TT a2 = tt_gemm(tt_bfrags(o2), lds.w[2], c, g);
-    tt_add_vec(a2, a.bo2, g);
+    tt_add_vec(a2, lds.vec + SV_BO2, g);
     if (a.h) tt_store(a.h + (size_t)row * 64, a2, valid, g);
-    TT y = tq_ffn(a, lds.w[3], lds.w[4], a2, key1, key2, row, valid, c, g);
+    TT y = tq_ffn(a, lds.vec, lds.w[3], lds.w[4], a2, key1, key2, row, valid, c, g);
     tt_add(y, a2);
     tt_add(y, dn[s]);
     if (!valid || a.ids[row] == 0) y = tt_zero();

@@ -105,11 +105,55 @@ ADT_DEVICE_INLINE void tt_store(float* row, const TT& t, bool valid, int g) {
   for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<float4*>(row + 16 * nt + 4 * g) = make_float4(t.v[nt][0], t.v[nt][1], t.v[nt][2], t.v[nt][3]);
 }
 
+// Exchanges between the four lanes (g = 0..3) that hold one token column.  v_permlane16_swap / v_permlane32_swap (gfx950) stay in
+// the vector ALU; __shfl_xor compiles to ds_bpermute_b32, a round trip through the LDS crossbar on the critical path of every
+// LayerNorm, softmax and classifier reduction.  With both operands the same register, the swap leaves lane ^ 16 (lane ^ 32) of the
+// value in one of the two results: rows of `a` that were swapped in hold the partner's value, the others find it in `b`.
+typedef unsigned tt_u2 __attribute__((ext_vector_type(2)));
+ADT_DEVICE_INLINE unsigned tt_xor16u(unsigned u) {
+  const tt_u2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return (threadIdx.x & 16) ? r[0] : r[1];
+}
+ADT_DEVICE_INLINE unsigned tt_xor32u(unsigned u) {
+  const tt_u2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return (threadIdx.x & 32) ? r[0] : r[1];
+}
+ADT_DEVICE_INLINE float tt_xor16(float v) { return __uint_as_float(tt_xor16u(__float_as_uint(v))); }
+ADT_DEVICE_INLINE float tt_xor32(float v) { return __uint_as_float(tt_xor32u(__float_as_uint(v))); }
+
 // feature reductions: every lane of a token column ends up with the column's total
 ADT_DEVICE_INLINE float tt_colsum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
+  v += tt_xor16(v);
+  v += tt_xor32(v);
   return v;
+}
+ADT_DEVICE_INLINE float tt_colmax(float v) {
+  v = fmaxf(v, tt_xor16(v));
+  v = fmaxf(v, tt_xor32(v));
+  return v;
+}
+ADT_DEVICE_INLINE uint32_t tt_color(uint32_t v) {
+  v |= tt_xor16u(v);
+  v |= tt_xor32u(v);
+  return v;
+}
+
+// sum over the 16 lanes of a row (the 16 tokens of a tile, for one g): every lane ends up with the row total.  Four DPP steps in the
+// vector ALU (quad butterflies, then the half-row and row mirrors).
+ADT_DEVICE_INLINE float tt_rowsum16(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+
+// Small per-feature vectors (biases, LayerNorm gamma / beta, classifier weights) are copied to LDS once per workgroup: as global
+// loads they sat on the critical path of every tile (one dependent L2 round trip, ~800 cycles, per bias add / LayerNorm).
+template <int NTHREADS>
+ADT_DEVICE_INLINE void tt_stage_vec(float* dst, const float* src, int n) {
+  if (src == nullptr) return;
+  for (int i = threadIdx.x; i < n; i += NTHREADS) dst[i] = src[i];
 }
 
 // LayerNorm over the 64 features of each token (eps inside the square root, as torch.nn.LayerNorm); returns gamma * xhat + beta
@@ -211,10 +255,9 @@ ADT_DEVICE_INLINE void tt_attn_tile(const __bf16* sK, const __bf16* sV, const bf
   float m = -INFINITY;
 #pragma unroll
   for (int kt = 0; kt < MAXKT; ++kt) m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
-  m = fmaxf(m, __shfl_xor(m, 16, 64));
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
-  const uint32_t idx_q = (bh_rng * (uint32_t)L + (uint32_t)q) * (uint32_t)L;
-  const bool quad = (L & 3) == 0;           // then idx_q is a multiple of 4 and a register quad of keys shares one hash word
+  m = tt_colmax(m);
+  const uint32_t idx_q = (bh_rng * (uint32_t)L + (uint32_t)q) * (uint32_t)L;      // a multiple of 4: L % 4 == 0 on this path, so a
+                                                                                  // register quad of keys shares one hash word
   float sum = 0.f;
   uint32_t mw[MAXKT / 2];
 #pragma unroll
@@ -230,10 +273,7 @@ ADT_DEVICE_INLINE void tt_attn_tile(const __bf16* sK, const __bf16* sV, const bf
         const int kt = 2 * kp + t;
         uint32_t bits = 15u;
         if (drop.thr && kt < nkt) {
-          const uint32_t i4 = idx_q + (uint32_t)(16 * kt + 4 * g);
-          if (quad) bits = adt_keep4(key_rng, i4, drop.thr);
-          else bits = (adt_keep(key_rng, i4, drop.thr) ? 1u : 0u) | (adt_keep(key_rng, i4 + 1, drop.thr) ? 2u : 0u) |
-                      (adt_keep(key_rng, i4 + 2, drop.thr) ? 4u : 0u) | (adt_keep(key_rng, i4 + 3, drop.thr) ? 8u : 0u);
+          bits = adt_keep4(key_rng, idx_q + (uint32_t)(16 * kt + 4 * g), drop.thr);
           mw[kp] |= bits << (16 * t + 4 * g);
         }
 #pragma unroll
@@ -256,12 +296,7 @@ ADT_DEVICE_INLINE void tt_attn_tile(const __bf16* sK, const __bf16* sV, const bf
   if (mask && drop.thr) {
     uint32_t ow[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      uint32_t v = i < MAXKT / 2 ? mw[i] : 0u;
-      v |= (uint32_t)__shfl_xor((int)v, 16, 64);
-      v |= (uint32_t)__shfl_xor((int)v, 32, 64);
-      ow[i] = v;
-    }
+    for (int i = 0; i < 8; ++i) ow[i] = i < MAXKT / 2 ? tt_color(mw[i]) : 0u;
     if (g == 0 && q < L) {
       uint4* dst = reinterpret_cast<uint4*>(mask + ((size_t)bh * L + q) * 8);
       dst[0] = make_uint4(ow[0], ow[1], ow[2], ow[3]);

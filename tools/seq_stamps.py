@@ -34,7 +34,9 @@ print("rc", rc)
 t0 = t[:, 0].min()
 names = ["start", "staged", "pre0", "pre1", "barrier", "attn0", "oproj0", "ffn0", "attn1", "oproj1", "ffn1"]
 if MODE == "attn":
-    names = ["start", "staged", "barrier", "passA", "passB"]
+    names = ["start", "staged", "recomp", "passA", "passB", "dW", "dx"]       # the fused attention-block backward (last launch of the step)
 print("wave " + " ".join("%8s" % n for n in names))
+if MODE != "attn":
+    print("prologue (issue loads, zero-fill, image stores, vector stores):", [[int(t[w, k] - t0) for k in (11, 12, 13, 14)] for w in (0, 4)])
 for w in range(8):
     print("%4d " % w + " ".join("%8d" % (t[w, k] - t0 if t[w, k] else -1) for k in range(len(names))))
