@@ -33,6 +33,7 @@ struct AttnArgs {
   float* dV; int lddv;
   uint32_t* mask;             // optional (B*H*L x 8 words): dropout keep bits written by the bf16 forward, read by its backward
   unsigned long long* stamps; // timing experiments only (ADT_SEQ_STAMPS): s_memtime per wave of workgroup 0
+  int in_bf16;                // backward, adt_seqattn.cuh only: Q, K, V, O point at bf16 rows and ldq / ldk / ldv / ldo count bf16 elements
 };
 
 template <int HD>

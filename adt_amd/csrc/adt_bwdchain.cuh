@@ -122,8 +122,8 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_bwd(BwdChainArgs a) {
     // every input of the round is requested at its top; carrying the next round's gy / h rows across the round cost 340 B of
     // scratch per lane (the kernel sits at the 256-register budget of two waves per SIMD)
     const RowRegs gy_cur = rows_load(a.gy, 64, row0, a.T, lane);
-    const RowRegs h_rows = rows_load(a.xin, 64, row0, a.T, lane);
-    const RowRegs u_cur = rows_load(a.u, 64, row0, a.T, lane);    // requested now, consumed later in the round
+    const RowRegs h_rows = rows_load_saved(a.xin, row0, a.T, lane, a.saved_bf16);
+    const RowRegs u_cur = rows_load_saved(a.u, row0, a.T, lane, a.saved_bf16);    // requested now, consumed later in the round
     // classifier log-probs and their upstream gradient for the 16 tile rows (H*H floats per row, reference row order
     // l*B + b): requested now as one element per lane and step, parked in LDS when needed
     float cls_rec[4], cls_drec[4];
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(NW * 64) void k_enc_post_bwd(BwdChainArgs a) {
     CT gm, dh2;
     ffn_bwd_tile<PREC, NW>(a, lds.scr, coop, lds.w[0], lds.w[1], dW2, dW1, db2, db1, h2, gy_cur, u_cur, key1, key2, row0, lane, c, g,
                            gm, dh2);
-    const RowRegs o_rows = rows_load(a.o, 64, row0, a.T, lane);   // requested after the FFN reverse (register budget), before the store below
+    const RowRegs o_rows = rows_load_saved(a.o, row0, a.T, lane, a.saved_bf16);   // requested after the FFN reverse (register budget), before the store below
     ct_add(dh2, gm);
     const CT dh = ln_bwd_ct(dh2, xhat, st, a.gamma, dgm, dbt, c, g);
     store_ct(lds.scr, a.out0, 64, dh, row0, a.T, lane, c, g);
@@ -254,9 +254,9 @@ __global__ __launch_bounds__(NW * 64) void k_dec_post_bwd(BwdChainArgs a) {
     const int row0 = tile * 16;
     // requested at the top of the round (no carry across rounds: register budget, see k_enc_post_bwd)
     const RowRegs gy_cur = rows_load(a.gy, 64, row0, a.T, lane);
-    const RowRegs u_cur = rows_load(a.u, 64, row0, a.T, lane);
-    const RowRegs a2_rows = rows_load(a.xin, 64, row0, a.T, lane);
-    const RowRegs o_rows = rows_load(a.o, 64, row0, a.T, lane);
+    const RowRegs u_cur = rows_load_saved(a.u, row0, a.T, lane, a.saved_bf16);
+    const RowRegs a2_rows = rows_load_saved(a.xin, row0, a.T, lane, a.saved_bf16);
+    const RowRegs o_rows = rows_load_saved(a.o, row0, a.T, lane, a.saved_bf16);
     const CT a2 = rows_to_ct(lds.scr, a2_rows, lane, c, g);
     const CT o = rows_to_ct(lds.scr, o_rows, lane, c, g);
     CT gm, da2;
@@ -367,8 +367,8 @@ __global__ __launch_bounds__(NW * 64) void k_dec_mid_bwd(BwdChainArgs a) {
   VAcc dbq, dbo;
   acc_zero(dWq); acc_zero(dWo); vacc_zero(dbq); vacc_zero(dbo);
   RowRegs dq_rows = rows_load(a.dqkv, a.lddqkv, tile * 16, a.T, lane);
-  RowRegs a1_rows = rows_load(a.xin, 64, tile * 16, a.T, lane);
-  RowRegs o1_rows = rows_load(a.o, 64, tile * 16, a.T, lane);
+  RowRegs a1_rows = rows_load_saved(a.xin, tile * 16, a.T, lane, a.saved_bf16);
+  RowRegs o1_rows = rows_load_saved(a.o, tile * 16, a.T, lane, a.saved_bf16);
   for (int rnd = 0; rnd < nrounds; ++rnd, tile += tstride) {
     const int row0 = tile * 16;
     const CT a1 = rows_to_ct(lds.scr, a1_rows, lane, c, g);
@@ -377,8 +377,8 @@ __global__ __launch_bounds__(NW * 64) void k_dec_mid_bwd(BwdChainArgs a) {
     const CT o1 = rows_to_ct(lds.scr, o1_rows, lane, c, g);
     const int nrow0 = (tile + tstride) * 16;
     dq_rows = rows_load(a.dqkv, a.lddqkv, nrow0, a.T, lane);
-    a1_rows = rows_load(a.xin, 64, nrow0, a.T, lane);
-    o1_rows = rows_load(a.o, 64, nrow0, a.T, lane);
+    a1_rows = rows_load_saved(a.xin, nrow0, a.T, lane, a.saved_bf16);
+    o1_rows = rows_load_saved(a.o, nrow0, a.T, lane, a.saved_bf16);
     coop.product(dWq, dq, a1);
     colsum_accum(dbq, dq);
     const CT da1 = gemm_w<PREC>(aq, lds.w[0], c, g);

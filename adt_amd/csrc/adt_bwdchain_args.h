@@ -36,6 +36,7 @@ struct BwdChainArgs {
   // 256-deep chain of same-address float atomics (10.5 us per million adds measured, 5.7 us with 8 replicas, 4.5 us private);
   // the executor sums the replicas into the gradient buffer afterwards (adt_replica_reduce).
   int nrep; size_t rep_stride;
+  int saved_bf16;             // u / xin / o were saved as bf16 rows by the transposed-chain forward (post and mid chains)
   const float* wp_base; const void* wp_img;      // pre-packed bf16 weight images (adt_wave.cuh: WPack); wp_img == nullptr: none
 };
 

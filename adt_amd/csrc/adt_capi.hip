@@ -393,6 +393,26 @@ int adt_attn_bwd(int prec, const float* Q, int ldq, const float* K, int ldk, con
   return dispatch_attn(prec, true, hd, a, (hipStream_t)stream);
 }
 
+}  // extern "C"
+
+int adt_attn_bwd_saved_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O, int ldo, const float* LSE,
+                            const float* dO, int lddo, int B, int H, int L, int hd, float p, const uint32_t* seed, uint32_t site, uint32_t b_offset,
+                            float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, const uint32_t* mask, void* stream) {
+  AttnArgs a{};
+  a.mask = const_cast<uint32_t*>(mask);
+  a.Q = reinterpret_cast<const float*>(Q); a.ldq = ldq; a.K = reinterpret_cast<const float*>(K); a.ldk = ldk;
+  a.V = reinterpret_cast<const float*>(V); a.ldv = ldv; a.O = reinterpret_cast<float*>(const_cast<void*>(O)); a.ldo = ldo; a.in_bf16 = 1;
+  a.LSE = const_cast<float*>(LSE); a.B = B; a.H = H; a.L = L; a.causal = 1; a.scale = 1.0f / sqrtf((float)hd);
+  a.drop = adt_make_drop(p, seed, site); a.bh_offset = b_offset * (uint32_t)H;
+  a.dO = dO; a.lddo = lddo; a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv;
+  if ((lddo % 4) || (lddq % 4) || (lddk % 4) || (lddv % 4) || (ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 8)) return adt_set_error("attn_bwd (bf16 operands): ld");
+  const int rc = adt_launch_seq_attn_bwd(hd, a, stream);
+  if (rc == 1) return adt_set_error("attn_bwd (bf16 operands): shape L=%d H=%d hd=%d is not covered by the per-sequence kernel", L, H, hd);
+  return rc;
+}
+
+extern "C" {
+
 int adt_headcls_fwd(const float* O, int ldo, const float* Ws, const float* bs, int B, int L, int H, int hd,
                     float* rec, void* stream) {
   if (H > MAXH || hd % 4) return adt_set_error("headcls: H=%d (max %d) hd=%d", H, MAXH, hd);

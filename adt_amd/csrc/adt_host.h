@@ -28,11 +28,20 @@ int adt_launch_fwdchain(int prec, int which, const adt::FwdChainArgs& a, void* s
 // per-sequence fused layer kernels (adt_seqfwd.cuh); defined in adt_seq.hip
 namespace adt { struct SeqFwdArgs; }
 int adt_seq_supported(int prec, int L, int d, int hd);      // bf16 mode, d = 64, L <= 224; ADT_SEQ=0 in the environment turns them off
+int adt_seq_lean(int prec, int L, int d, int hd);           // the forward may save bf16 tensors and skip LN(x) / qkv (see adt_seq.hip)
 int adt_launch_seq_enc_fwd(int hd, const adt::SeqFwdArgs& a, void* stream);
 int adt_launch_seq_dec_fwd(int hd, const adt::SeqFwdArgs& a, void* stream);
 // pre-packed bf16 weight images of n 64 x 64 blocks at base + offs[i] -> img + 6 * offs[i] (bf16 elements); defined in adt_seq.hip
 int adt_pack_wimg(const float* base, void* img, const int* offs, int n, void* stream);
 namespace adt { struct AttnArgs; }
 int adt_launch_seq_attn_bwd(int hd, const adt::AttnArgs& a, void* stream);     // 0 launched, 1 shape not covered, < 0 error
+// adt_attn_bwd with Q, K, V, O saved as bf16 rows (ld* of those four count bf16 elements); per-sequence kernel only: anything it does not
+// cover is an error.  Defined in adt_capi.hip.
+int adt_attn_bwd_saved_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O, int ldo, const float* LSE,
+                            const float* dO, int lddo, int B, int H, int L, int hd, float p, const uint32_t* seed, uint32_t site, uint32_t b_offset,
+                            float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, const uint32_t* mask, void* stream);
+// per-sequence backward of the token-wise chains (adt_seqpost_tt.cuh); enc: 1 encoder post chain, 0 decoder post chain; 0 launched, 1 not covered
+int adt_launch_seq_post_bwd(int hd, int enc, const adt::BwdChainArgs& a, void* stream);
+int adt_launch_seq_mid_bwd(int hd, const adt::BwdChainArgs& a, void* stream);      // dec_mid + kv chains in one launch
 namespace adt { struct SeqBwdArgs; }
 int adt_launch_seq_attn_pre_bwd(int hd, int dec, const adt::SeqBwdArgs& a, void* stream);     // 0 launched, 1 not covered, < 0 error

@@ -180,6 +180,7 @@ int encoder_forward(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, cons
   const uint32_t ro = b_offset * (uint32_t)L;
   const int dd = d * d;
   const bool use_seq = adt_seq_supported(prec, L, d, hd) != 0;
+  const bool lean = training_outputs && adt_seq_lean(prec, L, d, hd) != 0;   // bf16 saved tensors, no LN(x) / qkv (the fused backward recomputes them)
   CK(pack_weights(c, lo, w, P, ws, st));
   const float* wp_base = P + lo.posw();
   const void* wp_img = prec == ADT_PREC_BF16 ? (const void*)(ws + w.wpack) : nullptr;
@@ -201,6 +202,7 @@ int encoder_forward(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, cons
       a.x_out = x; a.xn = qn; a.qkv = qkv; a.o = o; a.lse = lse; a.mask = reinterpret_cast<uint32_t*>(base + w.e_mask); a.h = h; a.u = u; a.y = y;
       if (training_outputs && H > 1) { a.rec = rec; a.Ws = P + lo.enc(i, E_SW); a.bs = P + lo.enc(i, E_SB); }
       a.wp_base = wp_base; a.wp_img = wp_img;
+      if (lean) { a.xn = nullptr; a.qkv = nullptr; a.saved_bf16 = 1; }
       CK(adt_launch_seq_enc_fwd(hd, a, st));
       continue;
     }
@@ -331,6 +333,7 @@ int adt_sasrec_forward(const adt_sasrec_cfg* c, const float* P, float* ws, const
       a.a1 = a1; a.q2 = q2; a.kv2 = kv2; a.o2 = o2; a.lse2 = lse2; a.mask2 = reinterpret_cast<uint32_t*>(base + w.d_mask2);
       a.h = a2; a.u = u; a.y = y;
       a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack;
+      if (adt_seq_lean(prec, L, d, hd)) { a.xn = nullptr; a.qkv = nullptr; a.saved_bf16 = 1; }
       CK(adt_launch_seq_dec_fwd(hd, a, st));
       continue;
     }
@@ -410,6 +413,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   const int64_t dec_begin = lo.dec(0, 0);
   const float* f = ws + w.f;
   const bool use_seq = adt_seq_supported(prec, L, d, hd) != 0;
+  const int lean = adt_seq_lean(prec, L, d, hd);      // what the forward of this step saved (same predicate, same process)
   if (phase == 0 || phase == 1) {
     // d log_feats (overwrites g_f) and item-table rows of pos/neg      (sasrec/model.py:72-76)
     // item-table replicas and parameter replicas are adjacent in the workspace: one fill
@@ -436,31 +440,52 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       {  // FFN + mask + enc_attn.out_proj reverse -> dO2 (s1)
         adt::BwdChainArgs a = BA(dec, p, seed);
         a.site1 = dec_site(i, 2); a.site2 = dec_site(i, 3);
-        a.gy = gy; a.u = u; a.xin = a2; a.o = o2;
+        a.gy = gy; a.u = u; a.xin = a2; a.o = o2; a.saved_bf16 = lean;
         a.W0 = P + lo.dec(i, D_C2W); a.W1 = P + lo.dec(i, D_C1W); a.W2 = P + lo.dec(i, D_EOW);
         a.dW0 = Gq + lo.dec(i, D_C2W); a.dW1 = Gq + lo.dec(i, D_C1W); a.dW2 = Gq + lo.dec(i, D_EOW);
         a.db0 = Gq + lo.dec(i, D_C2B); a.db1 = Gq + lo.dec(i, D_C1B); a.db2 = Gq + lo.dec(i, D_EOB);
         a.out0 = s1;
-        CK(adt_launch_bwdchain(prec, 1, a, st));
+        const int rc = use_seq ? adt_launch_seq_post_bwd(hd, 0, a, st) : 1;
+        if (rc < 0) return rc;
+        if (rc) CK(adt_launch_bwdchain(prec, 1, a, st));
       }
       // cross attention core: dq2 -> s5, dkv2 -> s4
-      CK(adt_attn_bwd(prec, q2, d, kv2, 2 * d, kv2 + d, 2 * d, o2, d, lse2, s1, d, B, H, L, hd, 1, p, seed, dec_site(i, 1), b_offset,
-                      s5, d, s4, 2 * d, s4 + d, 2 * d, reinterpret_cast<const uint32_t*>(base + w.d_mask2), st));
-      {  // q2 = a1 Wq^T, a1 = o1 Wo1^T  -> dO1 (s1)
-        adt::BwdChainArgs a = BA(dec, 0.f, nullptr);
-        a.dqkv = s5; a.lddqkv = d; a.xin = a1; a.o = o1;
-        a.W0 = einw; a.W1 = P + lo.dec(i, D_SOW);
-        a.dW0 = geinw; a.dW1 = Gq + lo.dec(i, D_SOW); a.db0 = geinb; a.db1 = Gq + lo.dec(i, D_SOB);
-        a.out0 = s1;
-        CK(adt_launch_bwdchain(prec, 4, a, st));
+      if (lean) {
+        const uint16_t* kvb = reinterpret_cast<const uint16_t*>(kv2);      // rows of 128 bf16: k2 | v2
+        CK(adt_attn_bwd_saved_bf16(q2, d, kvb, 2 * d, kvb + d, 2 * d, o2, d, lse2, s1, d, B, H, L, hd, p, seed, dec_site(i, 1), b_offset,
+                                   s5, d, s4, 2 * d, s4 + d, 2 * d, reinterpret_cast<const uint32_t*>(base + w.d_mask2), st));
+      } else {
+        CK(adt_attn_bwd(prec, q2, d, kv2, 2 * d, kv2 + d, 2 * d, o2, d, lse2, s1, d, B, H, L, hd, 1, p, seed, dec_site(i, 1), b_offset,
+                        s5, d, s4, 2 * d, s4 + d, 2 * d, reinterpret_cast<const uint32_t*>(base + w.d_mask2), st));
       }
-      {  // [k2, v2] = f Wkv^T  -> g_f +=
+      int mid_rc = 1;
+      if (use_seq) {   // both projections' reverse in one launch per sequence (adt_seqpost_tt.cuh)
         adt::BwdChainArgs a = BA(dec, 0.f, nullptr);
-        a.dkv2 = s4; a.f = f;
-        a.W0 = einw + dd; a.W1 = einw + 2 * dd;
-        a.dW0 = geinw + dd; a.dW1 = geinw + 2 * dd; a.db0 = geinb + d; a.db1 = geinb + 2 * d;
-        a.out0 = gf; a.acc0 = 1;
-        CK(adt_launch_bwdchain(prec, 5, a, st));
+        a.dqkv = s5; a.lddqkv = d; a.xin = a1; a.o = o1; a.saved_bf16 = lean; a.dkv2 = s4; a.f = f;
+        a.W0 = einw; a.W1 = P + lo.dec(i, D_SOW); a.W2 = einw + dd; a.W3 = einw + 2 * dd;
+        a.dW0 = geinw; a.dW1 = Gq + lo.dec(i, D_SOW); a.dW2 = geinw + dd; a.dW3 = geinw + 2 * dd;
+        a.db0 = geinb; a.db1 = Gq + lo.dec(i, D_SOB); a.db2 = geinb + d; a.db3 = geinb + 2 * d;
+        a.out0 = s1; a.out1 = gf; a.acc1 = 1;
+        mid_rc = adt_launch_seq_mid_bwd(hd, a, st);
+        if (mid_rc < 0) return mid_rc;
+      }
+      if (mid_rc) {
+        {  // q2 = a1 Wq^T, a1 = o1 Wo1^T  -> dO1 (s1)
+          adt::BwdChainArgs a = BA(dec, 0.f, nullptr);
+          a.dqkv = s5; a.lddqkv = d; a.xin = a1; a.o = o1; a.saved_bf16 = lean;
+          a.W0 = einw; a.W1 = P + lo.dec(i, D_SOW);
+          a.dW0 = geinw; a.dW1 = Gq + lo.dec(i, D_SOW); a.db0 = geinb; a.db1 = Gq + lo.dec(i, D_SOB);
+          a.out0 = s1;
+          CK(adt_launch_bwdchain(prec, 4, a, st));
+        }
+        {  // [k2, v2] = f Wkv^T  -> g_f +=
+          adt::BwdChainArgs a = BA(dec, 0.f, nullptr);
+          a.dkv2 = s4; a.f = f;
+          a.W0 = einw + dd; a.W1 = einw + 2 * dd;
+          a.dW0 = geinw + dd; a.dW1 = geinw + 2 * dd; a.db0 = geinb + d; a.db1 = geinb + 2 * d;
+          a.out0 = gf; a.acc0 = 1;
+          CK(adt_launch_bwdchain(prec, 5, a, st));
+        }
       }
       bool fused_blk = false;
       if (adt_seq_supported(prec, L, d, hd)) {   // self-attention backward + layer_norm / in-projection backward in one launch per sequence
@@ -468,9 +493,10 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.x = x; a.gamma = P + lo.dec(i, D_LNW); a.beta = P + lo.dec(i, D_LNB); a.Win = sinw; a.bin = P + lo.dec(i, D_SINB);
         a.dO = s1; a.o = o1; a.lse = lse1; a.mask = reinterpret_cast<const uint32_t*>(base + w.d_mask1); a.dres = gy;
         a.gx = gx; a.acc = i > 0 ? 1 : 0; a.dWin = gsinw; a.dbin = gsinb; a.dgamma = Gq + lo.dec(i, D_LNW); a.dbeta = Gq + lo.dec(i, D_LNB);
-        a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride; a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack;
+        a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride; a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack; a.saved_bf16 = lean;
         const int rc = adt_launch_seq_attn_pre_bwd(hd, 1, a, st);
         if (rc < 0) return rc;
+        if (rc != 0 && lean) return adt_set_error("backward: the lean forward needs the fused attention-block backward (L=%d hd=%d)", L, hd);
         fused_blk = rc == 0;
       }
       if (!fused_blk) {
@@ -514,7 +540,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       {  // FFN + mask + forward_layernorm + out_proj reverse -> dh (s5), dO (s1)
         adt::BwdChainArgs a = BA(seq, p, seed);
         a.site1 = enc_site(i, 1); a.site2 = enc_site(i, 2);
-        a.gy = gy; a.u = u; a.xin = h; a.o = o;
+        a.gy = gy; a.u = u; a.xin = h; a.o = o; a.saved_bf16 = lean;
         a.W0 = P + lo.enc(i, E_C2W); a.W1 = P + lo.enc(i, E_C1W); a.W2 = P + lo.enc(i, E_OW);
         a.gamma = P + lo.enc(i, E_LN2W); a.beta = P + lo.enc(i, E_LN2B);
         a.dW0 = Gq + lo.enc(i, E_C2W); a.dW1 = Gq + lo.enc(i, E_C1W); a.dW2 = Gq + lo.enc(i, E_OW);
@@ -527,7 +553,9 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
           a.rec = rec; a.drec = ws + w.g_rec + i * recsz; a.Ws = P + lo.enc(i, E_SW); a.dWs = Gq + lo.enc(i, E_SW);
           a.dbs = Gq + lo.enc(i, E_SB); a.H = H;
         }
-        CK(adt_launch_bwdchain(prec, which, a, st));
+        const int rc = use_seq ? adt_launch_seq_post_bwd(hd, 1, a, st) : 1;
+        if (rc < 0) return rc;
+        if (rc) CK(adt_launch_bwdchain(prec, which, a, st));
       }
       if (H > 4)   // wider classifiers: separate kernel
         CK(adt_headcls_bwd(o, d, P + lo.enc(i, E_SW), rec, ws + w.g_rec + i * recsz, (int)w.B, L, H, hd, s1, d, G + lo.enc(i, E_SW),
@@ -538,9 +566,10 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.x = x; a.gamma = P + lo.enc(i, E_LN1W); a.beta = P + lo.enc(i, E_LN1B); a.Win = inw; a.bin = P + lo.enc(i, E_INB);
         a.dO = s1; a.o = o; a.lse = lse; a.mask = reinterpret_cast<const uint32_t*>(base + w.e_mask); a.dres = s5;
         a.gx = gx; a.acc = 1; a.dWin = ginw; a.dbin = ginb; a.dgamma = Gq + lo.enc(i, E_LN1W); a.dbeta = Gq + lo.enc(i, E_LN1B);
-        a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride; a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack;
+        a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride; a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack; a.saved_bf16 = lean;
         const int rc = adt_launch_seq_attn_pre_bwd(hd, 0, a, st);
         if (rc < 0) return rc;
+        if (rc != 0 && lean) return adt_set_error("backward: the lean forward needs the fused attention-block backward (L=%d hd=%d)", L, hd);
         fused_blk = rc == 0;
       }
       if (!fused_blk) {

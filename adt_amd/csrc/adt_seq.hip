@@ -5,6 +5,7 @@
 #include "adt_seqfwd_tt.cuh"
 #include "adt_seqattn.cuh"
 #include "adt_seqbwd_tt.cuh"
+#include "adt_seqpost_tt.cuh"
 
 using namespace adt;
 
@@ -70,6 +71,17 @@ int adt_seq_supported(int prec, int L, int d, int hd) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("ADT_SEQ"); on = (e && atoi(e) == 0) ? 0 : 1; }
   return on && prec == ADT_PREC_BF16 && d == 64 && L <= SQ_LP && (hd == 16 || hd == 32 || hd == 64);
+}
+
+static int env_on(const char* name) { const char* e = getenv(name); return (e && atoi(e) == 0) ? 0 : 1; }
+
+// Lean saved tensors: the transposed-chain forward writes o, h, u, a1, q2, kv2, o2 as bf16 rows and does not write LN(x) / qkv at all (the fused
+// block backward recomputes them from x).  Only when every kernel of the backward that reads them is the per-sequence / flag-aware one:
+// the caller must then treat a "not covered" (1) from adt_launch_seq_attn_pre_bwd / adt_launch_seq_attn_bwd as an error.  ADT_SEQ_LEAN=0: off.
+int adt_seq_lean(int prec, int L, int d, int hd) {
+  static int on = -1;
+  if (on < 0) on = env_on("ADT_SEQ_LEAN") && env_on("ADT_SEQ_TT") && env_on("ADT_SEQ_BWD") && env_on("ADT_SEQ_ATTN_BWD") && !getenv("ADT_SEQ_ABLATE");
+  return on && adt_seq_supported(prec, L, d, hd) && (L & 3) == 0 && L <= SB_R && L <= 224 && sab_lds_bytes(L, 64 / hd) <= 160 * 1024;
 }
 
 static unsigned long long* g_stamps = nullptr;
@@ -148,6 +160,7 @@ int adt_launch_seq_attn_bwd(int hd, const AttnArgs& a, void* stream) {
   if (on < 0) { const char* e = getenv("ADT_SEQ_ATTN_BWD"); on = (e && atoi(e) == 0) ? 0 : 1; }
   if (!on || !a.causal || a.H * hd != 64 || a.L > 224) return 1;
   if ((a.ldq % 4) || (a.ldk % 4) || (a.ldv % 4) || (a.ldo % 4)) return 1;
+  if (a.in_bf16 && ((a.ldq % 8) || (a.ldk % 8) || (a.ldv % 8) || (a.ldo % 8))) return 1;
   const size_t smem = sab_lds_bytes(a.L, a.H);
   if (smem > 160 * 1024) return 1;
   const int mode = a.drop.thr == 0 ? 0 : (a.mask != nullptr ? 1 : 2);
@@ -180,6 +193,7 @@ static int seq_attn_pre_bwd_t(int mode, const SeqBwdArgs& a, hipStream_t s) {
                         (const void*)k_seqtt_attn_pre_bwd<HD, 2, DEC>};
   SeqBwdArgs args = a;
   args.stamps = seq_stamp_buffer(true);
+  { static int ab = -1; if (ab < 0) { const char* e = getenv("ADT_SEQ_ABLATE_BWD"); ab = e ? atoi(e) : 0; } args.ablate = ab; }
   return seq_launch(fns[mode], smem, done[mode], a.B, &args, s, "seqtt_attn_pre_bwd");
 }
 
@@ -193,4 +207,27 @@ int adt_launch_seq_attn_pre_bwd(int hd, int dec, const SeqBwdArgs& a, void* stre
   if (hd == 64) return dec ? seq_attn_pre_bwd_t<64, true>(mode, a, s) : seq_attn_pre_bwd_t<64, false>(mode, a, s);
   if (hd == 16) return dec ? seq_attn_pre_bwd_t<16, true>(mode, a, s) : seq_attn_pre_bwd_t<16, false>(mode, a, s);
   return 1;
+}
+
+// per-sequence backward of the token-wise chains (adt_seqpost_tt.cuh); 0 launched, 1 not covered (the caller runs the row-major chain kernels)
+static bool seq_post_ok(const BwdChainArgs& a, int hd) {
+  static int on = -1;
+  if (on < 0) on = env_on("ADT_SEQ_POST_BWD");
+  return on && a.wp_img != nullptr && a.L <= SB_R && a.T == a.B * a.L && (hd == 16 || hd == 32 || hd == 64);
+}
+
+int adt_launch_seq_post_bwd(int hd, int enc, const BwdChainArgs& a, void* stream) {
+  if (!seq_post_ok(a, hd)) return 1;
+  if (enc && a.drec != nullptr && a.H * hd != 64) return 1;
+  static bool done[6] = {false, false, false, false, false, false};
+  const void* fns[6] = {(const void*)k_seqtt_post_bwd<64, false>, (const void*)k_seqtt_post_bwd<64, true>, (const void*)k_seqtt_post_bwd<32, false>,
+                        (const void*)k_seqtt_post_bwd<32, true>, (const void*)k_seqtt_post_bwd<16, false>, (const void*)k_seqtt_post_bwd<16, true>};
+  const int slot = (hd == 64 ? 0 : hd == 32 ? 2 : 4) + (enc ? 1 : 0);
+  return seq_launch(fns[slot], SeqPostLds<3>::bytes, done[slot], a.B, &a, (hipStream_t)stream, "seqtt_post_bwd");
+}
+
+int adt_launch_seq_mid_bwd(int hd, const BwdChainArgs& a, void* stream) {
+  if (!seq_post_ok(a, hd)) return 1;
+  static bool done = false;
+  return seq_launch((const void*)k_seqtt_mid_bwd, SeqPostLds<4>::bytes, done, a.B, &a, (hipStream_t)stream, "seqtt_mid_bwd");
 }

@@ -187,7 +187,16 @@ __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
     float q[8], k[8], v[8], d[8], o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) q[j] = k[j] = v[j] = d[j] = o[j] = 0.f;
-    if (r < L) {
+    if (r < L && a.in_bf16) {          // operands saved as bf16 rows by the lean forward; the gradient dO is always fp32
+      const __bf16* Qb = reinterpret_cast<const __bf16*>(a.Q); const __bf16* Kb = reinterpret_cast<const __bf16*>(a.K);
+      const __bf16* Vb = reinterpret_cast<const __bf16*>(a.V); const __bf16* Ob = reinterpret_cast<const __bf16*>(a.O);
+      const bf16x8 qb = *reinterpret_cast<const bf16x8*>(Qb + (row_b + r) * a.ldq + c8), kb = *reinterpret_cast<const bf16x8*>(Kb + (row_b + r) * a.ldk + c8);
+      const bf16x8 vb = *reinterpret_cast<const bf16x8*>(Vb + (row_b + r) * a.ldv + c8), ob = *reinterpret_cast<const bf16x8*>(Ob + (row_b + r) * a.ldo + c8);
+      *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(a.dO + (row_b + r) * a.lddo + c8);
+      *reinterpret_cast<float4*>(d + 4) = *reinterpret_cast<const float4*>(a.dO + (row_b + r) * a.lddo + c8 + 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { q[j] = (float)qb[j]; k[j] = (float)kb[j]; v[j] = (float)vb[j]; o[j] = (float)ob[j]; }
+    } else if (r < L) {
       *reinterpret_cast<float4*>(q) = *reinterpret_cast<const float4*>(a.Q + (row_b + r) * a.ldq + c8);
       *reinterpret_cast<float4*>(q + 4) = *reinterpret_cast<const float4*>(a.Q + (row_b + r) * a.ldq + c8 + 4);
       *reinterpret_cast<float4*>(k) = *reinterpret_cast<const float4*>(a.K + (row_b + r) * a.ldk + c8);

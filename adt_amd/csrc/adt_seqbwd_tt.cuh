@@ -114,13 +114,14 @@ ADT_DEVICE_INLINE TT tt_ln_bwd(const TT& dy, const TTLn& st, const float* gamma,
 
 // one weight-gradient product over all tokens of the sequence: dW[n][k] += sum_t G[t][n] X[t][k] (k = 64: the ones column -> db[n]).
 // 20 output tiles (4 n-tiles x (4 k-tiles + the bias column)) dealt round-robin over the waves; every wave calls (no barrier inside).
-ADT_DEVICE_INLINE void sb_dw_product(const __bf16* sG, const __bf16* sX, int npair, float* dW, float* db, int w, int c, int g) {
+ADT_DEVICE_INLINE void sb_dw_product(const __bf16* sG, const __bf16* sX, int npair, float* dW, float* db, int w, int c, int g, int ablate = 0) {
 #pragma unroll 1
   for (int id = w; id < 20; id += SB_NW) {
     const int nt = id / 5, kt = id - 5 * nt;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int kp = 0; kp < npair; ++kp) acc = mfma_bf16(acc, tt_trfrag(sG, kp * 32, 16 * nt, c, g), tt_trfrag(sX, kp * 32, 16 * kt, c, g));
+    if (ablate) { if (acc[0] == 12345.678f) dW[0] = acc[1] + acc[2] + acc[3]; continue; }
     if (kt < 4) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) atomicAdd(dW + (16 * nt + 4 * g + r) * 64 + 16 * kt + c, acc[r]);
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     sb_frags<HD>(v, 1.0f, fv[s]);
     tt_put_rows(img1, l, v, valid, g);
     const TT dO = tt_load(a.dO + (size_t)row * 64, valid, g);
-    const TT o = tt_load(a.o + (size_t)row * 64, valid, g);
+    const TT o = tt_load_saved(a.o, row, valid, g, a.saved_bf16);
     sb_frags<HD>(dO, 1.0f, fdo[s]);
 #pragma unroll
     for (int h = 0; h < H; ++h) {
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     sb_put_x(img1, l, tt_ln_apply(tt_ln_stats(x, a.ln_eps).xhat, vgamma, vbeta, g), valid, g);     // q always reads LN(x)
   }
   __syncthreads();
-  sb_dw_product(img0, img1, npair, a.dWin, a.dbin, w, c, g);
+  sb_dw_product(img0, img1, npair, a.dWin, a.dbin, w, c, g, a.ablate);
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     if (!DEC) sb_put_x(img1, l, tt_load(a.x + (size_t)row * 64, valid, g), valid, g);                  // encoder: k, v read the raw x
   }
   __syncthreads();
-  sb_dw_product(img0, img1, npair, a.dWin + 4096, a.dbin + 64, w, c, g);
+  sb_dw_product(img0, img1, npair, a.dWin + 4096, a.dbin + 64, w, c, g, a.ablate);
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     tt_put_rows(img0, l, dv[s], l < L, g);
   }
   __syncthreads();
-  sb_dw_product(img0, img1, npair, a.dWin + 8192, a.dbin + 128, w, c, g);
+  sb_dw_product(img0, img1, npair, a.dWin + 8192, a.dbin + 128, w, c, g, a.ablate);
   SB_STAMP(5);
   // ---- P5: gradient of the block input ----------------------------------------------------------------------------------------
   TT dgm = tt_zero(), dbt = tt_zero();

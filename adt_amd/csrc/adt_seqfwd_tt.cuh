@@ -188,7 +188,7 @@ ADT_DEVICE_INLINE TT tq_ffn(const SeqFwdArgs& a, const float* vec, const __bf16*
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) u.v[nt][r] = fmaxf(u.v[nt][r], 0.f);
-  if (a.u) tt_store(a.u + (size_t)row * 64, u, valid, g);
+  tt_save(a.u, row, u, valid, g, a.saved_bf16);
   TT y = tt_gemm(tt_bfrags(u), w2, c, g);
   tt_add_vec(y, vec + SV_B2, g);
   tt_dropout(y, key2, a.drop, rg, g);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
     const bool valid = l < L;
     const TT o = tt_attn_heads<HD, TQ_MAXKT>(lds.sK, lds.sV, fq[s], tile, L, b, a.b_offset, a.drop, a.site_attn, seedv, a.lse, a.mask, lane, c, g);
     TQ_STAMP(5 + 3 * s);
-    if (a.o) tt_store(a.o + (size_t)row * 64, o, valid, g);
+    tt_save(a.o, row, o, valid, g, a.saved_bf16);
     if (a.rec) {
       // head classifier (sasrec/modules.py:648-649): z[h][cc] = sum_j o[h hd + j] Ws[cc][j] + bs[cc]; log-softmax over cc.  The features of
       // a token are spread over this lane's 16 registers and the 4 lanes g: in-lane products, two cross-lane steps per class.
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
     tt_add_vec(hh, lds.vec + SV_BO, g);
     tt_add(hh, xn[s]);                                        // the residual adds LN1(x)                         (modules.py:651)
     TQ_STAMP(6 + 3 * s);
-    if (a.h) tt_store(a.h + (size_t)row * 64, hh, valid, g);
+    tt_save(a.h, row, hh, valid, g, a.saved_bf16);
     const TT h2 = tt_layernorm(hh, lds.vec + SV_GAMMA2, lds.vec + SV_BETA2, a.ln_eps, g);
     TT y = tq_ffn(a, lds.vec, lds.w[4], lds.w[5], h2, key1, key2, row, valid, c, g);
     tt_add(y, h2);
@@ -326,13 +326,13 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
     const TT o1 = tt_attn_heads<HD, TQ_MAXKT>(lds.sK, lds.sV, fq[s], tile, L, b, a.b_offset, a.drop, a.site_attn, seedv, a.lse, a.mask, lane, c, g);
-    if (a.o) tt_store(a.o + (size_t)row * 64, o1, valid, g);
+    tt_save(a.o, row, o1, valid, g, a.saved_bf16);
     TT a1 = tt_gemm(tt_bfrags(o1), lds.w[3], c, g);
     tt_add_vec(a1, lds.vec + SV_BO, g);
-    if (a.a1) tt_store(a.a1 + (size_t)row * 64, a1, valid, g);
+    tt_save(a.a1, row, a1, valid, g, a.saved_bf16);
     TT q2 = tt_gemm(tt_bfrags(a1), lds.w[4], c, g);
     tt_add_vec(q2, lds.vec + SV_BIN2, g);
-    if (a.q2) tt_store(a.q2 + (size_t)row * 64, q2, valid, g);
+    tt_save(a.q2, row, q2, valid, g, a.saved_bf16);
     tt_qfrags<HD>(q2, qmul, fq[s]);
   }
   const float* const wsB[5] = {a.Win2 + 4096, a.Win2 + 8192, a.Wo2, a.W1, a.W2};
@@ -352,7 +352,11 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
     tt_add_vec(k2, lds.vec + SV_BIN2 + 64, g);
     TT v2 = tt_gemm(bf, lds.w[1], c, g);
     tt_add_vec(v2, lds.vec + SV_BIN2 + 128, g);
-    if (a.kv2 && valid) {
+    if (a.kv2 && a.saved_bf16) {          // rows of 128 bf16: k2 | v2
+      __bf16* kvrow = reinterpret_cast<__bf16*>(a.kv2) + (size_t)row * 128;
+      tt_store_bf16(kvrow, k2, valid, g);
+      tt_store_bf16(kvrow + 64, v2, valid, g);
+    } else if (a.kv2 && valid) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         *reinterpret_cast<float4*>(a.kv2 + (size_t)row * 128 + 16 * nt + 4 * g) = make_float4(k2.v[nt][0], k2.v[nt][1], k2.v[nt][2], k2.v[nt][3]);
@@ -371,10 +375,10 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
     const TT o2 = tt_attn_heads<HD, TQ_MAXKT>(lds.sK, lds.sV, fq[s], tile, L, b, a.b_offset, a.drop, a.site_attn2, seedv, a.lse2, a.mask2, lane, c, g);
-    if (a.o2) tt_store(a.o2 + (size_t)row * 64, o2, valid, g);
+    tt_save(a.o2, row, o2, valid, g, a.saved_bf16);
     TT a2 = tt_gemm(tt_bfrags(o2), lds.w[2], c, g);
     tt_add_vec(a2, lds.vec + SV_BO2, g);
-    if (a.h) tt_store(a.h + (size_t)row * 64, a2, valid, g);
+    tt_save(a.h, row, a2, valid, g, a.saved_bf16);
     TT y = tq_ffn(a, lds.vec, lds.w[3], lds.w[4], a2, key1, key2, row, valid, c, g);
     tt_add(y, a2);
     tt_add(y, dn[s]);

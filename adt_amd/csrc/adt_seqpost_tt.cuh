@@ -1,0 +1,297 @@
+// Per-sequence BACKWARD of the token-wise chains of a layer on the transposed tiles of adt_tt.cuh (bf16 MFMA operands):
+//   k_seqtt_post_bwd<HD, true>   encoder: mask + PointWiseFeedForward + forward_layernorm + residual + out_proj (+ head classifier)
+//                                (the autograd of sasrec/modules.py:648-654, :629-633)          -> dh (residual path), dO
+//   k_seqtt_post_bwd<HD, false>  decoder: mask + PointWiseFeedForward + residual + enc_attn.out_proj (modules.py:673-676) -> dO2
+//   k_seqtt_mid_bwd              decoder: enc_attn q-projection + slf_attn.out_proj -> dO1 ; enc_attn k / v projections -> d log_feats +=
+// They replace k_enc_post_bwd / k_dec_post_bwd / k_dec_mid_bwd + k_kv_bwd of adt_bwdchain.cuh (same argument block, same outputs) when the
+// batch is whole sequences.  One workgroup = one user sequence; the gradient of a token tile runs through the chain in registers (no LDS
+// layout changes), and every weight gradient dW = G^T X is ONE product over all tokens of the sequence from two LDS row images
+// (sb_dw_product of adt_seqbwd_tt.cuh; the ones column of the X image yields the bias gradient) instead of per-wave register
+// accumulators: the row-major kernels held 3 x 64 accumulator registers per wave and sat at the 256-register limit.
+#pragma once
+#include "adt_bwdchain_args.h"
+#include "adt_seqbwd_tt.cuh"
+
+namespace adt {
+
+template <int NWT>
+struct SeqPostLds {
+  static constexpr size_t wbytes = (size_t)NWT * TT_WIMG * 2, ibytes = (size_t)SB_R * TT_RS * 2;
+  static constexpr size_t rbytes = (256 + 192) * 4;             // sRed: dgamma, dbeta, dWs, dbs ; sVec: gamma, beta, Ws
+  static constexpr size_t bytes = wbytes + 2 * ibytes + 64 + rbytes;
+};
+
+ADT_DEVICE_INLINE void sp_replica(BwdChainArgs& a) {
+  if (a.nrep <= 1) return;
+  const size_t off = (size_t)(blockIdx.x % a.nrep) * a.rep_stride;
+  float** const ptrs[] = {&a.dW0, &a.dW1, &a.dW2, &a.dW3, &a.db0, &a.db1, &a.db2, &a.db3, &a.dgamma, &a.dbeta, &a.dWs, &a.dbs};
+#pragma unroll
+  for (int i = 0; i < 12; ++i)
+    if (*ptrs[i]) *ptrs[i] += off;
+}
+
+// transposed slot-ordered images (the operand of dX^T = W^T dY^T) of N weights + zero-fill of the two token images
+template <int N>
+ADT_DEVICE_INLINE void sp_prologue(const BwdChainArgs& a, const float* const (&W)[N], __bf16* wimg, __bf16* img0) {
+  constexpr size_t ibytes = (size_t)SB_R * TT_RS * 2;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.wp_img) + 6 * (W[j] - a.wp_base) + 3 * WPACK_IMG);
+    uint4* dst = reinterpret_cast<uint4*>(wimg + j * TT_WIMG);
+    for (int i = threadIdx.x; i < TT_WIMG * 2 / 16; i += SB_NW * 64) dst[i] = src[i];
+  }
+  uint4* z = reinterpret_cast<uint4*>(img0);
+  for (int i = threadIdx.x; i < (int)((2 * ibytes + 64) / 16); i += SB_NW * 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+template <int HD, bool ENC>
+__global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
+  constexpr int H = 64 / HD, NT = HD / 16, NW = SB_NW;
+  typedef SeqPostLds<3> Lds;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* wimg = reinterpret_cast<__bf16*>(smem_raw);                       // conv2^T, conv1^T, out_proj^T
+  __bf16* img0 = reinterpret_cast<__bf16*>(smem_raw + Lds::wbytes);
+  __bf16* img1 = reinterpret_cast<__bf16*>(smem_raw + Lds::wbytes + Lds::ibytes);
+  float* sRed = reinterpret_cast<float*>(smem_raw + Lds::wbytes + 2 * Lds::ibytes + 64);   // [0,64) dgamma [64,128) dbeta [128,192) dWs [192,196) dbs
+  float* sVec = sRed + 256;                                                  // gamma, beta, Ws
+  const float *vgamma = sVec, *vbeta = sVec + 64, *vws = sVec + 128;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16, npair = (L + 31) / 32;
+  const bool cls = ENC && H > 1 && a.drec != nullptr;
+  sp_replica(a);
+  {
+    const float* const ws3[3] = {a.W0, a.W1, a.W2};
+    sp_prologue<3>(a, ws3, wimg, img0);
+    if (threadIdx.x < 256) sRed[threadIdx.x] = 0.f;
+    if (ENC) { tt_stage_vec<NW * 64>(sVec, a.gamma, 64); tt_stage_vec<NW * 64>(sVec + 64, a.beta, 64); }
+    if (cls) tt_stage_vec<NW * 64>(sVec + 128, a.Ws, 64);
+  }
+  const uint32_t seedv = a.drop.thr ? *a.drop.seed : 0u;
+  const uint32_t key1 = adt_site_key(seedv, a.site1), key2 = adt_site_key(seedv, a.site2);
+  __syncthreads();
+  // ---- A: masked upstream gradient through dropout2 and conv2 ; dW(conv2) = df^T u ----------------------------------------------------
+  TT dy[2], dt[2], hraw[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = l < L;
+    TT gyv = tt_load(a.gy + (size_t)row * 64, valid, g);
+    const TT u = tt_load_saved(a.u, row, valid, g, a.saved_bf16);
+    hraw[s] = tt_load_saved(a.xin, row, valid, g, a.saved_bf16);            // consumed in B: requested now
+    if (!valid || a.ids[row] == 0) gyv = tt_zero();
+    dy[s] = gyv;
+    tt_dropout(gyv, key2, a.drop, (uint32_t)row + a.row_offset, g);         // the forward's keep decisions and scale, applied to the gradient
+    tt_put_rows(img0, l, gyv, valid, g);
+    sb_put_x(img1, l, u, valid, g);
+    TT t = tt_gemm(tt_bfrags(gyv), wimg, c, g);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (!(u.v[nt][r] > 0.f)) t.v[nt][r] = 0.f;
+    tt_dropout(t, key1, a.drop, (uint32_t)row + a.row_offset, g);
+    dt[s] = t;
+  }
+  __syncthreads();
+  sb_dw_product(img0, img1, npair, a.dW0, a.db0, w, c, g);
+  __syncthreads();
+  // ---- B: conv1 ; encoder: forward_layernorm backward -> dh ; dW(conv1) = dt^T LN2(h) (decoder: dt^T a2) --------------------------------
+  TT dh[2], oraw[2];
+  TT dgm = tt_zero(), dbt = tt_zero();
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = l < L;
+    oraw[s] = tt_load_saved(a.o, row, valid, g, a.saved_bf16);              // consumed in C
+    tt_put_rows(img0, l, dt[s], valid, g);
+    TT d = tt_gemm(tt_bfrags(dt[s]), wimg + TT_WIMG, c, g);
+    tt_add(d, dy[s]);                                                       // the residual around the feed-forward
+    if (ENC) {
+      const TTLn st = tt_ln_stats(hraw[s], a.ln_eps);
+      sb_put_x(img1, l, tt_ln_apply(st.xhat, vgamma, vbeta, g), valid, g);
+      dh[s] = tt_ln_bwd(d, st, vgamma, dgm, dbt, g);
+      tt_store(a.out0 + (size_t)row * 64, dh[s], valid, g);                 // gradient wrt h == wrt the LN1 output on the residual path
+    } else {
+      sb_put_x(img1, l, hraw[s], valid, g);
+      dh[s] = d;                                                            // gradient wrt a2 (the Dn residual is handled by the pre chain)
+    }
+  }
+  __syncthreads();
+  sb_dw_product(img0, img1, npair, a.dW1, a.db1, w, c, g);
+  __syncthreads();
+  // ---- C: out_proj ; dW(out_proj) = dh^T o ; encoder: head classifier reverse joins dO ---------------------------------------------------
+  float dws[H][NT][4], dbs_acc[H];
+#pragma unroll
+  for (int cc = 0; cc < H; ++cc) {
+    dbs_acc[cc] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dws[cc][nt][r] = 0.f;
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = l < L;
+    tt_put_rows(img0, l, dh[s], valid, g);
+    sb_put_x(img1, l, oraw[s], valid, g);
+    TT dO = tt_gemm(tt_bfrags(dh[s]), wimg + 2 * TT_WIMG, c, g);
+    if (cls) {
+      // z[h][cc] = o_h . Ws[cc] + bs[cc], rec = log_softmax_cc(z): dz = drec - exp(rec) * sum_cc drec ; dO_h += dz Ws ; dWs += dz^T o_h ; dbs += dz
+      const size_t off = (size_t)(l * a.B + b) * (H * H);
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float dz[H], sd = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < H; ++cc) { dz[cc] = valid ? a.drec[off + h * H + cc] : 0.f; sd += dz[cc]; }
+#pragma unroll
+        for (int cc = 0; cc < H; ++cc) {
+          dz[cc] -= valid ? __expf(a.rec[off + h * H + cc]) * sd : 0.f;
+          if (g == 0) dbs_acc[cc] += dz[cc];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+          for (int cc = 0; cc < H; ++cc) {
+            const float4 wv = *reinterpret_cast<const float4*>(vws + cc * HD + 16 * nt + 4 * g);
+            const f32x4 wq = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              dO.v[h * NT + nt][r] += dz[cc] * wq[r];
+              dws[cc][nt][r] += dz[cc] * oraw[s].v[h * NT + nt][r];
+            }
+          }
+        }
+      }
+    }
+    tt_store((ENC ? a.out1 : a.out0) + (size_t)row * 64, dO, valid, g);
+  }
+  __syncthreads();
+  sb_dw_product(img0, img1, npair, a.dW2, a.db2, w, c, g);
+  if (ENC) {
+    // per-lane partials over this wave's tokens -> workgroup sums in LDS -> one atomic per element
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sg = tt_rowsum16(dgm.v[nt][r]), sb = tt_rowsum16(dbt.v[nt][r]);
+        if (c == 0) {
+          atomicAdd(sRed + 16 * nt + 4 * g + r, sg);
+          atomicAdd(sRed + 64 + 16 * nt + 4 * g + r, sb);
+        }
+      }
+    if (cls) {
+#pragma unroll
+      for (int cc = 0; cc < H; ++cc) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sw = tt_rowsum16(dws[cc][nt][r]);
+            if (c == 0) atomicAdd(sRed + 128 + cc * HD + 16 * nt + 4 * g + r, sw);
+          }
+        const float sb = tt_rowsum16(dbs_acc[cc]);
+        if (c == 0 && g == 0) atomicAdd(sRed + 192 + cc, sb);
+      }
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < 64) atomicAdd(a.dgamma + t, sRed[t]);
+    else if (t < 128) atomicAdd(a.dbeta + t - 64, sRed[t]);
+    else if (cls && t < 192) atomicAdd(a.dWs + t - 128, sRed[t]);
+    else if (cls && t < 192 + H) atomicAdd(a.dbs + t - 192, sRed[t]);
+  }
+}
+
+// W0 = enc_attn Wq, W1 = slf_attn.out_proj, W2 = enc_attn Wk, W3 = enc_attn Wv ; dqkv = dq2 (ld lddqkv), xin = a1, o = o1, dkv2 (B*L x 128),
+// f = log_feats ; out0 = dO1, out1 = d log_feats (acc1: add to what is there)
+__global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
+  constexpr int NW = SB_NW;
+  typedef SeqPostLds<4> Lds;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* wimg = reinterpret_cast<__bf16*>(smem_raw);
+  __bf16* img0 = reinterpret_cast<__bf16*>(smem_raw + Lds::wbytes);
+  __bf16* img1 = reinterpret_cast<__bf16*>(smem_raw + Lds::wbytes + Lds::ibytes);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16, npair = (L + 31) / 32;
+  sp_replica(a);
+  {
+    const float* const ws4[4] = {a.W0, a.W1, a.W2, a.W3};
+    sp_prologue<4>(a, ws4, wimg, img0);
+  }
+  __syncthreads();
+  // ---- A: cross-attention query projection: da1 = dq2 Wq ; dWq = dq2^T a1 ----------------------------------------------------------
+  TT da1[2], oraw[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = l < L;
+    const TT dq = tt_load(a.dqkv + (size_t)row * a.lddqkv, valid, g);
+    const TT a1 = tt_load_saved(a.xin, row, valid, g, a.saved_bf16);
+    oraw[s] = tt_load_saved(a.o, row, valid, g, a.saved_bf16);
+    tt_put_rows(img0, l, dq, valid, g);
+    sb_put_x(img1, l, a1, valid, g);
+    da1[s] = tt_gemm(tt_bfrags(dq), wimg, c, g);
+  }
+  __syncthreads();
+  sb_dw_product(img0, img1, npair, a.dW0, a.db0, w, c, g);
+  __syncthreads();
+  // ---- B: self-attention out_proj: dO1 = da1 Wo1 ; dWo1 = da1^T o1 --------------------------------------------------------------------
+  TT dk[2], fx[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = l < L;
+    dk[s] = tt_load(a.dkv2 + (size_t)row * 128, valid, g);
+    fx[s] = tt_load(a.f + (size_t)row * 64, valid, g);
+    tt_put_rows(img0, l, da1[s], valid, g);
+    sb_put_x(img1, l, oraw[s], valid, g);
+    tt_store(a.out0 + (size_t)row * 64, tt_gemm(tt_bfrags(da1[s]), wimg + TT_WIMG, c, g), valid, g);
+  }
+  __syncthreads();
+  sb_dw_product(img0, img1, npair, a.dW1, a.db1, w, c, g);
+  __syncthreads();
+  // ---- C: cross-attention keys: df = dk2 Wk ; dWk = dk2^T f -----------------------------------------------------------------------------
+  TT df[2], dv[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = l < L;
+    dv[s] = tt_load(a.dkv2 + (size_t)row * 128 + 64, valid, g);
+    tt_put_rows(img0, l, dk[s], valid, g);
+    sb_put_x(img1, l, fx[s], valid, g);
+    df[s] = tt_gemm(tt_bfrags(dk[s]), wimg + 2 * TT_WIMG, c, g);
+  }
+  __syncthreads();
+  sb_dw_product(img0, img1, npair, a.dW2, a.db2, w, c, g);
+  __syncthreads();
+  // ---- D: cross-attention values (the X image still holds f) --------------------------------------------------------------------------
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    if (tile < 0) continue;
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = l < L;
+    tt_put_rows(img0, l, dv[s], valid, g);
+    tt_add(df[s], tt_gemm(tt_bfrags(dv[s]), wimg + 3 * TT_WIMG, c, g));
+    float* dst = a.out1 + (size_t)row * 64;
+    if (a.acc1) tt_add(df[s], tt_load(dst, valid, g));
+    tt_store(dst, df[s], valid, g);
+  }
+  __syncthreads();
+  sb_dw_product(img0, img1, npair, a.dW3, a.db3, w, c, g);
+}
+
+}  // namespace adt

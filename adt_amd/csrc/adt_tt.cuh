@@ -105,6 +105,41 @@ ADT_DEVICE_INLINE void tt_store(float* row, const TT& t, bool valid, int g) {
   for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<float4*>(row + 16 * nt + 4 * g) = make_float4(t.v[nt][0], t.v[nt][1], t.v[nt][2], t.v[nt][3]);
 }
 
+// tensors SAVED for the backward as bf16 rows (`row` = this lane's token row); 8-byte accesses
+ADT_DEVICE_INLINE void tt_store_bf16(__bf16* row, const TT& t, bool valid, int g) {
+  if (!valid) return;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    bf16x4 b;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b[r] = (__bf16)t.v[nt][r];
+    *reinterpret_cast<bf16x4*>(row + 16 * nt + 4 * g) = b;
+  }
+}
+ADT_DEVICE_INLINE TT tt_load_bf16(const __bf16* row, bool valid, int g) {
+  TT t;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    t.v[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+      const bf16x4 b = *reinterpret_cast<const bf16x4*>(row + 16 * nt + 4 * g);
+      t.v[nt] = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+    }
+  }
+  return t;
+}
+
+// a saved (B*L x 64) tensor in either format: fp32 rows, or bf16 rows in the first half of the same buffer
+ADT_DEVICE_INLINE void tt_save(float* buf, size_t row, const TT& t, bool valid, int g, int as_bf16) {
+  if (!buf) return;
+  if (as_bf16) tt_store_bf16(reinterpret_cast<__bf16*>(buf) + row * 64, t, valid, g);
+  else tt_store(buf + row * 64, t, valid, g);
+}
+ADT_DEVICE_INLINE TT tt_load_saved(const float* buf, size_t row, bool valid, int g, int as_bf16) {
+  if (as_bf16) return tt_load_bf16(reinterpret_cast<const __bf16*>(buf) + row * 64, valid, g);
+  return tt_load(buf + row * 64, valid, g);
+}
+
 // Exchanges between the four lanes (g = 0..3) that hold one token column.  v_permlane16_swap / v_permlane32_swap (gfx950) stay in
 // the vector ALU; __shfl_xor compiles to ds_bpermute_b32, a round trip through the LDS crossbar on the critical path of every
 // LayerNorm, softmax and classifier reduction.  With both operands the same register, the swap leaves lane ^ 16 (lane ^ 32) of the
