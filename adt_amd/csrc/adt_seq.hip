@@ -101,6 +101,7 @@ static unsigned long long* seq_stamp_buffer(bool for_attention) {      // ADT_SE
   }
   return (st == (for_attention ? 2 : 1)) ? g_stamps : nullptr;
 }
+static unsigned long long* seq_stamp_buffer_post() { seq_stamp_buffer(false); const char* e = getenv("ADT_SEQ_STAMPS"); return (e && atoi(e) == 3) ? g_stamps : nullptr; }
 
 static void seq_ablate(SeqFwdArgs& a) {
   a.stamps = seq_stamp_buffer(false);
@@ -193,7 +194,6 @@ static int seq_attn_pre_bwd_t(int mode, const SeqBwdArgs& a, hipStream_t s) {
                         (const void*)k_seqtt_attn_pre_bwd<HD, 2, DEC>};
   SeqBwdArgs args = a;
   args.stamps = seq_stamp_buffer(true);
-  { static int ab = -1; if (ab < 0) { const char* e = getenv("ADT_SEQ_ABLATE_BWD"); ab = e ? atoi(e) : 0; } args.ablate = ab; }
   return seq_launch(fns[mode], smem, done[mode], a.B, &args, s, "seqtt_attn_pre_bwd");
 }
 
@@ -223,7 +223,9 @@ int adt_launch_seq_post_bwd(int hd, int enc, const BwdChainArgs& a, void* stream
   const void* fns[6] = {(const void*)k_seqtt_post_bwd<64, false>, (const void*)k_seqtt_post_bwd<64, true>, (const void*)k_seqtt_post_bwd<32, false>,
                         (const void*)k_seqtt_post_bwd<32, true>, (const void*)k_seqtt_post_bwd<16, false>, (const void*)k_seqtt_post_bwd<16, true>};
   const int slot = (hd == 64 ? 0 : hd == 32 ? 2 : 4) + (enc ? 1 : 0);
-  return seq_launch(fns[slot], SeqPostLds<3>::bytes, done[slot], a.B, &a, (hipStream_t)stream, "seqtt_post_bwd");
+  BwdChainArgs args = a;
+  args.stamps = enc ? seq_stamp_buffer_post() : nullptr;
+  return seq_launch(fns[slot], SeqPostLds<3>::bytes, done[slot], a.B, &args, (hipStream_t)stream, "seqtt_post_bwd");
 }
 
 int adt_launch_seq_mid_bwd(int hd, const BwdChainArgs& a, void* stream) {

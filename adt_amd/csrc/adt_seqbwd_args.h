@@ -21,7 +21,6 @@ struct SeqBwdArgs {
   const float* wp_base; const void* wp_img;        // pre-packed weight images (slot-ordered: + 2 plain, + 3 transposed)
   int saved_bf16;                     // `o` holds bf16 rows (written by the transposed-chain forward in its lean mode)
   unsigned long long* stamps;
-  int ablate;                         // timing experiments only (ADT_SEQ_ABLATE_BWD): 1 = weight-gradient products without their atomics
 };
 
 }  // namespace adt

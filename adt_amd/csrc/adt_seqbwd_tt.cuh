@@ -8,8 +8,7 @@
 // out_proj backward.  The two passes of adt_seqattn.cuh run on two image slots: K, V for pass A (the wave's own q and dO rows are
 // MFMA operands in registers), then Q, dO for pass B (own k, v rows in registers).  dq, dk, dv stay in registers as transposed tiles:
 //   * weight gradients dW = G^T X contract over ALL tokens of the sequence: G and X rows go to the two image slots and every wave
-//     computes its share of the 16 + 4 output tiles through ds_read_b64_tr_b16 fragments (column 64 of the X image holds 1 for real
-//     tokens, so the fifth tile column IS the bias gradient);
+//     computes two of the 16 output tiles through ds_read_b64_tr_b16 fragments (bias gradients: per-lane column sums);
 //   * the input gradient is two / three more transposed-chain products and the LayerNorm backward, all in registers.
 #pragma once
 #include "adt_seqattn.cuh"
@@ -25,7 +24,7 @@ constexpr int SB_R = 224;                          // image rows: L <= 224
 template <int H>
 struct SeqBwdLds {
   static constexpr size_t wbytes = 6 * (size_t)TT_WIMG * 2, ibytes = (size_t)SB_R * TT_RS * 2;
-  static constexpr size_t mbytes = (size_t)H * SB_R * 8 * 4, sbytes = 2 * (size_t)H * SB_R * 4, rbytes = (2 * 64 + 320) * 4;
+  static constexpr size_t mbytes = (size_t)H * SB_R * 8 * 4, sbytes = 2 * (size_t)H * SB_R * 4, rbytes = (320 + 320) * 4;         // sRed: dgamma, dbeta, dbin ; sVec: gamma, beta, bin
   static constexpr size_t bytes = wbytes + 2 * ibytes + 64 /* spill of the last row's ones-column read */ + mbytes + sbytes + rbytes;
 };
 
@@ -112,30 +111,69 @@ ADT_DEVICE_INLINE TT tt_ln_bwd(const TT& dy, const TTLn& st, const float* gamma,
   return dx;
 }
 
-// one weight-gradient product over all tokens of the sequence: dW[n][k] += sum_t G[t][n] X[t][k] (k = 64: the ones column -> db[n]).
-// 20 output tiles (4 n-tiles x (4 k-tiles + the bias column)) dealt round-robin over the waves; every wave calls (no barrier inside).
-ADT_DEVICE_INLINE void sb_dw_product(const __bf16* sG, const __bf16* sX, int npair, float* dW, float* db, int w, int c, int g, int ablate = 0) {
-#pragma unroll 1
-  for (int id = w; id < 20; id += SB_NW) {
-    const int nt = id / 5, kt = id - 5 * nt;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int kp = 0; kp < npair; ++kp) acc = mfma_bf16(acc, tt_trfrag(sG, kp * 32, 16 * nt, c, g), tt_trfrag(sX, kp * 32, 16 * kt, c, g));
-    if (ablate) { if (acc[0] == 12345.678f) dW[0] = acc[1] + acc[2] + acc[3]; continue; }
-    if (kt < 4) {
+// One weight-gradient product over all tokens of the sequence: dW[n][k] += sum_t G[t][n] X[t][k], from two natural-order LDS row images
+// through ds_read_b64_tr_b16 fragments; every wave calls (no barrier inside).
+// 16 output tiles, exactly two per wave -- (nt0, kt) and (nt0 + 2, kt), which share the X
+// fragments -- and the token loop unrolled (NP pairs of 16-token tiles; image rows beyond the sequence are zero).  A 20-tile form with a ones column in the
+// X image for the bias gradient gave four waves a third tile: 10k cycles per product on the critical path against 3k for the two-tile waves (profiles/r02_stamps_post.txt).
+template <int NP>
+ADT_DEVICE_INLINE void sb_dw_tiles(const __bf16* sG, const __bf16* sX, float* dW, int w, int c, int g) {
+  const int kt = w & 3, nt0 = w >> 2;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(dW + (16 * nt + 4 * g + r) * 64 + 16 * kt + c, acc[r]);
-    } else if (c == 0) {
+  for (int kp = 0; kp < NP; ++kp) {
+    const bf16x8 fx = tt_trfrag(sX, kp * 32, 16 * kt, c, g);
+    acc0 = mfma_bf16(acc0, tt_trfrag(sG, kp * 32, 16 * nt0, c, g), fx);
+    acc1 = mfma_bf16(acc1, tt_trfrag(sG, kp * 32, 16 * (nt0 + 2), c, g), fx);
+  }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(db + 16 * nt + 4 * g + r, acc[r]);
-    }
+  for (int r = 0; r < 4; ++r) {
+    atomicAdd(dW + (16 * nt0 + 4 * g + r) * 64 + 16 * kt + c, acc0[r]);
+    atomicAdd(dW + (16 * (nt0 + 2) + 4 * g + r) * 64 + 16 * kt + c, acc1[r]);
   }
 }
+ADT_DEVICE_INLINE void sb_dw_product16(const __bf16* sG, const __bf16* sX, int npair, float* dW, int w, int c, int g) {
+  if (npair <= 4) sb_dw_tiles<4>(sG, sX, dW, w, c, g);
+  else sb_dw_tiles<SB_R / 32>(sG, sX, dW, w, c, g);
+}
+// bias gradients (column sums of G over the tokens): per-lane sums of the tiles a wave holds, reduced over the 16 tokens of a lane row,
+// added to a 64-float LDS vector; the workgroup adds the vector to the global accumulator once, at its end
+ADT_DEVICE_INLINE void sb_colsum_flush(float* red, const TT& acc, int c, int g) {
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float sum = tt_rowsum16(acc.v[nt][r]);
+      if (c == 0) atomicAdd(red + 16 * nt + 4 * g + r, sum);
+    }
+}
 
-// rows of the X image of a weight-gradient product, with the ones column
-ADT_DEVICE_INLINE void sb_put_x(__bf16* img, int token, const TT& t, bool valid, int g) {
-  tt_put_rows(img, token, t, valid, g);
-  if (g == 0) img[token * TT_RS + 64] = (__bf16)(valid ? 1.0f : 0.0f);
+// N weight images global -> LDS in two steps: all the global loads (2 x 16 B per thread and image), later the LDS stores -- the loads are
+// the first vector-memory instructions of the kernel, the phase-1 activation loads queue behind them, and both stream during the zero-fills
+template <int N> struct SbImgRegs { uint4 r0[N], r1[N]; };
+template <int N>
+ADT_DEVICE_INLINE SbImgRegs<N> sb_img_load(const __bf16* const (&src)[N]) {
+  constexpr int CH = TT_WIMG * 2 / 16;
+  SbImgRegs<N> t;
+  const int i1 = threadIdx.x + SB_NW * 64;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const uint4* p = reinterpret_cast<const uint4*>(src[k]);
+    t.r0[k] = p[threadIdx.x];
+    t.r1[k] = p[i1 < CH ? i1 : 0];
+  }
+  return t;
+}
+template <int N>
+ADT_DEVICE_INLINE void sb_img_store(__bf16* wimg, const SbImgRegs<N>& t) {
+  constexpr int CH = TT_WIMG * 2 / 16;
+  const int i1 = threadIdx.x + SB_NW * 64;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    uint4* dst = reinterpret_cast<uint4*>(wimg + k * TT_WIMG);
+    dst[threadIdx.x] = t.r0[k];
+    if (i1 < CH) dst[i1] = t.r1[k];
+  }
 }
 
 #define SB_STAMP(k) do { if (a.stamps && blockIdx.x == 0 && lane == 0) a.stamps[w * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -153,8 +191,8 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   uint32_t* sM = reinterpret_cast<uint32_t*>(smem_raw + Lds::wbytes + 2 * Lds::ibytes + 64);
   float* sLse = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(sM) + Lds::mbytes);
   float* sDelta = sLse + H * R;
-  float* sRed = sDelta + H * R;                                              // [2][64] dgamma, dbeta of this workgroup
-  float* sVec = sRed + 128;                                                  // gamma, beta, packed in-projection bias (LDS copies)
+  float* sRed = sDelta + H * R;                                              // dgamma, dbeta, dbin[192] of this workgroup
+  float* sVec = sRed + 320;                                                  // gamma, beta, packed in-projection bias (LDS copies)
   const float *vgamma = sVec, *vbeta = sVec + 64, *vbin = sVec + 128;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16, npair = (L + 31) / 32;
@@ -163,17 +201,24 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     a.dWin += off; a.dbin += off; a.dgamma += off; a.dbeta += off;
   }
   SB_STAMP(0);
+  // The weight images are requested first and P1's activations right behind them: every workgroup of the launch runs the same phase at
+  // the same time, so HBM streams the activations while the prologue runs instead of idling through it (adt_seqpost_tt.cuh)
+  const __bf16* wsrc = reinterpret_cast<const __bf16*>(a.wp_img) + 6 * (a.Win - a.wp_base);
+  const __bf16* const src6[6] = {wsrc + 2 * WPACK_IMG, wsrc + 6 * 4096 + 2 * WPACK_IMG, wsrc + 12 * 4096 + 2 * WPACK_IMG,
+                                 wsrc + 3 * WPACK_IMG, wsrc + 6 * 4096 + 3 * WPACK_IMG, wsrc + 12 * 4096 + 3 * WPACK_IMG};
+  const SbImgRegs<6> wr = sb_img_load<6>(src6);
+  TT xa[2], doa[2], oa[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = tile >= 0 && l < L;
+    xa[s] = tt_load(a.x + (size_t)row * 64, valid, g);
+    doa[s] = tt_load(a.dO + (size_t)row * 64, valid, g);
+    oa[s] = tt_load_saved(a.o, row, valid, g, a.saved_bf16);
+  }
   // ---- P0: weight images, zeroed token images, keep bits, statistics -------------------------------------------------------------
   {
-    const __bf16* src = reinterpret_cast<const __bf16*>(a.wp_img) + 6 * (a.Win - a.wp_base);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const uint4* p2 = reinterpret_cast<const uint4*>(src + 6 * 4096 * j + 2 * WPACK_IMG);
-      const uint4* p3 = reinterpret_cast<const uint4*>(src + 6 * 4096 * j + 3 * WPACK_IMG);
-      uint4* d2 = reinterpret_cast<uint4*>(wimg + j * TT_WIMG);
-      uint4* d3 = reinterpret_cast<uint4*>(wimg + (3 + j) * TT_WIMG);
-      for (int i = threadIdx.x; i < TT_WIMG * 2 / 16; i += NW * 64) { d2[i] = p2[i]; d3[i] = p3[i]; }
-    }
     uint4* z = reinterpret_cast<uint4*>(img0);
     for (int i = threadIdx.x; i < (int)((2 * Lds::ibytes + 64) / 16); i += NW * 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
     if constexpr (MODE == 1) {
@@ -189,8 +234,9 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
       sLse[i] = r < L ? a.lse[(size_t)(b * H + h) * L + r] * 1.4426950408889634f : INFINITY;
       sDelta[i] = 0.f;
     }
-    if (threadIdx.x < 128) sRed[threadIdx.x] = 0.f;
+    if (threadIdx.x < 320) sRed[threadIdx.x] = 0.f;
     tt_stage_vec<NW * 64>(sVec, a.gamma, 64); tt_stage_vec<NW * 64>(sVec + 64, a.beta, 64); tt_stage_vec<NW * 64>(sVec + 128, a.bin, 192);
+    sb_img_store<6>(wimg, wr);
   }
   __syncthreads();
   SB_STAMP(1);
@@ -203,9 +249,9 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile(s, w, ntiles);
     if (tile < 0) continue;
-    const int l = tile * 16 + c, row = b * L + l;
+    const int l = tile * 16 + c;
     const bool valid = l < L;
-    const TT x = tt_load(a.x + (size_t)row * 64, valid, g);
+    const TT& x = xa[s];
     const TT xn = tt_ln_apply(tt_ln_stats(x, a.ln_eps).xhat, vgamma, vbeta, g);
     const TTB bn = tt_bfrags(xn);
     TTB bx;
@@ -221,8 +267,8 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     tt_add_vec(v, vbin + 128, g);
     sb_frags<HD>(v, 1.0f, fv[s]);
     tt_put_rows(img1, l, v, valid, g);
-    const TT dO = tt_load(a.dO + (size_t)row * 64, valid, g);
-    const TT o = tt_load_saved(a.o, row, valid, g, a.saved_bf16);
+    const TT& dO = doa[s];
+    const TT& o = oa[s];
     sb_frags<HD>(dO, 1.0f, fdo[s]);
 #pragma unroll
     for (int h = 0; h < H; ++h) {
@@ -286,18 +332,23 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   __syncthreads();
   SB_STAMP(4);
   // ---- P4: in-projection weight / bias gradients: three products over all tokens ------------------------------------------------------
+  {
+    TT sq = tt_zero(), sk = tt_zero(), sv = tt_zero();
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
-    if (tile < 0) continue;
-    const int l = tile * 16 + c, row = b * L + l;
-    const bool valid = l < L;
-    const TT x = tt_load(a.x + (size_t)row * 64, valid, g);
-    tt_put_rows(img0, l, dq[s], valid, g);
-    sb_put_x(img1, l, tt_ln_apply(tt_ln_stats(x, a.ln_eps).xhat, vgamma, vbeta, g), valid, g);     // q always reads LN(x)
+    for (int s = 0; s < 2; ++s) {
+      const int tile = tq_tile(s, w, ntiles);
+      if (tile < 0) continue;
+      const int l = tile * 16 + c, row = b * L + l;
+      const bool valid = l < L;
+      const TT x = tt_load(a.x + (size_t)row * 64, valid, g);
+      tt_put_rows(img0, l, dq[s], valid, g);
+      tt_put_rows(img1, l, tt_ln_apply(tt_ln_stats(x, a.ln_eps).xhat, vgamma, vbeta, g), valid, g);     // q always reads LN(x)
+      if (valid) { tt_add(sq, dq[s]); tt_add(sk, dk[s]); tt_add(sv, dv[s]); }
+    }
+    sb_colsum_flush(sRed + 128, sq, c, g); sb_colsum_flush(sRed + 192, sk, c, g); sb_colsum_flush(sRed + 256, sv, c, g);
   }
   __syncthreads();
-  sb_dw_product(img0, img1, npair, a.dWin, a.dbin, w, c, g, a.ablate);
+  sb_dw_product16(img0, img1, npair, a.dWin, w, c, g);
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -306,10 +357,10 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
     tt_put_rows(img0, l, dk[s], valid, g);
-    if (!DEC) sb_put_x(img1, l, tt_load(a.x + (size_t)row * 64, valid, g), valid, g);                  // encoder: k, v read the raw x
+    if (!DEC) tt_put_rows(img1, l, tt_load(a.x + (size_t)row * 64, valid, g), valid, g);                  // encoder: k, v read the raw x
   }
   __syncthreads();
-  sb_dw_product(img0, img1, npair, a.dWin + 4096, a.dbin + 64, w, c, g, a.ablate);
+  sb_dw_product16(img0, img1, npair, a.dWin + 4096, w, c, g);
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -319,7 +370,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     tt_put_rows(img0, l, dv[s], l < L, g);
   }
   __syncthreads();
-  sb_dw_product(img0, img1, npair, a.dWin + 8192, a.dbin + 128, w, c, g, a.ablate);
+  sb_dw_product16(img0, img1, npair, a.dWin + 8192, w, c, g);
   SB_STAMP(5);
   // ---- P5: gradient of the block input ----------------------------------------------------------------------------------------
   TT dgm = tt_zero(), dbt = tt_zero();
@@ -365,6 +416,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   __syncthreads();
   if (threadIdx.x < 64) atomicAdd(a.dgamma + threadIdx.x, sRed[threadIdx.x]);
   else if (threadIdx.x < 128) atomicAdd(a.dbeta + threadIdx.x - 64, sRed[threadIdx.x]);
+  else if (threadIdx.x < 320) atomicAdd(a.dbin + threadIdx.x - 128, sRed[threadIdx.x]);
   SB_STAMP(6);
 }
 

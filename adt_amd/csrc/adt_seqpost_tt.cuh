@@ -17,7 +17,7 @@ namespace adt {
 template <int NWT>
 struct SeqPostLds {
   static constexpr size_t wbytes = (size_t)NWT * TT_WIMG * 2, ibytes = (size_t)SB_R * TT_RS * 2;
-  static constexpr size_t rbytes = (256 + 192) * 4;             // sRed: dgamma, dbeta, dWs, dbs ; sVec: gamma, beta, Ws
+  static constexpr size_t rbytes = (448 + 192) * 4;             // sRed: dgamma, dbeta, dWs, dbs, 3-4 bias vectors ; sVec: gamma, beta, Ws
   static constexpr size_t bytes = wbytes + 2 * ibytes + 64 + rbytes;
 };
 
@@ -30,16 +30,16 @@ ADT_DEVICE_INLINE void sp_replica(BwdChainArgs& a) {
     if (*ptrs[i]) *ptrs[i] += off;
 }
 
-// transposed slot-ordered images (the operand of dX^T = W^T dY^T) of N weights + zero-fill of the two token images
+// transposed slot-ordered images (the operand of dX^T = W^T dY^T) of N weights: the global loads
 template <int N>
-ADT_DEVICE_INLINE void sp_prologue(const BwdChainArgs& a, const float* const (&W)[N], __bf16* wimg, __bf16* img0) {
-  constexpr size_t ibytes = (size_t)SB_R * TT_RS * 2;
+ADT_DEVICE_INLINE SbImgRegs<N> sp_wload(const BwdChainArgs& a, const float* const (&W)[N]) {
+  const __bf16* src[N];
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.wp_img) + 6 * (W[j] - a.wp_base) + 3 * WPACK_IMG);
-    uint4* dst = reinterpret_cast<uint4*>(wimg + j * TT_WIMG);
-    for (int i = threadIdx.x; i < TT_WIMG * 2 / 16; i += SB_NW * 64) dst[i] = src[i];
-  }
+  for (int j = 0; j < N; ++j) src[j] = reinterpret_cast<const __bf16*>(a.wp_img) + 6 * (W[j] - a.wp_base) + 3 * WPACK_IMG;
+  return sb_img_load<N>(src);
+}
+ADT_DEVICE_INLINE void sp_zero_images(__bf16* img0) {
+  constexpr size_t ibytes = (size_t)SB_R * TT_RS * 2;
   uint4* z = reinterpret_cast<uint4*>(img0);
   for (int i = threadIdx.x; i < (int)((2 * ibytes + 64) / 16); i += SB_NW * 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
 }
@@ -52,39 +52,59 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   __bf16* wimg = reinterpret_cast<__bf16*>(smem_raw);                       // conv2^T, conv1^T, out_proj^T
   __bf16* img0 = reinterpret_cast<__bf16*>(smem_raw + Lds::wbytes);
   __bf16* img1 = reinterpret_cast<__bf16*>(smem_raw + Lds::wbytes + Lds::ibytes);
-  float* sRed = reinterpret_cast<float*>(smem_raw + Lds::wbytes + 2 * Lds::ibytes + 64);   // [0,64) dgamma [64,128) dbeta [128,192) dWs [192,196) dbs
-  float* sVec = sRed + 256;                                                  // gamma, beta, Ws
+  float* sRed = reinterpret_cast<float*>(smem_raw + Lds::wbytes + 2 * Lds::ibytes + 64);   // [0,64) dgamma [64,128) dbeta [128,192) dWs [192,196) dbs [256,448) db0, db1, db2
+  float* sVec = sRed + 448;                                                  // gamma, beta, Ws
   const float *vgamma = sVec, *vbeta = sVec + 64, *vws = sVec + 128;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16, npair = (L + 31) / 32;
   const bool cls = ENC && H > 1 && a.drec != nullptr;
   sp_replica(a);
+  SB_STAMP(0);
+  // every workgroup of the launch runs the same phases at the same time: the activations of phase A are requested right behind the
+  // weight images, so that HBM streams them while the prologue runs (requested at the top of phase A they arrived ~8k cycles after it)
+  const float* const ws3[3] = {a.W0, a.W1, a.W2};
+  const SbImgRegs<3> wr = sp_wload<3>(a, ws3);
+  TT dy[2], ua[2], hraw[2];
+  int idv[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = tile >= 0 && l < L;
+    dy[s] = tt_load(a.gy + (size_t)row * 64, valid, g);
+    ua[s] = tt_load_saved(a.u, row, valid, g, a.saved_bf16);
+    hraw[s] = tt_load_saved(a.xin, row, valid, g, a.saved_bf16);
+    idv[s] = valid ? a.ids[row] : 0;
+  }
   {
-    const float* const ws3[3] = {a.W0, a.W1, a.W2};
-    sp_prologue<3>(a, ws3, wimg, img0);
-    if (threadIdx.x < 256) sRed[threadIdx.x] = 0.f;
+    sp_zero_images(img0);
+    if (threadIdx.x < 448) sRed[threadIdx.x] = 0.f;
     if (ENC) { tt_stage_vec<NW * 64>(sVec, a.gamma, 64); tt_stage_vec<NW * 64>(sVec + 64, a.beta, 64); }
     if (cls) tt_stage_vec<NW * 64>(sVec + 128, a.Ws, 64);
+    sb_img_store<3>(wimg, wr);
   }
   const uint32_t seedv = a.drop.thr ? *a.drop.seed : 0u;
   const uint32_t key1 = adt_site_key(seedv, a.site1), key2 = adt_site_key(seedv, a.site2);
+  SB_STAMP(1);
   __syncthreads();
+  SB_STAMP(2);
   // ---- A: masked upstream gradient through dropout2 and conv2 ; dW(conv2) = df^T u ----------------------------------------------------
-  TT dy[2], dt[2], hraw[2];
+  TT dt[2];
+  TT bsum = tt_zero();
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile(s, w, ntiles);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
-    TT gyv = tt_load(a.gy + (size_t)row * 64, valid, g);
-    const TT u = tt_load_saved(a.u, row, valid, g, a.saved_bf16);
-    hraw[s] = tt_load_saved(a.xin, row, valid, g, a.saved_bf16);            // consumed in B: requested now
-    if (!valid || a.ids[row] == 0) gyv = tt_zero();
-    dy[s] = gyv;
+    const TT& u = ua[s];
+    if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (s == 0) SB_STAMP(3); }
+    if (idv[s] == 0) dy[s] = tt_zero();
+    TT gyv = dy[s];
     tt_dropout(gyv, key2, a.drop, (uint32_t)row + a.row_offset, g);         // the forward's keep decisions and scale, applied to the gradient
     tt_put_rows(img0, l, gyv, valid, g);
-    sb_put_x(img1, l, u, valid, g);
+    tt_put_rows(img1, l, u, valid, g);
+    tt_add(bsum, gyv);                                                      // zero for absent and padded tokens
     TT t = tt_gemm(tt_bfrags(gyv), wimg, c, g);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -93,13 +113,20 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
         if (!(u.v[nt][r] > 0.f)) t.v[nt][r] = 0.f;
     tt_dropout(t, key1, a.drop, (uint32_t)row + a.row_offset, g);
     dt[s] = t;
+    if (s == 0) SB_STAMP(4);
   }
+  sb_colsum_flush(sRed + 256, bsum, c, g);
+  SB_STAMP(5);
   __syncthreads();
-  sb_dw_product(img0, img1, npair, a.dW0, a.db0, w, c, g);
+  SB_STAMP(6);
+  sb_dw_product16(img0, img1, npair, a.dW0, w, c, g);
+  SB_STAMP(7);
   __syncthreads();
+  SB_STAMP(8);
   // ---- B: conv1 ; encoder: forward_layernorm backward -> dh ; dW(conv1) = dt^T LN2(h) (decoder: dt^T a2) --------------------------------
   TT dh[2], oraw[2];
   TT dgm = tt_zero(), dbt = tt_zero();
+  bsum = tt_zero();
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile(s, w, ntiles);
@@ -108,22 +135,28 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
     const bool valid = l < L;
     oraw[s] = tt_load_saved(a.o, row, valid, g, a.saved_bf16);              // consumed in C
     tt_put_rows(img0, l, dt[s], valid, g);
+    tt_add(bsum, dt[s]);
     TT d = tt_gemm(tt_bfrags(dt[s]), wimg + TT_WIMG, c, g);
     tt_add(d, dy[s]);                                                       // the residual around the feed-forward
     if (ENC) {
       const TTLn st = tt_ln_stats(hraw[s], a.ln_eps);
-      sb_put_x(img1, l, tt_ln_apply(st.xhat, vgamma, vbeta, g), valid, g);
+      tt_put_rows(img1, l, tt_ln_apply(st.xhat, vgamma, vbeta, g), valid, g);
       dh[s] = tt_ln_bwd(d, st, vgamma, dgm, dbt, g);
       tt_store(a.out0 + (size_t)row * 64, dh[s], valid, g);                 // gradient wrt h == wrt the LN1 output on the residual path
     } else {
-      sb_put_x(img1, l, hraw[s], valid, g);
+      tt_put_rows(img1, l, hraw[s], valid, g);
       dh[s] = d;                                                            // gradient wrt a2 (the Dn residual is handled by the pre chain)
     }
   }
+  sb_colsum_flush(sRed + 320, bsum, c, g);
+  SB_STAMP(9);
   __syncthreads();
-  sb_dw_product(img0, img1, npair, a.dW1, a.db1, w, c, g);
+  sb_dw_product16(img0, img1, npair, a.dW1, w, c, g);
+  SB_STAMP(10);
   __syncthreads();
+  SB_STAMP(11);
   // ---- C: out_proj ; dW(out_proj) = dh^T o ; encoder: head classifier reverse joins dO ---------------------------------------------------
+  bsum = tt_zero();
   float dws[H][NT][4], dbs_acc[H];
 #pragma unroll
   for (int cc = 0; cc < H; ++cc) {
@@ -140,7 +173,8 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
     tt_put_rows(img0, l, dh[s], valid, g);
-    sb_put_x(img1, l, oraw[s], valid, g);
+    tt_put_rows(img1, l, oraw[s], valid, g);
+    if (valid) tt_add(bsum, dh[s]);
     TT dO = tt_gemm(tt_bfrags(dh[s]), wimg + 2 * TT_WIMG, c, g);
     if (cls) {
       // z[h][cc] = o_h . Ws[cc] + bs[cc], rec = log_softmax_cc(z): dz = drec - exp(rec) * sum_cc drec ; dO_h += dz Ws ; dWs += dz^T o_h ; dbs += dz
@@ -172,20 +206,15 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
     }
     tt_store((ENC ? a.out1 : a.out0) + (size_t)row * 64, dO, valid, g);
   }
+  sb_colsum_flush(sRed + 384, bsum, c, g);
+  SB_STAMP(12);
   __syncthreads();
-  sb_dw_product(img0, img1, npair, a.dW2, a.db2, w, c, g);
+  sb_dw_product16(img0, img1, npair, a.dW2, w, c, g);
+  SB_STAMP(13);
   if (ENC) {
     // per-lane partials over this wave's tokens -> workgroup sums in LDS -> one atomic per element
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float sg = tt_rowsum16(dgm.v[nt][r]), sb = tt_rowsum16(dbt.v[nt][r]);
-        if (c == 0) {
-          atomicAdd(sRed + 16 * nt + 4 * g + r, sg);
-          atomicAdd(sRed + 64 + 16 * nt + 4 * g + r, sb);
-        }
-      }
+    sb_colsum_flush(sRed, dgm, c, g);
+    sb_colsum_flush(sRed + 64, dbt, c, g);
     if (cls) {
 #pragma unroll
       for (int cc = 0; cc < H; ++cc) {
@@ -200,13 +229,19 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
         if (c == 0 && g == 0) atomicAdd(sRed + 192 + cc, sb);
       }
     }
-    __syncthreads();
-    const int t = threadIdx.x;
-    if (t < 64) atomicAdd(a.dgamma + t, sRed[t]);
-    else if (t < 128) atomicAdd(a.dbeta + t - 64, sRed[t]);
-    else if (cls && t < 192) atomicAdd(a.dWs + t - 128, sRed[t]);
-    else if (cls && t < 192 + H) atomicAdd(a.dbs + t - 192, sRed[t]);
   }
+  __syncthreads();
+  {
+    const int t = threadIdx.x;
+    if (t < 64) { if (ENC) atomicAdd(a.dgamma + t, sRed[t]); }
+    else if (t < 128) { if (ENC) atomicAdd(a.dbeta + t - 64, sRed[t]); }
+    else if (t < 192) { if (cls) atomicAdd(a.dWs + t - 128, sRed[t]); }
+    else if (t < 192 + H) { if (cls) atomicAdd(a.dbs + t - 192, sRed[t]); }
+    else if (t >= 256 && t < 320) atomicAdd(a.db0 + t - 256, sRed[t]);
+    else if (t >= 320 && t < 384) atomicAdd(a.db1 + t - 320, sRed[t]);
+    else if (t >= 384 && t < 448) atomicAdd(a.db2 + t - 384, sRed[t]);
+  }
+  SB_STAMP(14);
 }
 
 // W0 = enc_attn Wq, W1 = slf_attn.out_proj, W2 = enc_attn Wk, W3 = enc_attn Wv ; dqkv = dq2 (ld lddqkv), xin = a1, o = o1, dkv2 (B*L x 128),
@@ -218,34 +253,47 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
   __bf16* wimg = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* img0 = reinterpret_cast<__bf16*>(smem_raw + Lds::wbytes);
   __bf16* img1 = reinterpret_cast<__bf16*>(smem_raw + Lds::wbytes + Lds::ibytes);
+  float* sRed = reinterpret_cast<float*>(smem_raw + Lds::wbytes + 2 * Lds::ibytes + 64);   // the four bias gradients
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16, npair = (L + 31) / 32;
   sp_replica(a);
-  {
-    const float* const ws4[4] = {a.W0, a.W1, a.W2, a.W3};
-    sp_prologue<4>(a, ws4, wimg, img0);
+  const float* const ws4[4] = {a.W0, a.W1, a.W2, a.W3};
+  const SbImgRegs<4> wr = sp_wload<4>(a, ws4);
+  TT dqa[2], a1a[2], oraw[2];             // phase A's activations are requested right behind the weight images (see k_seqtt_post_bwd)
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = tile >= 0 && l < L;
+    dqa[s] = tt_load(a.dqkv + (size_t)row * a.lddqkv, valid, g);
+    a1a[s] = tt_load_saved(a.xin, row, valid, g, a.saved_bf16);
+    oraw[s] = tt_load_saved(a.o, row, valid, g, a.saved_bf16);
   }
+  sp_zero_images(img0);
+  if (threadIdx.x < 256) sRed[threadIdx.x] = 0.f;
+  sb_img_store<4>(wimg, wr);
   __syncthreads();
   // ---- A: cross-attention query projection: da1 = dq2 Wq ; dWq = dq2^T a1 ----------------------------------------------------------
-  TT da1[2], oraw[2];
+  TT da1[2];
+  TT bsum = tt_zero();
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile(s, w, ntiles);
     if (tile < 0) continue;
-    const int l = tile * 16 + c, row = b * L + l;
+    const int l = tile * 16 + c;
     const bool valid = l < L;
-    const TT dq = tt_load(a.dqkv + (size_t)row * a.lddqkv, valid, g);
-    const TT a1 = tt_load_saved(a.xin, row, valid, g, a.saved_bf16);
-    oraw[s] = tt_load_saved(a.o, row, valid, g, a.saved_bf16);
-    tt_put_rows(img0, l, dq, valid, g);
-    sb_put_x(img1, l, a1, valid, g);
-    da1[s] = tt_gemm(tt_bfrags(dq), wimg, c, g);
+    tt_put_rows(img0, l, dqa[s], valid, g);
+    tt_put_rows(img1, l, a1a[s], valid, g);
+    da1[s] = tt_gemm(tt_bfrags(dqa[s]), wimg, c, g);
+    tt_add(bsum, dqa[s]);                                                   // zero rows for absent tokens (loaded as zeros)
   }
+  sb_colsum_flush(sRed, bsum, c, g);
   __syncthreads();
-  sb_dw_product(img0, img1, npair, a.dW0, a.db0, w, c, g);
+  sb_dw_product16(img0, img1, npair, a.dW0, w, c, g);
   __syncthreads();
   // ---- B: self-attention out_proj: dO1 = da1 Wo1 ; dWo1 = da1^T o1 --------------------------------------------------------------------
   TT dk[2], fx[2];
+  bsum = tt_zero();
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile(s, w, ntiles);
@@ -255,14 +303,17 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
     dk[s] = tt_load(a.dkv2 + (size_t)row * 128, valid, g);
     fx[s] = tt_load(a.f + (size_t)row * 64, valid, g);
     tt_put_rows(img0, l, da1[s], valid, g);
-    sb_put_x(img1, l, oraw[s], valid, g);
+    tt_put_rows(img1, l, oraw[s], valid, g);
+    tt_add(bsum, da1[s]);
     tt_store(a.out0 + (size_t)row * 64, tt_gemm(tt_bfrags(da1[s]), wimg + TT_WIMG, c, g), valid, g);
   }
+  sb_colsum_flush(sRed + 64, bsum, c, g);
   __syncthreads();
-  sb_dw_product(img0, img1, npair, a.dW1, a.db1, w, c, g);
+  sb_dw_product16(img0, img1, npair, a.dW1, w, c, g);
   __syncthreads();
   // ---- C: cross-attention keys: df = dk2 Wk ; dWk = dk2^T f -----------------------------------------------------------------------------
   TT df[2], dv[2];
+  bsum = tt_zero();
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile(s, w, ntiles);
@@ -271,13 +322,16 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
     const bool valid = l < L;
     dv[s] = tt_load(a.dkv2 + (size_t)row * 128 + 64, valid, g);
     tt_put_rows(img0, l, dk[s], valid, g);
-    sb_put_x(img1, l, fx[s], valid, g);
+    tt_put_rows(img1, l, fx[s], valid, g);
+    tt_add(bsum, dk[s]);
     df[s] = tt_gemm(tt_bfrags(dk[s]), wimg + 2 * TT_WIMG, c, g);
   }
+  sb_colsum_flush(sRed + 128, bsum, c, g);
   __syncthreads();
-  sb_dw_product(img0, img1, npair, a.dW2, a.db2, w, c, g);
+  sb_dw_product16(img0, img1, npair, a.dW2, w, c, g);
   __syncthreads();
   // ---- D: cross-attention values (the X image still holds f) --------------------------------------------------------------------------
+  bsum = tt_zero();
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile(s, w, ntiles);
@@ -285,13 +339,20 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
     tt_put_rows(img0, l, dv[s], valid, g);
+    tt_add(bsum, dv[s]);
     tt_add(df[s], tt_gemm(tt_bfrags(dv[s]), wimg + 3 * TT_WIMG, c, g));
     float* dst = a.out1 + (size_t)row * 64;
     if (a.acc1) tt_add(df[s], tt_load(dst, valid, g));
     tt_store(dst, df[s], valid, g);
   }
+  sb_colsum_flush(sRed + 192, bsum, c, g);
   __syncthreads();
-  sb_dw_product(img0, img1, npair, a.dW3, a.db3, w, c, g);
+  sb_dw_product16(img0, img1, npair, a.dW3, w, c, g);
+  {
+    const int t = threadIdx.x;
+    float* const dst[4] = {a.db0, a.db1, a.db2, a.db3};
+    if (t < 256) atomicAdd(dst[t >> 6] + (t & 63), sRed[t]);
+  }
 }
 
 }  // namespace adt

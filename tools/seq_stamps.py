@@ -7,7 +7,7 @@ import os
 import sys
 
 MODE = sys.argv[1] if len(sys.argv) > 1 else "fwd"          # fwd: fused encoder forward ; attn: per-sequence attention backward
-os.environ["ADT_SEQ_STAMPS"] = "2" if MODE == "attn" else "1"
+os.environ["ADT_SEQ_STAMPS"] = {"attn": "2", "post": "3"}.get(MODE, "1")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import numpy as np  # noqa: E402
@@ -22,7 +22,7 @@ ids = [m._ids(a) for a in batch]
 from adt_amd.sasrec.trainer import FusedTrainer  # noqa: E402
 tr = FusedTrainer(m, bench.CFG["lambdas1"], bench.CFG["lambdas2"], weight_decay=1e-3, seed=3)
 for _ in range(3):
-    if MODE == "attn":
+    if MODE in ("attn", "post"):
         tr.step(*batch)
     else:
         m.run_forward(*ids, 256, True)
@@ -35,8 +35,10 @@ t0 = t[:, 0].min()
 names = ["start", "staged", "pre0", "pre1", "barrier", "attn0", "oproj0", "ffn0", "attn1", "oproj1", "ffn1"]
 if MODE == "attn":
     names = ["start", "staged", "recomp", "passA", "passB", "dW", "dx"]       # the fused attention-block backward (last launch of the step)
+if MODE == "post":      # k_seqtt_post_bwd<., true> (encoder), last launch of the step
+    names = ["start", "issued", "staged", "loadsA", "slot0A", "endA", "bar", "dW2", "bar", "endB", "dW1", "bar", "endC", "dWo", "end"]
 print("wave " + " ".join("%8s" % n for n in names))
-if MODE != "attn":
+if MODE == "fwd":
     print("prologue (issue loads, zero-fill, image stores, vector stores):", [[int(t[w, k] - t0) for k in (11, 12, 13, 14)] for w in (0, 4)])
 for w in range(8):
     print("%4d " % w + " ".join("%8d" % (t[w, k] - t0 if t[w, k] else -1) for k in range(len(names))))
