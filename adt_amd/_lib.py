@@ -80,6 +80,7 @@ SIGNATURES = {
     "adt_sasrec_workspace_floats": (_L, [_CP, _I]),
     "adt_sasrec_ws_offset": (_L, [_CP, _I, _I, _I]),
     "adt_sasrec_forward": (_I, [_CP, _P, _P, _P, _P, _P, _P, _I, _I, _P, _U, _P]),
+    "adt_sasrec_probe_dec_layer_fwd": (_I, [_CP, _P, _P, _P, _I, _I, _P, _U, _I, _P]),
     "adt_sasrec_loss_seed": (_I, [_CP, _P, _P, _I, _P, _P, _P]),
     "adt_sasrec_backward": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _U, _I, _P]),
     "adt_sasrec_predict": (_I, [_CP, _P, _P, _P, _P, _I, _I, _P, _P, _P]),

@@ -43,5 +43,8 @@ int adt_attn_bwd_saved_bf16(const void* Q, int ldq, const void* K, int ldk, cons
 // per-sequence backward of the token-wise chains (adt_seqpost_tt.cuh); enc: 1 encoder post chain, 0 decoder post chain; 0 launched, 1 not covered
 int adt_launch_seq_post_bwd(int hd, int enc, const adt::BwdChainArgs& a, void* stream);
 int adt_launch_seq_mid_bwd(int hd, const adt::BwdChainArgs& a, void* stream);      // dec_mid + kv chains in one launch
+// private per-workgroup partials of the 64 x 64 weight gradients instead of atomics (adt_seqbwd_tt.cuh: sb_dw_tiles) and their sum
+int adt_seq_partials(int prec, int L, int d, int hd);
+int adt_dwpart_reduce(float* G, const float* part, size_t stride, int nwg, const int* slots, const int* offs, int nslots, void* stream);
 namespace adt { struct SeqBwdArgs; }
 int adt_launch_seq_attn_pre_bwd(int hd, int dec, const adt::SeqBwdArgs& a, void* stream);     // 0 launched, 1 not covered, < 0 error

@@ -65,6 +65,7 @@ struct WS {
   int64_t rep, rep_stride;                                              // item-table gradient replicas
   int64_t prep, prep_stride;                                            // replicas of every other parameter gradient
   int64_t wpack;                                                        // pre-packed bf16 weight images (3 floats per parameter float)
+  int64_t part, part_stride;                                            // per-sequence partials of the 64 x 64 weight gradients (bf16 mode, d = 64)
   int64_t total;
 };
 
@@ -105,6 +106,8 @@ void make_ws(const adt_sasrec_cfg* c, int B, WS* w) {
     w->prep = take(NREPP * w->prep_stride);
     w->wpack = take(3 * w->prep_stride);
   }
+  w->part_stride = (c->prec == ADT_PREC_BF16 && c->hidden == 64) ? (int64_t)w->nl * 16 * 4096 : 0;
+  w->part = take((int64_t)B * w->part_stride);
   w->total = o;
 }
 
@@ -152,6 +155,33 @@ int pack_weights(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const f
     offs[n++] = (int)(lo.dec(i, D_C1W) - base); offs[n++] = (int)(lo.dec(i, D_C2W) - base);
   }
   return adt_pack_wimg(P + base, ws + w.wpack, offs, n, st);
+}
+
+// slot of a 64 x 64 block in a workgroup's partial area: the order of pack_weights
+enum { PS_E_IN = 0, PS_E_O = 3, PS_E_C1 = 4, PS_E_C2 = 5, PS_D_SIN = 6, PS_D_EIN = 9, PS_D_SO = 12, PS_D_EO = 13, PS_D_C1 = 14, PS_D_C2 = 15 };
+
+// sums the partials of the encoder (enc = true) and / or decoder (dec = true) blocks of every layer into G
+int reduce_partials(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, float* G, float* ws, bool enc, bool dec, void* st) {
+  int slots[256], offs[256];
+  int n = 0;
+  const int dd = c->hidden * c->hidden;
+  for (int i = 0; i < c->num_layers; ++i) {
+    if (enc) {
+      for (int j = 0; j < 3; ++j) { slots[n] = 16 * i + PS_E_IN + j; offs[n++] = (int)(lo.enc(i, E_INW) + j * dd); }
+      slots[n] = 16 * i + PS_E_O; offs[n++] = (int)lo.enc(i, E_OW);
+      slots[n] = 16 * i + PS_E_C1; offs[n++] = (int)lo.enc(i, E_C1W);
+      slots[n] = 16 * i + PS_E_C2; offs[n++] = (int)lo.enc(i, E_C2W);
+    }
+    if (dec) {
+      for (int j = 0; j < 3; ++j) { slots[n] = 16 * i + PS_D_SIN + j; offs[n++] = (int)(lo.dec(i, D_SINW) + j * dd); }
+      for (int j = 0; j < 3; ++j) { slots[n] = 16 * i + PS_D_EIN + j; offs[n++] = (int)(lo.dec(i, D_EINW) + j * dd); }
+      slots[n] = 16 * i + PS_D_SO; offs[n++] = (int)lo.dec(i, D_SOW);
+      slots[n] = 16 * i + PS_D_EO; offs[n++] = (int)lo.dec(i, D_EOW);
+      slots[n] = 16 * i + PS_D_C1; offs[n++] = (int)lo.dec(i, D_C1W);
+      slots[n] = 16 * i + PS_D_C2; offs[n++] = (int)lo.dec(i, D_C2W);
+    }
+  }
+  return adt_dwpart_reduce(G, ws + w.part, (size_t)w.part_stride, (int)w.B, slots, offs, n, st);
 }
 
 adt::SeqBwdArgs seq_bwd_args(int L, int B, int H, const int32_t* ids, float p, const uint32_t* seed, uint32_t site, uint32_t b_offset, int hd) {
@@ -253,6 +283,31 @@ int encoder_forward(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, cons
   return 0;
 }
 
+// one decoder layer, fused forward: one launch, one workgroup per sequence (adt_seqfwd_tt.cuh / adt_seqfwd.cuh)
+int dec_layer_seq_fwd(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const float* P, float* ws, const int32_t* dec, float p,
+                      const uint32_t* seed, uint32_t b_offset, int i, void* st) {
+  const int d = (int)w.d, H = (int)w.H, hd = d / H, L = (int)w.L, B_ = (int)w.B, prec = c->prec;
+  const int64_t Td = up64(w.T * w.d);
+  float* x = ws + w.dec_x + i * Td;
+  float* y = ws + w.dec_x + (i + 1) * Td;
+  float* base = ws + i * w.d_stride;   // d_* offsets are absolute for layer 0
+  float *dn = base + w.d_dn, *qkv = base + w.d_qkv, *o1 = base + w.d_o1, *lse1 = base + w.d_lse1, *a1 = base + w.d_a1,
+        *q2 = base + w.d_q2, *kv2 = base + w.d_kv2, *o2 = base + w.d_o2, *lse2 = base + w.d_lse2, *a2 = base + w.d_a2, *u = base + w.d_u;
+  adt::SeqFwdArgs a = seq_args(L, B_, H, dec, p, seed, b_offset, hd);
+  a.x = i == 0 ? nullptr : x; a.E = P + lo.item(); a.P = P + lo.posw(); a.emb_scale = sqrtf((float)d); a.site_emb = SITE_EMB_DEC;
+  a.site_attn = dec_site(i, 0); a.site_attn2 = dec_site(i, 1); a.site1 = dec_site(i, 2); a.site2 = dec_site(i, 3);
+  a.gamma = P + lo.dec(i, D_LNW); a.beta = P + lo.dec(i, D_LNB); a.Win = P + lo.dec(i, D_SINW); a.bin = P + lo.dec(i, D_SINB);
+  a.Wo = P + lo.dec(i, D_SOW); a.bo = P + lo.dec(i, D_SOB); a.f = ws + w.f; a.Win2 = P + lo.dec(i, D_EINW); a.bin2 = P + lo.dec(i, D_EINB);
+  a.Wo2 = P + lo.dec(i, D_EOW); a.bo2 = P + lo.dec(i, D_EOB);
+  a.W1 = P + lo.dec(i, D_C1W); a.b1 = P + lo.dec(i, D_C1B); a.W2 = P + lo.dec(i, D_C2W); a.b2 = P + lo.dec(i, D_C2B);
+  a.x_out = x; a.xn = dn; a.qkv = qkv; a.o = o1; a.lse = lse1; a.mask = reinterpret_cast<uint32_t*>(base + w.d_mask1);
+  a.a1 = a1; a.q2 = q2; a.kv2 = kv2; a.o2 = o2; a.lse2 = lse2; a.mask2 = reinterpret_cast<uint32_t*>(base + w.d_mask2);
+  a.h = a2; a.u = u; a.y = y;
+  a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack;
+  if (adt_seq_lean(prec, L, d, hd)) { a.xn = nullptr; a.qkv = nullptr; a.saved_bf16 = 1; }
+  return adt_launch_seq_dec_fwd(hd, a, st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -322,19 +377,7 @@ int adt_sasrec_forward(const adt_sasrec_cfg* c, const float* P, float* ws, const
     const float* einw = P + lo.dec(i, D_EINW);
     const float* einb = P + lo.dec(i, D_EINB);
     if (adt_seq_supported(prec, L, d, hd)) {   // the whole layer in one launch, one workgroup per sequence (adt_seqfwd.cuh)
-      adt::SeqFwdArgs a = seq_args(L, B_, H, dec, p, seed, b_offset, hd);
-      a.x = i == 0 ? nullptr : x; a.E = P + lo.item(); a.P = P + lo.posw(); a.emb_scale = sqrtf((float)d); a.site_emb = SITE_EMB_DEC;
-      a.site_attn = dec_site(i, 0); a.site_attn2 = dec_site(i, 1); a.site1 = dec_site(i, 2); a.site2 = dec_site(i, 3);
-      a.gamma = P + lo.dec(i, D_LNW); a.beta = P + lo.dec(i, D_LNB); a.Win = sinw; a.bin = sinb;
-      a.Wo = P + lo.dec(i, D_SOW); a.bo = P + lo.dec(i, D_SOB); a.f = f; a.Win2 = einw; a.bin2 = einb;
-      a.Wo2 = P + lo.dec(i, D_EOW); a.bo2 = P + lo.dec(i, D_EOB);
-      a.W1 = P + lo.dec(i, D_C1W); a.b1 = P + lo.dec(i, D_C1B); a.W2 = P + lo.dec(i, D_C2W); a.b2 = P + lo.dec(i, D_C2B);
-      a.x_out = x; a.xn = dn; a.qkv = qkv; a.o = o1; a.lse = lse1; a.mask = reinterpret_cast<uint32_t*>(base + w.d_mask1);
-      a.a1 = a1; a.q2 = q2; a.kv2 = kv2; a.o2 = o2; a.lse2 = lse2; a.mask2 = reinterpret_cast<uint32_t*>(base + w.d_mask2);
-      a.h = a2; a.u = u; a.y = y;
-      a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack;
-      if (adt_seq_lean(prec, L, d, hd)) { a.xn = nullptr; a.qkv = nullptr; a.saved_bf16 = 1; }
-      CK(adt_launch_seq_dec_fwd(hd, a, st));
+      CK(dec_layer_seq_fwd(c, lo, w, P, ws, dec, p, seed, b_offset, i, st));
       continue;
     }
     {  // [gather] ; D = LN(x) ; qkv = D Win^T + b                          (sasrec/model.py:53-59, modules.py:668-670)
@@ -366,6 +409,21 @@ int adt_sasrec_forward(const adt_sasrec_cfg* c, const float* P, float* ws, const
     }
   }
   return 0;
+}
+
+// Measurement hook (bench.py roofline): launches ONLY the fused forward of decoder layer `layer` on the workspace of a completed
+// adt_sasrec_forward of the same batch (its inputs -- log_feats, the layer input, the packed weight images -- are read from there).
+int adt_sasrec_probe_dec_layer_fwd(const adt_sasrec_cfg* c, const float* P, float* ws, const int32_t* dec, int B, int training,
+                                   const uint32_t* seed, uint32_t b_offset, int layer, void* st) {
+  CK(check_cfg(c));
+  Layout lo;
+  make_layout(c, &lo);
+  WS w;
+  make_ws(c, B, &w);
+  const int d = (int)w.d, hd = d / (int)w.H;
+  if (layer < 0 || layer >= c->num_layers) return adt_set_error("probe: layer %d", layer);
+  if (!adt_seq_supported(c->prec, (int)w.L, d, hd)) return adt_set_error("probe: the fused decoder layer does not cover this configuration");
+  return dec_layer_seq_fwd(c, lo, w, P, ws, dec, training ? c->dropout : 0.f, seed, b_offset, layer, st);
 }
 
 int adt_sasrec_loss_seed(const adt_sasrec_cfg* c, float* ws, const int32_t* pos, int B, const float* lambdas1,
@@ -414,6 +472,10 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   const float* f = ws + w.f;
   const bool use_seq = adt_seq_supported(prec, L, d, hd) != 0;
   const int lean = adt_seq_lean(prec, L, d, hd);      // what the forward of this step saved (same predicate, same process)
+  // weight gradients through private per-sequence partials + one ordered sum instead of float atomics (adt_seqbwd_tt.cuh: sb_dw_tiles)
+  const bool parts = w.part_stride > 0 && adt_seq_partials(prec, L, d, hd) != 0;
+  auto PART = [&](int layer, int slot) { return parts ? ws + w.part + (int64_t)(16 * layer + slot) * 4096 : nullptr; };
+  const char* const no_fallback = "backward: shape L=%d hd=%d left the per-sequence kernels although the partial-gradient path was chosen";
   if (phase == 0 || phase == 1) {
     // d log_feats (overwrites g_f) and item-table rows of pos/neg      (sasrec/model.py:72-76)
     // item-table replicas and parameter replicas are adjacent in the workspace: one fill
@@ -445,8 +507,10 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.dW0 = Gq + lo.dec(i, D_C2W); a.dW1 = Gq + lo.dec(i, D_C1W); a.dW2 = Gq + lo.dec(i, D_EOW);
         a.db0 = Gq + lo.dec(i, D_C2B); a.db1 = Gq + lo.dec(i, D_C1B); a.db2 = Gq + lo.dec(i, D_EOB);
         a.out0 = s1;
+        a.part[0] = PART(i, PS_D_C2); a.part[1] = PART(i, PS_D_C1); a.part[2] = PART(i, PS_D_EO); a.part_stride = (size_t)w.part_stride;
         const int rc = use_seq ? adt_launch_seq_post_bwd(hd, 0, a, st) : 1;
         if (rc < 0) return rc;
+        if (rc && parts) return adt_set_error(no_fallback, L, hd);
         if (rc) CK(adt_launch_bwdchain(prec, 1, a, st));
       }
       // cross attention core: dq2 -> s5, dkv2 -> s4
@@ -466,8 +530,11 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.dW0 = geinw; a.dW1 = Gq + lo.dec(i, D_SOW); a.dW2 = geinw + dd; a.dW3 = geinw + 2 * dd;
         a.db0 = geinb; a.db1 = Gq + lo.dec(i, D_SOB); a.db2 = geinb + d; a.db3 = geinb + 2 * d;
         a.out0 = s1; a.out1 = gf; a.acc1 = 1;
+        a.part[0] = PART(i, PS_D_EIN); a.part[1] = PART(i, PS_D_SO); a.part[2] = PART(i, PS_D_EIN + 1); a.part[3] = PART(i, PS_D_EIN + 2);
+        a.part_stride = (size_t)w.part_stride;
         mid_rc = adt_launch_seq_mid_bwd(hd, a, st);
         if (mid_rc < 0) return mid_rc;
+        if (mid_rc && parts) return adt_set_error(no_fallback, L, hd);
       }
       if (mid_rc) {
         {  // q2 = a1 Wq^T, a1 = o1 Wo1^T  -> dO1 (s1)
@@ -494,6 +561,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.dO = s1; a.o = o1; a.lse = lse1; a.mask = reinterpret_cast<const uint32_t*>(base + w.d_mask1); a.dres = gy;
         a.gx = gx; a.acc = i > 0 ? 1 : 0; a.dWin = gsinw; a.dbin = gsinb; a.dgamma = Gq + lo.dec(i, D_LNW); a.dbeta = Gq + lo.dec(i, D_LNB);
         a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride; a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack; a.saved_bf16 = lean;
+        a.part = PART(i, PS_D_SIN); a.part_stride = (size_t)w.part_stride;
         const int rc = adt_launch_seq_attn_pre_bwd(hd, 1, a, st);
         if (rc < 0) return rc;
         if (rc != 0 && lean) return adt_set_error("backward: the lean forward needs the fused attention-block backward (L=%d hd=%d)", L, hd);
@@ -520,6 +588,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
     if (phase == 1) {  // two-phase (data-parallel) use: fold what has been scattered so far, the replicas restart at zero
       CK(adt_replica_reduce(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, NREP, w.rep_stride, st));
       CK(adt_replica_reduce(G + dec_begin, Gq + dec_begin, lo.total - dec_begin, NREPP, w.prep_stride, st));
+      if (parts) CK(reduce_partials(c, lo, w, G, ws, false, true, st));
     }
   }
   if (phase == 0 || phase == 2) {
@@ -553,8 +622,10 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
           a.rec = rec; a.drec = ws + w.g_rec + i * recsz; a.Ws = P + lo.enc(i, E_SW); a.dWs = Gq + lo.enc(i, E_SW);
           a.dbs = Gq + lo.enc(i, E_SB); a.H = H;
         }
+        a.part[0] = PART(i, PS_E_C2); a.part[1] = PART(i, PS_E_C1); a.part[2] = PART(i, PS_E_O); a.part_stride = (size_t)w.part_stride;
         const int rc = use_seq ? adt_launch_seq_post_bwd(hd, 1, a, st) : 1;
         if (rc < 0) return rc;
+        if (rc && parts) return adt_set_error(no_fallback, L, hd);
         if (rc) CK(adt_launch_bwdchain(prec, which, a, st));
       }
       if (H > 4)   // wider classifiers: separate kernel
@@ -567,6 +638,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.dO = s1; a.o = o; a.lse = lse; a.mask = reinterpret_cast<const uint32_t*>(base + w.e_mask); a.dres = s5;
         a.gx = gx; a.acc = 1; a.dWin = ginw; a.dbin = ginb; a.dgamma = Gq + lo.enc(i, E_LN1W); a.dbeta = Gq + lo.enc(i, E_LN1B);
         a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride; a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack; a.saved_bf16 = lean;
+        a.part = PART(i, PS_E_IN); a.part_stride = (size_t)w.part_stride;
         const int rc = adt_launch_seq_attn_pre_bwd(hd, 0, a, st);
         if (rc < 0) return rc;
         if (rc != 0 && lean) return adt_set_error("backward: the lean forward needs the fused attention-block backward (L=%d hd=%d)", L, hd);
@@ -593,6 +665,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
     CK(adt_replica_reduce(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, NREP, w.rep_stride, st));
     if (phase == 0) CK(adt_replica_reduce(G + lo.posw(), Gq + lo.posw(), lo.total - lo.posw(), NREPP, w.prep_stride, st));
     else CK(adt_replica_reduce(G + lo.posw(), Gq + lo.posw(), dec_begin - lo.posw(), NREPP, w.prep_stride, st));
+    if (parts) CK(reduce_partials(c, lo, w, G, ws, true, phase == 0, st));
   }
   return 0;
 }

@@ -233,3 +233,53 @@ int adt_launch_seq_mid_bwd(int hd, const BwdChainArgs& a, void* stream) {
   static bool done = false;
   return seq_launch((const void*)k_seqtt_mid_bwd, SeqPostLds<4>::bytes, done, a.B, &a, (hipStream_t)stream, "seqtt_mid_bwd");
 }
+
+// ---- sum of the per-workgroup weight-gradient partials (adt_seqbwd_tt.cuh: sb_dw_tiles) --------------------------------------------
+// G[off[slot] + n * 64 + k] += sum_wg part[wg * stride + slot * 4096 + e], e = ((4 nt + kt) * 4 + r) * 64 + lane <-> n = 16 nt + 4 (lane >> 4) + r,
+// k = 16 kt + (lane & 15).  grid (slots * 4, NSPLIT): a thread owns four consecutive elements (one float4 of the partial layout = four
+// consecutive k of one row n) and a contiguous range of workgroups, summed in ascending order; the NSPLIT range sums meet in G by atomics.
+struct PartReduceArgs {
+  float* G; const float* part; size_t stride; int nwg; int nslots;
+  int slot[256]; int off[256];      // slot index inside a workgroup's partial ; float offset of the 64 x 64 block in G
+};
+constexpr int PR_SPLIT = 4;
+__global__ __launch_bounds__(256) void k_dwpart_reduce(PartReduceArgs a) {
+  const int j = blockIdx.x >> 2, e4 = ((blockIdx.x & 3) * 256 + threadIdx.x) * 4;
+  const int per = (a.nwg + PR_SPLIT - 1) / PR_SPLIT, w0 = blockIdx.y * per, w1 = min(a.nwg, w0 + per);
+  const float* p = a.part + (size_t)a.slot[j] * 4096 + e4;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  int wg = w0;
+  for (; wg + 8 <= w1; wg += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(wg + u) * a.stride);
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      s0.x += v[u].x; s0.y += v[u].y; s0.z += v[u].z; s0.w += v[u].w;
+      s1.x += v[u + 1].x; s1.y += v[u + 1].y; s1.z += v[u + 1].z; s1.w += v[u + 1].w;
+    }
+  }
+  for (; wg < w1; ++wg) {
+    const float4 v = *reinterpret_cast<const float4*>(p + (size_t)wg * a.stride);
+    s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+  }
+  const int tile = e4 >> 8, r = (e4 >> 6) & 3, lane = e4 & 63;
+  float* dst = a.G + a.off[j] + (16 * (tile >> 2) + 4 * (lane >> 4) + r) * 64 + 16 * (tile & 3) + (lane & 15);
+  atomicAdd(dst, s0.x + s1.x); atomicAdd(dst + 1, s0.y + s1.y); atomicAdd(dst + 2, s0.z + s1.z); atomicAdd(dst + 3, s0.w + s1.w);
+}
+
+int adt_dwpart_reduce(float* G, const float* part, size_t stride, int nwg, const int* slots, const int* offs, int nslots, void* stream) {
+  if (nslots < 1 || nslots > 256) return adt_set_error("dwpart_reduce: %d slots", nslots);
+  PartReduceArgs a;
+  a.G = G; a.part = part; a.stride = stride; a.nwg = nwg; a.nslots = nslots;
+  for (int i = 0; i < nslots; ++i) { a.slot[i] = slots[i]; a.off[i] = offs[i]; }
+  hipLaunchKernelGGL(k_dwpart_reduce, dim3(nslots * 4, PR_SPLIT), dim3(256), 0, (hipStream_t)stream, a);
+  return seq_check("dwpart_reduce");
+}
+
+// every block-weight gradient of the backward can go through private partials: all five per-sequence backward kernels cover the shape
+int adt_seq_partials(int prec, int L, int d, int hd) {
+  static int on = -1;
+  if (on < 0) on = env_on("ADT_SEQ_PARTIALS") && env_on("ADT_SEQ_POST_BWD");
+  return on && adt_seq_lean(prec, L, d, hd);
+}

@@ -17,6 +17,7 @@ struct SeqBwdArgs {
   const float* dres;                  // encoder: gradient wrt LN(x) from the residual path ; decoder: gradient wrt the layer output (masked here)
   float* gx; int acc;                 // gradient wrt x (acc: add to what is there)
   float* dWin; float* dbin; float* dgamma; float* dbeta;     // accumulators (global float atomics)
+  float* part; size_t part_stride;    // non-null: private partials of dWin (3 x 4096 floats at part + workgroup * part_stride) instead of atomics
   int nrep; size_t rep_stride;        // parameter-gradient replicas (adt_bwdchain_args.h): workgroup b adds into replica b % nrep
   const float* wp_base; const void* wp_img;        // pre-packed weight images (slot-ordered: + 2 plain, + 3 transposed)
   int saved_bf16;                     // `o` holds bf16 rows (written by the transposed-chain forward in its lean mode)

@@ -116,8 +116,15 @@ ADT_DEVICE_INLINE TT tt_ln_bwd(const TT& dy, const TTLn& st, const float* gamma,
 // 16 output tiles, exactly two per wave -- (nt0, kt) and (nt0 + 2, kt), which share the X
 // fragments -- and the token loop unrolled (NP pairs of 16-token tiles; image rows beyond the sequence are zero).  A 20-tile form with a ones column in the
 // X image for the bias gradient gave four waves a third tile: 10k cycles per product on the critical path against 3k for the two-tile waves (profiles/r02_stamps_post.txt).
+//
+// Where the result goes.  part == nullptr: float atomics into dW (a replica of the gradient).  They execute at the memory side at
+// ~1.3 TB/s chip-wide (MI355X_MICROARCH.md, Global float atomics): 16 KB per product and workgroup is ~8k cycles during which the wave's
+// next vector-memory instruction cannot issue (profiles/r02_stamps_post.txt), ~100 us per training step over the 32 products of a
+// 2-layer model.  part != nullptr: this workgroup's PRIVATE 4,096-float partial of the block, written with plain 256-byte stores in
+// register order -- element ((tile * 4 + r) * 64 + lane), tile = 4 nt + kt -- and summed over the workgroups, in a fixed order, by
+// k_dwpart_reduce (adt_seq.hip).  Nothing is zeroed and the sum does not depend on timing.
 template <int NP>
-ADT_DEVICE_INLINE void sb_dw_tiles(const __bf16* sG, const __bf16* sX, float* dW, int w, int c, int g) {
+ADT_DEVICE_INLINE void sb_dw_tiles(const __bf16* sG, const __bf16* sX, float* dW, float* part, int w, int c, int g) {
   const int kt = w & 3, nt0 = w >> 2;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -126,15 +133,24 @@ ADT_DEVICE_INLINE void sb_dw_tiles(const __bf16* sG, const __bf16* sX, float* dW
     acc0 = mfma_bf16(acc0, tt_trfrag(sG, kp * 32, 16 * nt0, c, g), fx);
     acc1 = mfma_bf16(acc1, tt_trfrag(sG, kp * 32, 16 * (nt0 + 2), c, g), fx);
   }
+  if (part) {
+    const int lane = 16 * g + c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      part[(w * 4 + r) * 64 + lane] = acc0[r];              // tile 4 nt0 + kt == w
+      part[((w + 8) * 4 + r) * 64 + lane] = acc1[r];
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     atomicAdd(dW + (16 * nt0 + 4 * g + r) * 64 + 16 * kt + c, acc0[r]);
     atomicAdd(dW + (16 * (nt0 + 2) + 4 * g + r) * 64 + 16 * kt + c, acc1[r]);
   }
 }
-ADT_DEVICE_INLINE void sb_dw_product16(const __bf16* sG, const __bf16* sX, int npair, float* dW, int w, int c, int g) {
-  if (npair <= 4) sb_dw_tiles<4>(sG, sX, dW, w, c, g);
-  else sb_dw_tiles<SB_R / 32>(sG, sX, dW, w, c, g);
+ADT_DEVICE_INLINE void sb_dw_product16(const __bf16* sG, const __bf16* sX, int npair, float* dW, float* part, int w, int c, int g) {
+  if (npair <= 4) sb_dw_tiles<4>(sG, sX, dW, part, w, c, g);
+  else sb_dw_tiles<SB_R / 32>(sG, sX, dW, part, w, c, g);
 }
 // bias gradients (column sums of G over the tokens): per-lane sums of the tiles a wave holds, reduced over the 16 tokens of a lane row,
 // added to a 64-float LDS vector; the workgroup adds the vector to the global accumulator once, at its end
@@ -200,6 +216,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     const size_t off = (size_t)(blockIdx.x % a.nrep) * a.rep_stride;
     a.dWin += off; a.dbin += off; a.dgamma += off; a.dbeta += off;
   }
+  float* const part = a.part ? a.part + (size_t)blockIdx.x * a.part_stride : nullptr;      // three consecutive blocks: Wq, Wk, Wv
   SB_STAMP(0);
   // The weight images are requested first and P1's activations right behind them: every workgroup of the launch runs the same phase at
   // the same time, so HBM streams the activations while the prologue runs instead of idling through it (adt_seqpost_tt.cuh)
@@ -348,7 +365,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     sb_colsum_flush(sRed + 128, sq, c, g); sb_colsum_flush(sRed + 192, sk, c, g); sb_colsum_flush(sRed + 256, sv, c, g);
   }
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dWin, w, c, g);
+  sb_dw_product16(img0, img1, npair, a.dWin, part, w, c, g);
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -360,7 +377,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     if (!DEC) tt_put_rows(img1, l, tt_load(a.x + (size_t)row * 64, valid, g), valid, g);                  // encoder: k, v read the raw x
   }
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dWin + 4096, w, c, g);
+  sb_dw_product16(img0, img1, npair, a.dWin + 4096, part ? part + 4096 : nullptr, w, c, g);
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -370,7 +387,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     tt_put_rows(img0, l, dv[s], l < L, g);
   }
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dWin + 8192, w, c, g);
+  sb_dw_product16(img0, img1, npair, a.dWin + 8192, part ? part + 8192 : nullptr, w, c, g);
   SB_STAMP(5);
   // ---- P5: gradient of the block input ----------------------------------------------------------------------------------------
   TT dgm = tt_zero(), dbt = tt_zero();

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   SB_STAMP(5);
   __syncthreads();
   SB_STAMP(6);
-  sb_dw_product16(img0, img1, npair, a.dW0, w, c, g);
+  sb_dw_product16(img0, img1, npair, a.dW0, a.part[0] ? a.part[0] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
   SB_STAMP(7);
   __syncthreads();
   SB_STAMP(8);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   sb_colsum_flush(sRed + 320, bsum, c, g);
   SB_STAMP(9);
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dW1, w, c, g);
+  sb_dw_product16(img0, img1, npair, a.dW1, a.part[1] ? a.part[1] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
   SB_STAMP(10);
   __syncthreads();
   SB_STAMP(11);
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   sb_colsum_flush(sRed + 384, bsum, c, g);
   SB_STAMP(12);
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dW2, w, c, g);
+  sb_dw_product16(img0, img1, npair, a.dW2, a.part[2] ? a.part[2] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
   SB_STAMP(13);
   if (ENC) {
     // per-lane partials over this wave's tokens -> workgroup sums in LDS -> one atomic per element
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
   }
   sb_colsum_flush(sRed, bsum, c, g);
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dW0, w, c, g);
+  sb_dw_product16(img0, img1, npair, a.dW0, a.part[0] ? a.part[0] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
   __syncthreads();
   // ---- B: self-attention out_proj: dO1 = da1 Wo1 ; dWo1 = da1^T o1 --------------------------------------------------------------------
   TT dk[2], fx[2];
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
   }
   sb_colsum_flush(sRed + 64, bsum, c, g);
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dW1, w, c, g);
+  sb_dw_product16(img0, img1, npair, a.dW1, a.part[1] ? a.part[1] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
   __syncthreads();
   // ---- C: cross-attention keys: df = dk2 Wk ; dWk = dk2^T f -----------------------------------------------------------------------------
   TT df[2], dv[2];
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
   }
   sb_colsum_flush(sRed + 128, bsum, c, g);
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dW2, w, c, g);
+  sb_dw_product16(img0, img1, npair, a.dW2, a.part[2] ? a.part[2] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
   __syncthreads();
   // ---- D: cross-attention values (the X image still holds f) --------------------------------------------------------------------------
   bsum = tt_zero();
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
   }
   sb_colsum_flush(sRed + 192, bsum, c, g);
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dW3, w, c, g);
+  sb_dw_product16(img0, img1, npair, a.dW3, a.part[3] ? a.part[3] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
   {
     const int t = threadIdx.x;
     float* const dst[4] = {a.db0, a.db1, a.db2, a.db3};

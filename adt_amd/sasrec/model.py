@@ -161,6 +161,11 @@ class SASRecADT(torch.nn.Module):
         _lib.check(self.lib.adt_sasrec_forward(ctypes.byref(self.cfg), _ptr(self.flat), _ptr(ws), _ptr(seq), _ptr(dec), _ptr(pos),
                                                _ptr(neg), B, int(training), _ptr(self._seed), b_offset, self._stream()), "sasrec_forward")
 
+    def probe_dec_layer_forward(self, dec, B, layer, training=True, b_offset=0):
+        """Measurement hook: only the fused forward launch of decoder layer `layer`, on the workspace of a completed run_forward."""
+        _lib.check(self.lib.adt_sasrec_probe_dec_layer_fwd(ctypes.byref(self.cfg), _ptr(self.flat), _ptr(self.workspace(B)), _ptr(dec), B,
+                                                           int(training), _ptr(self._seed), b_offset, layer, self._stream()), "probe_dec_layer_fwd")
+
     def run_loss_seed(self, pos, B, lambdas1, lambdas2):
         nl = self.num_layers
         l1 = (ctypes.c_float * nl)(*[float(x) for x in lambdas1])

@@ -117,13 +117,15 @@ def _time_us(fn, reps=20, warm=3):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-def roofline_probe(model, trainer, B, seq_per_s):
-    """`roofline` of the bench line.  The object itself describes the DOMINANT kernel of the step (attention backward, causal,
-    hd = 32: profiles/): algorithmic bytes per launch = B*H (b,h) units x 8 tensors (q, k, v, o, dO in; dQ, dK, dV out) x L*hd*4 B
-    (fp32 activations as stored today) / its average launch duration, measured live with HIP events on the launch stream on
-    step-shaped buffers.  `kernels` adds what north_star asks for by name: achieved HBM GB/s of the embedding gather and MFMA
-    utilisation of the attention kernels (causal-aware FLOPs, SURVEY 8d: 4*L(L+1)/2*hd per (b,h) forward, 2.5x that backward);
-    `step` is SURVEY 8d's step-level figure, sequences/s x 2.4 MB of ideal fused-step traffic against the HBM peak."""
+def roofline_probe(model, trainer, B, seq_per_s, batch):
+    """`roofline` of the bench line.  The object itself describes the DOMINANT kernel of the step -- the fused decoder-layer forward
+    k_seqtt_dec_fwd (one workgroup per sequence; the largest share of the step in profiles/r02_kernel_stats.csv): algorithmic bytes
+    per launch = tokens x (x 256 + log_feats 256 + y 256 fp32; o1, a1, q2, o2, a2, u 6 x 128 and k2|v2 256 bf16; 2 H log-sum-exp floats;
+    2 H x 32 B of dropout keep bits; 4 B id) / its average launch duration, measured live with HIP events on the launch stream by
+    launching that one kernel on the workspace of a completed forward (adt_sasrec_probe_dec_layer_fwd).  `kernels` adds what north_star
+    asks for by name: achieved HBM GB/s of the embedding gather and MFMA utilisation of the attention kernels (causal-aware FLOPs,
+    SURVEY 8d: 4*L(L+1)/2*hd per (b,h) forward, 2.5x that backward), measured on the standalone C-ABI kernels; `step` is SURVEY 8d's
+    step-level figure, sequences/s x 2.4 MB of ideal fused-step traffic against the HBM peak."""
     import torch
     from adt_amd import ops
     L, d, H = CFG["maxlen"], CFG["hidden_units"], CFG["num_heads"]
@@ -131,6 +133,11 @@ def roofline_probe(model, trainer, B, seq_per_s):
     T = B * L
     dev = model.dev
     prec, p, sd = model.cfg.prec, CFG["dropout"], model._seed
+    ids4 = [model._ids(a) for a in batch]
+    model.run_forward(*ids4, B, True)
+    us_dec = _time_us(lambda: model.probe_dec_layer_forward(ids4[1], B, 1))
+    dec_bytes = T * (3 * 256 + 6 * 128 + 256 + 2 * H * 4 + 2 * H * 32 + 4)
+    dec_flops = T * 10 * 2 * d * d + 2 * B * H * 4 * (L * (L + 1) // 2) * hd      # ten 64x64 products per token + two causal attentions
     qkv = torch.randn(T, 3 * d, device=dev)
     q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
     mask = torch.zeros(B * H * L * 8, device=dev, dtype=torch.int32)   # dropout keep bits, as inside the step
@@ -141,28 +148,29 @@ def roofline_probe(model, trainer, B, seq_per_s):
     ids = torch.randint(1, CFG["item_num"] + 1, (T,), device=dev, dtype=torch.int32)
     E, Pt = model.flat[:(CFG["item_num"] + 1) * d].view(-1, d), model.flat[model.offsets[1]:model.offsets[1] + L * d].view(L, d)
     us_emb = _time_us(lambda: ops.embed_fwd(ids, E, Pt, L, p, sd, 1, 0))
-    alg_bytes = B * H * 8 * L * hd * 4
-    achieved = alg_bytes / (us_bwd * 1e-6) / 1e9
+    achieved = dec_bytes / (us_dec * 1e-6) / 1e9
     fl_fwd = B * H * 4 * (L * (L + 1) // 2) * hd           # QK^T and PV, causal half
     emb_bytes = T * (4 + d * 4 + d * 4)                     # id + fp32 table row + fp32 output row (positional table stays in cache)
     # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes of this same command,
     # corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py): a profiler measurement, committed under profiles/
     traffic = None
-    pmc = os.path.join(REPO, "profiles", "r01_attn_bwd_pmc.json")
+    pmc = os.path.join(REPO, "profiles", "r02_dec_fwd_pmc.json")
     if os.path.exists(pmc):
         traffic = round(json.load(open(pmc))["traffic_bytes"])
     step_bytes = 2.4e6
-    return {"bound": "hbm", "kernel": "k_attn_bwd", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_us": round(us_bwd, 2),
-            "algorithmic_bytes_per_launch": alg_bytes,
+    return {"bound": "hbm", "kernel": "k_seqtt_dec_fwd (fused decoder-layer forward)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_us": round(us_dec, 2),
+            "algorithmic_bytes_per_launch": dec_bytes,
+            "mfma": {"flops_per_launch": dec_flops, "achieved_TFLOPs": round(dec_flops / (us_dec * 1e-6) / 1e12, 2),
+                     "mfma_util": round(dec_flops / (us_dec * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)},
             "kernels": [
                 {"kernel": "k_embed_fwd (item + positional gather, dropout, pad mask)", "bound": "hbm", "avg_launch_us": round(us_emb, 2),
                  "algorithmic_bytes_per_launch": emb_bytes, "achieved_GBps": round(emb_bytes / (us_emb * 1e-6) / 1e9, 1),
                  "frac": round(emb_bytes / (us_emb * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
-                {"kernel": "k_attn_fwd", "bound": "mfma", "avg_launch_us": round(us_fwd, 2), "flops_per_launch": fl_fwd,
+                {"kernel": "k_attn_fwd (standalone attention, C ABI)", "bound": "mfma", "avg_launch_us": round(us_fwd, 2), "flops_per_launch": fl_fwd,
                  "achieved_TFLOPs": round(fl_fwd / (us_fwd * 1e-6) / 1e12, 2), "mfma_util": round(fl_fwd / (us_fwd * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)},
-                {"kernel": "k_attn_bwd", "bound": "mfma", "avg_launch_us": round(us_bwd, 2), "flops_per_launch": int(2.5 * fl_fwd),
-                 "achieved_TFLOPs": round(2.5 * fl_fwd / (us_bwd * 1e-6) / 1e12, 2),
+                {"kernel": "k_seq_attn_bwd (standalone attention backward, C ABI)", "bound": "mfma", "avg_launch_us": round(us_bwd, 2),
+                 "flops_per_launch": int(2.5 * fl_fwd), "achieved_TFLOPs": round(2.5 * fl_fwd / (us_bwd * 1e-6) / 1e12, 2),
                  "mfma_util": round(2.5 * fl_fwd / (us_bwd * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)}],
             "step": {"bytes_per_sequence_ideal": step_bytes, "achieved_GBps": round(seq_per_s * step_bytes / 1e9, 1),
                      "frac": round(seq_per_s * step_bytes / 1e9 / HBM_PEAK_GBS, 4),
@@ -278,7 +286,7 @@ def main():
                           "parallelism": "dp%d%s" % (world, "-rccl" if pg is not None else ""), "hip_graph": not args.no_graph},
                "loss_last_step": round(loss, 5),
                "value_incl_h2d": round(world * B * args.steps / dt_h2d, 1), "ms_per_step_incl_h2d": round(dt_h2d / args.steps * 1e3, 4)}
-        res["roofline"] = roofline_probe(model, tr, B, B * args.steps / dt)
+        res["roofline"] = roofline_probe(model, tr, B, B * args.steps / dt, batches[0])
         if world == 1 and not args.no_cpu_baseline and not args.force_dp:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -272,6 +272,10 @@ int64_t adt_sasrec_ws_offset(const adt_sasrec_cfg* cfg, int B, int what, int lay
 int adt_sasrec_forward(const adt_sasrec_cfg* cfg, const float* params, float* ws, const int32_t* seq,
                        const int32_t* dec, const int32_t* pos, const int32_t* neg, int B, int training,
                        const uint32_t* seed, uint32_t b_offset, void* stream);
+/* Measurement hook (bench.py `roofline`): launches ONLY the fused forward of decoder layer `layer` (one workgroup per sequence) on the
+ * workspace of a completed adt_sasrec_forward of the same batch; bf16 mode, d = 64.  Not part of the reference's interface. */
+int adt_sasrec_probe_dec_layer_fwd(const adt_sasrec_cfg* cfg, const float* params, float* ws, const int32_t* dec, int B, int training,
+                                   const uint32_t* seed, uint32_t b_offset, int layer, void* stream);
 /* loss assembly (sasrec/main.py:151-169): fills G_POS/G_NEG, G_ENC_X[0..nl-1], G_DEC_X[1..nl], G_REC and the
  * loss slots from the forward activations.  lambdas1/lambdas2: host arrays of num_layers floats; the NLL
  * weight is lambdas2[num_layers-1] for every layer (stale loop index, sasrec/main.py:169).  NORMS must
