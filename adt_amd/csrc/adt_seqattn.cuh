@@ -190,8 +190,17 @@ __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
     if (r < L && a.in_bf16) {          // operands saved as bf16 rows by the lean forward; the gradient dO is always fp32
       const __bf16* Qb = reinterpret_cast<const __bf16*>(a.Q); const __bf16* Kb = reinterpret_cast<const __bf16*>(a.K);
       const __bf16* Vb = reinterpret_cast<const __bf16*>(a.V); const __bf16* Ob = reinterpret_cast<const __bf16*>(a.O);
-      const bf16x8 qb = *reinterpret_cast<const bf16x8*>(Qb + (row_b + r) * a.ldq + c8), kb = *reinterpret_cast<const bf16x8*>(Kb + (row_b + r) * a.ldk + c8);
-      const bf16x8 vb = *reinterpret_cast<const bf16x8*>(Vb + (row_b + r) * a.ldv + c8), ob = *reinterpret_cast<const bf16x8*>(Ob + (row_b + r) * a.ldo + c8);
+      // saved rows are in the register order of a transposed tile (adt_tt.cuh: tt_store_bf16): features c8 .. c8+3 and c8+4 .. c8+7 of a
+      // 64-feature row are two 8-byte pieces at 16 g + 4 nt and 16 (g + 1) + 4 nt, nt = c8 / 16, g = (c8 / 4) % 4
+      const int pa = 16 * ((c8 >> 2) & 3) + 4 * (c8 >> 4), pb = pa + 16;
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      const bf16x4_t qa = *reinterpret_cast<const bf16x4_t*>(Qb + (row_b + r) * a.ldq + pa), qc = *reinterpret_cast<const bf16x4_t*>(Qb + (row_b + r) * a.ldq + pb);
+      const bf16x4_t ka = *reinterpret_cast<const bf16x4_t*>(Kb + (row_b + r) * a.ldk + pa), kc = *reinterpret_cast<const bf16x4_t*>(Kb + (row_b + r) * a.ldk + pb);
+      const bf16x4_t va = *reinterpret_cast<const bf16x4_t*>(Vb + (row_b + r) * a.ldv + pa), vc = *reinterpret_cast<const bf16x4_t*>(Vb + (row_b + r) * a.ldv + pb);
+      const bf16x4_t oa = *reinterpret_cast<const bf16x4_t*>(Ob + (row_b + r) * a.ldo + pa), oc = *reinterpret_cast<const bf16x4_t*>(Ob + (row_b + r) * a.ldo + pb);
+      bf16x8 qb, kb, vb, ob;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { qb[j] = qa[j]; qb[4 + j] = qc[j]; kb[j] = ka[j]; kb[4 + j] = kc[j]; vb[j] = va[j]; vb[4 + j] = vc[j]; ob[j] = oa[j]; ob[4 + j] = oc[j]; }
       *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(a.dO + (row_b + r) * a.lddo + c8);
       *reinterpret_cast<float4*>(d + 4) = *reinterpret_cast<const float4*>(a.dO + (row_b + r) * a.lddo + c8 + 4);
 #pragma unroll

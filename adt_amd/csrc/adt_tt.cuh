@@ -105,26 +105,22 @@ ADT_DEVICE_INLINE void tt_store(float* row, const TT& t, bool valid, int g) {
   for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<float4*>(row + 16 * nt + 4 * g) = make_float4(t.v[nt][0], t.v[nt][1], t.v[nt][2], t.v[nt][3]);
 }
 
-// tensors SAVED for the backward as bf16 rows (`row` = this lane's token row); 8-byte accesses
+// Tensors SAVED for the backward as bf16 rows use the REGISTER ORDER of a transposed tile: feature f = 16 nt + 4 g + r sits at element
+// 16 g + 4 nt + r of its 64-element row (adt_saved_pos), so a lane's sixteen values are 32 contiguous bytes -- two 16-byte accesses, a
+// token's row 128 contiguous bytes.  In natural order a lane wrote four 8-byte pieces and the write counter showed 1.6x the bytes
+// stored (profiles/r02_dec_fwd_pmc.json).  Every reader of these buffers goes through tt_load_bf16 / rows_load_saved / the bf16 staging
+// of k_seq_attn_bwd, which undo the permutation.
 ADT_DEVICE_INLINE void tt_store_bf16(__bf16* row, const TT& t, bool valid, int g) {
   if (!valid) return;
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    bf16x4 b;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) b[r] = (__bf16)t.v[nt][r];
-    *reinterpret_cast<bf16x4*>(row + 16 * nt + 4 * g) = b;
-  }
+  *reinterpret_cast<bf16x8*>(row + 16 * g) = tt_pack(t.v[0], t.v[1]);
+  *reinterpret_cast<bf16x8*>(row + 16 * g + 8) = tt_pack(t.v[2], t.v[3]);
 }
 ADT_DEVICE_INLINE TT tt_load_bf16(const __bf16* row, bool valid, int g) {
-  TT t;
+  TT t = tt_zero();
+  if (valid) {
+    const bf16x8 lo = *reinterpret_cast<const bf16x8*>(row + 16 * g), hi = *reinterpret_cast<const bf16x8*>(row + 16 * g + 8);
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    t.v[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (valid) {
-      const bf16x4 b = *reinterpret_cast<const bf16x4*>(row + 16 * nt + 4 * g);
-      t.v[nt] = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
-    }
+    for (int r = 0; r < 4; ++r) { t.v[0][r] = (float)lo[r]; t.v[1][r] = (float)lo[4 + r]; t.v[2][r] = (float)hi[r]; t.v[3][r] = (float)hi[4 + r]; }
   }
   return t;
 }

@@ -152,7 +152,8 @@ ADT_DEVICE_INLINE RowRegs rows_load(const float* g, int ld, int row0, int T, int
 }
 
 // the same tile from a tensor SAVED by the forward: fp32 rows, or -- when the transposed-chain forward (adt_seqfwd_tt.cuh) wrote it --
-// bf16 rows of 64 (128 bytes; the buffer keeps its fp32-sized slot in the workspace)
+// bf16 rows of 64 (128 bytes; the buffer keeps its fp32-sized slot in the workspace) in the register order of a transposed tile:
+// features 4q .. 4q+3 (q = 4 nt + g) sit at elements 16 g + 4 nt .. + 3 (adt_tt.cuh: tt_store_bf16)
 ADT_DEVICE_INLINE RowRegs rows_load_saved(const float* g, int row0, int T, int lane, int saved_bf16) {
   if (!saved_bf16) return rows_load(g, 64, row0, T, lane);
   typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
@@ -163,7 +164,7 @@ ADT_DEVICE_INLINE RowRegs rows_load_saved(const float* g, int row0, int T, int l
     const int i = q * 64 + lane, r = i >> 4, c4 = (i & 15) * 4;
     x.v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row0 + r < T) {
-      const bf16x4_t b = *reinterpret_cast<const bf16x4_t*>(gb + (size_t)(row0 + r) * 64 + c4);
+      const bf16x4_t b = *reinterpret_cast<const bf16x4_t*>(gb + (size_t)(row0 + r) * 64 + 16 * ((c4 >> 2) & 3) + 4 * (c4 >> 4));
       x.v[q] = make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
     }
   }
