@@ -54,6 +54,7 @@ SIGNATURES = {
     "adt_axpy": (_I, [_P, _P, _F, _I, _L, _P, _I, _P]),
     "adt_grad_sumsq": (_I, [_P, _L, _P, _P]),
     "adt_adam_range": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
+    "adt_adamw_range": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
     "adt_log_softmax_fwd": (_I, [_P, _L, _I, _P, _P]),
     "adt_log_softmax_bwd": (_I, [_P, _P, _L, _I, _P, _I, _P]),
     "adt_dense_bwd": (_I, [_I, _P, _I, _I, _I, _I, _P, _F, _P, _U, _U, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P]),

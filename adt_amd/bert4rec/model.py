@@ -41,10 +41,11 @@ REF_ORDER = ["mask_bias", "item_emb", "encoder", "decoder", "mask_trans_feat", "
              "out_transfer", "fc1", "fc2", "weight", "bias"]
 
 
-def param_table(item_num, maxlen, d, H, nl, inner, type_vocab):
+def param_table(item_num, maxlen, d, H, nl, inner, type_vocab, vocab=None, block=0):
     """[(state_dict name, shape)] in flat order.  Within an attention block the three projection weights, then the three
-    biases, are consecutive so that q/k/v (or k/v) run as one GEMM."""
-    V = item_num + 100
+    biases, are consecutive so that q/k/v (or k/v) run as one GEMM.  block > 0: the supernet's layout -- `block` candidate layers
+    per depth, named encoder.encoder_layers.<depth>.<candidate>.* (bert4rec/model/modules.py:227-239, :366-378)."""
+    V = item_num + 100 if vocab is None else vocab
     hd = d // H
     t = [("mask_bias", (V,)), ("item_emb.word_emb.weight", (V, d)), ("item_emb.pos_emb.weight", (maxlen, d)),
          ("item_emb.sent_emb.weight", (type_vocab, d)), ("item_emb.layer_norm.weight", (d,)), ("item_emb.layer_norm.bias", (d,))]
@@ -59,35 +60,36 @@ def param_table(item_num, maxlen, d, H, nl, inner, type_vocab):
     def ffn(p):
         return [(p + ".fc1.weight", (inner, d)), (p + ".fc1.bias", (inner,)), (p + ".fc2.weight", (d, inner)), (p + ".fc2.bias", (d,))]
 
+    prefixes = lambda kind, i: ["%s.%s_layers.%d" % (kind, kind, i)] if block == 0 else ["%s.%s_layers.%d.%d" % (kind, kind, i, c) for c in range(block)]
     for i in range(nl):
-        p = "encoder.encoder_layers.%d" % i
-        t += mha(p + ".multi_head_attention") + ln(p + ".drop_residual_normalize_layer_after_multi") + ffn(p + ".ffn")
-        t += ln(p + ".drop_residual_normalize_layer_final") + [(p + ".head_classifier.weight", (H, hd)), (p + ".head_classifier.bias", (H,))]
+        for p in prefixes("encoder", i):
+            t += mha(p + ".multi_head_attention") + ln(p + ".drop_residual_normalize_layer_after_multi") + ffn(p + ".ffn")
+            t += ln(p + ".drop_residual_normalize_layer_final") + [(p + ".head_classifier.weight", (H, hd)), (p + ".head_classifier.bias", (H,))]
     for i in range(nl):
-        p = "decoder.decoder_layers.%d" % i
-        t += mha(p + ".dec_multi_head_attention") + ln(p + ".drop_residual_normalize_layer_after_multi")
-        t += mha(p + ".src_dec_attention") + ln(p + ".drop_residual_normalize_layer_after_src_dec") + ffn(p + ".ffn")
-        t += ln(p + ".drop_residual_normalize_layer_final")
+        for p in prefixes("decoder", i):
+            t += mha(p + ".dec_multi_head_attention") + ln(p + ".drop_residual_normalize_layer_after_multi")
+            t += mha(p + ".src_dec_attention") + ln(p + ".drop_residual_normalize_layer_after_src_dec") + ffn(p + ".ffn")
+            t += ln(p + ".drop_residual_normalize_layer_final")
     t += [("mask_trans_feat.weight", (d, d)), ("mask_trans_feat.bias", (d,)), ("mask_layer_norm.weight", (d,)), ("mask_layer_norm.bias", (d,))]
     return t
 
 
 class BertModel(FlatModule):
-    def __init__(self, usernum, itemnum, args):
+    def __init__(self, usernum, itemnum, args, vocab=None, inner_units=None, block=0):
         super().__init__()
         self.usernum, self.itemnum = usernum, itemnum
         self.maxlen, self.num_heads, self.num_layers = args.maxlen, args.num_heads, args.num_layers
-        self.hidden_units, self.inner_units = args.hidden_units, args.inner_units
+        self.hidden_units, self.inner_units = args.hidden_units, (args.inner_units if inner_units is None else inner_units)
         self.dropout, self.attention_dropout = float(args.dropout), float(args.attention_dropout)
-        self.vocab = itemnum + 100          # bert4rec/model/bert.py:20
+        self.vocab = itemnum + 100 if vocab is None else vocab          # bert4rec/model/bert.py:20 (the supernet: itemnum + 2)
         self.ldv = (self.vocab + 3) // 4 * 4
         self.args = args
         self.prec = {"f32": ops.PREC_F32, "fp32": ops.PREC_F32, "bf16": ops.PREC_BF16}[getattr(args, "precision", "bf16")]
         if self.hidden_units % 64 or (self.hidden_units // self.num_heads) not in (16, 32, 64):
             raise _lib.AdtError("BertModel (adt_amd): hidden_units must be a multiple of 64 with head size 16/32/64, got d=%d H=%d"
                                 % (self.hidden_units, self.num_heads))
-        self._build_flat(param_table(itemnum, args.maxlen, args.hidden_units, args.num_heads, args.num_layers, args.inner_units,
-                                     getattr(args, "type_vocab_size", 2)), args.device, REF_ORDER)
+        self._build_flat(param_table(itemnum, args.maxlen, args.hidden_units, args.num_heads, args.num_layers, self.inner_units,
+                                     getattr(args, "type_vocab_size", 2), self.vocab, block), args.device, REF_ORDER)
         # bert4rec/trainer.py:29-37 re-initialises every Linear/Embedding weight N(0.01, initializer_range), LayerNorm 1/0,
         # Linear bias 0; do the same here so that a freshly constructed model is usable
         g = torch.Generator(device="cpu").manual_seed(torch.initial_seed() % (1 << 31))
@@ -185,15 +187,27 @@ class BertModel(FlatModule):
         x = self._embed(tp, src, SITE_EMB_SEQ)
         enc_inputs, recs = [], []
         for i in range(self.num_layers):
-            p = "encoder.encoder_layers.%d" % i
-            st = enc_sites(i)
             enc_inputs.append(x)
-            h, o = self._attn_drn(tp, p + ".multi_head_attention", p + ".drop_residual_normalize_layer_after_multi", x, x, src, B, st["attn"],
-                                  st["after_multi"])
-            recs.append(tp.headcls(o, P(p + ".head_classifier.weight"), P(p + ".head_classifier.bias"), G(p + ".head_classifier.weight"),
-                                   G(p + ".head_classifier.bias")))
-            x = self._ffn_drn(tp, p + ".ffn", h, p + ".drop_residual_normalize_layer_final", st["final"])
+            x, rec = self._enc_layer(tp, "encoder.encoder_layers.%d" % i, x, src, B, enc_sites(i))
+            recs.append(rec)
         return x, enc_inputs, recs
+
+    def _enc_layer(self, tp, p, x, src, B, st):
+        """EncoderLayer.forward (modules.py:165-182) -> (output, head-classifier log-probabilities)."""
+        P, G = self.P, self.G
+        h, o = self._attn_drn(tp, p + ".multi_head_attention", p + ".drop_residual_normalize_layer_after_multi", x, x, src, B, st["attn"],
+                              st["after_multi"])
+        rec = tp.headcls(o, P(p + ".head_classifier.weight"), P(p + ".head_classifier.bias"), G(p + ".head_classifier.weight"),
+                         G(p + ".head_classifier.bias"))
+        return self._ffn_drn(tp, p + ".ffn", h, p + ".drop_residual_normalize_layer_final", st["final"]), rec
+
+    def _dec_layer(self, tp, p, x, dec, src, enc, B, st):
+        """DecoderLayer.forward (modules.py:297-325)."""
+        g, _ = self._attn_drn(tp, p + ".dec_multi_head_attention", p + ".drop_residual_normalize_layer_after_multi", x, x, dec, B, st["attn"],
+                              st["after_multi"])
+        g2, _ = self._attn_drn(tp, p + ".src_dec_attention", p + ".drop_residual_normalize_layer_after_src_dec", g, enc, src, B, st["src_attn"],
+                               st["after_src"])
+        return self._ffn_drn(tp, p + ".ffn", g2, p + ".drop_residual_normalize_layer_final", st["final"])
 
     def _decode(self, tp, dec, src, enc, B):
         """decode + Decoder.forward (bert.py:69-78, modules.py:297-325, 352-358); outputs in layer order (not yet reversed)."""
@@ -201,13 +215,7 @@ class BertModel(FlatModule):
         tp.mark_decoder_start()
         outs = []
         for i in range(self.num_layers):
-            p = "decoder.decoder_layers.%d" % i
-            st = dec_sites(i)
-            g, _ = self._attn_drn(tp, p + ".dec_multi_head_attention", p + ".drop_residual_normalize_layer_after_multi", x, x, dec, B, st["attn"],
-                                  st["after_multi"])
-            g2, _ = self._attn_drn(tp, p + ".src_dec_attention", p + ".drop_residual_normalize_layer_after_src_dec", g, enc, src, B, st["src_attn"],
-                                   st["after_src"])
-            x = self._ffn_drn(tp, p + ".ffn", g2, p + ".drop_residual_normalize_layer_final", st["final"])
+            x = self._dec_layer(tp, "decoder.decoder_layers.%d" % i, x, dec, src, enc, B, dec_sites(i))
             outs.append(x)
         return outs
 

@@ -250,6 +250,7 @@ struct RangeOptArgs {
   float l2, clip, lr, b1, b2, eps, step;
   const float* gn2_slots;   // 64 partial sums of ||g||^2 over ALL parameters
   float* out64;
+  float wd_dec;             // torch.optim.AdamW's decoupled decay: p *= 1 - lr * wd_dec before the update (0 = off)
 };
 
 __global__ __launch_bounds__(256) void k_sumsq64(RangeOptArgs a) {
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void k_adam_range(RangeOptArgs a) {
     const float v = a.b2 * a.V[i] + (1.0f - a.b2) * g * g;
     a.M[i] = m;
     a.V[i] = v;
-    a.P[i] -= stepsz * m / (sqrtf(v) * rs2 + a.eps);
+    a.P[i] = a.P[i] * (1.0f - a.lr * a.wd_dec) - stepsz * m / (sqrtf(v) * rs2 + a.eps);
   }
 }
 

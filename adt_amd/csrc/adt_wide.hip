@@ -445,9 +445,17 @@ int adt_grad_sumsq(const float* G, int64_t n, float* out64, void* stream) {
 int adt_adam_range(float* P, float* G, float* M, float* V, int64_t n, float l2, float clip, float lr, float b1, float b2, float eps, float step,
                    const float* gn2_slots, void* stream) {
   if (n <= 0) return 0;
-  RangeOptArgs a{P, G, M, V, (size_t)n, l2, clip, lr, b1, b2, eps, step, gn2_slots, nullptr};
+  RangeOptArgs a{P, G, M, V, (size_t)n, l2, clip, lr, b1, b2, eps, step, gn2_slots, nullptr, 0.f};
   hipLaunchKernelGGL(k_adam_range, dim3(grid_for((size_t)n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("adam_range");
+}
+
+int adt_adamw_range(float* P, float* G, float* M, float* V, int64_t n, float wd, float clip, float lr, float b1, float b2, float eps, float step,
+                    const float* gn2_slots, void* stream) {
+  if (n <= 0) return 0;
+  RangeOptArgs a{P, G, M, V, (size_t)n, 0.f, clip, lr, b1, b2, eps, step, gn2_slots, nullptr, wd};
+  hipLaunchKernelGGL(k_adam_range, dim3(grid_for((size_t)n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("adamw_range");
 }
 
 // ---- STOSA-ADT (adt_stosa.cuh) ----------------------------------------------------------------------------------

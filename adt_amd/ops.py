@@ -379,6 +379,12 @@ def adam_range(P, G, M, V, l2, clip, lr, b1, b2, eps, step, gn2_slots):
                                           float(step), _p(gn2_slots), _stream()), "adam_range")
 
 
+def adamw_range(P, G, M, V, wd, clip, lr, b1, b2, eps, step, gn2_slots):
+    """adam_range with torch.optim.AdamW's decoupled weight decay."""
+    _lib.check(_lib.load().adt_adamw_range(_p(P), _p(G), _p(M), _p(V), P.numel(), float(wd), float(clip), float(lr), float(b1), float(b2), float(eps),
+                                           float(step), _p(gn2_slots), _stream()), "adamw_range")
+
+
 def dense_gradsrc(dY, act, U, p=0.0, seed=None, site=0, row_offset=0, mask_ids=None, t_dev=None):
     """G = dY * rowmask * dropmask * act'(U), materialised (see adt_dense_gradsrc)."""
     T, N = dY.shape

@@ -7,19 +7,17 @@ under that candidate (get_cand_auc :173-180; random init, top-k selection, mutat
     python -m adt_amd.sasrec.evolution --dataset ml-1m --synthetic ml1m --warmup_epochs 2 --search_epochs 2 ...
 
 Same flags and same output file (one JSON object per surviving candidate, written by hand: `jsonlines` is not needed).
-The supernet forward/backward/optimizer run in libadt_hip.so (adt_amd/sasrec/supersasrec.py); only the population
-bookkeeping below is host Python, as in the reference.
+The supernet forward/backward/optimizer run in libadt_hip.so (adt_amd/sasrec/supersasrec.py); the population bookkeeping and the
+batched candidate evaluation are adt_amd/supersearch.py, shared with the BERT4Rec-ADT and STOSA-ADT searches.
 """
 import argparse
-import json
 import os
 import random
-import sys
-from random import choice
 
 import numpy as np
 import torch
 
+from ..supersearch import EvolutionSearch, cand_to_block, get_shared, result_name
 from . import utils as U
 from .supersasrec import SuperSASRecModel, SuperTrainer
 
@@ -58,10 +56,11 @@ def parse_args(argv=None):
 
 
 class SearcherEvolution:
+    """sasrec/evolution.py:60-360 on adt_amd.supersearch: the supernet and its warm-up step run in libadt_hip.so, candidates are scored
+    a chunk at a time (validation AUC of the supernet under each candidate's block choice, one batched pass per chunk)."""
+
     def __init__(self, args):
         self.args = args
-        self.select_num, self.population_num, self.m_prob = args.select_num, args.population_num, args.m_prob
-        self.crossover_num, self.mutation_num, self.num_layers = args.crossover_num, args.mutation_num, args.num_layers
         path = os.path.join(args.data_dir, "%s.txt" % args.dataset)
         if not os.path.exists(path) and args.synthetic:
             from . import synth
@@ -79,102 +78,38 @@ class SearcherEvolution:
         torch.manual_seed(args.seed)
         self.model = SuperSASRecModel(usernum, itemnum, self.rec_choice, self.ind_choice, args)
         self.trainer = SuperTrainer(self.model, lr=args.lr, betas=(0.9, 0.999), weight_decay=args.weight_decay, clip=args.clip, seed=args.seed)
-        self.memory, self.epoch, self.candidates = [], 0, []
-        self.keep_top_k = {self.select_num: []}
-        self.vis_dict = {}
-        self.scale_factor = args.scale_factor
+        self.search_state = EvolutionSearch(args.num_layers, self.evaluate_candidates, "auc", args.select_num, args.population_num, args.m_prob,
+                                            args.crossover_num, args.mutation_num, args.scale_factor)
         self.rng = np.random.RandomState(args.seed)
-
-    # ---- candidates ------------------------------------------------------------------------------------------------------
-    @property
-    def rec_weights(self):
-        return self.trainer.rec_weights
+        self.eval_stats = {}
 
     @property
-    def ind_weights(self):
-        return self.trainer.ind_weights
+    def vis_dict(self):
+        return self.search_state.vis_dict
 
-    def _set_choice(self, cand):
-        self.trainer.set_choice(cand)
+    def evaluate_candidates(self, cands, dataset=None, group=32):
+        """Validation metrics of the supernet under every candidate of `cands` (get_cand_auc :173-180, for a whole chunk): each
+        validation batch is scored for `group` candidates per pass."""
+        ds = self.val_ds if dataset is None else dataset
+        shared = [get_shared(self.rec_choice, self.ind_choice, cand_to_block(self.rec_choice, self.ind_choice, c)[0]) for c in cands]
+        ranks = [[] for _ in cands]
+        ncand = None
+        for (u, seq, item_idx), _ in ds.batches(self.args.eval_batch_size):
+            item_idx = np.asarray(item_idx)
+            ncand = item_idx.shape[1]
+            for g0 in range(0, len(cands), group):
+                r = self.model.predict_rank_candidates(np.asarray(seq), item_idx, shared[g0:g0 + group], stats=self.eval_stats).cpu().numpy()
+                for k in range(r.shape[0]):
+                    ranks[g0 + k].append(r[k])
+        out = []
+        for rk in ranks:
+            (ndcg, hr), auc = U.metrics_from_ranks(np.concatenate(rk), ncand, [10])
+            out.append({"V_NDCG": float(ndcg[10]), "V_HR": float(hr[10]), "V_AUC": float(auc), "auc": float(auc)})
+        return out
 
-    def sample_random(self):
-        return [random.random() for _ in range(2 * self.args.num_layers)]
-
-    def stack_random_cand(self, random_func, *, batch_size=10):
-        while True:
-            cands = [random_func() for _ in range(batch_size)]
-            for cand in cands:
-                self.vis_dict.setdefault(str(cand), {})
-            for cand in cands:
-                yield cand
-
-    def get_cand_auc(self, cand):
-        self._set_choice(cand)
-        self.model.eval()
-        t_valid, auc = U.evaluate_loader(self.model, self.val_ds.batches(self.args.eval_batch_size), self.args, "val", ks=[10])
-        info = self.vis_dict[str(cand)]
-        info["V_NDCG"], info["V_HR"], info["V_AUC"] = float(t_valid[0][10]), float(t_valid[1][10]), float(auc)
-        return float(auc)
-
-    def check_cand(self, cand):
-        info = self.vis_dict.setdefault(str(cand), {})
-        if "visited" in info:
-            return False
-        info["visited"] = True
-        info["auc"] = float(self.get_cand_auc(cand))
-        return True
-
-    def get_random(self, population_num):
-        cand_iter = self.stack_random_cand(self.sample_random)
-        max_iter = (population_num - len(self.candidates) + 1) * 50
-        while len(self.candidates) < population_num and max_iter > 0:
-            max_iter -= 1
-            cand = next(cand_iter)
-            if self.check_cand(cand):
-                self.candidates.append(cand)
-
-    def update_top_k(self, candidates, *, k, key, reverse=True):
-        t = self.keep_top_k[k]
-        t += candidates
-        t.sort(key=key, reverse=reverse)
-        self.keep_top_k[k] = t[:k]
-
-    def get_crossover(self, k, crossover_num):
-        res, max_iter = [], crossover_num * 10
-
-        def random_func():
-            c1, c2 = choice(self.keep_top_k[k]), choice(self.keep_top_k[k])
-            return [choice([i, j]) for i, j in zip(c1, c2)]
-        cand_iter = self.stack_random_cand(random_func)
-        while len(res) < crossover_num and max_iter > 0:
-            max_iter -= 1
-            cand = next(cand_iter)
-            if self.check_cand(cand):
-                res.append(cand)
-        return res
-
-    def get_mutation(self, k, mutation_num, m_prob):
-        res, max_iter = [], mutation_num * 10
-
-        def random_func():     # differential mutation (sasrec/evolution.py:262-271)
-            cand = list(choice(self.keep_top_k[k]))
-            for i in range(self.num_layers * 2):
-                if np.random.random_sample() < m_prob:
-                    cand2, cand3 = list(choice(self.keep_top_k[k])), list(choice(self.keep_top_k[k]))
-                    cand[i] = min(1 - 1e-10, max(1e-10, cand[i] + self.scale_factor * (cand2[i] - cand3[i])))
-            return cand
-        cand_iter = self.stack_random_cand(random_func)
-        while len(res) < mutation_num and max_iter > 0:
-            max_iter -= 1
-            cand = next(cand_iter)
-            if self.check_cand(cand):
-                res.append(cand)
-        return res
-
-    # ---- training / search ----------------------------------------------------------------------------------------------------
     def _train_warmup(self):
         for epoch in range(self.args.warmup_epochs):
-            self._set_choice(self.sample_random())
+            self.trainer.set_choice(self.search_state.sample_random())
             for u, seq, dec, pos, neg in self.warp.epoch_batches(self.args.batch_size, self.rng):
                 self.trainer.step(seq, dec, pos, neg)
             print("warmup epoch %d / %d loss %.4f" % (epoch + 1, self.args.warmup_epochs, float(self.trainer.loss())), flush=True)
@@ -183,27 +118,8 @@ class SearcherEvolution:
         self._train_warmup()
         os.makedirs("./checkpoint", exist_ok=True)
         torch.save(self.model.state_dict(), "./checkpoint/super.pth")
-        self.get_random(self.population_num)
-        for _ in range(self.args.search_epochs):
-            self.epoch += 1
-            self.memory.append(list(self.candidates))
-            self.update_top_k(self.candidates, k=self.select_num, key=lambda x: self.vis_dict[str(x)]["auc"])
-            mutation = self.get_mutation(self.select_num, self.mutation_num, self.m_prob)
-            crossover = self.get_crossover(self.select_num, self.crossover_num)
-            self.candidates = mutation + crossover
-            self.get_random(self.population_num)
-        os.makedirs(self.args.out_dir, exist_ok=True)
-        a = self.args
-        fname = os.path.join(a.out_dir, "res_%s_lr_%s_reg_%s_warm_%d_search_%d_layers_%d_select_%d_population_%d_cross_%d_mutation_%d.jsonl" % (
-            a.dataset, a.lr, a.weight_decay, a.warmup_epochs, a.search_epochs, a.num_layers, a.select_num, a.population_num, a.crossover_num,
-            a.mutation_num))
-        with open(fname, "w") as f:
-            for cand in self.keep_top_k[self.select_num]:
-                info = dict(self.vis_dict[str(cand)])
-                self._set_choice(cand)
-                info["cand"], info["rec"], info["ind"] = str(cand), str([float(x) for x in self.rec_weights]), str([float(x) for x in self.ind_weights])
-                f.write(json.dumps(info) + "\n")
-        return fname
+        self.search_state.run(self.args.search_epochs, log=lambda m: print(m, flush=True))
+        return self.search_state.write(result_name(self.args.out_dir, self.args), self.rec_choice, self.ind_choice)
 
 
 def set_rng_seed(seed):

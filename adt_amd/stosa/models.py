@@ -35,8 +35,10 @@ REF_ORDER = ["item_mean_embeddings", "item_cov_embeddings", "position_mean_embed
              "cov_value", "mean_dense", "cov_dense", "dense_1", "dense_2", "LayerNorm", "decLayerNorm", "weight", "bias"]
 
 
-def param_table(item_size, maxlen, d, H, nl, num_users):
-    """([(state_dict name, shape)] in flat order, index of the first parameter outside the loss graph).  Within an
+def param_table(item_size, maxlen, d, H, nl, num_users, block=0, dec_layernorm=True):
+    """([(state_dict name, shape)] in flat order, index of the first parameter outside the loss graph).  block > 0: the supernet's
+    layout, `block` candidate layers per depth named item_encoder.layer.<depth>.<candidate>.* (stosa/super_modules.py:66-72);
+    dec_layernorm: the plain model's unused decLayerNorm (stosa/models.py:176; the supernet has none).  Within an
     attention block the mean q/k/v weights (then biases), and the covariance ones, are consecutive so that each triple
     runs as one GEMM.  Parameters the reference never trains (grad None: user_margins, decLayerNorm, every decoder
     layer's dec_attention, stosa/modules.py:537-538) sit at the end, outside the optimizer's prefix."""
@@ -58,23 +60,27 @@ def param_table(item_size, maxlen, d, H, nl, num_users):
     t = [("item_mean_embeddings.weight", (item_size, d)), ("item_cov_embeddings.weight", (item_size, d)),
          ("position_mean_embeddings.weight", (maxlen, d)), ("position_cov_embeddings.weight", (maxlen, d)),
          ("LayerNorm.weight", (d,)), ("LayerNorm.bias", (d,))]
+    prefixes = lambda kind, i: ["%s.layer.%d" % (kind, i)] if block == 0 else ["%s.layer.%d.%d" % (kind, i, c) for c in range(block)]
     for i in range(nl):
-        p = "item_encoder.layer.%d" % i
-        t += att(p + ".attention") + inter(p + ".mean_intermediate") + inter(p + ".cov_intermediate")
-        t += [(p + ".mean_independence_layer.weight", (H, hd)), (p + ".mean_independence_layer.bias", (H,)),
-              (p + ".cov_independence_layer.weight", (H, hd)), (p + ".cov_independence_layer.bias", (H,))]
+        for p in prefixes("item_encoder", i):
+            t += att(p + ".attention") + inter(p + ".mean_intermediate") + inter(p + ".cov_intermediate")
+            t += [(p + ".mean_independence_layer.weight", (H, hd)), (p + ".mean_independence_layer.bias", (H,)),
+                  (p + ".cov_independence_layer.weight", (H, hd)), (p + ".cov_independence_layer.bias", (H,))]
     for i in range(nl):
-        p = "item_decoder.layer.%d" % i
-        t += att(p + ".enc_attention") + inter(p + ".mean_intermediate") + inter(p + ".cov_intermediate")
+        for p in prefixes("item_decoder", i):
+            t += att(p + ".enc_attention") + inter(p + ".mean_intermediate") + inter(p + ".cov_intermediate")
     n_trained = len(t)
-    t += [("user_margins.weight", (num_users, 1)), ("decLayerNorm.weight", (d,)), ("decLayerNorm.bias", (d,))]
+    t += [("user_margins.weight", (num_users, 1))]
+    if dec_layernorm:
+        t += [("decLayerNorm.weight", (d,)), ("decLayerNorm.bias", (d,))]
     for i in range(nl):
-        t += att("item_decoder.layer.%d.dec_attention" % i)
+        for p in prefixes("item_decoder", i):
+            t += att(p + ".dec_attention")
     return t, n_trained
 
 
 class DisenDistSAModel(FlatModule):
-    def __init__(self, args):
+    def __init__(self, args, block=0, dec_layernorm=True):
         super().__init__()
         self.args = args
         self.item_size, self.maxlen, self.hidden_units = args.item_size, args.maxlen, args.hidden_units
@@ -86,7 +92,7 @@ class DisenDistSAModel(FlatModule):
             raise _lib.AdtError("DisenDistSAModel (adt_amd): hidden_units must be a multiple of 64 with head size 16/32/64, got d=%d H=%d" % (d, H))
         if getattr(args, "distance_metric", "wasserstein") != "wasserstein":
             raise _lib.AdtError("DisenDistSAModel (adt_amd): only distance_metric='wasserstein' is built")
-        table, n_trained = param_table(args.item_size, args.maxlen, d, H, args.num_layers, args.num_users)
+        table, n_trained = param_table(args.item_size, args.maxlen, d, H, args.num_layers, args.num_users, block, dec_layernorm)
         self._build_flat(table, getattr(args, "device", "cuda:0"), REF_ORDER)
         self.n_trained_floats = self._views[table[n_trained][0]][0]     # optimizer prefix (flat floats)
         # init_weights (stosa/models.py:262-272): N(0.01, initializer_range) on Linear/Embedding weights, LayerNorm 1/0, biases 0
@@ -181,6 +187,25 @@ class DisenDistSAModel(FlatModule):
         y = tp.layernorm(z, P(p + ".LayerNorm.weight"), P(p + ".LayerNorm.bias"), G(p + ".LayerNorm.weight"), G(p + ".LayerNorm.bias"), LN_EPS)
         return tp.dropact(y, 0.0, 0, ops.ACT_ELU1) if elu1 else y
 
+    def _enc_layer(self, tp, p, m, c, inp, B, st):
+        """DistLayer.forward (stosa/modules.py:518-525) -> (mean, cov, mean / cov head-classifier log-probabilities)."""
+        P, G = self.P, self.G
+        hm, hc, om, oc = self._attention(tp, p + ".attention", m, c, m, c, inp, B, st)
+        rm = tp.headcls(om, P(p + ".mean_independence_layer.weight"), P(p + ".mean_independence_layer.bias"),
+                        G(p + ".mean_independence_layer.weight"), G(p + ".mean_independence_layer.bias"))
+        rc = tp.headcls(oc, P(p + ".cov_independence_layer.weight"), P(p + ".cov_independence_layer.bias"),
+                        G(p + ".cov_independence_layer.weight"), G(p + ".cov_independence_layer.bias"))
+        m2 = self._intermediate(tp, p + ".mean_intermediate", hm, st["ffn_mean"], False)
+        c2 = self._intermediate(tp, p + ".cov_intermediate", hc, st["ffn_cov"], True)
+        return m2, c2, rm, rc
+
+    def _dec_layer(self, tp, p, dm, dc, m, c, inp, B, st):
+        """DistDecLayer.forward (modules.py:535-541): dec_attention's output is discarded by the reference, so it is not computed;
+        enc_attention takes queries from the decoder input and keys / values (and the mask) from the encoder side."""
+        hm, hc, _, _ = self._attention(tp, p + ".enc_attention", dm, dc, m, c, inp, B, st)
+        return (self._intermediate(tp, p + ".mean_intermediate", hm, st["ffn_mean"], False),
+                self._intermediate(tp, p + ".cov_intermediate", hc, st["ffn_cov"], True))
+
     def _finetune(self, tp, inp, dec, B):
         """Token-major body of finetune (stosa/models.py:212-260)."""
         P, G = self.P, self.G
@@ -188,26 +213,12 @@ class DisenDistSAModel(FlatModule):
         dm, dc = self._embed(tp, dec, "mean", SITE_EMB["dec_mean"]), self._embed(tp, dec, "cov", SITE_EMB["dec_cov"])
         enc_inputs, enc_recs, dec_outs = [], [], []
         for i in range(self.num_layers):
-            p = "item_encoder.layer.%d" % i
-            st = enc_sites(i)
             enc_inputs.append((m, c))
-            hm, hc, om, oc = self._attention(tp, p + ".attention", m, c, m, c, inp, B, st)
-            rm = tp.headcls(om, P(p + ".mean_independence_layer.weight"), P(p + ".mean_independence_layer.bias"),
-                            G(p + ".mean_independence_layer.weight"), G(p + ".mean_independence_layer.bias"))
-            rc = tp.headcls(oc, P(p + ".cov_independence_layer.weight"), P(p + ".cov_independence_layer.bias"),
-                            G(p + ".cov_independence_layer.weight"), G(p + ".cov_independence_layer.bias"))
+            m, c, rm, rc = self._enc_layer(tp, "item_encoder.layer.%d" % i, m, c, inp, B, enc_sites(i))
             enc_recs.append((rm, rc))
-            m = self._intermediate(tp, p + ".mean_intermediate", hm, st["ffn_mean"], False)
-            c = self._intermediate(tp, p + ".cov_intermediate", hc, st["ffn_cov"], True)
         tp.mark_decoder_start()
         for i in range(self.num_layers):
-            p = "item_decoder.layer.%d" % i
-            st = dec_sites(i)
-            # DistDecLayer (modules.py:535-541): dec_attention's output is discarded by the reference, so it is not computed;
-            # enc_attention takes queries from the decoder input and keys/values (and the mask) from the encoder side
-            hm, hc, _, _ = self._attention(tp, p + ".enc_attention", dm, dc, m, c, inp, B, st)
-            dm = self._intermediate(tp, p + ".mean_intermediate", hm, st["ffn_mean"], False)
-            dc = self._intermediate(tp, p + ".cov_intermediate", hc, st["ffn_cov"], True)
+            dm, dc = self._dec_layer(tp, "item_decoder.layer.%d" % i, dm, dc, m, c, inp, B, dec_sites(i))
             dec_outs.append((dm, dc))
         return m, c, enc_inputs, enc_recs, dec_outs
 

@@ -202,6 +202,10 @@ int adt_clip_adam_l2(float* P, float* G, float* M, float* V, int64_t n, float l2
 int adt_grad_sumsq(const float* G, int64_t n, float* out64, void* stream);
 int adt_adam_range(float* P, float* G, float* M, float* V, int64_t n, float l2, float clip, float lr, float b1, float b2,
                    float eps, float step, const float* gn2_slots, void* stream);
+/* the same with torch.optim.AdamW's DECOUPLED weight decay (p *= 1 - lr * wd, then the Adam update): the optimizer of the BERT4Rec-ADT
+ * supernet warm-up (bert4rec/evolution.py:101) */
+int adt_adamw_range(float* P, float* G, float* M, float* V, int64_t n, float wd, float clip, float lr, float b1, float b2,
+                    float eps, float step, const float* gn2_slots, void* stream);
 /* adt_score_rank with a per-item bias (bert4rec/model/bert.py:89,110-116) */
 int adt_score_rank_bias(const float* F, int ldf, const float* E, const float* bias, const int32_t* cand, int B, int C,
                         int d, float* logits, int32_t* rank, void* stream);

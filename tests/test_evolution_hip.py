@@ -1,0 +1,64 @@
+"""GPU smoke of the three evolution entry points (adt_amd/{sasrec,bert4rec}/evolution.py, adt_amd/stosa/evolution.py: the counterparts
+of the reference's sasrec/evolution.py, bert4rec/evolution.py, stosa/evolution.py + searcher.py) on the `tiny` synthetic preset: one
+warm-up epoch, two search epochs, the result file with one record per surviving candidate, candidates scored in batched passes."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+COMMON = ["--warmup_epochs", "1", "--search_epochs", "2", "--population_num", "8", "--select_num", "4", "--crossover_num", "2", "--mutation_num",
+          "2", "--num_layers", "2", "--hidden_units", "64", "--num_heads", "2", "--batch_size", "16", "--eval_batch_size", "32", "--precision", "f32"]
+
+
+def _check(path, key, nl):
+    recs = [json.loads(l) for l in open(path)]
+    assert len(recs) == 4
+    scores = [r[key] for r in recs]
+    assert scores == sorted(scores, reverse=True) and all(np.isfinite(s) for s in scores)
+    for r in recs:
+        assert len(json.loads(r["cand"])) == 2 * nl and len(json.loads(r["rec"])) == nl and len(json.loads(r["ind"])) == nl
+    return recs
+
+
+def test_sasrec_evolution(tmp_path, monkeypatch):
+    from adt_amd.sasrec import evolution as ev
+    monkeypatch.chdir(tmp_path)
+    args = ev.parse_args(["--dataset", "tiny", "--data_dir", str(tmp_path), "--synthetic", "tiny", "--maxlen", "20", "--sample_size", "20",
+                          "--out_dir", str(tmp_path / "res")] + COMMON)
+    ev.set_rng_seed(args.seed)
+    s = ev.SearcherEvolution(args)
+    recs = _check(s.search(), "auc", 2)
+    assert "V_NDCG" in recs[0] and os.path.exists(tmp_path / "checkpoint" / "super.pth")
+    st = s.search_state
+    assert st.batches < st.evaluated          # several candidates per validation pass
+    assert s.eval_stats["layer_calls"] < s.eval_stats["layer_copies"] or s.eval_stats["layer_calls"] < 8 * st.evaluated
+
+
+def test_bert_evolution(tmp_path, monkeypatch):
+    from adt_amd.bert4rec import evolution as ev
+    monkeypatch.chdir(tmp_path)
+    args = ev.parse_args(["--dataset", "tiny", "--data_dir", str(tmp_path), "--synthetic", "tiny", "--maxlen", "20", "--eval_negative_sample_size",
+                          "20", "--dupe_factor", "1", "--out_dir", str(tmp_path / "res")] + COMMON)
+    ev.set_rng_seed(args.seed)
+    s = ev.SearcherEvolution(args)
+    _check(s.search(), "auc", 2)
+    assert s.search_state.batches < s.search_state.evaluated
+
+
+def test_stosa_evolution(tmp_path, monkeypatch):
+    from adt_amd.stosa import evolution as ev
+    from adt_amd.stosa.main import _write_synthetic
+    monkeypatch.chdir(tmp_path)
+    _write_synthetic(str(tmp_path / "Tiny.txt"), users=96, items=150, seed=3)
+    argv = ["--dataset", "Tiny", "--data_dir", str(tmp_path) + "/", "--maxlen", "20", "--out_dir", str(tmp_path / "res")] + COMMON
+    args = ev.parse_args(argv)
+    args.data_file = os.path.join(args.data_dir, args.dataset + ".txt")
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    s = ev.SearcherEvolution(args)
+    recs = _check(s.search(), "MRR", 2)
+    assert "V_HR" in recs[0] and s.search_state.batches < s.search_state.evaluated

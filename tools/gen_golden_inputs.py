@@ -55,3 +55,19 @@ def golden_err(got, g, key, k=1024):
     e_s = np.abs(s - want).max() / scale
     e_n = abs(np.sqrt((t ** 2).sum()) - norm) / max(norm, 1e-9)
     return max(e_s, e_n)
+
+
+def seeded_params(named_shapes, seed):
+    """Deterministic fp32 fill of a {name: shape} table, identical wherever it is called (the golden generator fills the REFERENCE
+    model with it, the tests fill ours): tensors in sorted-name order from one RandomState; LayerNorm scales ~1, everything else
+    N(0, 0.06) (biases included, so that their gradients are exercised)."""
+    r = np.random.RandomState(seed)
+    out = {}
+    for name in sorted(named_shapes):
+        shape = tuple(named_shapes[name])
+        v = 0.06 * r.standard_normal(shape)
+        low = name.lower()
+        if ("layer_norm" in low or "layernorm" in low) and name.endswith("weight"):
+            v = 1.0 + v
+        out[name] = v.astype(np.float32)
+    return out
