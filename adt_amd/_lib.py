@@ -69,6 +69,9 @@ SIGNATURES = {
     "adt_ce_rows": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P]),
     "adt_clip_adam_l2": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
     "adt_score_rank_bias": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "adt_wattn_mfma_fwd": (_I, [_I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P, _U, _U, _P, _I, _P, _I, _P, _P]),
+    "adt_wattn_mfma_bwd": (_I, [_I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F,
+                                _P, _U, _U, _P, _P, _P, _P, _P, _P, _I, _P]),
     "adt_wattn_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P, _U, _U, _P, _I, _P, _I, _P, _P]),
     "adt_wattn_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F,
                            _P, _U, _U, _P, _P, _P, _P, _P, _P, _I, _P]),

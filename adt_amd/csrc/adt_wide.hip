@@ -7,6 +7,7 @@
 #include "adt_gemm.cuh"
 #include "adt_dense_rows.cuh"
 #include "adt_stosa.cuh"
+#include "adt_wattn_mfma.cuh"
 #include "adt_wide.cuh"
 
 using namespace adt;
@@ -286,6 +287,39 @@ static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
   return check_launch("dense_bwd");
 }
 
+// The same attention on the matrix cores (adt_wattn_mfma.cuh): hd 16 or 32, L <= 128; prec picks bf16 operands or the exact fp32 MFMA.
+// Returns 1 when the shape is not covered (the caller uses adt_wattn_fwd / adt_wattn_bwd).
+static bool wattn_mfma_ok(int L, int hd, const int* lds, int n) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("ADT_WATTN_MFMA"); on = (e && atoi(e) == 0) ? 0 : 1; }
+  if (!on || (hd != 16 && hd != 32) || L > 128) return false;
+  for (int i = 0; i < n; ++i)
+    if (lds[i] % 4) return false;
+  return true;
+}
+
+template <int PREC, int HD>
+static int wattn_mfma_launch(bool bwd, const WAttnArgs& a, hipStream_t s) {
+  const void* fn = bwd ? (const void*)k_wattn_mfma_bwd<PREC, HD> : (const void*)k_wattn_mfma_fwd<PREC, HD, 8>;
+  const size_t smem = wattn_mfma_lds_bytes(a.L, HD, bwd);
+  if (smem > 160 * 1024) return 1;
+  static bool done[2] = {false, false};
+  if (!done[bwd]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return adt_set_error("wattn_mfma: hipFuncSetAttribute");
+    done[bwd] = true;
+  }
+  WAttnArgs args = a;
+  void* kargs[] = {&args};
+  if (hipLaunchKernel(fn, dim3(a.B * a.H), dim3(WM_NW * 64), kargs, smem, s) != hipSuccess) return adt_set_error("wattn_mfma: launch failed");
+  return check_launch(bwd ? "wattn_mfma_bwd" : "wattn_mfma_fwd");
+}
+
+static int wattn_mfma_dispatch(int prec, bool bwd, const WAttnArgs& a, hipStream_t s) {
+  if (prec == ADT_PREC_BF16) return a.hd == 16 ? wattn_mfma_launch<PREC_BF16, 16>(bwd, a, s) : wattn_mfma_launch<PREC_BF16, 32>(bwd, a, s);
+  return a.hd == 16 ? wattn_mfma_launch<PREC_F32, 16>(bwd, a, s) : wattn_mfma_launch<PREC_F32, 32>(bwd, a, s);
+}
+
+
 extern "C" {
 
 int adt_dense_rows_enable(int on) {
@@ -503,6 +537,37 @@ int adt_wattn_bwd(const float* Qm, int ldqm, const float* Qc, int ldqc, const fl
   }
   hipLaunchKernelGGL(k_wattn_bwd, dim3(B * H), dim3(256), smem, (hipStream_t)stream, a);
   return check_launch("wattn_bwd");
+}
+
+// The same attention on the matrix cores; 1 = shape not covered (see wattn_mfma_ok above)
+int adt_wattn_mfma_fwd(int prec, const float* Qm, int ldqm, const float* Qc, int ldqc, const float* Km, int ldkm, const float* Kc, int ldkc,
+                       const float* Vm, int ldvm, const float* Vc, int ldvc, const int32_t* key_ids, int B, int H, int L, int hd, float p,
+                       const uint32_t* seed, uint32_t site, uint32_t b_offset, float* Om, int ldom, float* Oc, int ldoc, float* LSE,
+                       void* stream) {
+  const int lds[8] = {ldqm, ldqc, ldkm, ldkc, ldvm, ldvc, ldom, ldoc};
+  if (!wattn_mfma_ok(L, hd, lds, 8)) return 1;
+  WAttnArgs a{};
+  a.Qm = Qm; a.ldqm = ldqm; a.Qc = Qc; a.ldqc = ldqc; a.Km = Km; a.ldkm = ldkm; a.Kc = Kc; a.ldkc = ldkc; a.Vm = Vm; a.ldvm = ldvm;
+  a.Vc = Vc; a.ldvc = ldvc; a.kid = key_ids; a.B = B; a.H = H; a.L = L; a.hd = hd; a.scale = 1.0f / sqrtf((float)hd);
+  a.drop = adt_make_drop(p, seed, site); a.bh_offset = b_offset * (uint32_t)H; a.Om = Om; a.ldom = ldom; a.Oc = Oc; a.ldoc = ldoc; a.LSE = LSE;
+  return wattn_mfma_dispatch(prec, false, a, (hipStream_t)stream);
+}
+
+int adt_wattn_mfma_bwd(int prec, const float* Qm, int ldqm, const float* Qc, int ldqc, const float* Km, int ldkm, const float* Kc, int ldkc,
+                       const float* Vm, int ldvm, const float* Vc, int ldvc, const int32_t* key_ids, const float* Om, int ldom, const float* Oc,
+                       int ldoc, const float* LSE, const float* dOm, int lddom, const float* dOc, int lddoc, int B, int H, int L, int hd, float p,
+                       const uint32_t* seed, uint32_t site, uint32_t b_offset, float* dQm, float* dQc, float* dKm, float* dKc, float* dVm,
+                       float* dVc, int ldd, void* stream) {
+  const int lds[11] = {ldqm, ldqc, ldkm, ldkc, ldvm, ldvc, lddom, lddoc, ldd, ldom, ldoc};
+  if (!wattn_mfma_ok(L, hd, lds, 11)) return 1;
+  WAttnArgs a{};
+  a.Qm = Qm; a.ldqm = ldqm; a.Qc = Qc; a.ldqc = ldqc; a.Km = Km; a.ldkm = ldkm; a.Kc = Kc; a.ldkc = ldkc; a.Vm = Vm; a.ldvm = ldvm;
+  a.Vc = Vc; a.ldvc = ldvc; a.kid = key_ids; a.B = B; a.H = H; a.L = L; a.hd = hd; a.scale = 1.0f / sqrtf((float)hd);
+  a.drop = adt_make_drop(p, seed, site); a.bh_offset = b_offset * (uint32_t)H; a.LSE = const_cast<float*>(LSE);
+  a.Om = const_cast<float*>(Om); a.ldom = ldom; a.Oc = const_cast<float*>(Oc); a.ldoc = ldoc;
+  a.dOm = dOm; a.lddom = lddom; a.dOc = dOc; a.lddoc = lddoc;
+  a.dQm = dQm; a.dQc = dQc; a.dKm = dKm; a.dKc = dKc; a.dVm = dVm; a.dVc = dVc; a.ldd = ldd;
+  return wattn_mfma_dispatch(prec, true, a, (hipStream_t)stream);
 }
 
 int adt_wdist_bpr(const float* Sm, const float* Sc, int lds, const float* Em, const float* Ec, const int32_t* pos, const int32_t* neg, int T,

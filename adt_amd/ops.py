@@ -303,25 +303,42 @@ def score_rank_bias(F, ldf, E, bias, cand, B, C, want_rank=True):
     return logits, rank
 
 
-def wattn_fwd(Qm, Qc, Km, Kc, Vm, Vc, key_ids, B, H, L, p=0.0, seed=None, site=0, b_offset=0):
+def wattn_fwd(Qm, Qc, Km, Kc, Vm, Vc, key_ids, B, H, L, p=0.0, seed=None, site=0, b_offset=0, prec=None):
+    """prec: PREC_BF16 / PREC_F32 selects the matrix-core kernels (adt_wattn_mfma.cuh) where they cover the shape; None (or an
+    uncovered shape) the exact vector-ALU kernels."""
     d = Qm.shape[1]
     hd = d // H
     Om = torch.empty(B * L, d, device=Qm.device, dtype=torch.float32)
     Oc = torch.empty_like(Om)
     LSE = torch.empty(B * H * L, device=Qm.device, dtype=torch.float32)
+    if prec is not None:
+        rc = _lib.load().adt_wattn_mfma_fwd(int(prec), _p(_f32(Qm)), _ld(Qm), _p(_f32(Qc)), _ld(Qc), _p(_f32(Km)), _ld(Km), _p(_f32(Kc)), _ld(Kc),
+                                            _p(_f32(Vm)), _ld(Vm), _p(_f32(Vc)), _ld(Vc), _p(_i32(key_ids)), B, H, L, hd, float(p), _p(seed), site,
+                                            b_offset, _p(Om), d, _p(Oc), d, _p(LSE), _stream())
+        if rc != 1:
+            _lib.check(rc, "wattn_mfma_fwd")
+            return Om, Oc, LSE
     _lib.check(_lib.load().adt_wattn_fwd(_p(_f32(Qm)), _ld(Qm), _p(_f32(Qc)), _ld(Qc), _p(_f32(Km)), _ld(Km), _p(_f32(Kc)), _ld(Kc), _p(_f32(Vm)), _ld(Vm),
                                          _p(_f32(Vc)), _ld(Vc), _p(_i32(key_ids)), B, H, L, hd, float(p), _p(seed), site, b_offset, _p(Om), d, _p(Oc), d,
                                          _p(LSE), _stream()), "wattn_fwd")
     return Om, Oc, LSE
 
 
-def wattn_bwd(Qm, Qc, Km, Kc, Vm, Vc, key_ids, Om, Oc, LSE, dOm, dOc, B, H, L, p=0.0, seed=None, site=0, b_offset=0, out=None):
-    """out: optional (dQm, dQc, dKm, dKc, dVm, dVc) views sharing one row stride."""
+def wattn_bwd(Qm, Qc, Km, Kc, Vm, Vc, key_ids, Om, Oc, LSE, dOm, dOc, B, H, L, p=0.0, seed=None, site=0, b_offset=0, out=None, prec=None):
+    """out: optional (dQm, dQc, dKm, dKc, dVm, dVc) views sharing one row stride.  prec: as wattn_fwd (use the same value)."""
     d = Qm.shape[1]
     hd = d // H
     outs = [torch.empty(B * L, d, device=Qm.device, dtype=torch.float32) for _ in range(6)] if out is None else list(out)
     ldd = _ld(outs[0])
     assert all(_ld(o) == ldd for o in outs)
+    if prec is not None:
+        rc = _lib.load().adt_wattn_mfma_bwd(int(prec), _p(_f32(Qm)), _ld(Qm), _p(_f32(Qc)), _ld(Qc), _p(_f32(Km)), _ld(Km), _p(_f32(Kc)), _ld(Kc),
+                                            _p(_f32(Vm)), _ld(Vm), _p(_f32(Vc)), _ld(Vc), _p(_i32(key_ids)), _p(Om), _ld(Om), _p(Oc), _ld(Oc), _p(LSE),
+                                            _p(_f32(dOm)), _ld(dOm), _p(_f32(dOc)), _ld(dOc), B, H, L, hd, float(p), _p(seed), site, b_offset,
+                                            *[_p(o) for o in outs], ldd, _stream())
+        if rc != 1:
+            _lib.check(rc, "wattn_mfma_bwd")
+            return outs
     _lib.check(_lib.load().adt_wattn_bwd(_p(_f32(Qm)), _ld(Qm), _p(_f32(Qc)), _ld(Qc), _p(_f32(Km)), _ld(Km), _p(_f32(Kc)), _ld(Kc), _p(_f32(Vm)), _ld(Vm),
                                          _p(_f32(Vc)), _ld(Vc), _p(_i32(key_ids)), _p(Om), _ld(Om), _p(Oc), _ld(Oc), _p(LSE), _p(_f32(dOm)), _ld(dOm),
                                          _p(_f32(dOc)), _ld(dOc), B, H, L, hd, float(p), _p(seed), site, b_offset, *[_p(o) for o in outs], ldd, _stream()),

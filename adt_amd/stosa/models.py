@@ -151,7 +151,7 @@ class DisenDistSAModel(FlatModule):
             Qm, Km, Vm = qm.t, km.t[:, :d], km.t[:, d:]
             Qc, Kc, Vc = qc.t, kc.t[:, :d], kc.t[:, d:]
             holders = ((qm, km), (qc, kc))
-        Om, Oc, LSE = ops.wattn_fwd(Qm, Qc, Km, Kc, Vm, Vc, key_ids, B, H, L, pa, self._seed, st["attn"], tp.b_offset)
+        Om, Oc, LSE = ops.wattn_fwd(Qm, Qc, Km, Kc, Vm, Vc, key_ids, B, H, L, pa, self._seed, st["attn"], tp.b_offset, prec=self.prec)
         om, oc = Act(Om), Act(Oc)
 
         def bw():
@@ -163,7 +163,7 @@ class DisenDistSAModel(FlatModule):
             gm = torch.empty(T, 3 * d, device=self.dev, dtype=torch.float32)
             gc = torch.empty(T, 3 * d, device=self.dev, dtype=torch.float32)
             ops.wattn_bwd(Qm, Qc, Km, Kc, Vm, Vc, key_ids, Om, Oc, LSE, gom, goc, B, H, L, pa, self._seed, st["attn"], tp.b_offset,
-                          out=(gm[:, :d], gc[:, :d], gm[:, d:2 * d], gc[:, d:2 * d], gm[:, 2 * d:], gc[:, 2 * d:]))
+                          out=(gm[:, :d], gc[:, :d], gm[:, d:2 * d], gc[:, d:2 * d], gm[:, 2 * d:], gc[:, 2 * d:]), prec=self.prec)
             for hold, g in ((holders[0], gm), (holders[1], gc)):
                 if len(hold) == 1:
                     hold[0].g = g

@@ -221,6 +221,17 @@ int adt_wattn_bwd(const float* Qm, int ldqm, const float* Qc, int ldqc, const fl
                   const float* Oc, int ldoc, const float* LSE, const float* dOm, int lddom, const float* dOc, int lddoc, int B,
                   int H, int L, int hd, float p, const uint32_t* seed, uint32_t site, uint32_t b_offset, float* dQm, float* dQc,
                   float* dKm, float* dKc, float* dVm, float* dVc, int ldd, void* stream);
+/* The same attention on the matrix cores (one 16x16x32 MFMA per score tile over the concatenation [mean | sqrt cov]); prec: ADT_PREC_BF16
+ * (bf16 operands) or ADT_PREC_F32 (exact fp32 MFMA).  Return 1 = shape not covered (head size 16 / 32, L <= 128): use the functions above. */
+int adt_wattn_mfma_fwd(int prec, const float* Qm, int ldqm, const float* Qc, int ldqc, const float* Km, int ldkm, const float* Kc, int ldkc,
+                       const float* Vm, int ldvm, const float* Vc, int ldvc, const int32_t* key_ids, int B, int H, int L, int hd, float p,
+                       const uint32_t* seed, uint32_t site, uint32_t b_offset, float* Om, int ldom, float* Oc, int ldoc, float* LSE,
+                       void* stream);
+int adt_wattn_mfma_bwd(int prec, const float* Qm, int ldqm, const float* Qc, int ldqc, const float* Km, int ldkm, const float* Kc, int ldkc,
+                       const float* Vm, int ldvm, const float* Vc, int ldvc, const int32_t* key_ids, const float* Om, int ldom, const float* Oc,
+                       int ldoc, const float* LSE, const float* dOm, int lddom, const float* dOc, int lddoc, int B, int H, int L, int hd, float p,
+                       const uint32_t* seed, uint32_t site, uint32_t b_offset, float* dQm, float* dQc, float* dKm, float* dKc, float* dVm,
+                       float* dVc, int ldd, void* stream);
 /* bpr_optimization (stosa/trainer.py:358-391), loss and gradients in one pass: loss3 = 3 x 64 slots {bpr, pvn_weight *
  * pvn, auc}, all already divided by sum(istarget) (= 1 / *inv_count); dSm/dSc overwritten, dEm/dEc accumulated. */
 int adt_wdist_bpr(const float* Sm, const float* Sc, int lds, const float* Em, const float* Ec, const int32_t* pos,

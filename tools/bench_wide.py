@@ -101,7 +101,7 @@ def run_stosa(args):
     dt = time.perf_counter() - t0
     print(json.dumps({"workload": "STOSA-ADT Beauty shape: d=64 H=4 L=100 1+1 layers item_size=12103, batch %d, dropout 0.3, full train step" % B,
                       "ms_per_step": round(dt / args.steps * 1e3, 3), "sequences_per_s": round(B * args.steps / dt, 1), "loss": round(float(tr.loss()), 4),
-                      "dtype": "f32 attention/losses, bf16 dense operands"}))
+                      "dtype": "bf16 MFMA operands (dense layers and Wasserstein attention), fp32 accumulation, statistics and losses"}))
 
 
 def run_sasrec256(args):
