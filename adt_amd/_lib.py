@@ -21,6 +21,21 @@ class SasrecCfg(ctypes.Structure):
 
 _CP = ctypes.POINTER(SasrecCfg)
 
+
+class EncLayerPtrs(ctypes.Structure):
+    """struct adt_enc_layer_ptrs: device pointers of one encoder layer's tensors (or of their gradient accumulators)."""
+    NAMES = ("ln1_w", "ln1_b", "in_w", "in_b", "out_w", "out_b", "ln2_w", "ln2_b", "c1_w", "c1_b", "c2_w", "c2_b", "cls_w", "cls_b")
+    _fields_ = [(n, ctypes.c_void_p) for n in NAMES]
+
+
+class DecLayerPtrs(ctypes.Structure):
+    """struct adt_dec_layer_ptrs."""
+    NAMES = ("ln_w", "ln_b", "sin_w", "sin_b", "so_w", "so_b", "ein_w", "ein_b", "eo_w", "eo_b", "c1_w", "c1_b", "c2_w", "c2_b")
+    _fields_ = [(n, ctypes.c_void_p) for n in NAMES]
+
+
+_EP, _DP = ctypes.POINTER(EncLayerPtrs), ctypes.POINTER(DecLayerPtrs)
+
 # name -> (restype, argtypes); the single source of truth for symbol coverage (tests/test_capi_symbols.py)
 SIGNATURES = {
     "adt_version": (_I, []),
@@ -85,6 +100,13 @@ SIGNATURES = {
     "adt_sasrec_ws_offset": (_L, [_CP, _I, _I, _I]),
     "adt_sasrec_forward": (_I, [_CP, _P, _P, _P, _P, _P, _P, _I, _I, _P, _U, _P]),
     "adt_sasrec_probe_dec_layer_fwd": (_I, [_CP, _P, _P, _P, _I, _I, _P, _U, _I, _P]),
+    "adt_seq_layer_supported": (_I, [_I, _I, _I, _I]),
+    "adt_seq_layer_save_floats": (_L, [_I, _I, _I, _I]),
+    "adt_pack_wimg": (_I, [_P, _P, _P, _I, _P]),
+    "adt_seq_enc_layer_fwd": (_I, [_I, _I, _I, _P, _P, _EP, _P, _P, _F, _P, _U, _U, _U, _U, _I, _P, _P, _F, _I, _P, _P]),
+    "adt_seq_enc_layer_bwd": (_I, [_I, _I, _I, _P, _P, _EP, _EP, _P, _P, _F, _P, _U, _U, _U, _U, _P, _P, _F, _P, _P, _P, _I, _P, _P]),
+    "adt_seq_dec_layer_fwd": (_I, [_I, _I, _I, _P, _P, _P, _DP, _P, _P, _F, _P, _U, _U, _U, _U, _U, _P, _P, _F, _I, _P]),
+    "adt_seq_dec_layer_bwd": (_I, [_I, _I, _I, _P, _P, _P, _DP, _DP, _P, _P, _F, _P, _U, _U, _U, _U, _U, _P, _P, _F, _P, _I, _P, _P, _P]),
     "adt_sasrec_loss_seed": (_I, [_CP, _P, _P, _I, _P, _P, _P]),
     "adt_sasrec_backward": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _U, _I, _P]),
     "adt_sasrec_predict": (_I, [_CP, _P, _P, _P, _P, _I, _I, _P, _P, _P]),

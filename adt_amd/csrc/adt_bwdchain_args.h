@@ -36,6 +36,7 @@ struct BwdChainArgs {
   // 256-deep chain of same-address float atomics (10.5 us per million adds measured, 5.7 us with 8 replicas, 4.5 us private);
   // the executor sums the replicas into the gradient buffer afterwards (adt_replica_reduce).
   int nrep; size_t rep_stride;
+  float gy_scale;             // adt_seqpost_tt.cuh: the upstream gradient is gy * gy_scale (0 means 1): the supernet's mixing weight of this candidate
   float* part[4]; size_t part_stride;   // adt_seqpost_tt.cuh: non-null part[k] = private partials of dWk (4096 floats at part[k] + workgroup * part_stride)
   int saved_bf16;             // u / xin / o were saved as bf16 rows by the transposed-chain forward (post and mid chains)
   unsigned long long* stamps;  // timing experiments only (ADT_SEQ_STAMPS=3): s_memtime per wave of workgroup 0 (adt_seqpost_tt.cuh)

@@ -31,8 +31,7 @@ int adt_seq_supported(int prec, int L, int d, int hd);      // bf16 mode, d = 64
 int adt_seq_lean(int prec, int L, int d, int hd);           // the forward may save bf16 tensors and skip LN(x) / qkv (see adt_seq.hip)
 int adt_launch_seq_enc_fwd(int hd, const adt::SeqFwdArgs& a, void* stream);
 int adt_launch_seq_dec_fwd(int hd, const adt::SeqFwdArgs& a, void* stream);
-// pre-packed bf16 weight images of n 64 x 64 blocks at base + offs[i] -> img + 6 * offs[i] (bf16 elements); defined in adt_seq.hip
-int adt_pack_wimg(const float* base, void* img, const int* offs, int n, void* stream);
+// adt_pack_wimg (pre-packed bf16 weight images) is part of the C ABI now: include/adt_hip.h; defined in adt_seq.hip
 namespace adt { struct AttnArgs; }
 int adt_launch_seq_attn_bwd(int hd, const adt::AttnArgs& a, void* stream);     // 0 launched, 1 shape not covered, < 0 error
 // adt_attn_bwd with Q, K, V, O saved as bf16 rows (ld* of those four count bf16 elements); per-sequence kernel only: anything it does not

@@ -683,4 +683,126 @@ int adt_sasrec_predict(const adt_sasrec_cfg* c, const float* P, float* ws, const
   return adt_score_rank(ws + w.f + (int64_t)(L - 1) * d, L * d, P + lo.item(), cand, B, C, d, logits, rank, st);
 }
 
+
+// ---- one layer per call (the supernet's candidate layers): include/adt_hip.h --------------------------------------------------------
+namespace {
+struct LayerSave { float *o, *h, *u, *lse, *mask, *a1, *q2, *kv2, *o2, *lse2, *mask2; int64_t total; };
+LayerSave layer_save(float* base, int B, int L, int H, int dec) {
+  const int64_t T = (int64_t)B * L, row = up64(T * 32), ls = up64((int64_t)B * H * L), mk = up64((int64_t)B * H * L * 8);
+  LayerSave s{};
+  int64_t o = 0;
+  auto take = [&](int64_t n) { float* r = base ? base + o : nullptr; o += n; return r; };
+  s.o = take(row); s.h = take(row); s.u = take(row); s.lse = take(ls); s.mask = take(mk);
+  if (dec) { s.a1 = take(row); s.q2 = take(row); s.kv2 = take(2 * row); s.o2 = take(row); s.lse2 = take(ls); s.mask2 = take(mk); }
+  s.total = o;
+  return s;
+}
+}  // namespace
+
+int adt_seq_layer_supported(int prec, int L, int d, int hd) { return adt_seq_lean(prec, L, d, hd) && adt_seq_partials(prec, L, d, hd) ? 1 : 0; }
+
+int64_t adt_seq_layer_save_floats(int B, int L, int H, int dec) { return layer_save(nullptr, B, L, H, dec).total; }
+
+int adt_seq_enc_layer_fwd(int B, int L, int H, const int32_t* ids, const float* x, const adt_enc_layer_ptrs* P, const float* wp_base,
+                          const void* wp_img, float p, const uint32_t* seed, uint32_t site_attn, uint32_t site_ffn1, uint32_t site_ffn2,
+                          uint32_t b_offset, int training, float* save, float* y, float y_scale, int y_acc, float* rec, void* st) {
+  const int hd = 64 / H;
+  if (!adt_seq_layer_supported(ADT_PREC_BF16, L, 64, hd)) return adt_set_error("seq_enc_layer_fwd: L=%d H=%d is not covered", L, H);
+  const LayerSave s = layer_save(save, B, L, H, 0);
+  adt::SeqFwdArgs a = seq_args(L, B, H, ids, p, seed, b_offset, hd);
+  a.x = x; a.site_attn = site_attn; a.site1 = site_ffn1; a.site2 = site_ffn2;
+  a.gamma = P->ln1_w; a.beta = P->ln1_b; a.Win = P->in_w; a.bin = P->in_b; a.Wo = P->out_w; a.bo = P->out_b;
+  a.gamma2 = P->ln2_w; a.beta2 = P->ln2_b; a.W1 = P->c1_w; a.b1 = P->c1_b; a.W2 = P->c2_w; a.b2 = P->c2_b;
+  a.y = y; a.y_scale = y_scale; a.y_acc = y_acc; a.wp_base = wp_base; a.wp_img = wp_img;
+  if (training) { a.o = s.o; a.h = s.h; a.u = s.u; a.lse = s.lse; a.mask = reinterpret_cast<uint32_t*>(s.mask); a.saved_bf16 = 1; }
+  else { a.lse = s.lse; }
+  if (rec && H > 1) { a.rec = rec; a.Ws = P->cls_w; a.bs = P->cls_b; }
+  return adt_launch_seq_enc_fwd(hd, a, st);
+}
+
+int adt_seq_enc_layer_bwd(int B, int L, int H, const int32_t* ids, const float* x, const adt_enc_layer_ptrs* P, const adt_enc_layer_ptrs* G,
+                          const float* wp_base, const void* wp_img, float p, const uint32_t* seed, uint32_t site_attn, uint32_t site_ffn1,
+                          uint32_t site_ffn2, uint32_t b_offset, const float* save, const float* gy, float gy_scale, const float* rec,
+                          const float* drec, float* gx, int gx_acc, float* scratch, void* st) {
+  const int hd = 64 / H, T = B * L;
+  if (!adt_seq_layer_supported(ADT_PREC_BF16, L, 64, hd)) return adt_set_error("seq_enc_layer_bwd: L=%d H=%d is not covered", L, H);
+  const LayerSave s = layer_save(const_cast<float*>(save), B, L, H, 0);
+  float *dO = scratch, *dh = scratch + up64((int64_t)T * 64);
+  {  // FFN + mask + forward_layernorm + out_proj (+ head classifier) reverse -> dh, dO
+    adt::BwdChainArgs a = bwd_args(T, L, B, ids, p, seed, b_offset * (uint32_t)L);
+    a.site1 = site_ffn1; a.site2 = site_ffn2; a.gy = gy; a.gy_scale = gy_scale; a.u = s.u; a.xin = s.h; a.o = s.o; a.saved_bf16 = 1;
+    a.W0 = P->c2_w; a.W1 = P->c1_w; a.W2 = P->out_w; a.gamma = P->ln2_w; a.beta = P->ln2_b;
+    a.dW0 = G->c2_w; a.dW1 = G->c1_w; a.dW2 = G->out_w; a.db0 = G->c2_b; a.db1 = G->c1_b; a.db2 = G->out_b; a.dgamma = G->ln2_w; a.dbeta = G->ln2_b;
+    a.out0 = dh; a.out1 = dO; a.wp_base = wp_base; a.wp_img = wp_img;
+    if (H > 1 && drec) { a.rec = rec; a.drec = drec; a.Ws = P->cls_w; a.dWs = G->cls_w; a.dbs = G->cls_b; a.H = H; }
+    const int rc = adt_launch_seq_post_bwd(hd, 1, a, st);
+    if (rc) return rc < 0 ? rc : adt_set_error("seq_enc_layer_bwd: post chain not covered");
+  }
+  adt::SeqBwdArgs a = seq_bwd_args(L, B, H, ids, p, seed, site_attn, b_offset, hd);
+  a.x = x; a.gamma = P->ln1_w; a.beta = P->ln1_b; a.Win = P->in_w; a.bin = P->in_b;
+  a.dO = dO; a.o = s.o; a.lse = s.lse; a.mask = reinterpret_cast<const uint32_t*>(s.mask); a.dres = dh; a.saved_bf16 = 1;
+  a.gx = gx; a.acc = gx_acc; a.dWin = G->in_w; a.dbin = G->in_b; a.dgamma = G->ln1_w; a.dbeta = G->ln1_b;
+  a.wp_base = wp_base; a.wp_img = wp_img;
+  const int rc = adt_launch_seq_attn_pre_bwd(hd, 0, a, st);
+  return rc <= 0 ? rc : adt_set_error("seq_enc_layer_bwd: attention block not covered");
+}
+
+int adt_seq_dec_layer_fwd(int B, int L, int H, const int32_t* ids, const float* x, const float* feats, const adt_dec_layer_ptrs* P,
+                          const float* wp_base, const void* wp_img, float p, const uint32_t* seed, uint32_t site_slf, uint32_t site_enc,
+                          uint32_t site_ffn1, uint32_t site_ffn2, uint32_t b_offset, float* save, float* y, float y_scale, int y_acc, void* st) {
+  const int hd = 64 / H;
+  if (!adt_seq_layer_supported(ADT_PREC_BF16, L, 64, hd)) return adt_set_error("seq_dec_layer_fwd: L=%d H=%d is not covered", L, H);
+  const LayerSave s = layer_save(save, B, L, H, 1);
+  adt::SeqFwdArgs a = seq_args(L, B, H, ids, p, seed, b_offset, hd);
+  a.x = x; a.f = feats; a.site_attn = site_slf; a.site_attn2 = site_enc; a.site1 = site_ffn1; a.site2 = site_ffn2;
+  a.gamma = P->ln_w; a.beta = P->ln_b; a.Win = P->sin_w; a.bin = P->sin_b; a.Wo = P->so_w; a.bo = P->so_b;
+  a.Win2 = P->ein_w; a.bin2 = P->ein_b; a.Wo2 = P->eo_w; a.bo2 = P->eo_b; a.W1 = P->c1_w; a.b1 = P->c1_b; a.W2 = P->c2_w; a.b2 = P->c2_b;
+  a.o = s.o; a.lse = s.lse; a.mask = reinterpret_cast<uint32_t*>(s.mask); a.a1 = s.a1; a.q2 = s.q2; a.kv2 = s.kv2; a.o2 = s.o2;
+  a.lse2 = s.lse2; a.mask2 = reinterpret_cast<uint32_t*>(s.mask2); a.h = s.h; a.u = s.u; a.saved_bf16 = 1;
+  a.y = y; a.y_scale = y_scale; a.y_acc = y_acc; a.wp_base = wp_base; a.wp_img = wp_img;
+  return adt_launch_seq_dec_fwd(hd, a, st);
+}
+
+int adt_seq_dec_layer_bwd(int B, int L, int H, const int32_t* ids, const float* x, const float* feats, const adt_dec_layer_ptrs* P,
+                          const adt_dec_layer_ptrs* G, const float* wp_base, const void* wp_img, float p, const uint32_t* seed,
+                          uint32_t site_slf, uint32_t site_enc, uint32_t site_ffn1, uint32_t site_ffn2, uint32_t b_offset, const float* save,
+                          const float* gy, float gy_scale, float* gx, int gx_acc, float* gfeats, float* scratch, void* st) {
+  const int hd = 64 / H, T = B * L, d = 64;
+  if (!adt_seq_layer_supported(ADT_PREC_BF16, L, 64, hd)) return adt_set_error("seq_dec_layer_bwd: L=%d H=%d is not covered", L, H);
+  const LayerSave s = layer_save(const_cast<float*>(save), B, L, H, 1);
+  const int64_t Td = up64((int64_t)T * 64);
+  float *s1 = scratch, *s5 = scratch + Td, *s4 = scratch + 2 * Td;      // dO (T x 64), dq2 (T x 64), dk2 | dv2 (T x 128)
+  const uint32_t ro = b_offset * (uint32_t)L;
+  {  // FFN + mask + enc_attn.out_proj reverse -> dO2 (s1)
+    adt::BwdChainArgs a = bwd_args(T, L, B, ids, p, seed, ro);
+    a.site1 = site_ffn1; a.site2 = site_ffn2; a.gy = gy; a.gy_scale = gy_scale; a.u = s.u; a.xin = s.h; a.o = s.o2; a.saved_bf16 = 1;
+    a.W0 = P->c2_w; a.W1 = P->c1_w; a.W2 = P->eo_w; a.dW0 = G->c2_w; a.dW1 = G->c1_w; a.dW2 = G->eo_w;
+    a.db0 = G->c2_b; a.db1 = G->c1_b; a.db2 = G->eo_b; a.out0 = s1; a.wp_base = wp_base; a.wp_img = wp_img;
+    const int rc = adt_launch_seq_post_bwd(hd, 0, a, st);
+    if (rc) return rc < 0 ? rc : adt_set_error("seq_dec_layer_bwd: post chain not covered");
+  }
+  {  // cross attention core: dq2 -> s5, dk2 | dv2 -> s4
+    const uint16_t* kvb = reinterpret_cast<const uint16_t*>(s.kv2);
+    CK(adt_attn_bwd_saved_bf16(s.q2, d, kvb, 2 * d, kvb + d, 2 * d, s.o2, d, s.lse2, s1, d, B, H, L, hd, p, seed, site_enc, b_offset, s5, d, s4,
+                               2 * d, s4 + d, 2 * d, reinterpret_cast<const uint32_t*>(s.mask2), st));
+  }
+  {  // enc_attn q / k / v projections and slf_attn.out_proj reverse -> dO1 (s1), d feats +=
+    adt::BwdChainArgs a = bwd_args(T, L, B, ids, 0.f, nullptr, ro);
+    a.dqkv = s5; a.lddqkv = d; a.xin = s.a1; a.o = s.o; a.saved_bf16 = 1; a.dkv2 = s4; a.f = feats;
+    a.W0 = P->ein_w; a.W1 = P->so_w; a.W2 = P->ein_w + d * d; a.W3 = P->ein_w + 2 * d * d;
+    a.dW0 = G->ein_w; a.dW1 = G->so_w; a.dW2 = G->ein_w + d * d; a.dW3 = G->ein_w + 2 * d * d;
+    a.db0 = G->ein_b; a.db1 = G->so_b; a.db2 = G->ein_b + d; a.db3 = G->ein_b + 2 * d;
+    a.out0 = s1; a.out1 = gfeats; a.acc1 = 1; a.wp_base = wp_base; a.wp_img = wp_img;
+    const int rc = adt_launch_seq_mid_bwd(hd, a, st);
+    if (rc) return rc < 0 ? rc : adt_set_error("seq_dec_layer_bwd: mid chain not covered");
+  }
+  adt::SeqBwdArgs a = seq_bwd_args(L, B, H, ids, p, seed, site_slf, b_offset, hd);
+  a.x = x; a.gamma = P->ln_w; a.beta = P->ln_b; a.Win = P->sin_w; a.bin = P->sin_b;
+  a.dO = s1; a.o = s.o; a.lse = s.lse; a.mask = reinterpret_cast<const uint32_t*>(s.mask); a.dres = gy; a.dres_scale = gy_scale; a.saved_bf16 = 1;
+  a.gx = gx; a.acc = gx_acc; a.dWin = G->sin_w; a.dbin = G->sin_b; a.dgamma = G->ln_w; a.dbeta = G->ln_b;
+  a.wp_base = wp_base; a.wp_img = wp_img;
+  const int rc = adt_launch_seq_attn_pre_bwd(hd, 1, a, st);
+  return rc <= 0 ? rc : adt_set_error("seq_dec_layer_bwd: attention block not covered");
+}
+
 }  // extern "C"

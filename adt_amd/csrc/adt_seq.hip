@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_pack_wimg(PackArgs a) {
   }
 }
 
-int adt_pack_wimg(const float* base, void* img, const int* offs, int n, void* stream) {
+extern "C" int adt_pack_wimg(const float* base, void* img, const int* offs, int n, void* stream) {
   if (n < 1 || n > 256) return adt_set_error("pack_wimg: %d blocks", n);
   PackArgs a;
   a.base = base; a.img = reinterpret_cast<__bf16*>(img); a.n = n;

@@ -34,6 +34,8 @@ struct SeqFwdArgs {
   float* rec;                          // encoder: (L*B, H, H) head-classifier log-probabilities, reference row order
   float* a1; float* q2; float* kv2;    // decoder: slf_attn.out_proj(o), cross query (B*L x 64), cross keys / values (B*L x 128)
   float* o2; float* lse2; uint32_t* mask2;         // decoder: cross attention
+  float y_scale; int y_acc;            // layer output: y = (y_acc ? y : 0) + y_scale * layer(x)  (y_scale == 0 means 1: plain store) -- the supernet's
+                                       // candidate mixing as an epilogue (sasrec/super_modules.py:42-49)
   int saved_bf16;                      // o, h, u, a1, q2, kv2, o2 are written as bf16 rows (first half of the same buffers); see adt_seq_lean
   const float* wp_base; const void* wp_img;        // pre-packed bf16 weight images (adt_wave.cuh: WPack); wp_img == nullptr: none
   unsigned long long* stamps;          // timing experiments only (ADT_SEQ_STAMPS): s_memtime per wave of workgroup 0 at phase ends

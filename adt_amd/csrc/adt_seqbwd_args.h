@@ -14,6 +14,7 @@ struct SeqBwdArgs {
   const float* Win; const float* bin;              // packed in-projection (3 x 64 x 64, 3 x 64)
   const float* dO; const float* o;                 // gradient wrt the attention output ; the forward's attention output
   const float* lse; const uint32_t* mask;          // (B*H*L) log-sum-exp ; (B*H*L x 8) dropout keep bits
+  float dres_scale;                   // decoder only: the residual gradient is dres * dres_scale (0 means 1; the supernet's mixing weight)
   const float* dres;                  // encoder: gradient wrt LN(x) from the residual path ; decoder: gradient wrt the layer output (masked here)
   float* gx; int acc;                 // gradient wrt x (acc: add to what is there)
   float* dWin; float* dbin; float* dgamma; float* dbeta;     // accumulators (global float atomics)

@@ -404,6 +404,10 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     tt_add(dkv, tt_gemm(tt_bfrags(dv[s]), wimg + 5 * TT_WIMG, c, g));
     TT res = tt_load(a.dres + (size_t)row * 64, valid, g);
     if (DEC && (!valid || a.ids[row] == 0)) res = tt_zero();
+    if (DEC && a.dres_scale != 0.f) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) res.v[nt] *= a.dres_scale;
+    }
     tt_add(dn, res);
     TT dx;
     if (!DEC) {

@@ -71,6 +71,17 @@ ADT_DEVICE_INLINE void tq_vec_store(float* vec, const TqVecRegs& r) {
   }
 }
 
+// the layer output, optionally scaled and accumulated (supernet mixing epilogue)
+ADT_DEVICE_INLINE void tq_store_y(const SeqFwdArgs& a, size_t row, TT y, bool valid, int g) {
+  float* dst = a.y + row * 64;
+  if (a.y_scale != 0.f) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) y.v[nt] *= a.y_scale;
+    if (a.y_acc) tt_add(y, tt_load(dst, valid, g));
+  }
+  tt_store(dst, y, valid, g);
+}
+
 ADT_DEVICE_INLINE int tq_tile(int s, int w, int ntiles) {        // heaviest causal tile paired with the lightest (adt_seqfwd.cuh)
   if (s == 0) return ntiles - 1 - w;
   return w < ntiles - TQ_NW ? w : -1;
@@ -282,7 +293,7 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
     TT y = tq_ffn(a, lds.vec, lds.w[4], lds.w[5], h2, key1, key2, row, valid, c, g);
     tt_add(y, h2);
     if (!valid || a.ids[row] == 0) y = tt_zero();
-    tt_store(a.y + (size_t)row * 64, y, valid, g);
+    tq_store_y(a, row, y, valid, g);
     TQ_STAMP(7 + 3 * s);
   }
 }
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
     tt_add(y, a2);
     tt_add(y, dn[s]);
     if (!valid || a.ids[row] == 0) y = tt_zero();
-    tt_store(a.y + (size_t)row * 64, y, valid, g);
+    tq_store_y(a, row, y, valid, g);
   }
 }
 

@@ -72,6 +72,10 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = tile >= 0 && l < L;
     dy[s] = tt_load(a.gy + (size_t)row * 64, valid, g);
+    if (a.gy_scale != 0.f) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) dy[s].v[nt] *= a.gy_scale;
+    }
     ua[s] = tt_load_saved(a.u, row, valid, g, a.saved_bf16);
     hraw[s] = tt_load_saved(a.xin, row, valid, g, a.saved_bf16);
     idv[s] = valid ? a.ids[row] : 0;

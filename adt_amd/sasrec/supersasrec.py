@@ -12,6 +12,7 @@ rec_weights[i] * MSE + ind_weights[stale i] * NLL, backward, clip_grad_norm_, Ad
 torch's semantics for parameters whose grad is None (candidates that were not mixed in keep their moments, their own
 step count and are not decayed).
 """
+import ctypes
 import math
 
 import numpy as np
@@ -95,6 +96,140 @@ class SuperSASRecModel(FlatModule):
         lo = self._views[p + names[0]][0]
         o, n, _ = self._views[p + last]
         return lo, o + (n + 3) // 4 * 4
+
+    # ---- grouped candidate execution on the per-sequence fused layer kernels -----------------------------------------------------
+    # (adt_seq_enc_layer_fwd / bwd, adt_seq_dec_layer_fwd / bwd: one launch per candidate layer forward, two / four per backward,
+    # instead of ~10 / ~25 stage launches; the bilinear mixing weight is the output epilogue y_mix (+)= w_k * layer_k(x) and the
+    # gradient prologue dy_k = w_k * dy_mix.)  bf16 operands, L % 4 == 0, L <= 224; ADT_SUPER_FUSED=0 keeps the stage kernels.
+    _ENC_FIELDS = dict(zip(_lib.EncLayerPtrs.NAMES, _ENC))
+    _DEC_FIELDS = dict(zip(_lib.DecLayerPtrs.NAMES, _DEC[:14]))
+
+    def fused_layers(self):
+        if getattr(self, "_fused", None) is None:
+            import os
+            on = os.environ.get("ADT_SUPER_FUSED", "1") != "0" and self.prec == ops.PREC_BF16
+            self._fused = bool(on and self.lib.adt_seq_layer_supported(self.prec, self.maxlen, self.hidden_units, self.hidden_units // self.num_heads))
+            if self._fused:
+                self._wimg = torch.empty(3 * self.flat.numel(), device=self.dev, dtype=torch.float32)      # 6 bf16 per parameter float
+                self._blocks = {}
+        return self._fused
+
+    def _ptrs(self, kind, prefix, grad):
+        cls, fields = (_lib.EncLayerPtrs, self._ENC_FIELDS) if kind == "enc" else (_lib.DecLayerPtrs, self._DEC_FIELDS)
+        key = (prefix, grad)
+        cache = self.__dict__.setdefault("_ptr_cache", {})
+        if key not in cache:
+            src = self.G if grad else self.P
+            cache[key] = cls(**{f: src(prefix + "." + n).data_ptr() for f, n in fields.items()})
+        return cache[key]
+
+    def pack_selected(self, layers=None):
+        """bf16 LDS images of every 64 x 64 weight of the selected candidate layers (once per step: the weights change); `layers`: an
+        explicit set of (depth, candidate) pairs instead of the current block choice."""
+        offs = []
+        d = self.hidden_units
+        if layers is None:
+            layers = sorted({(depth, idx) for depth, (idxs, _) in enumerate(self.shared) for idx in idxs})
+        for depth, idx in layers:
+            if True:
+                e, dd = "encoder.encoder_layers.%d.%d." % (depth, idx), "decoder.decoder_layers.%d.%d." % (depth, idx)
+                base = self._views[e + "attention_layer.in_proj_weight"][0]
+                offs += [base, base + d * d, base + 2 * d * d] + [self._views[e + n][0] for n in ("attention_layer.out_proj.weight",
+                                                                                                  "forward_layer.conv1.weight", "forward_layer.conv2.weight")]
+                for n in ("slf_attn.in_proj_weight", "enc_attn.in_proj_weight"):
+                    base = self._views[dd + n][0]
+                    offs += [base, base + d * d, base + 2 * d * d]
+                offs += [self._views[dd + n][0] for n in ("slf_attn.out_proj.weight", "enc_attn.out_proj.weight", "pos_ffn.conv1.weight",
+                                                          "pos_ffn.conv2.weight")]
+        for s0 in range(0, len(offs), 256):
+            chunk = offs[s0:s0 + 256]
+            arr = (ctypes.c_int * len(chunk))(*chunk)
+            _lib.check(self.lib.adt_pack_wimg(ops._p(self.flat), ops._p(self._wimg), arr, len(chunk), ops._stream()), "pack_wimg")
+
+    def _scratch(self, T):
+        n = 4 * ((T * 64 + 63) // 64 * 64)
+        if getattr(self, "_scr", None) is None or self._scr.numel() < n:
+            self._scr = torch.empty(n, device=self.dev, dtype=torch.float32)
+        return self._scr
+
+    def _enc_layers_fused(self, tp, depth, x, ids, B):
+        """The four selected encoder layers of one depth: -> (mixed output Act, [head-classifier Acts], weights)."""
+        L, H = self.maxlen, self.num_heads
+        idxs, ws = self.shared[depth]
+        T = B * L
+        p = tp.p_eff(self.dropout)
+        y = Act(torch.empty(T, self.hidden_units, device=self.dev, dtype=torch.float32))
+        nsave = self.lib.adt_seq_layer_save_floats(B, L, H, 0)
+        recs, saves = [], []
+        for k, (idx, wk) in enumerate(zip(idxs, ws)):
+            pre = "encoder.encoder_layers.%d.%d" % (depth, idx)
+            st = enc_sites(depth, k)
+            save = torch.empty(nsave, device=self.dev, dtype=torch.float32)
+            rec = Act(torch.empty(T, H * H, device=self.dev, dtype=torch.float32)) if H > 1 else None
+            _lib.check(self.lib.adt_seq_enc_layer_fwd(B, L, H, ops._p(ids), ops._p(x.t), ctypes.byref(self._ptrs("enc", pre, False)), ops._p(self.flat),
+                                                      ops._p(self._wimg), float(p), ops._p(self._seed), st["attn"], st["ffn1"], st["ffn2"], tp.b_offset,
+                                                      int(tp.training), ops._p(save), ops._p(y.t), float(wk), int(k > 0),
+                                                      ops._p(rec.t) if rec is not None else None, ops._stream()), "seq_enc_layer_fwd")
+            recs.append(rec)
+            saves.append(save)
+
+        def bw():
+            if y.g is None and all(r is None or r.g is None for r in recs):
+                return
+            gy = y.g if y.g is not None else torch.zeros_like(y.t)
+            for k, (idx, wk) in enumerate(zip(idxs, ws)):
+                pre = "encoder.encoder_layers.%d.%d" % (depth, idx)
+                st = enc_sites(depth, k)
+                acc = x.g is not None
+                if not acc:
+                    x.g = torch.empty_like(x.t)
+                rec = recs[k]
+                drec = rec.g if (rec is not None and rec.g is not None) else None
+                _lib.check(self.lib.adt_seq_enc_layer_bwd(B, L, H, ops._p(ids), ops._p(x.t), ctypes.byref(self._ptrs("enc", pre, False)),
+                                                          ctypes.byref(self._ptrs("enc", pre, True)), ops._p(self.flat), ops._p(self._wimg), float(p),
+                                                          ops._p(self._seed), st["attn"], st["ffn1"], st["ffn2"], tp.b_offset, ops._p(saves[k]),
+                                                          ops._p(gy), float(wk), ops._p(rec.t) if rec is not None else None,
+                                                          ops._p(drec) if drec is not None else None, ops._p(x.g), int(acc), ops._p(self._scratch(T)),
+                                                          ops._stream()), "seq_enc_layer_bwd")
+        tp.bw.append(bw)
+        return y, recs, ws
+
+    def _dec_layers_fused(self, tp, depth, x, feats, ids, B):
+        L, H = self.maxlen, self.num_heads
+        idxs, ws = self.shared[depth]
+        T = B * L
+        p = tp.p_eff(self.dropout)
+        y = Act(torch.empty(T, self.hidden_units, device=self.dev, dtype=torch.float32))
+        nsave = self.lib.adt_seq_layer_save_floats(B, L, H, 1)
+        saves = []
+        for k, (idx, wk) in enumerate(zip(idxs, ws)):
+            pre = "decoder.decoder_layers.%d.%d" % (depth, idx)
+            st = dec_sites(depth, k)
+            save = torch.empty(nsave, device=self.dev, dtype=torch.float32)
+            _lib.check(self.lib.adt_seq_dec_layer_fwd(B, L, H, ops._p(ids), ops._p(x.t), ops._p(feats.t), ctypes.byref(self._ptrs("dec", pre, False)),
+                                                      ops._p(self.flat), ops._p(self._wimg), float(p), ops._p(self._seed), st["slf"], st["enc"], st["ffn1"],
+                                                      st["ffn2"], tp.b_offset, ops._p(save), ops._p(y.t), float(wk), int(k > 0), ops._stream()),
+                       "seq_dec_layer_fwd")
+            saves.append(save)
+
+        def bw():
+            if y.g is None:
+                return
+            if feats.g is None:
+                feats.g = torch.zeros_like(feats.t)
+            for k, (idx, wk) in enumerate(zip(idxs, ws)):
+                pre = "decoder.decoder_layers.%d.%d" % (depth, idx)
+                st = dec_sites(depth, k)
+                acc = x.g is not None
+                if not acc:
+                    x.g = torch.empty_like(x.t)
+                _lib.check(self.lib.adt_seq_dec_layer_bwd(B, L, H, ops._p(ids), ops._p(x.t), ops._p(feats.t), ctypes.byref(self._ptrs("dec", pre, False)),
+                                                          ctypes.byref(self._ptrs("dec", pre, True)), ops._p(self.flat), ops._p(self._wimg), float(p),
+                                                          ops._p(self._seed), st["slf"], st["enc"], st["ffn1"], st["ffn2"], tp.b_offset, ops._p(saves[k]),
+                                                          ops._p(y.g), float(wk), ops._p(x.g), int(acc), ops._p(feats.g), ops._p(self._scratch(T)),
+                                                          ops._stream()), "seq_dec_layer_bwd")
+        tp.bw.append(bw)
+        return y
 
     # ------------------------------------------------------------------------------------------------------------------
     def _embed(self, tp, ids, site):
@@ -183,8 +318,18 @@ class SuperSASRecModel(FlatModule):
     def _encode(self, tp, seq, B):
         x = self._embed(tp, seq, SITE_EMB_SEQ)
         enc_in, recs = [], []
+        fused = self.fused_layers()
+        if fused:
+            self.pack_selected()
         for i, (idxs, ws) in enumerate(self.shared):
             enc_in.append(x)
+            if fused:
+                x, rk, wk = self._enc_layers_fused(tp, i, x, seq, B)
+                if self.num_heads > 1:
+                    recs.append(tp.log_softmax(tp.mix([(r, float(w)) for r, w in zip(rk, wk)]), self.num_heads))
+                else:
+                    recs.append(Act(torch.zeros(x.t.shape[0], 1, device=self.dev, dtype=torch.float32)))     # log_softmax over one class
+                continue
             outs, inds = [], []
             for k, (idx, w) in enumerate(zip(idxs, ws)):
                 y, rec = self._enc_layer(tp, "encoder.encoder_layers.%d.%d" % (i, idx), x, seq, B, enc_sites(i, k))
@@ -197,7 +342,12 @@ class SuperSASRecModel(FlatModule):
     def _decode(self, tp, dec, feats, B):
         y = self._embed(tp, dec, SITE_EMB_DEC)
         outs = []
+        fused = self.fused_layers()
         for i, (idxs, ws) in enumerate(self.shared):
+            if fused:
+                y = self._dec_layers_fused(tp, i, y, feats, dec, B)
+                outs.append(y)
+                continue
             parts = [(self._dec_layer(tp, "decoder.decoder_layers.%d.%d" % (i, idx), y, feats, dec, B, dec_sites(i, k)), float(w))
                      for k, (idx, w) in enumerate(zip(idxs, ws))]
             y = tp.mix(parts)
@@ -272,10 +422,23 @@ class SuperSASRecModel(FlatModule):
         flat = seq.view(-1)
         x0 = self._embed(tp, flat, SITE_EMB_SEQ)
 
+        fused = self.fused_layers()
+        if fused:
+            self.pack_selected(sorted({(depth, idx) for sh in shared_list for depth, (idxs, _) in enumerate(sh) for idx in idxs}))
+        H = self.num_heads
+
         def run_layer(depth, idx, x, n):
             ids = flat if n == 1 else flat.repeat(n)
-            y, _ = self._enc_layer(tp, "encoder.encoder_layers.%d.%d" % (depth, idx), Act(x[0]), ids, B * n, enc_sites(depth, 0))
-            return (y.t,)
+            pre = "encoder.encoder_layers.%d.%d" % (depth, idx)
+            if not fused:
+                y, _ = self._enc_layer(tp, pre, Act(x[0]), ids, B * n, enc_sites(depth, 0))
+                return (y.t,)
+            y = torch.empty_like(x[0])          # the same per-sequence kernel a single-candidate predict() runs: identical numbers
+            save = torch.empty(self.lib.adt_seq_layer_save_floats(B * n, L, H, 0), device=self.dev, dtype=torch.float32)
+            _lib.check(self.lib.adt_seq_enc_layer_fwd(B * n, L, H, ops._p(ids), ops._p(x[0]), ctypes.byref(self._ptrs("enc", pre, False)), ops._p(self.flat),
+                                                      ops._p(self._wimg), 0.0, ops._p(self._seed), 0, 0, 0, 0, 0, ops._p(save), ops._p(y), 0.0, 0, None,
+                                                      ops._stream()), "seq_enc_layer_fwd")
+            return (y,)
         feats = candidate_features(run_layer, (x0.t,), shared_list, self.num_layers, stats=stats)
         self.train(was)
         P = len(shared_list)

@@ -291,6 +291,36 @@ int adt_sasrec_forward(const adt_sasrec_cfg* cfg, const float* params, float* ws
  * workspace of a completed adt_sasrec_forward of the same batch; bf16 mode, d = 64.  Not part of the reference's interface. */
 int adt_sasrec_probe_dec_layer_fwd(const adt_sasrec_cfg* cfg, const float* params, float* ws, const int32_t* dec, int B, int training,
                                    const uint32_t* seed, uint32_t b_offset, int layer, void* stream);
+/* ---- One EncoderLayer / DecoderLayer (sasrec/modules.py:644-655, :666-677) per call, on the per-sequence fused kernels: what the
+ * supernet (sasrec/super_modules.py:35-50,74-85) runs for each of its four selected candidate layers.  bf16 operands, d = 64,
+ * head size 16 / 32 / 64, L <= 224, L % 4 == 0 (adt_seq_layer_supported).  Pointers are device fp32 tensors of the layer (parameters, or
+ * their gradient accumulators in the backward: gradients are ADDED).  wp_base / wp_img: the packed bf16 weight images of the 64x64
+ * blocks (adt_pack_wimg over the same flat buffer: image of block W at wp_img + 6 * (W - wp_base) bf16 elements).  `save`: the layer's
+ * saved activations (adt_seq_layer_save_floats floats), written by the forward, read by the backward.  y = (y_acc ? y : 0) + y_scale *
+ * layer(x): the candidate-mixing epilogue; the backward takes the gradient of the MIXED output and the same scale. */
+typedef struct { float *ln1_w, *ln1_b, *in_w, *in_b, *out_w, *out_b, *ln2_w, *ln2_b, *c1_w, *c1_b, *c2_w, *c2_b, *cls_w, *cls_b; } adt_enc_layer_ptrs;
+typedef struct { float *ln_w, *ln_b, *sin_w, *sin_b, *so_w, *so_b, *ein_w, *ein_b, *eo_w, *eo_b, *c1_w, *c1_b, *c2_w, *c2_b; } adt_dec_layer_ptrs;
+int adt_seq_layer_supported(int prec, int L, int d, int hd);
+int64_t adt_seq_layer_save_floats(int B, int L, int H, int dec);
+int adt_pack_wimg(const float* base, void* img, const int* offs, int n, void* stream);   /* n <= 256 blocks at base + offs[i] */
+int adt_seq_enc_layer_fwd(int B, int L, int H, const int32_t* ids, const float* x, const adt_enc_layer_ptrs* P, const float* wp_base,
+                          const void* wp_img, float p, const uint32_t* seed, uint32_t site_attn, uint32_t site_ffn1, uint32_t site_ffn2,
+                          uint32_t b_offset, int training, float* save, float* y, float y_scale, int y_acc, float* rec, void* stream);
+/* gy: gradient of the mixed output (B*L x 64); drec: gradient of this candidate's head-classifier log-probabilities (reference row order,
+ * may be null); gx: gradient of the layer input (gx_acc: add); scratch: 2 * B*L*64 floats */
+int adt_seq_enc_layer_bwd(int B, int L, int H, const int32_t* ids, const float* x, const adt_enc_layer_ptrs* P, const adt_enc_layer_ptrs* G,
+                          const float* wp_base, const void* wp_img, float p, const uint32_t* seed, uint32_t site_attn, uint32_t site_ffn1,
+                          uint32_t site_ffn2, uint32_t b_offset, const float* save, const float* gy, float gy_scale, const float* rec,
+                          const float* drec, float* gx, int gx_acc, float* scratch, void* stream);
+int adt_seq_dec_layer_fwd(int B, int L, int H, const int32_t* ids, const float* x, const float* feats, const adt_dec_layer_ptrs* P,
+                          const float* wp_base, const void* wp_img, float p, const uint32_t* seed, uint32_t site_slf, uint32_t site_enc,
+                          uint32_t site_ffn1, uint32_t site_ffn2, uint32_t b_offset, float* save, float* y, float y_scale, int y_acc,
+                          void* stream);
+/* gfeats: gradient of `feats` (ADDED); scratch: 4 * B*L*64 floats */
+int adt_seq_dec_layer_bwd(int B, int L, int H, const int32_t* ids, const float* x, const float* feats, const adt_dec_layer_ptrs* P,
+                          const adt_dec_layer_ptrs* G, const float* wp_base, const void* wp_img, float p, const uint32_t* seed,
+                          uint32_t site_slf, uint32_t site_enc, uint32_t site_ffn1, uint32_t site_ffn2, uint32_t b_offset, const float* save,
+                          const float* gy, float gy_scale, float* gx, int gx_acc, float* gfeats, float* scratch, void* stream);
 /* loss assembly (sasrec/main.py:151-169): fills G_POS/G_NEG, G_ENC_X[0..nl-1], G_DEC_X[1..nl], G_REC and the
  * loss slots from the forward activations.  lambdas1/lambdas2: host arrays of num_layers floats; the NLL
  * weight is lambdas2[num_layers-1] for every layer (stale loop index, sasrec/main.py:169).  NORMS must
