@@ -28,6 +28,10 @@ def header_prototypes():
 def code_of(arg):
     if "adt_sasrec_cfg" in arg:
         return "CP"
+    if "adt_enc_layer_ptrs" in arg:
+        return "EP"
+    if "adt_dec_layer_ptrs" in arg:
+        return "DP"
     if "*" in arg:
         return "P"
     t = arg.split()[0] if not arg.startswith("const") else arg.split()[1]
@@ -45,8 +49,8 @@ def test_header_and_ctypes_signatures_agree():
         assert len(args) == len(argtypes), (name, len(args), len(argtypes))
         for i, (a, t) in enumerate(zip(args, argtypes)):
             c = code_of(a)
-            if c == "CP":
-                assert t is ctypes.POINTER(_lib.SasrecCfg), (name, i, a)
+            if c in ("CP", "EP", "DP"):
+                assert t is ctypes.POINTER({"CP": _lib.SasrecCfg, "EP": _lib.EncLayerPtrs, "DP": _lib.DecLayerPtrs}[c]), (name, i, a)
             else:
                 assert t is CT[c], (name, i, a, t)
         want = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "const char*": ctypes.c_char_p}[ret]
