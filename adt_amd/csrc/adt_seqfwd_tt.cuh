@@ -82,9 +82,14 @@ ADT_DEVICE_INLINE void tq_store_y(const SeqFwdArgs& a, size_t row, TT y, bool va
   tt_store(dst, y, valid, g);
 }
 
-ADT_DEVICE_INLINE int tq_tile(int s, int w, int ntiles) {        // heaviest causal tile paired with the lightest (adt_seqfwd.cuh)
+// Tile of wave w in slot s.  Slot 0: the heaviest causal tiles, n-1-w.  Slot 1 in SNAKE order, tile n-16+w (waves 16-n .. 7): waves w and
+// w + 4 share a SIMD, and with the straight order (tile w for w < n-8) SIMD 0 carried causal weight 13+9+1+5 = 28 of 91 at n = 13
+// against 20 for SIMD 3 -- its waves finished the attention phases 5k cycles after the others (profiles/r02_stamps_fwd.txt);
+// the snake gives 24 / 23 / 22 / 22.
+ADT_DEVICE_INLINE int tq_tile(int s, int w, int ntiles) {
   if (s == 0) return ntiles - 1 - w;
-  return w < ntiles - TQ_NW ? w : -1;
+  const int t = ntiles - 2 * TQ_NW + w;
+  return t >= 0 ? t : -1;
 }
 
 // slot-ordered packed image of the 64 x 64 block at W (adt_seq.hip: k_pack_wimg writes it at + 2 images, transposed at + 3)
