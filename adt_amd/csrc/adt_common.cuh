@@ -122,6 +122,15 @@ __device__ __forceinline__ float wave_max(float v) {
 
 #define ADT_DEVICE_INLINE __device__ __forceinline__
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop that is unrolled in the front end.  `#pragma unroll` runs late in
+// the optimizer: a register array indexed by the loop counter is still dynamically indexed when scalar replacement looks at it, stays an
+// alloca and ends up in scratch (the weight-image staging registers of the per-sequence kernels: 96-208 B of scratch per lane).
+#include <utility>
+template <typename F, int... I>
+ADT_DEVICE_INLINE void adt_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+ADT_DEVICE_INLINE void adt_static_for(F&& f) { adt_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // Zero-fill as an ordinary kernel.  The library never uses hipMemsetAsync: its entry points are captured into HIP graphs by the
 // trainers, and on this stack a captured memset NODE was observed to start writing a stale non-zero pattern after a few hundred
 // replays (the gradient-norm accumulators then read ~4e30 or NaN for the rest of the process; see DESIGN.md "graph memset").

@@ -100,32 +100,14 @@ ADT_DEVICE_INLINE void tq_stage(__bf16* img, const float* W, bool transposed, co
   for (int i = threadIdx.x; i < TT_WIMG * 2 / 16; i += NTHREADS) dst[i] = src[i];
 }
 
-// N weight images: all global loads first (2 x 16 B per thread and image), the LDS stores later
-template <int N> struct TqImgRegs { uint4 r0[N], r1[N]; };
-template <int NTHREADS, int N>
-ADT_DEVICE_INLINE TqImgRegs<N> tq_img_load(const float* const (&W)[N], bool transposed, const SeqFwdArgs& a) {
-  constexpr int CH = TT_WIMG * 2 / 16;            // 576 chunks of 16 bytes
-  TqImgRegs<N> t;
-  const int i1 = threadIdx.x + NTHREADS;
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.wp_img) + 6 * (W[k] - a.wp_base) + (transposed ? 3 : 2) * WPACK_IMG);
-    t.r0[k] = src[threadIdx.x];
-    t.r1[k] = src[i1 < CH ? i1 : 0];
-  }
-  return t;
+ADT_DEVICE_INLINE const uint4* tq_img_src(const SeqFwdArgs& a, const float* W, bool transposed) {
+  return reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.wp_img) + 6 * (W - a.wp_base) + (transposed ? 3 : 2) * WPACK_IMG);
 }
-template <int NTHREADS, int N>
-ADT_DEVICE_INLINE void tq_img_store(__bf16* const (&img)[N], const TqImgRegs<N>& t) {
-  constexpr int CH = TT_WIMG * 2 / 16;
-  const int i1 = threadIdx.x + NTHREADS;
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    uint4* dst = reinterpret_cast<uint4*>(img[k]);
-    dst[threadIdx.x] = t.r0[k];
-    if (i1 < CH) dst[i1] = t.r1[k];
-  }
-}
+// one weight image per statement, in named registers: the array-of-registers form (tq_img_load) was kept in scratch by the compiler in
+// these two kernels, with a wait for the loads right behind their issue
+#define TQ_IMG_LOAD(k, Wk) const uint4* tqp##k = tq_img_src(a, Wk, false); const uint4 tqr##k = tqp##k[threadIdx.x]; \
+  uint4 tqt##k = make_uint4(0u, 0u, 0u, 0u); if (tq_tail) tqt##k = tqp##k[threadIdx.x + TQ_NW * 64];
+#define TQ_IMG_STORE(k, dstk) reinterpret_cast<uint4*>(dstk)[threadIdx.x] = tqr##k; if (tq_tail) reinterpret_cast<uint4*>(dstk)[threadIdx.x + TQ_NW * 64] = tqt##k;
 
 ADT_DEVICE_INLINE void tq_zero(__bf16* p, size_t nbytes) {
   uint4* q = reinterpret_cast<uint4*>(p);
@@ -222,14 +204,13 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
   const uint32_t seedv = a.drop.thr ? *a.drop.seed : 0u;
   TQ_STAMP(0);
   {
-    __bf16* const im[6] = {lds.w[0], lds.w[1], lds.w[2], lds.w[3], lds.w[4], lds.w[5]};
-    const float* const ws6[6] = {a.Win, a.Win + 4096, a.Win + 8192, a.Wo, a.W1, a.W2};
-    const TqImgRegs<6> wr = tq_img_load<TQ_NW * 64, 6>(ws6, false, a);
+    const bool tq_tail = threadIdx.x < TT_WIMG * 2 / 16 - TQ_NW * 64;        // the last 64 chunks of an image: the first wave (wave-uniform)
+    TQ_IMG_LOAD(0, a.Win) TQ_IMG_LOAD(1, a.Win + 4096) TQ_IMG_LOAD(2, a.Win + 8192) TQ_IMG_LOAD(3, a.Wo) TQ_IMG_LOAD(4, a.W1) TQ_IMG_LOAD(5, a.W2)
     const TqVecRegs vr = tq_vec_load<TQ_NW * 64>(a, H, HD);
     TQ_STAMP(11);
     tq_zero(lds.sK, 2 * SeqTtLds<6>::ibytes);
     TQ_STAMP(12);
-    tq_img_store<TQ_NW * 64, 6>(im, wr);
+    TQ_IMG_STORE(0, lds.w[0]) TQ_IMG_STORE(1, lds.w[1]) TQ_IMG_STORE(2, lds.w[2]) TQ_IMG_STORE(3, lds.w[3]) TQ_IMG_STORE(4, lds.w[4]) TQ_IMG_STORE(5, lds.w[5])
     TQ_STAMP(13);
     tq_vec_store<TQ_NW * 64>(lds.vec, vr);
     TQ_STAMP(14);
@@ -313,13 +294,12 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
   SeqTtLds<5> lds(smem_raw);
   const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16;
   const uint32_t seedv = a.drop.thr ? *a.drop.seed : 0u;
-  __bf16* const im5[5] = {lds.w[0], lds.w[1], lds.w[2], lds.w[3], lds.w[4]};
+  const bool tq_tail = threadIdx.x < TT_WIMG * 2 / 16 - TQ_NW * 64;        // the last 64 chunks of an image: the first wave (wave-uniform)
   {
-    const float* const wsA[5] = {a.Win, a.Win + 4096, a.Win + 8192, a.Wo, a.Win2};
-    const TqImgRegs<5> wr = tq_img_load<TQ_NW * 64, 5>(wsA, false, a);
+    TQ_IMG_LOAD(0, a.Win) TQ_IMG_LOAD(1, a.Win + 4096) TQ_IMG_LOAD(2, a.Win + 8192) TQ_IMG_LOAD(3, a.Wo) TQ_IMG_LOAD(4, a.Win2)
     const TqVecRegs vr = tq_vec_load<TQ_NW * 64>(a, H, HD);
     tq_zero(lds.sK, 2 * SeqTtLds<5>::ibytes);
-    tq_img_store<TQ_NW * 64, 5>(im5, wr);
+    TQ_IMG_STORE(0, lds.w[0]) TQ_IMG_STORE(1, lds.w[1]) TQ_IMG_STORE(2, lds.w[2]) TQ_IMG_STORE(3, lds.w[3]) TQ_IMG_STORE(4, lds.w[4])
     tq_vec_store<TQ_NW * 64>(lds.vec, vr);
   }
   __syncthreads();
@@ -351,10 +331,10 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
     tt_save(a.q2, row, q2, valid, g, a.saved_bf16);
     tt_qfrags<HD>(q2, qmul, fq[s]);
   }
-  const float* const wsB[5] = {a.Win2 + 4096, a.Win2 + 8192, a.Wo2, a.W1, a.W2};
-  const TqImgRegs<5> wrB = tq_img_load<TQ_NW * 64, 5>(wsB, false, a);      // weight set B is requested before the barrier ...
+  // weight set B is requested before the barrier ...
+  TQ_IMG_LOAD(5, a.Win2 + 4096) TQ_IMG_LOAD(6, a.Win2 + 8192) TQ_IMG_LOAD(7, a.Wo2) TQ_IMG_LOAD(8, a.W1) TQ_IMG_LOAD(9, a.W2)
   __syncthreads();                      // every wave is done with the self-attention images and with weight set A
-  tq_img_store<TQ_NW * 64, 5>(im5, wrB);                                   // ... and lands after it
+  TQ_IMG_STORE(5, lds.w[0]) TQ_IMG_STORE(6, lds.w[1]) TQ_IMG_STORE(7, lds.w[2]) TQ_IMG_STORE(8, lds.w[3]) TQ_IMG_STORE(9, lds.w[4])      // ... and lands after it
   __syncthreads();
   // cross attention keys / values from the encoder's log_feats: [k2, v2] = f Wkv^T + b              (memory = log_feats, model.py:69-70)
 #pragma unroll
