@@ -220,6 +220,30 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   SB_STAMP(0);
   // The weight images are requested first and P1's activations right behind them: every workgroup of the launch runs the same phase at
   // the same time, so HBM streams the activations while the prologue runs instead of idling through it (adt_seqpost_tt.cuh)
+  // Vector-memory results return in issue order, so the SMALL tables (keep bits, log-sum-exp, LayerNorm / bias vectors) are requested
+  // first: their LDS stores then wait for nothing but themselves, while the weight images and the activations stream behind them.
+  // (Requested after the big loads, their stores waited for every byte in front of them: the prologue took 21.7k cycles.)
+  constexpr int MI = (H * R * 2 + NW * 64 - 1) / (NW * 64), LI = (H * R + NW * 64 - 1) / (NW * 64);
+  uint4 mreg[MI];
+  float lreg[LI];
+  if constexpr (MODE == 1) {
+    adt_static_for<MI>([&](auto k) {
+      const int i = threadIdx.x + k * NW * 64, hr = i >> 1, h = hr / R, r = hr - h * R;
+      mreg[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (i < H * R * 2 && r < L) mreg[k] = reinterpret_cast<const uint4*>(a.mask + ((size_t)(b * H + h) * L + r) * 8)[i & 1];
+    });
+  }
+  adt_static_for<LI>([&](auto k) {
+    const int i = threadIdx.x + k * NW * 64, h = i / R, r = i - h * R;
+    lreg[k] = (i < H * R && r < L) ? a.lse[(size_t)(b * H + h) * L + r] * 1.4426950408889634f : INFINITY;
+  });
+  float vreg = 0.f;
+  {
+    const int t = threadIdx.x;
+    if (t < 64) vreg = a.gamma[t];
+    else if (t < 128) vreg = a.beta[t - 64];
+    else if (t < 320) vreg = a.bin[t - 128];
+  }
   const __bf16* wsrc = reinterpret_cast<const __bf16*>(a.wp_img) + 6 * (a.Win - a.wp_base);
   const __bf16* const src6[6] = {wsrc + 2 * WPACK_IMG, wsrc + 6 * 4096 + 2 * WPACK_IMG, wsrc + 12 * 4096 + 2 * WPACK_IMG,
                                  wsrc + 3 * WPACK_IMG, wsrc + 6 * 4096 + 3 * WPACK_IMG, wsrc + 12 * 4096 + 3 * WPACK_IMG};
@@ -234,25 +258,22 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     doa[s] = tt_load(a.dO + (size_t)row * 64, valid, g);
     oa[s] = tt_load_saved(a.o, row, valid, g, a.saved_bf16);
   }
-  // ---- P0: weight images, zeroed token images, keep bits, statistics -------------------------------------------------------------
+  // ---- P0: zeroed token images, then the tables and the weight images land in LDS ------------------------------------------------
   {
     uint4* z = reinterpret_cast<uint4*>(img0);
     for (int i = threadIdx.x; i < (int)((2 * Lds::ibytes + 64) / 16); i += NW * 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
-    if constexpr (MODE == 1) {
-      for (int i = threadIdx.x; i < H * R * 2; i += NW * 64) {
-        const int hr = i >> 1, h = hr / R, r = hr - h * R;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (r < L) v = reinterpret_cast<const uint4*>(a.mask + ((size_t)(b * H + h) * L + r) * 8)[i & 1];
-        reinterpret_cast<uint4*>(sM + (size_t)hr * 8)[i & 1] = v;
-      }
-    }
-    for (int i = threadIdx.x; i < H * R; i += NW * 64) {
-      const int h = i / R, r = i - h * R;
-      sLse[i] = r < L ? a.lse[(size_t)(b * H + h) * L + r] * 1.4426950408889634f : INFINITY;
-      sDelta[i] = 0.f;
-    }
     if (threadIdx.x < 320) sRed[threadIdx.x] = 0.f;
-    tt_stage_vec<NW * 64>(sVec, a.gamma, 64); tt_stage_vec<NW * 64>(sVec + 64, a.beta, 64); tt_stage_vec<NW * 64>(sVec + 128, a.bin, 192);
+    if constexpr (MODE == 1) {
+      adt_static_for<MI>([&](auto k) {
+        const int i = threadIdx.x + k * NW * 64;
+        if (i < H * R * 2) reinterpret_cast<uint4*>(sM + (size_t)(i >> 1) * 8)[i & 1] = mreg[k];
+      });
+    }
+    adt_static_for<LI>([&](auto k) {
+      const int i = threadIdx.x + k * NW * 64;
+      if (i < H * R) { sLse[i] = lreg[k]; sDelta[i] = 0.f; }
+    });
+    if (threadIdx.x < 320) sVec[threadIdx.x] = vreg;
     sb_img_store<6>(wimg, wr);
   }
   __syncthreads();
