@@ -369,6 +369,15 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   }
   __syncthreads();
   SB_STAMP(4);
+  // x is read once more here for P4 and P5 (its registers were needed by the attention passes) instead of three times; prefetching the
+  // residual-path gradient and the accumulated gx as well overflowed the register file (118-140 spills)
+  TT xk[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    const int l = tile * 16 + c, row = b * L + l;
+    xk[s] = tt_load(a.x + (size_t)row * 64, tile >= 0 && l < L, g);
+  }
   // ---- P4: in-projection weight / bias gradients: three products over all tokens ------------------------------------------------------
   {
     TT sq = tt_zero(), sk = tt_zero(), sv = tt_zero();
@@ -376,11 +385,10 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     for (int s = 0; s < 2; ++s) {
       const int tile = tq_tile(s, w, ntiles);
       if (tile < 0) continue;
-      const int l = tile * 16 + c, row = b * L + l;
+      const int l = tile * 16 + c;
       const bool valid = l < L;
-      const TT x = tt_load(a.x + (size_t)row * 64, valid, g);
       tt_put_rows(img0, l, dq[s], valid, g);
-      tt_put_rows(img1, l, tt_ln_apply(tt_ln_stats(x, a.ln_eps).xhat, vgamma, vbeta, g), valid, g);     // q always reads LN(x)
+      tt_put_rows(img1, l, tt_ln_apply(tt_ln_stats(xk[s], a.ln_eps).xhat, vgamma, vbeta, g), valid, g);     // q always reads LN(x)
       if (valid) { tt_add(sq, dq[s]); tt_add(sk, dk[s]); tt_add(sv, dv[s]); }
     }
     sb_colsum_flush(sRed + 128, sq, c, g); sb_colsum_flush(sRed + 192, sk, c, g); sb_colsum_flush(sRed + 256, sv, c, g);
@@ -392,10 +400,10 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile(s, w, ntiles);
     if (tile < 0) continue;
-    const int l = tile * 16 + c, row = b * L + l;
+    const int l = tile * 16 + c;
     const bool valid = l < L;
     tt_put_rows(img0, l, dk[s], valid, g);
-    if (!DEC) tt_put_rows(img1, l, tt_load(a.x + (size_t)row * 64, valid, g), valid, g);                  // encoder: k, v read the raw x
+    if (!DEC) tt_put_rows(img1, l, xk[s], valid, g);                  // encoder: k, v read the raw x
   }
   __syncthreads();
   sb_dw_product16(img0, img1, npair, a.dWin + 4096, part ? part + 4096 : nullptr, w, c, g);
@@ -418,8 +426,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
-    const TT x = tt_load(a.x + (size_t)row * 64, valid, g);
-    const TTLn st = tt_ln_stats(x, a.ln_eps);
+    const TTLn st = tt_ln_stats(xk[s], a.ln_eps);
     TT dn = tt_gemm(tt_bfrags(dq[s]), wimg + 3 * TT_WIMG, c, g);
     TT dkv = tt_gemm(tt_bfrags(dk[s]), wimg + 4 * TT_WIMG, c, g);
     tt_add(dkv, tt_gemm(tt_bfrags(dv[s]), wimg + 5 * TT_WIMG, c, g));
