@@ -112,3 +112,37 @@ def test_warmup_step_with_dropout_matches_oracle():
     for k in P:
         if G[k] is not None:
             assert np.abs(m.G(k).cpu().numpy() - G[k]).max() < 5e-4 * max(np.abs(G[k]).max(), 1e-3 * gmax), k
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.3])
+@pytest.mark.parametrize("tag", ["c3", "l2"])
+def test_grouped_candidate_layers_match_stage_kernels(tag, dropout, monkeypatch):
+    """bf16 mode runs the four selected candidate layers of a depth on the per-sequence fused layer kernels (mixing weight as output
+    epilogue / gradient prologue, adt_seq_{enc,dec}_layer_{fwd,bwd}); ADT_SUPER_FUSED=0 keeps one stage-kernel sequence per candidate.
+    Same weights, batch and dropout seed: loss within 1e-2 relative, whole gradient within 6 % relative Frobenius (two bf16 roundings of
+    the same arithmetic), every tensor the reference leaves at grad None exactly zero in both."""
+    from adt_amd.sasrec.supersasrec import SuperTrainer
+    g, cfg, P = load_case(tag, dropout)
+    res = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("ADT_SUPER_FUSED", fused)
+        m = build(cfg, P, "bf16")
+        assert m.fused_layers() == (fused == "1" and cfg.maxlen % 4 == 0)
+        tr = SuperTrainer(m, lr=float(g["lr"]), weight_decay=float(g["wd"]), clip=float(g["clip"]), seed=7)
+        tr.set_choice([float(x) for x in g["cand"]])
+        m.train()
+        ids = tuple(m.ids(g[k]) for k in ("seq", "dec", "pos", "neg"))
+        B, L = ids[0].shape
+        norms = torch.tensor([float(np.count_nonzero(g["pos"])), float(B * L * cfg.hidden_units), float(B * L * cfg.num_heads)], device=m.dev)
+        tr.loss_slots.zero_()
+        m.flat_grad.zero_()
+        m.loss_forward_backward(ids, tr.rec_weights, tr.ind_weights, norms, tr.loss_slots)
+        torch.cuda.synchronize()
+        res.append((float(tr.loss()), m.flat_grad.clone(), m))
+    (l1, g1, m1), (l0, g0, m0) = res
+    if not m1.fused_layers():
+        pytest.skip("maxlen %d: the fused layer kernels need L %% 4 == 0" % cfg.maxlen)
+    assert abs(l1 - l0) < 1e-2 * abs(l0)
+    assert float((g1 - g0).norm()) < 0.06 * float(g0.norm())
+    for name in [str(x) for x in g["grad_none"]]:
+        assert float(m1.G(name).abs().max()) == 0.0, name
