@@ -82,6 +82,10 @@ SIGNATURES = {
     "adt_gather_rows": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P]),
     "adt_scatter_rows": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P]),
     "adt_ce_rows": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P]),
+    "adt_lce_supported": (_I, [_I, _I]),
+    "adt_lce_slots": (_I, [_I]),
+    "adt_lce_workspace_bytes": (_L, [_I, _I, _I]),
+    "adt_lce_fwd_bwd": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P, _L, _P]),
     "adt_clip_adam_l2": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
     "adt_score_rank_bias": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "adt_wattn_mfma_fwd": (_I, [_I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P, _U, _U, _P, _I, _P, _I, _P, _P]),

@@ -289,6 +289,27 @@ def ce_rows(logits, labels, V, inv_count, loss64, M=None, m_dev=None):
     _lib.check(_lib.load().adt_ce_rows(_p(_f32(logits)), _ld(logits), _p(_i32(labels)), M, _p(m_dev), V, _p(inv_count), _p(loss64), _stream()), "ce_rows")
 
 
+def lce_supported(prec, K):
+    return bool(_lib.load().adt_lce_supported(prec, K))
+
+
+_LCE_WS = {}
+
+
+def lce_fwd_bwd(h, rows, labels, mcap, m_dev, E, bias, inv_count, loss64, dh, dE, dbias, lse_out=None):
+    """Fused all-item logits + cross-entropy on the masked rows (include/adt_hip.h: adt_lce_fwd_bwd).  The workspace is cached per
+    (device, mcap, V, K): a captured graph keeps pointing at it."""
+    V, K = E.shape
+    lib = _lib.load()
+    key = (h.device, mcap, V, K, lib.adt_lce_slots(0))
+    ws = _LCE_WS.get(key)
+    if ws is None:
+        ws = _LCE_WS[key] = torch.empty(int(lib.adt_lce_workspace_bytes(mcap, V, K)), device=h.device, dtype=torch.uint8)
+    _lib.check(lib.adt_lce_fwd_bwd(_p(_f32(h)), _ld(h), _p(_i32(rows)), _p(_i32(labels)), mcap, _p(m_dev), _p(_f32(E)), _ld(E), _p(bias), V, K,
+                                   _p(inv_count), _p(loss64), _p(lse_out), _p(dh), _ld(dh) if dh is not None else 0, _p(dE), _ld(dE), _p(dbias),
+                                   _p(ws), ws.numel(), _stream()), "lce_fwd_bwd")
+
+
 def clip_adam_l2(P, G, M, V, l2, clip, lr, b1, b2, eps, scal, grad_scale=1.0, n=None):
     n = P.numel() if n is None else n
     _lib.check(_lib.load().adt_clip_adam_l2(_p(P), _p(G), _p(M), _p(V), n, float(l2), float(clip), float(lr), float(b1), float(b2), float(eps),

@@ -137,6 +137,26 @@ int adt_score_rank(const float* F, int ldf, const float* E, const int32_t* cand,
 int adt_dense_gradsrc(const float* dY, int lddy, int T, int N, const int32_t* mask_ids, float p, const uint32_t* seed,
                       uint32_t site, uint32_t row_offset, int act, const float* U, int ldu, float* G, int ldg,
                       const int32_t* t_dev, void* stream);
+/* ---- fused all-item logits + cross-entropy on the masked rows (bf16 operands; K = 128 or 256) ---------------------------------
+ * Replaces, for BERT4Rec-ADT's output layer, `logits = h @ word_emb^T + bias` over all V (+100) items (bert4rec/model/bert.py:80-90)
+ * followed by CrossEntropyLoss(ignore_index=0) (bert4rec/trainer.py:45,113-115) and their backward, without ever writing the
+ * (rows x V) logits: an online log-sum-exp forward and a backward that recomputes each score tile on the matrix cores
+ * (adt_amd/csrc/adt_lce.cuh).  h: (B*L, K) activations, row stride ldh; rows[m] (m < min(mcap, *m_dev)): the rows whose label is
+ * non-zero, labels[m] their labels (1..V-1); E: (V, K) item table, bias: (V).  With n = 1 / *inv_count labelled rows:
+ *   loss64[m & 63] += (lse_m - logit_m[label_m]) / n;   lse_out[m] = lse_m (optional);
+ *   dh[rows[m]] = sum_v (softmax_m[v] - [v == label_m]) / n * E[v]            (plain store; dh NULL = loss only)
+ *   dE[v] += sum_m (softmax_m[v] - [v == label_m]) / n * h[rows[m]];  dbias[v] += sum_m (...)      (accumulated)
+ * m_dev (optional) is a DEVICE count, so a captured graph replays with a different number of masked rows.  workspace: at least
+ * adt_lce_workspace_bytes(mcap, V, K) bytes, 256-byte aligned, contents irrelevant on entry. */
+int adt_lce_supported(int prec, int K);
+/* Workgroups the passes are split over (default: the device's CU count); slots > 0 sets it (tests use a small grid so that every
+ * workgroup walks several work items), returns the value in force.  The workspace size depends on it. */
+int adt_lce_slots(int slots);
+int64_t adt_lce_workspace_bytes(int mcap, int V, int K);
+int adt_lce_fwd_bwd(const float* h, int ldh, const int32_t* rows, const int32_t* labels, int mcap, const int32_t* m_dev,
+                    const float* E, int lde, const float* bias, int V, int K, const float* inv_count, float* loss64,
+                    float* lse_out, float* dh, int lddh, float* dE, int lddE, float* dbias, void* workspace,
+                    int64_t workspace_bytes, void* stream);
 /* Kernel selection for the dense layers in bf16 mode: 1 (default) = row-streaming kernels (adt_dense_rows.cuh) where the shape
  * allows (contraction 64/128/256 per chunk, N <= 1024), 0 = always the tiled kernels.  Returns the previous setting.  Results
  * agree to bf16 rounding either way; the switch exists for A/B measurements and tests. */
