@@ -11,6 +11,8 @@ row kernels, and an all-item logits + cross-entropy evaluated on the masked rows
 `train_step()` runs forward, loss assembly (bert4rec/trainer.py:112-134), backward, clip_grad_norm_ and Adam with its
 coupled weight decay on the device; it is HIP-graph capturable (masked-row counts live in device memory).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -83,6 +85,7 @@ class BertModel(FlatModule):
         self.dropout, self.attention_dropout = float(args.dropout), float(args.attention_dropout)
         self.vocab = itemnum + 100 if vocab is None else vocab          # bert4rec/model/bert.py:20 (the supernet: itemnum + 2)
         self.ldv = (self.vocab + 3) // 4 * 4
+        self.use_lce = os.environ.get("ADT_LCE", "1") != "0"            # fused all-item logits + CE where the shape allows (bf16, d 128 / 256)
         self.args = args
         self.prec = {"f32": ops.PREC_F32, "fp32": ops.PREC_F32, "bf16": ops.PREC_BF16}[getattr(args, "precision", "bf16")]
         if self.hidden_units % 64 or (self.hidden_units // self.num_heads) not in (16, 32, 64):
@@ -312,14 +315,19 @@ class BertModel(FlatModule):
         # all-item logits + CE on the masked rows only
         mcap = T if mcap is None else min(T, mcap)
         Mdev = st["M"]
-        hm = ops.gather_rows(h.t, st["rows"], mcap, Mdev)
         E, gE = self.P("item_emb.word_emb.weight"), self.G("item_emb.word_emb.weight")
-        logits, _ = ops.dense_fwd(self.prec, hm, E, self.P("mask_bias"), t_dev=Mdev, ldy=self.ldv)
-        ops.ce_rows(logits, st["labels"], self.vocab, st["inv_count"], loss_slots[0], mcap, Mdev)
-        dhm = torch.empty_like(hm)
-        ops.dense_bwd(self.prec, logits, hm, E, gE, self.G("mask_bias"), dhm, False, t_dev=Mdev)
         h.g = torch.zeros_like(h.t)
-        ops.scatter_rows(dhm, st["rows"], h.g, False, mcap, Mdev)
+        if self.use_lce and ops.lce_supported(self.prec, d):
+            # fused: online log-sum-exp forward, tile-recomputing backward; no (rows, V) logits in memory (adt_amd/csrc/adt_lce.cuh)
+            ops.lce_fwd_bwd(h.t, st["rows"], st["labels"], mcap, Mdev, E, self.P("mask_bias"), st["inv_count"], loss_slots[0], h.g, gE,
+                            self.G("mask_bias"))
+        else:
+            hm = ops.gather_rows(h.t, st["rows"], mcap, Mdev)
+            logits, _ = ops.dense_fwd(self.prec, hm, E, self.P("mask_bias"), t_dev=Mdev, ldy=self.ldv)
+            ops.ce_rows(logits, st["labels"], self.vocab, st["inv_count"], loss_slots[0], mcap, Mdev)
+            dhm = torch.empty_like(hm)
+            ops.dense_bwd(self.prec, logits, hm, E, gE, self.G("mask_bias"), dhm, False, t_dev=Mdev)
+            ops.scatter_rows(dhm, st["rows"], h.g, False, mcap, Mdev)
         # reconstruction (MSE) and independence (NLL) seeds
         for i in range(nl):
             if lambda1[i] != 0:

@@ -328,25 +328,27 @@ __global__ __launch_bounds__(256) void k_lce_combine(LceCombineArgs a) {
       continue;
     }
     const int xb = m / LCE_XR_FWD, xr = m - xb * LCE_XR_FWD;
+    const int lab = a.labels[m];
     float pm = -INFINITY, ps = 0.f;
     if (lane < sp.C) {
       const size_t o = (size_t)(lane * sp.nxb + xb) * LCE_XR_FWD + xr;
       pm = a.part_m[o];
       ps = a.part_s[o];
     }
+    typedef __bf16 lce_b4 __attribute__((ext_vector_type(4)));
+    float dot = 0.f;
+    for (int k = lane * 4; k < a.K; k += 256) {            // every load of the row ahead of the atomics (they may alias for the compiler)
+      const lce_b4 hv = *reinterpret_cast<const lce_b4*>(a.Hb + (size_t)m * a.K + k);
+      const lce_b4 ev = *reinterpret_cast<const lce_b4*>(a.Eb + (size_t)lab * a.K + k);
+      float* g = a.dE + (size_t)lab * a.lddE + k;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dot = fmaf((float)hv[e], (float)ev[e], dot);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(g + e, -wn * (float)hv[e]);
+    }
     const float mx = wave_max(pm);
     const float s = wave_sum(ps * __builtin_amdgcn_exp2f((pm - mx) * LCE_L2E));
     const float lse = mx + __logf(s);
-    const int lab = a.labels[m];
-    float dot = 0.f;
-    for (int k = lane * 4; k < a.K; k += 256) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float hv = (float)a.Hb[(size_t)m * a.K + k + e];
-        dot = fmaf(hv, (float)a.Eb[(size_t)lab * a.K + k + e], dot);
-        atomicAdd(a.dE + (size_t)lab * a.lddE + k + e, -wn * hv);
-      }
-    }
     dot = wave_sum(dot);
     if (lane == 0) {
       atomicAdd(a.loss64 + (m & 63), wn * (lse - (dot + a.bias[lab])));
