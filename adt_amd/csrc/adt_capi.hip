@@ -274,6 +274,26 @@ int adt_item_scatter(const int32_t* ids, const float* G, int ldg, const float* r
   return check_launch("item_scatter");
 }
 
+// fused forms used by the executor (adt_host.h)
+int adt_logits_bwd_scatter(const float* F, int ldf, const float* E, const int32_t* pos, const int32_t* neg, const float* dpos, const float* dneg,
+                           int T, int d, float* dF, int lddf, float* rep, int nrep, int64_t rep_stride, void* stream) {
+  LogitsScatterArgs a{F, ldf, E, pos, neg, dpos, dneg, T, d, dF, lddf, rep, nrep, (size_t)rep_stride};
+  hipLaunchKernelGGL(k_logits_bwd_scatter, dim3(grid_for(T, 4, 2048)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("logits_bwd_scatter");
+}
+
+int adt_embed_bwd_rep(const int32_t* ids, const float* dX, int T, int L, int d, float p, const uint32_t* seed, uint32_t site, uint32_t row_offset,
+                      float* dP, float* rep, int nrep, int64_t rep_stride, void* stream) {
+  if (d != 64 || T % L) {   // general widths: the two separate passes
+    if (int rc = adt_posemb_bwd(ids, dX, T, L, d, p, seed, site, row_offset, dP, stream)) return rc;
+    return adt_item_scatter(ids, dX, d, nullptr, T, d, sqrtf((float)d), p, seed, site, row_offset, rep, nrep, rep_stride, stream);
+  }
+  const int B = T / L, ns = B < 32 ? B : 32;
+  EmbedBwdArgs a{ids, dX, T, L, sqrtf((float)d), adt_make_drop(p, seed, site), row_offset, dP, rep, nrep, (size_t)rep_stride, ns};
+  hipLaunchKernelGGL(k_embed_bwd64, dim3((L * ns + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("embed_bwd_rep");
+}
+
 int adt_replica_reduce(float* dE, const float* rep, int64_t n, int nrep, int64_t rep_stride, void* stream) {
   if (n % 4 || rep_stride % 4) return adt_set_error("replica_reduce: n, stride %% 4");
   hipLaunchKernelGGL(k_replica_reduce, dim3(grid_for((size_t)n / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream, dE, rep, (size_t)n, nrep,

@@ -47,3 +47,12 @@ int adt_seq_partials(int prec, int L, int d, int hd);
 int adt_dwpart_reduce(float* G, const float* part, size_t stride, int nwg, const int* slots, const int* offs, int nslots, void* stream);
 namespace adt { struct SeqBwdArgs; }
 int adt_launch_seq_attn_pre_bwd(int hd, int dec, const adt::SeqBwdArgs& a, void* stream);     // 0 launched, 1 not covered, < 0 error
+
+// fused small kernels of the flagship backward (adt_misc.cuh; defined in adt_capi.hip): d log_feats + both item scatters in one pass,
+// positional + item embedding gradient in one pass
+extern "C" {
+int adt_logits_bwd_scatter(const float* F, int ldf, const float* E, const int32_t* pos, const int32_t* neg, const float* dpos, const float* dneg,
+                           int T, int d, float* dF, int lddf, float* rep, int nrep, int64_t rep_stride, void* stream);
+int adt_embed_bwd_rep(const int32_t* ids, const float* dX, int T, int L, int d, float p, const uint32_t* seed, uint32_t site, uint32_t row_offset,
+                      float* dP, float* rep, int nrep, int64_t rep_stride, void* stream);
+}

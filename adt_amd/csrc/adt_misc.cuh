@@ -281,6 +281,62 @@ __global__ __launch_bounds__(256) void k_logits_bwd(LogitsArgs a) {
   }
 }
 
+// d log_feats and the item-table rows of the positive / negative items in ONE pass over the tokens (k_logits_bwd + two k_item_scatter
+// launches re-read F and the ids three times): dF = dpos E[pos] + dneg E[neg]; rep[pos] += dpos F; rep[neg] += dneg F.  One wave per
+// token row (every atomic wave-instruction covers 256 contiguous bytes), replica = wave % nrep as in k_item_scatter; same arithmetic.
+struct LogitsScatterArgs {
+  const float* F; int ldf; const float* E; const int* pos; const int* neg; const float* dpos; const float* dneg;
+  int T, d; float* dF; int lddf; float* rep; int nrep; size_t rep_stride;
+};
+__global__ __launch_bounds__(256) void k_logits_bwd_scatter(LogitsScatterArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  float* dE = a.rep + (a.nrep > 1 ? (size_t)(wave % a.nrep) * a.rep_stride : 0);
+  for (int row = wave; row < a.T; row += nwaves) {
+    const int ip = a.pos[row], in = a.neg[row];
+    const float gp = a.dpos[row], gn = a.dneg[row];
+    for (int c = lane; c < a.d; c += 64) {
+      const float p = a.E[(size_t)ip * a.d + c], q = a.E[(size_t)in * a.d + c], f = a.F[(size_t)row * a.ldf + c];
+      a.dF[(size_t)row * a.lddf + c] = gp * p + gn * q;
+      if (ip != 0 && gp != 0.f) atomicAdd(dE + (size_t)ip * a.d + c, f * gp);
+      if (in != 0 && gn != 0.f) atomicAdd(dE + (size_t)in * a.d + c, f * gn);
+    }
+  }
+}
+
+// Embedding backward, d = 64, one pass over dX (k_posemb_bwd + k_item_scatter read it twice): a wave owns position l and a slice of the
+// batch; per row it adds dX * sqrt(d) * keep/(1-p) to the item replica row and keeps the positional sum in a register (one atomic per
+// lane at the end).  sasrec/model.py:34-41 / :53-59 reversed.
+struct EmbedBwdArgs {
+  const int* ids; const float* dX; int T, L; float scale; DropCfg drop; uint32_t row_offset;
+  float* dP; float* rep; int nrep; size_t rep_stride; int nslices;
+};
+__global__ __launch_bounds__(256) void k_embed_bwd64(EmbedBwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= a.L * a.nslices) return;
+  const uint32_t key = drop_key(a.drop);
+  const int l = wave % a.L, s = wave / a.L, B = a.T / a.L;
+  const int bper = (B + a.nslices - 1) / a.nslices, b0 = s * bper, b1 = min(B, b0 + bper);
+  float* dE = a.rep + (a.nrep > 1 ? (size_t)(wave % a.nrep) * a.rep_stride : 0);
+  float acc = 0.f;
+  for (int b = b0; b < b1; ++b) {
+    const int row = b * a.L + l;
+    const int id = a.ids[row];
+    if (id == 0) continue;
+    const float g = a.dX[(size_t)row * 64 + lane];
+    float vi = g * a.scale, vp = g;
+    if (a.drop.thr) {
+      const bool keep = adt_keep(key, (uint32_t)(row + a.row_offset) * 64u + (uint32_t)lane, a.drop.thr);
+      vi = keep ? vi * a.drop.scale : 0.f;
+      vp = keep ? vp * a.drop.scale : 0.f;
+    }
+    atomicAdd(dE + (size_t)id * 64 + lane, vi);
+    acc += vp;
+  }
+  atomicAdd(a.dP + (size_t)l * 64 + lane, acc);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Loss seeds of sasrec/main.py:151-169.  `norms` is a device array {n_bce, n_mse, n_nll} holding the
 // GLOBAL normalisers (data-parallel exactness).  loss slots: [0] bce_pos [1] bce_neg

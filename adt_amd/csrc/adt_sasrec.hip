@@ -481,9 +481,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
     // item-table replicas and parameter replicas are adjacent in the workspace: one fill
     if (w.prep != w.rep + NREP * w.rep_stride) return adt_set_error("workspace layout: replica areas not adjacent");
     if (adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride + (size_t)NREPP * w.prep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
-    CK(adt_logits_bwd_df(P + lo.item(), pos, neg, ws + w.g_pos, ws + w.g_neg, T, d, gf, d, st));
-    CK(adt_item_scatter(pos, f, d, ws + w.g_pos, T, d, 1.0f, 0.f, nullptr, 0, 0, ws + w.rep, NREP, w.rep_stride, st));
-    CK(adt_item_scatter(neg, f, d, ws + w.g_neg, T, d, 1.0f, 0.f, nullptr, 0, 0, ws + w.rep, NREP, w.rep_stride, st));
+    CK(adt_logits_bwd_scatter(f, d, P + lo.item(), pos, neg, ws + w.g_pos, ws + w.g_neg, T, d, gf, d, ws + w.rep, NREP, w.rep_stride, st));
     for (int i = nl - 1; i >= 0; --i) {
       float* gy = ws + w.g_dec_x + (i + 1) * Td;      // d loss / d (output of decoder layer i), complete
       float* gx = ws + w.g_dec_x + i * Td;            // accumulates d / d (input of layer i)
@@ -583,8 +581,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       }
     }
     // decoder input embedding (sasrec/model.py:53-59)
-    CK(adt_posemb_bwd(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), st));
-    CK(adt_item_scatter(dec, ws + w.g_dec_x, d, nullptr, T, d, sqrtf((float)d), p, seed, SITE_EMB_DEC, ro, ws + w.rep, NREP, w.rep_stride, st));
+    CK(adt_embed_bwd_rep(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
     if (phase == 1) {  // two-phase (data-parallel) use: fold what has been scattered so far, the replicas restart at zero
       CK(adt_replica_reduce(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, NREP, w.rep_stride, st));
       CK(adt_replica_reduce(G + dec_begin, Gq + dec_begin, lo.total - dec_begin, NREPP, w.prep_stride, st));
@@ -660,8 +657,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       }
     }
     if (phase == 2 && adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
-    CK(adt_posemb_bwd(seq, ws + w.g_enc_x, T, L, d, p, seed, SITE_EMB_SEQ, ro, G + lo.posw(), st));
-    CK(adt_item_scatter(seq, ws + w.g_enc_x, d, nullptr, T, d, sqrtf((float)d), p, seed, SITE_EMB_SEQ, ro, ws + w.rep, NREP, w.rep_stride, st));
+    CK(adt_embed_bwd_rep(seq, ws + w.g_enc_x, T, L, d, p, seed, SITE_EMB_SEQ, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
     CK(adt_replica_reduce(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, NREP, w.rep_stride, st));
     if (phase == 0) CK(adt_replica_reduce(G + lo.posw(), Gq + lo.posw(), lo.total - lo.posw(), NREPP, w.prep_stride, st));
     else CK(adt_replica_reduce(G + lo.posw(), Gq + lo.posw(), dec_begin - lo.posw(), NREPP, w.prep_stride, st));
