@@ -63,6 +63,7 @@ SIGNATURES = {
     "adt_mse_seed": (_I, [_P, _P, _L, _F, _P, _P, _I, _P, _P, _P]),
     "adt_nll_seed": (_I, [_P, _I, _I, _F, _P, _P, _P, _P]),
     "adt_clip_adam": (_I, [_P, _P, _P, _P, _L, _L, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
+    "adt_clip_adam_pre": (_I, [_P, _P, _P, _P, _L, _L, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
     "adt_score_rank": (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
     # ---- general ("wide") stage kernels
     "adt_dense_fwd": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _F, _P, _U, _U, _P, _I, _P, _I, _P, _P, _I, _P, _P]),
@@ -112,6 +113,8 @@ SIGNATURES = {
     "adt_seq_dec_layer_fwd": (_I, [_I, _I, _I, _P, _P, _P, _DP, _P, _P, _F, _P, _U, _U, _U, _U, _U, _P, _P, _F, _I, _P]),
     "adt_seq_dec_layer_bwd": (_I, [_I, _I, _I, _P, _P, _P, _DP, _DP, _P, _P, _F, _P, _U, _U, _U, _U, _U, _P, _P, _F, _P, _I, _P, _P, _P]),
     "adt_sasrec_loss_seed": (_I, [_CP, _P, _P, _I, _P, _P, _P]),
+    "adt_sasrec_loss_seed_nz": (_I, [_CP, _P, _P, _I, _P, _P, _P]),
+    "adt_sasrec_step_begin": (_I, [_CP, _P, _I, _P, _U, _P, _P, _P, _L, _P, _P]),
     "adt_sasrec_backward": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _U, _I, _P]),
     "adt_sasrec_predict": (_I, [_CP, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
 }

@@ -334,10 +334,18 @@ int adt_layernorm_fwd(const float* X, int ldx, const float* gamma, const float* 
 
 int adt_layernorm_bwd(const float* dY, int lddy, const float* X, int ldx, const float* gamma, float eps, int T,
                       int d, float* dX, int lddx, int accumulate, float* dgamma, float* dbeta, void* stream) {
+  return adt_layernorm_bwd_rep(dY, lddy, X, ldx, gamma, eps, T, d, dX, lddx, accumulate, dgamma, dbeta, 1, 0, stream);
+}
+
+// dgamma / dbeta into nrep replicas (block b -> replica b % nrep): with one copy the grid is capped at 256 blocks (every block ends with one
+// atomic per column on the same 2 d addresses: a 256-deep chain, ~6 us) and one wave per SIMD cannot hide the row latency; with replicas
+// the grid is 1,024 blocks.
+int adt_layernorm_bwd_rep(const float* dY, int lddy, const float* X, int ldx, const float* gamma, float eps, int T, int d, float* dX, int lddx,
+                          int accumulate, float* dgamma, float* dbeta, int nrep, int64_t rep_stride, void* stream) {
   LnArgs a{};
   a.X = X; a.ldx = ldx; a.gamma = gamma; a.eps = eps; a.T = T; a.dY = dY; a.lddy = lddy; a.dX = dX; a.lddx = lddx;
-  a.acc = accumulate; a.dgamma = dgamma; a.dbeta = dbeta;
-  const int grid = grid_for(T, 16, 256);
+  a.acc = accumulate; a.dgamma = dgamma; a.dbeta = dbeta; a.nrep = nrep; a.rep_stride = (size_t)rep_stride;
+  const int grid = grid_for(T, 16, nrep > 1 ? 1024 : 256);
   if (d == 64) hipLaunchKernelGGL(k_ln_bwd<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   else if (d == 128) hipLaunchKernelGGL(k_ln_bwd<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   else if (d == 256) hipLaunchKernelGGL(k_ln_bwd<256>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
@@ -511,6 +519,25 @@ int adt_clip_adam(float* P, float* G, float* M, float* V, int64_t n, int64_t nE,
   hipLaunchKernelGGL(k_wd_gradnorm, dim3(grid_for((size_t)n, 256, 512)), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_adam, dim3(grid_for((size_t)n, 256, 1024)), dim3(256), 0, s, a);
   return check_launch("clip_adam");
+}
+
+/* adt_clip_adam for a step opened by adt_sasrec_step_begin: scal[64..128) already holds the partial sums of ||E||^2 and scal[128..192) is zero */
+int adt_clip_adam_pre(float* P, float* G, float* M, float* V, int64_t n, int64_t nE, float wd, float clip, float lr,
+                      float b1, float b2, float eps, float grad_scale, float* scal, void* stream) {
+  OptArgs a{};
+  a.P = P; a.G = G; a.M = M; a.Vv = V; a.n = (size_t)n; a.nE = (size_t)nE; a.wd = wd; a.clip = clip; a.lr = lr;
+  a.b1 = b1; a.b2 = b2; a.eps = eps; a.scal = scal; a.grad_scale = grad_scale;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_wd_gradnorm, dim3(grid_for((size_t)n, 256, 512)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_adam, dim3(grid_for((size_t)n, 256, 1024)), dim3(256), 0, s, a);
+  return check_launch("clip_adam_pre");
+}
+
+int adt_step_begin_launch(uint32_t* seed, uint32_t inc, float* norms_dst, const float* norms_src, float* loss, int nloss, float* scal, float* G,
+                          int64_t n, const float* E, int64_t nE, void* stream) {
+  StepBeginArgs a{seed, inc, norms_dst, norms_src, loss, nloss, scal, G, (size_t)n, E, (size_t)nE};
+  hipLaunchKernelGGL(k_step_begin, dim3(256), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("step_begin");
 }
 
 int adt_clip_adam_l2(float* P, float* G, float* M, float* V, int64_t n, float l2, float clip, float lr, float b1, float b2,

@@ -55,4 +55,8 @@ int adt_logits_bwd_scatter(const float* F, int ldf, const float* E, const int32_
                            int T, int d, float* dF, int lddf, float* rep, int nrep, int64_t rep_stride, void* stream);
 int adt_embed_bwd_rep(const int32_t* ids, const float* dX, int T, int L, int d, float p, const uint32_t* seed, uint32_t site, uint32_t row_offset,
                       float* dP, float* rep, int nrep, int64_t rep_stride, void* stream);
+int adt_layernorm_bwd_rep(const float* dY, int lddy, const float* X, int ldx, const float* gamma, float eps, int T, int d, float* dX, int lddx,
+                          int accumulate, float* dgamma, float* dbeta, int nrep, int64_t rep_stride, void* stream);
+int adt_step_begin_launch(uint32_t* seed, uint32_t inc, float* norms_dst, const float* norms_src, float* loss, int nloss, float* scal, float* G,
+                          int64_t n, const float* E, int64_t nE, void* stream);
 }

@@ -462,6 +462,34 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* x, size_t n, float* 
   if (threadIdx.x == 0) atomicAdd(out + (blockIdx.x & 63), s);
 }
 
+// Everything a training step does before its forward, in one launch (the trainer used to issue five: seed += inc, normaliser copy, gradient
+// fill, loss-slot fill, optimizer-scalar fill -- and a sixth, k_sumsq, later): G = 0; loss slots = 0; scal[128..192) = 0;
+// scal[64 + b] = block b's share of ||E||^2 (stored, not added: no zero needed; the parameters do not change before adt_clip_adam_pre);
+// norms_dst = norms_src; *seed += inc.  grid >= 66 blocks.
+struct StepBeginArgs {
+  uint32_t* seed; uint32_t inc; float* norms_dst; const float* norms_src; float* loss; int nloss; float* scal; float* G; size_t n;
+  const float* E; size_t nE;
+};
+__global__ __launch_bounds__(256) void k_step_begin(StepBeginArgs a) {
+  __shared__ float sbuf[4];
+  const size_t n4 = a.n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+    reinterpret_cast<float4*>(a.G)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (blockIdx.x == 0 && threadIdx.x < (int)(a.n - n4 * 4)) a.G[n4 * 4 + threadIdx.x] = 0.f;
+  if (blockIdx.x < 64) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.nE; i += (size_t)64 * 256) acc += a.E[i] * a.E[i];
+    const float s = block_sum(acc, sbuf);
+    if (threadIdx.x == 0) a.scal[64 + blockIdx.x] = s;
+  } else if (blockIdx.x == 64) {
+    if (threadIdx.x < 64) a.scal[128 + threadIdx.x] = 0.f;
+    for (int i = threadIdx.x; i < a.nloss; i += 256) a.loss[i] = 0.f;
+  } else if (blockIdx.x == 65) {
+    if (threadIdx.x < 4 && a.norms_dst) a.norms_dst[threadIdx.x] = a.norms_src[threadIdx.x];
+    if (threadIdx.x == 4 && a.seed) *a.seed += a.inc;
+  }
+}
+
 ADT_DEVICE_INLINE float sum64(const float* part, float* sbuf) {
   // every thread returns the sum of 64 partial slots
   float v = threadIdx.x < 64 ? part[threadIdx.x] : 0.f;

@@ -426,15 +426,36 @@ int adt_sasrec_probe_dec_layer_fwd(const adt_sasrec_cfg* c, const float* P, floa
   return dec_layer_seq_fwd(c, lo, w, P, ws, dec, training ? c->dropout : 0.f, seed, b_offset, layer, st);
 }
 
+int adt_sasrec_step_begin(const adt_sasrec_cfg* c, float* ws, int B, uint32_t* seed, uint32_t seed_inc, const float* norms_src, const float* P,
+                          float* G, int64_t n, float* scal, void* st) {
+  CK(check_cfg(c));
+  Layout lo;
+  make_layout(c, &lo);
+  WS w;
+  make_ws(c, B, &w);
+  return adt_step_begin_launch(seed, seed_inc, ws + w.norms, norms_src, ws + w.loss, 64 * (2 + 2 * c->num_layers), scal, G, n, P + lo.item(),
+                               (int64_t)(c->item_num + 1) * c->hidden, st);
+}
+
+static int loss_seed_impl(const adt_sasrec_cfg* c, float* ws, const int32_t* pos, int B, const float* lambdas1, const float* lambdas2,
+                          bool zero_loss, void* st);
 int adt_sasrec_loss_seed(const adt_sasrec_cfg* c, float* ws, const int32_t* pos, int B, const float* lambdas1,
                          const float* lambdas2, void* st) {
+  return loss_seed_impl(c, ws, pos, B, lambdas1, lambdas2, true, st);
+}
+int adt_sasrec_loss_seed_nz(const adt_sasrec_cfg* c, float* ws, const int32_t* pos, int B, const float* lambdas1,
+                            const float* lambdas2, void* st) {
+  return loss_seed_impl(c, ws, pos, B, lambdas1, lambdas2, false, st);
+}
+static int loss_seed_impl(const adt_sasrec_cfg* c, float* ws, const int32_t* pos, int B, const float* lambdas1, const float* lambdas2,
+                          bool zero_loss, void* st) {
   WS w;
   make_ws(c, B, &w);
   const int nl = c->num_layers, T = (int)w.T, H = (int)w.H;
   const int64_t Td = up64(w.T * w.d), rec = up64(w.T * w.H * w.H);
   float* loss = ws + w.loss;
   const float* norms = ws + w.norms;
-  if (adt::zero_f32_async(loss, (size_t)64 * (2 + 2 * nl), (hipStream_t)st)) return adt_set_error("loss zero");
+  if (zero_loss && adt::zero_f32_async(loss, (size_t)64 * (2 + 2 * nl), (hipStream_t)st)) return adt_set_error("loss zero");
   CK(adt_bce_seed(ws + w.posl, ws + w.negl, pos, T, norms, ws + w.g_pos, ws + w.g_neg, loss, st));
   for (int i = 0; i < nl; ++i)   // enc_in[i] pairs with dec_out_rev[i] = DEC_X[nl - i]      (sasrec/main.py:155-158)
     CK(adt_mse_seed(ws + w.enc_x + i * Td, ws + w.dec_x + (nl - i) * Td, w.T * w.d, lambdas1[i], norms, ws + w.g_enc_x + i * Td, 0,
@@ -590,8 +611,8 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   }
   if (phase == 0 || phase == 2) {
     // last_layernorm: g_enc_x[nl] = LN'(g_f)
-    CK(adt_layernorm_bwd(gf, d, ws + w.enc_x + nl * Td, d, P + lo.lnl_w(), LN_EPS, T, d, ws + w.g_enc_x + nl * Td, d, 0,
-                         G + lo.lnl_w(), G + lo.lnl_b(), st));
+    CK(adt_layernorm_bwd_rep(gf, d, ws + w.enc_x + nl * Td, d, P + lo.lnl_w(), LN_EPS, T, d, ws + w.g_enc_x + nl * Td, d, 0,
+                             Gq + lo.lnl_w(), Gq + lo.lnl_b(), NREPP, w.prep_stride, st));
     for (int i = nl - 1; i >= 0; --i) {
       float* gy = ws + w.g_enc_x + (i + 1) * Td;
       float* gx = ws + w.g_enc_x + i * Td;     // already holds the reconstruction seed for enc_in[i]

@@ -189,6 +189,13 @@ def clip_adam(P, G, M, V, nE, wd, clip, lr, b1, b2, eps, scal, grad_scale=1.0, n
                                          float(eps), float(grad_scale), _p(scal), _stream()), "clip_adam")
 
 
+def clip_adam_pre(P, G, M, V, nE, wd, clip, lr, b1, b2, eps, scal, grad_scale=1.0, n=None):
+    """clip_adam for a step opened by SASRecADT.run_step_begin (||E||^2 partials and zeroed slots already in scal)."""
+    n = P.numel() if n is None else n
+    _lib.check(_lib.load().adt_clip_adam_pre(_p(P), _p(G), _p(M), _p(V), n, nE, float(wd), float(clip), float(lr), float(b1), float(b2),
+                                             float(eps), float(grad_scale), _p(scal), _stream()), "clip_adam_pre")
+
+
 def score_rank(F, ldf, E, cand, B, C, want_rank=True):
     d = E.shape[1]
     logits = torch.empty(B, C, device=E.device, dtype=torch.float32)

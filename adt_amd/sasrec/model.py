@@ -166,12 +166,18 @@ class SASRecADT(torch.nn.Module):
         _lib.check(self.lib.adt_sasrec_probe_dec_layer_fwd(ctypes.byref(self.cfg), _ptr(self.flat), _ptr(self.workspace(B)), _ptr(dec), B,
                                                            int(training), _ptr(self._seed), b_offset, layer, self._stream()), "probe_dec_layer_fwd")
 
-    def run_loss_seed(self, pos, B, lambdas1, lambdas2):
+    def run_step_begin(self, B, norms_src, scal, seed_inc=0x9E3779B1):
+        """One launch: zero_grad, loss slots, normalisers, the dropout seed += seed_inc, ||E||^2 partials (adt_sasrec_step_begin)."""
+        _lib.check(self.lib.adt_sasrec_step_begin(ctypes.byref(self.cfg), _ptr(self.workspace(B)), B, _ptr(self._seed), seed_inc, _ptr(norms_src),
+                                                  _ptr(self.flat), _ptr(self.flat_grad), self.flat_grad.numel(), _ptr(scal), self._stream()),
+                   "sasrec_step_begin")
+
+    def run_loss_seed(self, pos, B, lambdas1, lambdas2, zero_loss=True):
         nl = self.num_layers
         l1 = (ctypes.c_float * nl)(*[float(x) for x in lambdas1])
         l2 = (ctypes.c_float * nl)(*[float(x) for x in lambdas2])
-        _lib.check(self.lib.adt_sasrec_loss_seed(ctypes.byref(self.cfg), _ptr(self.workspace(B)), _ptr(pos), B, l1, l2, self._stream()),
-                   "sasrec_loss_seed")
+        fn = self.lib.adt_sasrec_loss_seed if zero_loss else self.lib.adt_sasrec_loss_seed_nz
+        _lib.check(fn(ctypes.byref(self.cfg), _ptr(self.workspace(B)), _ptr(pos), B, l1, l2, self._stream()), "sasrec_loss_seed")
 
     def run_backward(self, seq, dec, pos, neg, B, training, b_offset=0, phase=0):
         _lib.check(self.lib.adt_sasrec_backward(ctypes.byref(self.cfg), _ptr(self.flat), _ptr(self.flat_grad), _ptr(self.workspace(B)),

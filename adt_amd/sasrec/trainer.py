@@ -73,12 +73,12 @@ class FusedTrainer:
         """Everything after the H2D copy; capturable."""
         m = self.model
         seq, dec, pos, neg = self._ids
-        m._seed.add_(-1640531535)   # += 0x9E3779B1 (mod 2^32): a fresh dropout stream every step, on the device
-        # a kernel, not tensor.copy_: inside a captured step that would be a memcpy NODE (see DESIGN.md on captured memset nodes)
-        ops.axpy(m.ws_view(B, WS_NORMS, 0, 4), self._norms_dev, 1.0, False)
+        # one launch: seed += 0x9E3779B1 (a fresh dropout stream every step, on the device), the normalisers into the workspace (a kernel, not
+        # tensor.copy_: inside a captured step that would be a memcpy NODE, see DESIGN.md on captured memset nodes), zero_grad, loss slots,
+        # ||E||^2 partials for the weight-decay term
+        m.run_step_begin(B, self._norms_dev, self.scal)
         m.run_forward(seq, dec, pos, neg, B, True, b_offset)
-        m.run_loss_seed(pos, B, self.lambdas1, self.lambdas2)
-        m.flat_grad.zero_()
+        m.run_loss_seed(pos, B, self.lambdas1, self.lambdas2, zero_loss=False)
         if not self._buckets.active:
             m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=0)
         else:
@@ -89,8 +89,8 @@ class FusedTrainer:
             self._buckets.tail_ready()
             m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=2)
             self._buckets.finish()
-        ops.clip_adam(m.flat, m.flat_grad, self.m, self.v, (m.item_num + 1) * m.hidden_units, self.wd, self.clip, self.lr,
-                      self.betas[0], self.betas[1], self.eps, self.scal)
+        ops.clip_adam_pre(m.flat, m.flat_grad, self.m, self.v, (m.item_num + 1) * m.hidden_units, self.wd, self.clip, self.lr,
+                          self.betas[0], self.betas[1], self.eps, self.scal)
 
     def _fill_host(self, seq, dec, pos, neg, norms):
         m = self.model

@@ -118,6 +118,10 @@ int adt_nll_seed(const float* rec, int n_rows, int H, float lambda2, const float
  * (incremented), [3] wd*||E||, [64..192) partial-sum slots zeroed inside. */
 int adt_clip_adam(float* P, float* G, float* M, float* V, int64_t n, int64_t nE, float wd, float clip, float lr,
                   float b1, float b2, float eps, float grad_scale, float* scal, void* stream);
+/* The same for a step opened by adt_sasrec_step_begin (which has already stored the partial sums of ||E||^2 in scal[64..128) and zeroed
+ * scal[128..192)): two launches instead of four. */
+int adt_clip_adam_pre(float* P, float* G, float* M, float* V, int64_t n, int64_t nE, float wd, float clip, float lr,
+                      float b1, float b2, float eps, float grad_scale, float* scal, void* stream);
 
 /* ---- SASRecADT.predict scoring (sasrec/model.py:89-96) + rank of evaluate_loader (sasrec/utils.py:410).
  * cand == NULL scores items 0..C-1 (full=True). rank may be NULL. */
@@ -347,6 +351,14 @@ int adt_seq_dec_layer_bwd(int B, int L, int H, const int32_t* ids, const float* 
  * already hold the global normalisers. */
 int adt_sasrec_loss_seed(const adt_sasrec_cfg* cfg, float* ws, const int32_t* pos, int B, const float* lambdas1,
                          const float* lambdas2, void* stream);
+/* One launch for everything a training step (sasrec/main.py:146-173) does before its forward: grads[0..n) = 0 (optimizer.zero_grad), the loss
+ * slots = 0, NORMS = norms_src[0..4), *seed += seed_inc (the per-step dropout stream), scal[128..192) = 0 and scal[64..128) = partial sums of
+ * ||item table||^2 (the weight-decay term of adt_clip_adam_pre; the parameters do not change in between).  Pair it with
+ * adt_sasrec_loss_seed_nz (adt_sasrec_loss_seed without its loss-slot fill) and adt_clip_adam_pre. */
+int adt_sasrec_step_begin(const adt_sasrec_cfg* cfg, float* ws, int B, uint32_t* seed, uint32_t seed_inc, const float* norms_src,
+                          const float* params, float* grads, int64_t n, float* scal, void* stream);
+int adt_sasrec_loss_seed_nz(const adt_sasrec_cfg* cfg, float* ws, const int32_t* pos, int B, const float* lambdas1,
+                            const float* lambdas2, void* stream);
 /* reverse pass: consumes the G_* buffers (destroyed), accumulates into `grads` (same layout as params).
  * phase: 0 = everything; 1 = logits + decoder stack only; 2 = last LN + encoder stack + embeddings (lets the
  * host overlap the gradient all-reduce of the decoder bucket with phase 2). */
