@@ -174,7 +174,7 @@ __global__ __launch_bounds__(LCE_NTH) void k_lce(LceArgs a) {
       for (int ks = 0; ks < G::NKS; ++ks) xf[n][ks] = xp[2 * ks];
     }
     float xvl = 0.f;
-    if constexpr (MODE != LCE_FWD) xvl = a.xv[x0 + r];
+    if constexpr (MODE != LCE_FWD) xvl = a.xv[x0 + r] * LCE_L2E;      // log2 units: added inside the exponent
     // a "use" of every register the loads above fill, in front of the tile loop: hipcc then waits for them HERE.  Left to itself it puts
     // its vmcnt(15) ... vmcnt(0) in front of their first use inside the loop, where they would drain the LDS-DMA ring on every tile.
 #pragma unroll
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(LCE_NTH) void k_lce(LceArgs a) {
       for (int i = 0; i < 4; ++i) {
         const float4 y = yvp[2 * i + h];                   // rows 8 i + 4 h .. + 3 of the tile = accumulator registers 4 i .. 4 i + 3
 #pragma unroll
-        for (int n = 0; n < NX; ++n) {
-          acc[n][4 * i + 0] = y.x + xvl; acc[n][4 * i + 1] = y.y + xvl; acc[n][4 * i + 2] = y.z + xvl; acc[n][4 * i + 3] = y.w + xvl;
+        for (int n = 0; n < NX; ++n) {                     // the accumulator starts at the Y-side constant; the X-side one joins in the exponent
+          acc[n][4 * i + 0] = y.x; acc[n][4 * i + 1] = y.y; acc[n][4 * i + 2] = y.z; acc[n][4 * i + 3] = y.w;
         }
       }
 #pragma unroll
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(LCE_NTH) void k_lce(LceArgs a) {
       } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          acc[0][e] = __builtin_amdgcn_exp2f(acc[0][e] * LCE_L2E);
+          acc[0][e] = __builtin_amdgcn_exp2f(fmaf(acc[0][e], LCE_L2E, xvl));
           if constexpr (MODE == LCE_DE) bsum += acc[0][e];
         }
         const bf16x8 pf0 = lce_pack8(acc[0], 0), pf1 = lce_pack8(acc[0], 8);
@@ -316,13 +316,17 @@ struct LceCombineArgs {
   const float* inv_count; float* loss64; float* nlse; float* lse_out;
   float* dE; int lddE; float* dbias;
 };
+template <int KD>
 __global__ __launch_bounds__(256) void k_lce_combine(LceCombineArgs a) {
   const int M = a.m_dev ? min(*a.m_dev, a.mcap) : a.mcap;
   const int Mpad = (M + LCE_XR_FWD - 1) / LCE_XR_FWD * LCE_XR_FWD;
   const LceSplit sp = lce_split(M, LCE_XR_FWD, a.slots, (a.V + 31) / 32);
   const float wn = *a.inv_count;
   const int lane = threadIdx.x & 63;
-  for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < Mpad; m += gridDim.x * 4) {
+  __shared__ float lce_wsum[4];
+  float lsum = 0.f;                                       // lane 0: this wave's share of the loss
+  for (int m0 = blockIdx.x * 16; m0 < Mpad; m0 += gridDim.x * 16)        // a block owns 16 consecutive rows: one loss atomic per 16 rows
+  for (int m = m0 + (threadIdx.x >> 6); m < m0 + 16; m += 4) {
     if (m >= M) {
       if (lane == 0) a.nlse[m] = -INFINITY;
       continue;
@@ -335,27 +339,37 @@ __global__ __launch_bounds__(256) void k_lce_combine(LceCombineArgs a) {
       pm = a.part_m[o];
       ps = a.part_s[o];
     }
-    typedef __bf16 lce_b4 __attribute__((ext_vector_type(4)));
+    // lane <-> consecutive columns: every atomic wave-instruction covers 256 contiguous bytes of the table row (the shape that runs at the
+    // full float-atomic rate); all loads of the row are issued ahead of the atomics (they may alias for the compiler)
     float dot = 0.f;
-    for (int k = lane * 4; k < a.K; k += 256) {            // every load of the row ahead of the atomics (they may alias for the compiler)
-      const lce_b4 hv = *reinterpret_cast<const lce_b4*>(a.Hb + (size_t)m * a.K + k);
-      const lce_b4 ev = *reinterpret_cast<const lce_b4*>(a.Eb + (size_t)lab * a.K + k);
-      float* g = a.dE + (size_t)lab * a.lddE + k;
+    float hv[KD / 64], ev[KD / 64];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dot = fmaf((float)hv[e], (float)ev[e], dot);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(g + e, -wn * (float)hv[e]);
+    for (int j = 0; j < KD / 64; ++j) {                    // unconditional: the loads issue back to back (one round trip, not KD / 32)
+      hv[j] = (float)a.Hb[(size_t)m * KD + lane + 64 * j];
+      ev[j] = (float)a.Eb[(size_t)lab * KD + lane + 64 * j];
     }
+#pragma unroll
+    for (int j = 0; j < KD / 64; ++j) dot = fmaf(hv[j], ev[j], dot);
+#pragma unroll
+    for (int j = 0; j < KD / 64; ++j) atomicAdd(a.dE + (size_t)lab * a.lddE + lane + 64 * j, -wn * hv[j]);
     const float mx = wave_max(pm);
     const float s = wave_sum(ps * __builtin_amdgcn_exp2f((pm - mx) * LCE_L2E));
     const float lse = mx + __logf(s);
     dot = wave_sum(dot);
     if (lane == 0) {
-      atomicAdd(a.loss64 + (m & 63), wn * (lse - (dot + a.bias[lab])));
+      lsum += wn * (lse - (dot + a.bias[lab]));
       a.nlse[m] = __logf(wn) - lse;
       if (a.lse_out) a.lse_out[m] = lse;
       atomicAdd(a.dbias + lab, -wn);
     }
+  }
+  // one loss atomic per BLOCK: an atomic per row (5.9k adds on 64 addresses within a few microseconds) was a ~90-deep same-address chain
+  // across XCDs and cost 34 of this kernel's 44 us
+  if (lane == 0) lce_wsum[threadIdx.x >> 6] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = (lce_wsum[0] + lce_wsum[1]) + (lce_wsum[2] + lce_wsum[3]);
+    if (t != 0.f) atomicAdd(a.loss64 + (blockIdx.x & 63), t);
   }
 }
 

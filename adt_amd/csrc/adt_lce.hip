@@ -97,7 +97,7 @@ static int lce_run(const float* h, int ldh, const int32_t* rows, const int32_t* 
     LceArgs a{Hb, Eb, nullptr, biasp, m_dev, nullptr, mcap, V, part_m, part_s, nullptr, nullptr, slots};
     if (int rc = lce_launch<KD, LCE_FWD>(a, s, "lce: forward")) return rc;
     LceCombineArgs c{part_m, part_s, Hb, Eb, bias, labels, m_dev, mcap, V, KD, slots, inv_count, loss64, nlse, lse_out, dE, lddE, dbias};
-    hipLaunchKernelGGL(k_lce_combine, dim3(1024), dim3(256), 0, s, c);
+    hipLaunchKernelGGL(k_lce_combine<KD>, dim3(std::min(4096, (L.Mpad + 15) / 16)), dim3(256), 0, s, c);
     if (int rc = lce_check("lce: combine")) return rc;
   }
   if (!dh) return 0;                                       // loss only

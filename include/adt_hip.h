@@ -147,7 +147,7 @@ int adt_dense_gradsrc(const float* dY, int lddy, int T, int N, const int32_t* ma
  * (rows x V) logits: an online log-sum-exp forward and a backward that recomputes each score tile on the matrix cores
  * (adt_amd/csrc/adt_lce.cuh).  h: (B*L, K) activations, row stride ldh; rows[m] (m < min(mcap, *m_dev)): the rows whose label is
  * non-zero, labels[m] their labels (1..V-1); E: (V, K) item table, bias: (V).  With n = 1 / *inv_count labelled rows:
- *   loss64[m & 63] += (lse_m - logit_m[label_m]) / n;   lse_out[m] = lse_m (optional);
+ *   sum(loss64[0..64)) += sum_m (lse_m - logit_m[label_m]) / n  (64 partial slots);   lse_out[m] = lse_m (optional);
  *   dh[rows[m]] = sum_v (softmax_m[v] - [v == label_m]) / n * E[v]            (plain store; dh NULL = loss only)
  *   dE[v] += sum_m (softmax_m[v] - [v == label_m]) / n * h[rows[m]];  dbias[v] += sum_m (...)      (accumulated)
  * m_dev (optional) is a DEVICE count, so a captured graph replays with a different number of masked rows.  workspace: at least
