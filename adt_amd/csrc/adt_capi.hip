@@ -508,6 +508,24 @@ int adt_nll_seed(const float* rec, int n_rows, int H, float lambda2, const float
   return check_launch("nll_seed");
 }
 
+// the executor's loss assembly in one launch (adt_host.h); nmse, nnll <= 4
+int adt_loss_seeds(const float* pos_logits, const float* neg_logits, const int32_t* pos, int T, const float* norms, float* dpos, float* dneg,
+                   float* loss_bce, int nmse, const float* const* A, const float* const* Bm, int64_t n, const float* lambdas, float* const* GA,
+                   int accumulate_a, float* const* GB, float* const* loss_mse, int nnll, const float* const* rec, int n_rows, int H, float lambda2,
+                   float* const* drec, float* const* loss_nll, void* stream) {
+  if (nmse > 4 || nnll > 4 || n % 4) return adt_set_error("loss_seeds: at most 4 + 4 terms, n %% 4");
+  LossSeedsArgs a{};
+  a.bce = BceArgs{pos_logits, neg_logits, pos, T, norms, dpos, dneg, loss_bce};
+  for (int i = 0; i < nmse; ++i) a.mse[i] = MseArgs{A[i], Bm[i], (size_t)n, lambdas[i], norms, GA[i], accumulate_a, GB[i], loss_mse[i]};
+  for (int i = 0; i < nnll; ++i) a.nll[i] = NllArgs{rec[i], n_rows, H, lambda2, norms, drec[i], loss_nll[i]};
+  a.nmse = nmse; a.nnll = nnll;
+  a.gb = grid_for(T, 256, 256);
+  a.gm = nmse ? grid_for((size_t)n / 4, 256, 512) : 1;
+  a.gn = nnll ? grid_for((size_t)n_rows * H * H, 256, 512) : 1;
+  hipLaunchKernelGGL(k_loss_seeds, dim3(a.gb + nmse * a.gm + nnll * a.gn), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("loss_seeds");
+}
+
 int adt_clip_adam(float* P, float* G, float* M, float* V, int64_t n, int64_t nE, float wd, float clip, float lr,
                   float b1, float b2, float eps, float grad_scale, float* scal, void* stream) {
   OptArgs a{};

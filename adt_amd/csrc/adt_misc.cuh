@@ -359,11 +359,10 @@ ADT_DEVICE_INLINE float block_sum(float v, float* sbuf) {
   return r;  // valid on thread 0
 }
 
-__global__ __launch_bounds__(256) void k_bce(BceArgs a) {
-  __shared__ float sbuf[4];
+ADT_DEVICE_INLINE void bce_body(const BceArgs& a, int bid, int nblk, float* sbuf) {
   const float inv = 1.0f / a.norms[0];
   float lp = 0.f, ln = 0.f;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.T; i += gridDim.x * 256) {
+  for (int i = bid * 256 + threadIdx.x; i < a.T; i += nblk * 256) {
     float gp = 0.f, gn = 0.f;
     if (a.pos[i] != 0) {
       const float xp = a.pos_logits[i], xn = a.neg_logits[i];
@@ -380,7 +379,11 @@ __global__ __launch_bounds__(256) void k_bce(BceArgs a) {
   const float sn = block_sum(ln, sbuf);
   // 64 sub-slots per loss term: same-address float atomics serialise (~10 ns each), thousands of blocks would cost
   // tens of microseconds on one address
-  if (threadIdx.x == 0) { atomicAdd(a.loss + (blockIdx.x & 63), sp * inv); atomicAdd(a.loss + 64 + (blockIdx.x & 63), sn * inv); }
+  if (threadIdx.x == 0) { atomicAdd(a.loss + (bid & 63), sp * inv); atomicAdd(a.loss + 64 + (bid & 63), sn * inv); }
+}
+__global__ __launch_bounds__(256) void k_bce(BceArgs a) {
+  __shared__ float sbuf[4];
+  bce_body(a, blockIdx.x, gridDim.x, sbuf);
 }
 
 // g = 2*lambda/n_mse * (A - Bm);  GA += g (or = g), GB = -g;  loss += sum (A-B)^2 / n_mse
@@ -394,12 +397,11 @@ struct MseArgs {
   float* loss;               // one slot
 };
 
-__global__ __launch_bounds__(256) void k_mse_seed(MseArgs a) {
-  __shared__ float sbuf[4];
+ADT_DEVICE_INLINE void mse_body(const MseArgs& a, int bid, int nblk, float* sbuf) {
   const float inv = 1.0f / a.norms[1];
   const float coef = 2.0f * a.lambda * inv;
   float acc = 0.f;
-  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < a.n; i += (size_t)gridDim.x * 1024) {
+  for (size_t i = ((size_t)bid * 256 + threadIdx.x) * 4; i < a.n; i += (size_t)nblk * 1024) {
     const float4 x = *reinterpret_cast<const float4*>(a.A + i);
     const float4 y = *reinterpret_cast<const float4*>(a.Bm + i);
     float4 dlt = make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
@@ -413,7 +415,11 @@ __global__ __launch_bounds__(256) void k_mse_seed(MseArgs a) {
     *reinterpret_cast<float4*>(a.GA + i) = g;
   }
   const float s = block_sum(acc, sbuf);
-  if (threadIdx.x == 0) atomicAdd(a.loss + (blockIdx.x & 63), s * inv);
+  if (threadIdx.x == 0) atomicAdd(a.loss + (bid & 63), s * inv);
+}
+__global__ __launch_bounds__(256) void k_mse_seed(MseArgs a) {
+  __shared__ float sbuf[4];
+  mse_body(a, blockIdx.x, gridDim.x, sbuf);
 }
 
 // drec[n][h][c] = -(lambda2 / n_nll) * [h == c];  loss += -sum_n,h rec[n][h][h] / n_nll
@@ -425,20 +431,42 @@ struct NllArgs {
   float* loss;
 };
 
-__global__ __launch_bounds__(256) void k_nll_seed(NllArgs a) {
-  __shared__ float sbuf[4];
+ADT_DEVICE_INLINE void nll_body(const NllArgs& a, int bid, int nblk, float* sbuf) {
   const float inv = 1.0f / a.norms[2];
   const int HH = a.H * a.H;
   const int n = a.n_rows * HH;
   float acc = 0.f;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+  for (int i = bid * 256 + threadIdx.x; i < n; i += nblk * 256) {
     const int e = i % HH;
     const bool diag = (e / a.H) == (e % a.H);
     if (diag) acc -= a.rec[i];
     a.drec[i] = diag ? -a.lambda2 * inv : 0.f;
   }
   const float s = block_sum(acc, sbuf);
-  if (threadIdx.x == 0) atomicAdd(a.loss + (blockIdx.x & 63), s * inv);
+  if (threadIdx.x == 0) atomicAdd(a.loss + (bid & 63), s * inv);
+}
+__global__ __launch_bounds__(256) void k_nll_seed(NllArgs a) {
+  __shared__ float sbuf[4];
+  nll_body(a, blockIdx.x, gridDim.x, sbuf);
+}
+
+// All loss seeds of a step (sasrec/main.py:151-169) in one launch: the BCE seed, up to four reconstruction seeds and up to four independence
+// seeds are independent streaming passes; as five launches of 5-11 us each they cost 39 us at the flagship shape.  Blocks [0, gb) run the
+// BCE body, the next nmse * gm the MSE bodies, the last nnll * gn the NLL bodies (same arithmetic, same per-task block counts as the
+// stand-alone kernels).
+struct LossSeedsArgs {
+  BceArgs bce; MseArgs mse[4]; NllArgs nll[4];
+  int nmse, nnll, gb, gm, gn;
+};
+__global__ __launch_bounds__(256) void k_loss_seeds(LossSeedsArgs a) {
+  __shared__ float sbuf[4];
+  int b = blockIdx.x;
+  if (b < a.gb) { bce_body(a.bce, b, a.gb, sbuf); return; }
+  b -= a.gb;
+  if (b < a.nmse * a.gm) { const int k = b / a.gm; mse_body(a.mse[k], b - k * a.gm, a.gm, sbuf); return; }
+  b -= a.nmse * a.gm;
+  const int k = b / a.gn;
+  nll_body(a.nll[k], b - k * a.gn, a.gn, sbuf);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -456,6 +456,17 @@ static int loss_seed_impl(const adt_sasrec_cfg* c, float* ws, const int32_t* pos
   float* loss = ws + w.loss;
   const float* norms = ws + w.norms;
   if (zero_loss && adt::zero_f32_async(loss, (size_t)64 * (2 + 2 * nl), (hipStream_t)st)) return adt_set_error("loss zero");
+  if (nl <= 4) {   // one launch for all of them (adt_misc.cuh: k_loss_seeds)
+    const float *A[4], *Bm[4], *rc[4];
+    float *GA[4], *GB[4], *lm[4], *dr[4], *ln[4];
+    for (int i = 0; i < nl; ++i) {
+      A[i] = ws + w.enc_x + i * Td; Bm[i] = ws + w.dec_x + (nl - i) * Td; GA[i] = ws + w.g_enc_x + i * Td; GB[i] = ws + w.g_dec_x + (nl - i) * Td;
+      lm[i] = loss + 64 * (2 + i);
+      rc[i] = ws + i * w.e_stride + w.e_rec; dr[i] = ws + w.g_rec + i * rec; ln[i] = loss + 64 * (2 + nl + i);
+    }
+    return adt_loss_seeds(ws + w.posl, ws + w.negl, pos, T, norms, ws + w.g_pos, ws + w.g_neg, loss, nl, A, Bm, w.T * w.d, lambdas1, GA, 0, GB, lm,
+                          H > 1 ? nl : 0, rc, T, H, lambdas2[nl - 1], dr, ln, st);
+  }
   CK(adt_bce_seed(ws + w.posl, ws + w.negl, pos, T, norms, ws + w.g_pos, ws + w.g_neg, loss, st));
   for (int i = 0; i < nl; ++i)   // enc_in[i] pairs with dec_out_rev[i] = DEC_X[nl - i]      (sasrec/main.py:155-158)
     CK(adt_mse_seed(ws + w.enc_x + i * Td, ws + w.dec_x + (nl - i) * Td, w.T * w.d, lambdas1[i], norms, ws + w.g_enc_x + i * Td, 0,
