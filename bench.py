@@ -208,6 +208,11 @@ def main():
         sys.exit(self_launch(args.gpus))
     if args.force_dp:
         os.environ["ADT_FORCE_DP"] = "1"
+    # stdout carries exactly ONE line, the JSON result: whatever a library prints to fd 1 (RCCL's version banner when the communicator
+    # is created) is routed to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -289,7 +294,7 @@ def main():
         res["roofline"] = roofline_probe(model, tr, B, B * args.steps / dt, batches[0])
         if world == 1 and not args.no_cpu_baseline and not args.force_dp:
             res["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(res), flush=True)
+        print(json.dumps(res), file=json_out, flush=True)
     if pg is not None:
         dist.barrier()
         dist.destroy_process_group()
