@@ -294,6 +294,18 @@ int adt_embed_bwd_rep(const int32_t* ids, const float* dX, int T, int L, int d, 
   return check_launch("embed_bwd_rep");
 }
 
+int adt_replica_reduce2(float* d0, const float* r0, int64_t n0, int nrep0, int64_t s0, float* d1, const float* r1, int64_t n1, int nrep1, int64_t s1,
+                        void* stream) {
+  if (n0 % 4 || s0 % 4 || n1 % 4 || s1 % 4) return adt_set_error("replica_reduce2: n, stride %% 4");
+  if (n0 <= 0) return adt_replica_reduce(d1, r1, n1, nrep1, s1, stream);
+  if (n1 <= 0) return adt_replica_reduce(d0, r0, n0, nrep0, s0, stream);
+  RepReduce2Args a{{d0, d1}, {r0, r1}, {(size_t)n0, (size_t)n1}, {nrep0, nrep1}, {(size_t)s0, (size_t)s1}, 0};
+  const int g0 = grid_for((size_t)n0 / 4, 256, 1024), g1 = grid_for((size_t)n1 / 4, 256, 1024);
+  a.g0 = g0;
+  hipLaunchKernelGGL(k_replica_reduce2, dim3(g0 + g1), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("replica_reduce2");
+}
+
 int adt_replica_reduce(float* dE, const float* rep, int64_t n, int nrep, int64_t rep_stride, void* stream) {
   if (n % 4 || rep_stride % 4) return adt_set_error("replica_reduce: n, stride %% 4");
   hipLaunchKernelGGL(k_replica_reduce, dim3(grid_for((size_t)n / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream, dE, rep, (size_t)n, nrep,

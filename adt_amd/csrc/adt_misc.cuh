@@ -84,6 +84,25 @@ __global__ __launch_bounds__(256) void k_replica_reduce(float* dst, const float*
   }
 }
 
+// two replica folds in one launch (the item table and the other parameters at the end of a backward phase): blocks [0, g0) take job 0
+struct RepReduce2Args { float* dst[2]; const float* rep[2]; size_t n[2]; int nrep[2]; size_t stride[2]; int g0; };
+__global__ __launch_bounds__(256) void k_replica_reduce2(RepReduce2Args a) {
+  const int j = (int)blockIdx.x >= a.g0 ? 1 : 0;
+  const int bid = j ? blockIdx.x - a.g0 : blockIdx.x, nblk = j ? gridDim.x - a.g0 : a.g0;
+  float* dst = a.dst[j];
+  const float* rep = a.rep[j];
+  const size_t n = a.n[j], stride = a.stride[j];
+  const int nrep = a.nrep[j];
+  for (size_t i = ((size_t)bid * 256 + threadIdx.x) * 4; i < n; i += (size_t)nblk * 1024) {
+    float4 s = *reinterpret_cast<const float4*>(dst + i);
+    for (int r = 0; r < nrep; ++r) {
+      const float4 v = *reinterpret_cast<const float4*>(rep + (size_t)r * stride + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dst + i) = s;
+  }
+}
+
 // dP[l] += sum_b dX[b, l] * keep/(1-p) * (ids != 0).  grid: (blocks over L*d/4 columns, slices over the
 // batch); each thread sums its batch slice for one (l, 4 columns) in registers, then one atomic per column.
 __global__ __launch_bounds__(256) void k_posemb_bwd(EmbedArgs a) {
@@ -320,19 +339,26 @@ __global__ __launch_bounds__(256) void k_embed_bwd64(EmbedBwdArgs a) {
   const int bper = (B + a.nslices - 1) / a.nslices, b0 = s * bper, b1 = min(B, b0 + bper);
   float* dE = a.rep + (a.nrep > 1 ? (size_t)(wave % a.nrep) * a.rep_stride : 0);
   float acc = 0.f;
-  for (int b = b0; b < b1; ++b) {
-    const int row = b * a.L + l;
-    const int id = a.ids[row];
-    if (id == 0) continue;
-    const float g = a.dX[(size_t)row * 64 + lane];
-    float vi = g * a.scale, vp = g;
-    if (a.drop.thr) {
-      const bool keep = adt_keep(key, (uint32_t)(row + a.row_offset) * 64u + (uint32_t)lane, a.drop.thr);
-      vi = keep ? vi * a.drop.scale : 0.f;
-      vp = keep ? vp * a.drop.scale : 0.f;
+  for (int b = b0; b < b1; b += 4) {                      // four rows in flight: ids, then the rows, then the atomics
+    int id[4];
+    float g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) id[u] = b + u < b1 ? a.ids[(b + u) * a.L + l] : 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) g[u] = id[u] != 0 ? a.dX[(size_t)((b + u) * a.L + l) * 64 + lane] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (id[u] == 0) continue;
+      const int row = (b + u) * a.L + l;
+      float vi = g[u] * a.scale, vp = g[u];
+      if (a.drop.thr) {
+        const bool keep = adt_keep(key, (uint32_t)(row + a.row_offset) * 64u + (uint32_t)lane, a.drop.thr);
+        vi = keep ? vi * a.drop.scale : 0.f;
+        vp = keep ? vp * a.drop.scale : 0.f;
+      }
+      atomicAdd(dE + (size_t)id[u] * 64 + lane, vi);
+      acc += vp;
     }
-    atomicAdd(dE + (size_t)id * 64 + lane, vi);
-    acc += vp;
   }
   atomicAdd(a.dP + (size_t)l * 64 + lane, acc);
 }

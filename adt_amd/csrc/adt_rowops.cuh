@@ -338,55 +338,74 @@ __global__ __launch_bounds__(NTHREADS) void k_ln_bwd(LnArgs a) {
   const int sub = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int rows_per_block = NTHREADS / 16;
   float dg[E] = {}, dbt[E] = {};
-  for (int row = blockIdx.x * rows_per_block + rg; row < a.T; row += gridDim.x * rows_per_block) {
-    float x[E], dy[E], gm[E];
+  float gm[E];
 #pragma unroll
-    for (int e = 0; e < E; e += 4) {
-      const int col = (e / 4) * 64 + 4 * sub;
-      *reinterpret_cast<float4*>(x + e) = *reinterpret_cast<const float4*>(a.X + (size_t)row * a.ldx + col);
-      *reinterpret_cast<float4*>(dy + e) = *reinterpret_cast<const float4*>(a.dY + (size_t)row * a.lddy + col);
-      *reinterpret_cast<float4*>(gm + e) = *reinterpret_cast<const float4*>(a.gamma + col);
-    }
-    float s = 0.f;
+  for (int e = 0; e < E; e += 4) *reinterpret_cast<float4*>(gm + e) = *reinterpret_cast<const float4*>(a.gamma + (e / 4) * 64 + 4 * sub);
+  // K = 64: TWO rows per 16-lane group and iteration, all four row loads issued before the first reduction (the grid is capped: every block
+  // ends with one atomic per column on the same addresses, so memory-level parallelism has to come from inside the wave).  At K = 256 the
+  // same change costs registers and was slower (BERT 13.55 -> 13.77 ms per step): one row at a time there.
+  constexpr int U = K <= 64 ? 2 : 1;
+  const int stride = gridDim.x * rows_per_block;
+  for (int row0 = blockIdx.x * rows_per_block + rg; row0 < a.T; row0 += U * stride) {
+    float x[U][E], dy[U][E];
+    bool ok[U];
 #pragma unroll
-    for (int e = 0; e < E; ++e) s += x[e];
+    for (int u = 0; u < U; ++u) {
+      const int row = row0 + u * stride;
+      ok[u] = row < a.T;
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    const float mu = s * (1.0f / K);
-    float q = 0.f;
-#pragma unroll
-    for (int e = 0; e < E; ++e) { x[e] -= mu; q += x[e] * x[e]; }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-    const float rstd = 1.0f / sqrtf(q * (1.0f / K) + a.eps);
-    float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      x[e] *= rstd;                 // xhat
-      dg[e] += dy[e] * x[e];
-      dbt[e] += dy[e];
-      dy[e] *= gm[e];               // dxhat
-      m1 += dy[e];
-      m2 += dy[e] * x[e];
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
-    m1 *= (1.0f / K);
-    m2 *= (1.0f / K);
-#pragma unroll
-    for (int e = 0; e < E; e += 4) {
-      const int col = (e / 4) * 64 + 4 * sub;
-      float* dst = a.dX + (size_t)row * a.lddx + col;
-      float4 r;
-      r.x = rstd * (dy[e + 0] - m1 - x[e + 0] * m2);
-      r.y = rstd * (dy[e + 1] - m1 - x[e + 1] * m2);
-      r.z = rstd * (dy[e + 2] - m1 - x[e + 2] * m2);
-      r.w = rstd * (dy[e + 3] - m1 - x[e + 3] * m2);
-      if (a.acc) {
-        const float4 o = *reinterpret_cast<const float4*>(dst);
-        r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+      for (int e = 0; e < E; e += 4) {
+        const int col = (e / 4) * 64 + 4 * sub;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(x[u] + e) = ok[u] ? *reinterpret_cast<const float4*>(a.X + (size_t)row * a.ldx + col) : z;
+        *reinterpret_cast<float4*>(dy[u] + e) = ok[u] ? *reinterpret_cast<const float4*>(a.dY + (size_t)row * a.lddy + col) : z;
       }
-      *reinterpret_cast<float4*>(dst) = r;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;                       // uniform over the 16-lane group; the shuffles below stay inside it
+      const int row = row0 + u * stride;
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) s += x[u][e];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      const float mu = s * (1.0f / K);
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) { x[u][e] -= mu; q += x[u][e] * x[u][e]; }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+      const float rstd = 1.0f / sqrtf(q * (1.0f / K) + a.eps);
+      float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        x[u][e] *= rstd;                 // xhat
+        dg[e] += dy[u][e] * x[u][e];
+        dbt[e] += dy[u][e];
+        dy[u][e] *= gm[e];               // dxhat
+        m1 += dy[u][e];
+        m2 += dy[u][e] * x[u][e];
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
+      m1 *= (1.0f / K);
+      m2 *= (1.0f / K);
+#pragma unroll
+      for (int e = 0; e < E; e += 4) {
+        const int col = (e / 4) * 64 + 4 * sub;
+        float* dst = a.dX + (size_t)row * a.lddx + col;
+        float4 r;
+        r.x = rstd * (dy[u][e + 0] - m1 - x[u][e + 0] * m2);
+        r.y = rstd * (dy[u][e + 1] - m1 - x[u][e + 1] * m2);
+        r.z = rstd * (dy[u][e + 2] - m1 - x[u][e + 2] * m2);
+        r.w = rstd * (dy[u][e + 3] - m1 - x[u][e + 3] * m2);
+        if (a.acc) {
+          const float4 o = *reinterpret_cast<const float4*>(dst);
+          r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+        }
+        *reinterpret_cast<float4*>(dst) = r;
+      }
     }
   }
   // block reduction of dgamma / dbeta over the 16 row groups, then one atomic per column per block

@@ -615,8 +615,8 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
     // decoder input embedding (sasrec/model.py:53-59)
     CK(adt_embed_bwd_rep(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
     if (phase == 1) {  // two-phase (data-parallel) use: fold what has been scattered so far, the replicas restart at zero
-      CK(adt_replica_reduce(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, NREP, w.rep_stride, st));
-      CK(adt_replica_reduce(G + dec_begin, Gq + dec_begin, lo.total - dec_begin, NREPP, w.prep_stride, st));
+      CK(adt_replica_reduce2(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, NREP, w.rep_stride, G + dec_begin, Gq + dec_begin,
+                             lo.total - dec_begin, NREPP, w.prep_stride, st));
       if (parts) CK(reduce_partials(c, lo, w, G, ws, false, true, st));
     }
   }
@@ -690,9 +690,8 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
     }
     if (phase == 2 && adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
     CK(adt_embed_bwd_rep(seq, ws + w.g_enc_x, T, L, d, p, seed, SITE_EMB_SEQ, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
-    CK(adt_replica_reduce(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, NREP, w.rep_stride, st));
-    if (phase == 0) CK(adt_replica_reduce(G + lo.posw(), Gq + lo.posw(), lo.total - lo.posw(), NREPP, w.prep_stride, st));
-    else CK(adt_replica_reduce(G + lo.posw(), Gq + lo.posw(), dec_begin - lo.posw(), NREPP, w.prep_stride, st));
+    CK(adt_replica_reduce2(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, NREP, w.rep_stride, G + lo.posw(), Gq + lo.posw(),
+                           (phase == 0 ? lo.total : dec_begin) - lo.posw(), NREPP, w.prep_stride, st));
     if (parts) CK(reduce_partials(c, lo, w, G, ws, true, phase == 0, st));
   }
   return 0;
