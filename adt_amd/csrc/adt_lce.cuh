@@ -34,10 +34,7 @@ typedef short lce_s4 __attribute__((ext_vector_type(4)));
 enum { LCE_FWD = 0, LCE_DH = 1, LCE_DE = 2 };
 constexpr int LCE_NW = 8;                 // waves per workgroup (two per SIMD, 256 registers each)
 constexpr int LCE_NTH = LCE_NW * 64;
-constexpr int LCE_NBUF = 3;              // ring slots of the forward; the staggered backward passes keep one more (LceGeo::lds)
-#ifndef LCE_STAGGER
-#define LCE_STAGGER 1
-#endif
+constexpr int LCE_NBUF = 3;
 constexpr int LCE_CMAX = 64;              // at most this many Y ranges per X block
 constexpr int LCE_XR_FWD = LCE_NW * 64;   // X rows per workgroup
 constexpr int LCE_XR_BWD = LCE_NW * 32;
@@ -54,8 +51,7 @@ template <int KD> struct LceGeo {
   static constexpr int BUF = IMG + YV;
   static constexpr int PIECES = IMG / 1024;          // 1 KiB LDS-DMA pieces per tile
   static constexpr int PPW = PIECES / LCE_NW;        // per wave
-  static constexpr int nbuf(int mode) { return mode == 0 || !LCE_STAGGER ? LCE_NBUF : LCE_NBUF + 1; }
-  static constexpr int lds(int mode) { return nbuf(mode) * BUF; }
+  static constexpr int LDS = LCE_NBUF * BUF;
   static constexpr int VM = PPW + 1;                 // vector-memory operations a wave issues per tile
 };
 
@@ -122,7 +118,6 @@ __global__ __launch_bounds__(LCE_NTH) void k_lce(LceArgs a) {
   using G = LceGeo<KD>;
   constexpr int NX = MODE == LCE_FWD ? 2 : 1;
   constexpr int XR = LCE_NW * 32 * NX;
-  constexpr int NBUF = G::nbuf(MODE);
   extern __shared__ __attribute__((aligned(1024))) unsigned char lce_smem[];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
   const int nx = a.nx_dev ? min(*a.nx_dev, a.nx) : a.nx;
@@ -199,54 +194,14 @@ __global__ __launch_bounds__(LCE_NTH) void k_lce(LceArgs a) {
     }
     float bsum = 0.f;
 
-    // ---- the tile loop, STAGGERED -----------------------------------------------------------------------------------------------------
-    // One barrier per tile keeps the two waves of a SIMD in lockstep: both run the score MFMAs together, then both the exponentials (the
-    // matrix pipe idles), then both the gradient MFMAs.  Waves 4-7 therefore run one phase behind (MI355X_MICROARCH.md, "Two waves that run
-    // the SAME program with one barrier per block: try a stagger"): in the backward passes they finish tile t-1's gradient product at the
-    // top of iteration t (its image stays in the ring: four slots), in the forward they fold tile t-1's scores into the running sums while
-    // their partner multiplies tile t.  Same arithmetic per wave, only its place in the loop differs.
-    const bool late = LCE_STAGGER && w >= 4;               // wave-uniform
-    bf16x8 pf0, pf1;
-    f32x16 acc[NX];
-    auto softmax_fold = [&]() {                            // FWD: fold acc[] into (sm, ss)
-#pragma unroll
-      for (int n = 0; n < NX; ++n) {
-        float mx = acc[n][0];
-#pragma unroll
-        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, acc[n][e]);
-        const float mn = fmaxf(fmaxf(sm[n], mx), -1e30f);
-        const float mb = -mn * LCE_L2E;
-        float sacc = ss[n] * __builtin_amdgcn_exp2f(fmaf(sm[n], LCE_L2E, mb));
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sacc += __builtin_amdgcn_exp2f(fmaf(acc[n][e], LCE_L2E, mb));
-        sm[n] = mn;
-        ss[n] = sacc;
-      }
-    };
-    auto grad_product = [&](const unsigned char* buf) {    // dacc += Y^T P, P = (pf0, pf1)
-#pragma unroll
-      for (int ft = 0; ft < G::NFT; ++ft) {
-#pragma unroll
-        for (int sk = 0; sk < 2; ++sk) {
-          union { struct { lce_s4 lo, hi; } p; bf16x8 v; } u;
-          u.p.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lce_s4 __attribute__((address_space(3)))*)(buf + tb[0] + G::SUB * (2 * sk) + 512 * ft));
-          u.p.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lce_s4 __attribute__((address_space(3)))*)(buf + tb[1] + G::SUB * (2 * sk + 1) + 512 * ft));
-          dacc[MODE == LCE_FWD ? 0 : ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, sk ? pf1 : pf0, dacc[MODE == LCE_FWD ? 0 : ft], 0, 0, 0);
-        }
-      }
-    };
     int slot = 0;
-    const unsigned char* prev = lce_smem;
     for (int t = t0; t < t1; ++t) {
       lce_wait_vm<G::VM>();                               // tile t has landed (tile t + 1 may still be in flight)
-      __builtin_amdgcn_s_barrier();                       // ... for every wave; and every wave is done with tile t - 1 (late waves: t - 2)
-      issue(t + 2, slot + 2 >= NBUF ? slot + 2 - NBUF : slot + 2);
+      __builtin_amdgcn_s_barrier();                       // ... for every wave; and every wave is done with tile t - 1
+      issue(t + 2, slot >= 1 ? slot - 1 : LCE_NBUF - 1);
       const unsigned char* buf = lce_smem + slot * G::BUF;
-      if (late && t > t0) {
-        if constexpr (MODE == LCE_FWD) softmax_fold();
-        else grad_product(prev);
-      }
       const float4* yvp = reinterpret_cast<const float4*>(buf + G::IMG + w * 256);
+      f32x16 acc[NX];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float4 y = yvp[2 * i + h];                   // rows 8 i + 4 h .. + 3 of the tile = accumulator registers 4 i .. 4 i + 3
@@ -262,23 +217,38 @@ __global__ __launch_bounds__(LCE_NTH) void k_lce(LceArgs a) {
         for (int n = 0; n < NX; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya, xf[n][ks], acc[n], 0, 0, 0);
       }
       if constexpr (MODE == LCE_FWD) {
-        if (!late) softmax_fold();
+#pragma unroll
+        for (int n = 0; n < NX; ++n) {
+          float mx = acc[n][0];
+#pragma unroll
+          for (int e = 1; e < 16; ++e) mx = fmaxf(mx, acc[n][e]);
+          const float mn = fmaxf(fmaxf(sm[n], mx), -1e30f);
+          const float mb = -mn * LCE_L2E;
+          float s = ss[n] * __builtin_amdgcn_exp2f(fmaf(sm[n], LCE_L2E, mb));
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s += __builtin_amdgcn_exp2f(fmaf(acc[n][e], LCE_L2E, mb));
+          sm[n] = mn;
+          ss[n] = s;
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           acc[0][e] = __builtin_amdgcn_exp2f(fmaf(acc[0][e], LCE_L2E, xvl));
           if constexpr (MODE == LCE_DE) bsum += acc[0][e];
         }
-        pf0 = lce_pack8(acc[0], 0);
-        pf1 = lce_pack8(acc[0], 8);
-        if (!late) grad_product(buf);
+        const bf16x8 pf0 = lce_pack8(acc[0], 0), pf1 = lce_pack8(acc[0], 8);
+#pragma unroll
+        for (int ft = 0; ft < G::NFT; ++ft) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            union { struct { lce_s4 lo, hi; } p; bf16x8 v; } u;
+            u.p.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lce_s4 __attribute__((address_space(3)))*)(buf + tb[0] + G::SUB * (2 * s) + 512 * ft));
+            u.p.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lce_s4 __attribute__((address_space(3)))*)(buf + tb[1] + G::SUB * (2 * s + 1) + 512 * ft));
+            dacc[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, s ? pf1 : pf0, dacc[ft], 0, 0, 0);
+          }
+        }
       }
-      prev = buf;
-      slot = slot + 1 == NBUF ? 0 : slot + 1;
-    }
-    if (late && t1 > t0) {
-      if constexpr (MODE == LCE_FWD) softmax_fold();
-      else grad_product(prev);
+      slot = slot + 1 == LCE_NBUF ? 0 : slot + 1;
     }
     lce_wait_vm<0>();                                      // the two tail fetches
 

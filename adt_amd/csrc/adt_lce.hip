@@ -52,10 +52,10 @@ static int lce_launch(const LceArgs& a, hipStream_t s, const char* what) {
   static bool done = false;
   const void* fn = (const void*)k_lce<KD, MODE>;
   if (!done) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LceGeo<KD>::lds(MODE)) != hipSuccess) return adt_set_error("%s: hipFuncSetAttribute", what);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LceGeo<KD>::LDS) != hipSuccess) return adt_set_error("%s: hipFuncSetAttribute", what);
     done = true;
   }
-  hipLaunchKernelGGL((k_lce<KD, MODE>), dim3(a.slots), dim3(LCE_NTH), LceGeo<KD>::lds(MODE), s, a);
+  hipLaunchKernelGGL((k_lce<KD, MODE>), dim3(a.slots), dim3(LCE_NTH), LceGeo<KD>::LDS, s, a);
   return lce_check(what);
 }
 
