@@ -254,9 +254,9 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     const int tile = tq_tile(s, w, ntiles);
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = tile >= 0 && l < L;
-    xa[s] = tt_load(a.x + (size_t)row * 64, valid, g);
-    doa[s] = tt_load(a.dO + (size_t)row * 64, valid, g);
-    oa[s] = tt_load_saved(a.o, row, valid, g, a.saved_bf16);
+    xa[s] = tt_load_if(a.x + (size_t)row * 64, valid, g);            // branching loads here: see tt_load_if
+    doa[s] = tt_load_if(a.dO + (size_t)row * 64, valid, g);
+    oa[s] = tt_load_saved_if(a.o, row, valid, g, a.saved_bf16);
   }
   // ---- P0: zeroed token images, then the tables and the weight images land in LDS ------------------------------------------------
   {
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile(s, w, ntiles);
     const int l = tile * 16 + c, row = b * L + l;
-    xk[s] = tt_load(a.x + (size_t)row * 64, tile >= 0 && l < L, g);
+    xk[s] = tt_load_if(a.x + (size_t)row * 64, tile >= 0 && l < L, g);
   }
   // ---- P4: in-projection weight / bias gradients: three products over all tokens ------------------------------------------------------
   {
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     TT dn = tt_gemm(tt_bfrags(dq[s]), wimg + 3 * TT_WIMG, c, g);
     TT dkv = tt_gemm(tt_bfrags(dk[s]), wimg + 4 * TT_WIMG, c, g);
     tt_add(dkv, tt_gemm(tt_bfrags(dv[s]), wimg + 5 * TT_WIMG, c, g));
-    TT res = tt_load(a.dres + (size_t)row * 64, valid, g);
+    TT res = tt_load_if(a.dres + (size_t)row * 64, valid, g);
     if (DEC && (!valid || a.ids[row] == 0)) res = tt_zero();
     if (DEC && a.dres_scale != 0.f) {
 #pragma unroll
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     }
     if (valid) {
       float* dst = a.gx + (size_t)row * 64;
-      if (a.acc) tt_add(dx, tt_load(dst, true, g));
+      if (a.acc) tt_add(dx, tt_load_if(dst, true, g));
       tt_store(dst, dx, true, g);
     }
   }

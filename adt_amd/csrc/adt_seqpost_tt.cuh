@@ -64,7 +64,8 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   // weight images, so that HBM streams them while the prologue runs (requested at the top of phase A they arrived ~8k cycles after it)
   const float* const ws3[3] = {a.W0, a.W1, a.W2};
   const SbImgRegs<3> wr = sp_wload<3>(a, ws3);
-  TT dy[2], ua[2], hraw[2];
+  TT dy[2];
+  TTSaved uraw[2], hreq[2];                              // requested here, converted where they are first needed (tt_saved_value)
   int idv[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -72,13 +73,15 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = tile >= 0 && l < L;
     dy[s] = tt_load(a.gy + (size_t)row * 64, valid, g);
-    if (a.gy_scale != 0.f) {
+    uraw[s] = tt_saved_request(a.u, row, valid, g, a.saved_bf16);
+    hreq[s] = tt_saved_request(a.xin, row, valid, g, a.saved_bf16);
+    idv[s] = valid ? a.ids[row] : 0;
+  }
+  if (a.gy_scale != 0.f) {                                 // after every load of the prologue has been issued: a use is a wait
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) dy[s].v[nt] *= a.gy_scale;
-    }
-    ua[s] = tt_load_saved(a.u, row, valid, g, a.saved_bf16);
-    hraw[s] = tt_load_saved(a.xin, row, valid, g, a.saved_bf16);
-    idv[s] = valid ? a.ids[row] : 0;
   }
   {
     sp_zero_images(img0);
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
-    const TT& u = ua[s];
+    const TT u = tt_saved_value(uraw[s], a.saved_bf16);
     if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (s == 0) SB_STAMP(3); }
     if (idv[s] == 0) dy[s] = tt_zero();
     TT gyv = dy[s];
@@ -128,7 +131,8 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   __syncthreads();
   SB_STAMP(8);
   // ---- B: conv1 ; encoder: forward_layernorm backward -> dh ; dW(conv1) = dt^T LN2(h) (decoder: dt^T a2) --------------------------------
-  TT dh[2], oraw[2];
+  TT dh[2];
+  TTSaved oreq[2];
   TT dgm = tt_zero(), dbt = tt_zero();
   bsum = tt_zero();
 #pragma unroll
@@ -137,18 +141,19 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
-    oraw[s] = tt_load_saved(a.o, row, valid, g, a.saved_bf16);              // consumed in C
+    oreq[s] = tt_saved_request(a.o, row, valid, g, a.saved_bf16);           // consumed in C
+    const TT hraw_s = tt_saved_value(hreq[s], a.saved_bf16);
     tt_put_rows(img0, l, dt[s], valid, g);
     tt_add(bsum, dt[s]);
     TT d = tt_gemm(tt_bfrags(dt[s]), wimg + TT_WIMG, c, g);
     tt_add(d, dy[s]);                                                       // the residual around the feed-forward
     if (ENC) {
-      const TTLn st = tt_ln_stats(hraw[s], a.ln_eps);
+      const TTLn st = tt_ln_stats(hraw_s, a.ln_eps);
       tt_put_rows(img1, l, tt_ln_apply(st.xhat, vgamma, vbeta, g), valid, g);
       dh[s] = tt_ln_bwd(d, st, vgamma, dgm, dbt, g);
       tt_store(a.out0 + (size_t)row * 64, dh[s], valid, g);                 // gradient wrt h == wrt the LN1 output on the residual path
     } else {
-      tt_put_rows(img1, l, hraw[s], valid, g);
+      tt_put_rows(img1, l, hraw_s, valid, g);
       dh[s] = d;                                                            // gradient wrt a2 (the Dn residual is handled by the pre chain)
     }
   }
@@ -176,8 +181,9 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
+    const TT oraw_s = tt_saved_value(oreq[s], a.saved_bf16);
     tt_put_rows(img0, l, dh[s], valid, g);
-    tt_put_rows(img1, l, oraw[s], valid, g);
+    tt_put_rows(img1, l, oraw_s, valid, g);
     if (valid) tt_add(bsum, dh[s]);
     TT dO = tt_gemm(tt_bfrags(dh[s]), wimg + 2 * TT_WIMG, c, g);
     if (cls) {
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               dO.v[h * NT + nt][r] += dz[cc] * wq[r];
-              dws[cc][nt][r] += dz[cc] * oraw[s].v[h * NT + nt][r];
+              dws[cc][nt][r] += dz[cc] * oraw_s.v[h * NT + nt][r];
             }
           }
         }
@@ -263,15 +269,16 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
   sp_replica(a);
   const float* const ws4[4] = {a.W0, a.W1, a.W2, a.W3};
   const SbImgRegs<4> wr = sp_wload<4>(a, ws4);
-  TT dqa[2], a1a[2], oraw[2];             // phase A's activations are requested right behind the weight images (see k_seqtt_post_bwd)
+  TT dqa[2];
+  TTSaved a1req[2], oreq[2];             // phase A's activations are requested right behind the weight images (see k_seqtt_post_bwd)
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile(s, w, ntiles);
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = tile >= 0 && l < L;
     dqa[s] = tt_load(a.dqkv + (size_t)row * a.lddqkv, valid, g);
-    a1a[s] = tt_load_saved(a.xin, row, valid, g, a.saved_bf16);
-    oraw[s] = tt_load_saved(a.o, row, valid, g, a.saved_bf16);
+    a1req[s] = tt_saved_request(a.xin, row, valid, g, a.saved_bf16);
+    oreq[s] = tt_saved_request(a.o, row, valid, g, a.saved_bf16);
   }
   sp_zero_images(img0);
   if (threadIdx.x < 256) sRed[threadIdx.x] = 0.f;
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
     const int l = tile * 16 + c;
     const bool valid = l < L;
     tt_put_rows(img0, l, dqa[s], valid, g);
-    tt_put_rows(img1, l, a1a[s], valid, g);
+    tt_put_rows(img1, l, tt_saved_value(a1req[s], a.saved_bf16), valid, g);
     da1[s] = tt_gemm(tt_bfrags(dqa[s]), wimg, c, g);
     tt_add(bsum, dqa[s]);                                                   // zero rows for absent tokens (loaded as zeros)
   }
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
     dk[s] = tt_load(a.dkv2 + (size_t)row * 128, valid, g);
     fx[s] = tt_load(a.f + (size_t)row * 64, valid, g);
     tt_put_rows(img0, l, da1[s], valid, g);
-    tt_put_rows(img1, l, oraw[s], valid, g);
+    tt_put_rows(img1, l, tt_saved_value(oreq[s], a.saved_bf16), valid, g);
     tt_add(bsum, da1[s]);
     tt_store(a.out0 + (size_t)row * 64, tt_gemm(tt_bfrags(da1[s]), wimg + TT_WIMG, c, g), valid, g);
   }

@@ -89,7 +89,22 @@ ADT_DEVICE_INLINE TT tt_zero() {
 }
 
 // global fp32 rows <-> TT: `row` points at this lane's token row (64 floats); lanes whose token is absent pass valid = false
+// Lanes without a row read a block of zeros instead of skipping the load.  `if (valid) x = *p` made hipcc branch around every load and --
+// because the loaded registers are re-packed inside the branch -- wait vmcnt(0) right behind it: the prologues of the per-sequence kernels were
+// six to ten SERIAL memory round trips (cdna_hip_programming.md, ".s-level traps" (c)).  Selecting the ADDRESS keeps the loads unconditional
+// and back to back; the wait moves to the first use.
+static __device__ __attribute__((aligned(256))) const float tt_zero_row[64] = {};
 ADT_DEVICE_INLINE TT tt_load(const float* row, bool valid, int g) {
+  TT t;
+  typedef const f32x4 __attribute__((address_space(1))) * gp4;       // explicitly global: a select of two generic pointers becomes flat_load
+  const gp4 p = valid ? (gp4)(row + 4 * g) : (gp4)(tt_zero_row + 4 * g);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) t.v[nt] = p[4 * nt];
+  return t;
+}
+// The branching form (a load only where there is a row).  k_seqtt_attn_pre_bwd keeps it: at its 256-register budget the 26 loads that the
+// unconditional form puts in flight at once spilled 208 bytes per lane and cost 5 us per launch (52.5 -> 57.0 us).
+ADT_DEVICE_INLINE TT tt_load_if(const float* row, bool valid, int g) {
   TT t;
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
@@ -116,12 +131,12 @@ ADT_DEVICE_INLINE void tt_store_bf16(__bf16* row, const TT& t, bool valid, int g
   *reinterpret_cast<bf16x8*>(row + 16 * g + 8) = tt_pack(t.v[2], t.v[3]);
 }
 ADT_DEVICE_INLINE TT tt_load_bf16(const __bf16* row, bool valid, int g) {
-  TT t = tt_zero();
-  if (valid) {
-    const bf16x8 lo = *reinterpret_cast<const bf16x8*>(row + 16 * g), hi = *reinterpret_cast<const bf16x8*>(row + 16 * g + 8);
+  TT t;
+  typedef const bf16x8 __attribute__((address_space(1))) * gp8;       // see tt_load
+  const gp8 p = valid ? (gp8)(row + 16 * g) : (gp8)(tt_zero_row + 8 * g);
+  const bf16x8 lo = p[0], hi = p[1];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { t.v[0][r] = (float)lo[r]; t.v[1][r] = (float)lo[4 + r]; t.v[2][r] = (float)hi[r]; t.v[3][r] = (float)hi[4 + r]; }
-  }
+  for (int r = 0; r < 4; ++r) { t.v[0][r] = (float)lo[r]; t.v[1][r] = (float)lo[4 + r]; t.v[2][r] = (float)hi[r]; t.v[3][r] = (float)hi[4 + r]; }
   return t;
 }
 
@@ -130,6 +145,57 @@ ADT_DEVICE_INLINE void tt_save(float* buf, size_t row, const TT& t, bool valid, 
   if (!buf) return;
   if (as_bf16) tt_store_bf16(reinterpret_cast<__bf16*>(buf) + row * 64, t, valid, g);
   else tt_store(buf + row * 64, t, valid, g);
+}
+// A saved tile in two steps: tt_saved_request issues the loads (raw registers, nothing consumes them), tt_saved_value converts where the
+// tile is first needed.  tt_load_saved converts inside the `as_bf16` branch right behind its loads, and a use behind a load is a wait behind a
+// load: in a prologue that requests ten tensors every such call was one more serial memory round trip.
+typedef unsigned tt_u4 __attribute__((ext_vector_type(4)));
+struct TTSaved { tt_u4 q[4]; };
+ADT_DEVICE_INLINE TTSaved tt_saved_request(const float* buf, size_t row, bool valid, int g, int as_bf16) {
+  typedef const tt_u4 __attribute__((address_space(1))) * gq;
+  TTSaved r;
+  if (as_bf16) {
+    const gq p = valid ? (gq)(reinterpret_cast<const __bf16*>(buf) + row * 64 + 16 * g) : (gq)tt_zero_row;
+    r.q[0] = p[0]; r.q[1] = p[1];
+    r.q[2] = r.q[3] = tt_u4{0u, 0u, 0u, 0u};
+  } else {
+    const gq p = valid ? (gq)(buf + row * 64 + 4 * g) : (gq)(tt_zero_row + 4 * g);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) r.q[nt] = p[4 * nt];
+  }
+  return r;
+}
+ADT_DEVICE_INLINE TT tt_saved_value(TTSaved r, int as_bf16) {
+  // opaque: keeps the conversion below from being hoisted back into the branch that loaded the registers
+  uint32_t w0 = r.q[0].x, w1 = r.q[0].y, w2 = r.q[0].z, w3 = r.q[0].w, w4 = r.q[1].x, w5 = r.q[1].y, w6 = r.q[1].z, w7 = r.q[1].w;
+  asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6), "+v"(w7));
+  TT t;
+  if (as_bf16) {
+    union { tt_u4 u; bf16x8 b; } lo, hi;
+    lo.u = tt_u4{w0, w1, w2, w3}; hi.u = tt_u4{w4, w5, w6, w7};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { t.v[0][e] = (float)lo.b[e]; t.v[1][e] = (float)lo.b[4 + e]; t.v[2][e] = (float)hi.b[e]; t.v[3][e] = (float)hi.b[4 + e]; }
+  } else {
+    t.v[0] = f32x4{__uint_as_float(w0), __uint_as_float(w1), __uint_as_float(w2), __uint_as_float(w3)};
+    t.v[1] = f32x4{__uint_as_float(w4), __uint_as_float(w5), __uint_as_float(w6), __uint_as_float(w7)};
+#pragma unroll
+    for (int nt = 2; nt < 4; ++nt)
+      t.v[nt] = f32x4{__uint_as_float(r.q[nt].x), __uint_as_float(r.q[nt].y), __uint_as_float(r.q[nt].z), __uint_as_float(r.q[nt].w)};
+  }
+  return t;
+}
+ADT_DEVICE_INLINE TT tt_load_saved_if(const float* buf, size_t row, bool valid, int g, int as_bf16) {      // branching form, see tt_load_if
+  if (as_bf16) {
+    TT t = tt_zero();
+    if (valid) {
+      const __bf16* r = reinterpret_cast<const __bf16*>(buf) + row * 64;
+      const bf16x8 lo = *reinterpret_cast<const bf16x8*>(r + 16 * g), hi = *reinterpret_cast<const bf16x8*>(r + 16 * g + 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { t.v[0][e] = (float)lo[e]; t.v[1][e] = (float)lo[4 + e]; t.v[2][e] = (float)hi[e]; t.v[3][e] = (float)hi[4 + e]; }
+    }
+    return t;
+  }
+  return tt_load_if(buf + row * 64, valid, g);
 }
 ADT_DEVICE_INLINE TT tt_load_saved(const float* buf, size_t row, bool valid, int g, int as_bf16) {
   if (as_bf16) return tt_load_bf16(reinterpret_cast<const __bf16*>(buf) + row * 64, valid, g);
