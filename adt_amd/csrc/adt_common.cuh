@@ -131,6 +131,30 @@ ADT_DEVICE_INLINE void adt_static_for_impl(F&& f, std::integer_sequence<int, I..
 template <int N, typename F>
 ADT_DEVICE_INLINE void adt_static_for(F&& f) { adt_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
+// Touch every 64-byte line of the kernel-argument segment at kernel entry.  The per-sequence kernels take 300-450 bytes of arguments; hipcc
+// loads the fields where they are first needed, so a prologue met four or five scalar-cache misses ONE AFTER THE OTHER (each behind the branch
+// or wait that precedes it) before its first vector load was issued.  Requested back to back here, the lines arrive in one round trip and the
+// compiler's own s_loads hit the scalar cache.  One asm statement, ending in the wait: the destination SGPR is written asynchronously, so it
+// must not be handed back to the compiler before the loads have returned.
+template <int BYTES>
+ADT_DEVICE_INLINE void adt_prefetch_kernargs() {
+  static_assert(BYTES > 0 && BYTES <= 512, "kernel-argument struct of at most 512 bytes");
+  const auto p = __builtin_amdgcn_kernarg_segment_ptr();
+  unsigned t;
+  if constexpr (BYTES <= 128)
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p) : "memory");
+  else if constexpr (BYTES <= 256)
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_load_dword %0, %1, 0x80\n\ts_load_dword %0, %1, 0xc0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(t) : "s"(p) : "memory");
+  else if constexpr (BYTES <= 384)
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_load_dword %0, %1, 0x80\n\ts_load_dword %0, %1, 0xc0\n\t"
+                 "s_load_dword %0, %1, 0x100\n\ts_load_dword %0, %1, 0x140\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p) : "memory");
+  else
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_load_dword %0, %1, 0x80\n\ts_load_dword %0, %1, 0xc0\n\t"
+                 "s_load_dword %0, %1, 0x100\n\ts_load_dword %0, %1, 0x140\n\ts_load_dword %0, %1, 0x180\n\ts_load_dword %0, %1, 0x1c0\n\t"
+                 "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p) : "memory");
+}
+
 // Zero-fill as an ordinary kernel.  The library never uses hipMemsetAsync: its entry points are captured into HIP graphs by the
 // trainers, and on this stack a captured memset NODE was observed to start writing a stale non-zero pattern after a few hundred
 // replays (the gradient-norm accumulators then read ~4e30 or NaN for the rest of the process; see DESIGN.md "graph memset").

@@ -152,6 +152,7 @@ ADT_DEVICE_INLINE void sab_pass_b(const __bf16* sQ, const __bf16* sdO, const bf1
 
 template <int HD, int MODE>
 __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
+  adt_prefetch_kernargs<(sizeof(AttnArgs) + 63) / 64 * 64 <= 512 ? sizeof(AttnArgs) : 512>();      // adt_common.cuh
   constexpr int H = 64 / HD, NT = HD / 16, KB = (HD + 31) / 32, MAXKT = 14, NW = SAB_NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, R = sab_rows(L);

@@ -198,6 +198,7 @@ ADT_DEVICE_INLINE void sb_img_store(__bf16* wimg, const SbImgRegs<N>& t) {
 // DEC = true : decoder self-attention block (q, k, v from LN(x); the masked layer-output gradient joins at the LayerNorm output).
 template <int HD, int MODE, bool DEC>
 __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a) {
+  adt_prefetch_kernargs<(sizeof(SeqBwdArgs) + 63) / 64 * 64 <= 512 ? sizeof(SeqBwdArgs) : 512>();      // adt_common.cuh
   constexpr int H = 64 / HD, NT = HD / 16, KB = (HD + 31) / 32, NF = H * KB, NW = SB_NW, R = SB_R;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef SeqBwdLds<H> Lds;

@@ -105,8 +105,9 @@ ADT_DEVICE_INLINE const uint4* tq_img_src(const SeqFwdArgs& a, const float* W, b
 }
 // one weight image per statement, in named registers: the array-of-registers form (tq_img_load) was kept in scratch by the compiler in
 // these two kernels, with a wait for the loads right behind their issue
+// (the tail load is unconditional -- lanes without a tail chunk re-read their first chunk: a load inside `if (tq_tail)` drew a vmcnt(0) behind it)
 #define TQ_IMG_LOAD(k, Wk) const uint4* tqp##k = tq_img_src(a, Wk, false); const uint4 tqr##k = tqp##k[threadIdx.x]; \
-  uint4 tqt##k = make_uint4(0u, 0u, 0u, 0u); if (tq_tail) tqt##k = tqp##k[threadIdx.x + TQ_NW * 64];
+  const uint4 tqt##k = tqp##k[tq_tail ? threadIdx.x + TQ_NW * 64 : threadIdx.x];
 #define TQ_IMG_STORE(k, dstk) reinterpret_cast<uint4*>(dstk)[threadIdx.x] = tqr##k; if (tq_tail) reinterpret_cast<uint4*>(dstk)[threadIdx.x + TQ_NW * 64] = tqt##k;
 
 ADT_DEVICE_INLINE void tq_zero(__bf16* p, size_t nbytes) {
@@ -196,17 +197,19 @@ ADT_DEVICE_INLINE TT tq_ffn(const SeqFwdArgs& a, const float* vec, const __bf16*
 // ---- encoder layer: weight images 0 Wq, 1 Wk, 2 Wv, 3 out_proj, 4 conv1, 5 conv2 ------------------------------------------------
 template <int HD>
 __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
+  adt_prefetch_kernargs<(sizeof(SeqFwdArgs) + 63) / 64 * 64 <= 512 ? sizeof(SeqFwdArgs) : 512>();      // adt_common.cuh
   constexpr int H = 64 / HD, KB = (HD + 31) / 32, NF = H * KB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   SeqTtLds<6> lds(smem_raw);
   const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16;
-  const uint32_t seedv = a.drop.thr ? *a.drop.seed : 0u;
   TQ_STAMP(0);
+  uint32_t seedv = 0u;
   {
     const bool tq_tail = threadIdx.x < TT_WIMG * 2 / 16 - TQ_NW * 64;        // the last 64 chunks of an image: the first wave (wave-uniform)
     TQ_IMG_LOAD(0, a.Win) TQ_IMG_LOAD(1, a.Win + 4096) TQ_IMG_LOAD(2, a.Win + 8192) TQ_IMG_LOAD(3, a.Wo) TQ_IMG_LOAD(4, a.W1) TQ_IMG_LOAD(5, a.W2)
     const TqVecRegs vr = tq_vec_load<TQ_NW * 64>(a, H, HD);
+    if (a.drop.thr) seedv = *a.drop.seed;     // behind the image requests: read first, its round trip preceded every other load of the kernel
     TQ_STAMP(11);
     tq_zero(lds.sK, 2 * SeqTtLds<6>::ibytes);
     TQ_STAMP(12);
@@ -288,16 +291,18 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
 // 3 conv1, 4 conv2 -------------------------------------------------------------------------------------------------------------------
 template <int HD>
 __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
+  adt_prefetch_kernargs<(sizeof(SeqFwdArgs) + 63) / 64 * 64 <= 512 ? sizeof(SeqFwdArgs) : 512>();      // adt_common.cuh
   constexpr int H = 64 / HD, KB = (HD + 31) / 32, NF = H * KB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   SeqTtLds<5> lds(smem_raw);
   const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16;
-  const uint32_t seedv = a.drop.thr ? *a.drop.seed : 0u;
+  uint32_t seedv = 0u;
   const bool tq_tail = threadIdx.x < TT_WIMG * 2 / 16 - TQ_NW * 64;        // the last 64 chunks of an image: the first wave (wave-uniform)
   {
     TQ_IMG_LOAD(0, a.Win) TQ_IMG_LOAD(1, a.Win + 4096) TQ_IMG_LOAD(2, a.Win + 8192) TQ_IMG_LOAD(3, a.Wo) TQ_IMG_LOAD(4, a.Win2)
     const TqVecRegs vr = tq_vec_load<TQ_NW * 64>(a, H, HD);
+    if (a.drop.thr) seedv = *a.drop.seed;     // behind the image requests (see k_seqtt_enc_fwd)
     tq_zero(lds.sK, 2 * SeqTtLds<5>::ibytes);
     TQ_IMG_STORE(0, lds.w[0]) TQ_IMG_STORE(1, lds.w[1]) TQ_IMG_STORE(2, lds.w[2]) TQ_IMG_STORE(3, lds.w[3]) TQ_IMG_STORE(4, lds.w[4])
     tq_vec_store<TQ_NW * 64>(lds.vec, vr);

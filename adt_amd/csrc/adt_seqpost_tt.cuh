@@ -46,6 +46,7 @@ ADT_DEVICE_INLINE void sp_zero_images(__bf16* img0) {
 
 template <int HD, bool ENC>
 __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
+  adt_prefetch_kernargs<(sizeof(BwdChainArgs) + 63) / 64 * 64 <= 512 ? sizeof(BwdChainArgs) : 512>();      // adt_common.cuh
   constexpr int H = 64 / HD, NT = HD / 16, NW = SB_NW;
   typedef SeqPostLds<3> Lds;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
     dy[s] = tt_load(a.gy + (size_t)row * 64, valid, g);
     uraw[s] = tt_saved_request(a.u, row, valid, g, a.saved_bf16);
     hreq[s] = tt_saved_request(a.xin, row, valid, g, a.saved_bf16);
-    idv[s] = valid ? a.ids[row] : 0;
+    idv[s] = tt_load_id(a.ids, row, valid);
   }
   if (a.gy_scale != 0.f) {                                 // after every load of the prologue has been issued: a use is a wait
 #pragma unroll
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
 // W0 = enc_attn Wq, W1 = slf_attn.out_proj, W2 = enc_attn Wk, W3 = enc_attn Wv ; dqkv = dq2 (ld lddqkv), xin = a1, o = o1, dkv2 (B*L x 128),
 // f = log_feats ; out0 = dO1, out1 = d log_feats (acc1: add to what is there)
 __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
+  adt_prefetch_kernargs<(sizeof(BwdChainArgs) + 63) / 64 * 64 <= 512 ? sizeof(BwdChainArgs) : 512>();      // adt_common.cuh
   constexpr int NW = SB_NW;
   typedef SeqPostLds<4> Lds;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

@@ -94,6 +94,11 @@ ADT_DEVICE_INLINE TT tt_zero() {
 // six to ten SERIAL memory round trips (cdna_hip_programming.md, ".s-level traps" (c)).  Selecting the ADDRESS keeps the loads unconditional
 // and back to back; the wait moves to the first use.
 static __device__ __attribute__((aligned(256))) const float tt_zero_row[64] = {};
+// ids[row] for lanes with a row, 0 for the others -- by address select (see tt_load): `valid ? ids[row] : 0` is a branch with the wait inside
+ADT_DEVICE_INLINE int tt_load_id(const int* ids, int row, bool valid) {
+  typedef const int __attribute__((address_space(1))) * gi;
+  return *(valid ? (gi)(ids + row) : (gi)tt_zero_row);
+}
 ADT_DEVICE_INLINE TT tt_load(const float* row, bool valid, int g) {
   TT t;
   typedef const f32x4 __attribute__((address_space(1))) * gp4;       // explicitly global: a select of two generic pointers becomes flat_load
