@@ -115,18 +115,31 @@ ADT_DEVICE_INLINE void tq_zero(__bf16* p, size_t nbytes) {
   for (int i = threadIdx.x; i < (int)(nbytes / 16); i += TQ_NW * 64) q[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
-// layer input of this lane's token: a load, or the embedding gather x = dropout(E[id] * sqrt(d) + P[l]) * (id != 0)   (model.py:34-41)
-ADT_DEVICE_INLINE TT tq_load_x(const SeqFwdArgs& a, int row, int l, bool valid, uint32_t key0, int g) {
-  if (a.x) return tt_load(a.x + (size_t)row * 64, valid, g);
+// layer input of this lane's token: a load, or the embedding gather x = dropout(E[id] * sqrt(d) + P[l]) * (id != 0)   (model.py:34-41).
+// In two steps, so that the prologue can put the requests of BOTH of a wave's tiles in flight beside the weight images (they used to be
+// issued inside the tile loop behind the first barrier: one exposed round trip per tile, two for the gather, whose row address needs the id):
+// tq_x_request issues the loads (lanes without a token read the zero row, tt_load), tq_x_finish forms x where the tile is processed.
+struct TqX { TT e; TT p; int id; };
+ADT_DEVICE_INLINE TqX tq_x_request(const SeqFwdArgs& a, int row, int l, bool valid, int id, int g) {
+  TqX r;
+  r.id = id;
+  if (a.x) {
+    r.e = tt_load(a.x + (size_t)row * 64, valid, g);
+    r.p = tt_zero();
+  } else {
+    r.e = tt_load(a.E + (size_t)id * 64, valid, g);        // id == 0 (padding, or no token): row 0 of the table, discarded below
+    r.p = tt_load(a.P + (size_t)l * 64, valid, g);
+  }
+  return r;
+}
+ADT_DEVICE_INLINE TT tq_x_finish(const SeqFwdArgs& a, const TqX& r, int row, bool valid, uint32_t key0, int g) {
+  if (a.x) return r.e;
   TT x = tt_zero();
-  const int id = valid ? a.ids[row] : 0;
-  if (id != 0) {
+  if (r.id != 0) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const float4 e = *reinterpret_cast<const float4*>(a.E + (size_t)id * 64 + 16 * nt + 4 * g);
-      const float4 p = *reinterpret_cast<const float4*>(a.P + (size_t)l * 64 + 16 * nt + 4 * g);
-      x.v[nt] = f32x4{e.x * a.emb_scale + p.x, e.y * a.emb_scale + p.y, e.z * a.emb_scale + p.z, e.w * a.emb_scale + p.w};
-    }
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x.v[nt][e] = r.e.v[nt][e] * a.emb_scale + r.p.v[nt][e];
     tt_dropout(x, key0, a.drop, (uint32_t)row + a.b_offset * (uint32_t)a.L, g);
   }
   if (a.x_out) tt_store(a.x_out + (size_t)row * 64, x, valid, g);
@@ -137,10 +150,10 @@ ADT_DEVICE_INLINE TT tq_load_x(const SeqFwdArgs& a, int row, int l, bool valid, 
 template <int HD, bool ENC>
 ADT_DEVICE_INLINE void tq_pre_tile(const SeqFwdArgs& a, const float* vec, const __bf16* wq, const __bf16* wk, const __bf16* wv, __bf16* sK, __bf16* sV,
                                    int tile, int b, uint32_t key0, float qmul, int c, int g,
-                                   bf16x8 (&fq)[(64 / HD) * ((HD + 31) / 32)], TT& xn_out) {
+                                   bf16x8 (&fq)[(64 / HD) * ((HD + 31) / 32)], TT& xn_out, const TqX& xr) {
   const int l = tile * 16 + c, row = b * a.L + l;
   const bool valid = l < a.L;
-  const TT x = tq_load_x(a, row, l, valid, key0, g);
+  const TT x = tq_x_finish(a, xr, row, valid, key0, g);
   const TT xn = tt_layernorm(x, vec + SV_GAMMA, vec + SV_BETA, a.ln_eps, g);
   if (a.xn) tt_store(a.xn + (size_t)row * 64, xn, valid, g);
   xn_out = xn;
@@ -205,11 +218,25 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
   const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16;
   TQ_STAMP(0);
   uint32_t seedv = 0u;
+  TqX xr[2];
   {
+    int idr[2] = {0, 0};                      // the ids first: vector-memory results return in issue order, and the gather's row loads wait for them
+    if (!a.x) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int tile = tq_tile(s, w, ntiles), l = tile * 16 + c;
+        idr[s] = tt_load_id(a.ids, b * L + l, tile >= 0 && l < L);
+      }
+    }
     const bool tq_tail = threadIdx.x < TT_WIMG * 2 / 16 - TQ_NW * 64;        // the last 64 chunks of an image: the first wave (wave-uniform)
     TQ_IMG_LOAD(0, a.Win) TQ_IMG_LOAD(1, a.Win + 4096) TQ_IMG_LOAD(2, a.Win + 8192) TQ_IMG_LOAD(3, a.Wo) TQ_IMG_LOAD(4, a.W1) TQ_IMG_LOAD(5, a.W2)
     const TqVecRegs vr = tq_vec_load<TQ_NW * 64>(a, H, HD);
     if (a.drop.thr) seedv = *a.drop.seed;     // behind the image requests: read first, its round trip preceded every other load of the kernel
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {             // the layer input of both tiles, in flight while the images are stored
+      const int tile = tq_tile(s, w, ntiles), l = tile * 16 + c;
+      xr[s] = tq_x_request(a, b * L + l, l, tile >= 0 && l < L, idr[s], g);
+    }
     TQ_STAMP(11);
     tq_zero(lds.sK, 2 * SeqTtLds<6>::ibytes);
     TQ_STAMP(12);
@@ -227,7 +254,7 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile(s, w, ntiles);
-    if (tile >= 0) tq_pre_tile<HD, true>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[s], xn[s]);
+    if (tile >= 0) tq_pre_tile<HD, true>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[s], xn[s], xr[s]);
     TQ_STAMP(2 + s);
   }
   __syncthreads();
@@ -299,10 +326,24 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
   const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16;
   uint32_t seedv = 0u;
   const bool tq_tail = threadIdx.x < TT_WIMG * 2 / 16 - TQ_NW * 64;        // the last 64 chunks of an image: the first wave (wave-uniform)
+  TqX xr[2];
   {
+    int idr[2] = {0, 0};                      // ids first, layer inputs of both tiles behind the images (see k_seqtt_enc_fwd)
+    if (!a.x) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int tile = tq_tile(s, w, ntiles), l = tile * 16 + c;
+        idr[s] = tt_load_id(a.ids, b * L + l, tile >= 0 && l < L);
+      }
+    }
     TQ_IMG_LOAD(0, a.Win) TQ_IMG_LOAD(1, a.Win + 4096) TQ_IMG_LOAD(2, a.Win + 8192) TQ_IMG_LOAD(3, a.Wo) TQ_IMG_LOAD(4, a.Win2)
     const TqVecRegs vr = tq_vec_load<TQ_NW * 64>(a, H, HD);
     if (a.drop.thr) seedv = *a.drop.seed;     // behind the image requests (see k_seqtt_enc_fwd)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int tile = tq_tile(s, w, ntiles), l = tile * 16 + c;
+      xr[s] = tq_x_request(a, b * L + l, l, tile >= 0 && l < L, idr[s], g);
+    }
     tq_zero(lds.sK, 2 * SeqTtLds<5>::ibytes);
     TQ_IMG_STORE(0, lds.w[0]) TQ_IMG_STORE(1, lds.w[1]) TQ_IMG_STORE(2, lds.w[2]) TQ_IMG_STORE(3, lds.w[3]) TQ_IMG_STORE(4, lds.w[4])
     tq_vec_store<TQ_NW * 64>(lds.vec, vr);
@@ -316,7 +357,7 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile(s, w, ntiles);
-    if (tile >= 0) tq_pre_tile<HD, false>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[s], dn[s]);
+    if (tile >= 0) tq_pre_tile<HD, false>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[s], dn[s], xr[s]);
   }
   __syncthreads();
   // a1 = out_proj(o1) ; q2 = a1 Wq2^T + b : the cross attention's queries replace the self attention's in the registers
