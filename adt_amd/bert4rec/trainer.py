@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from ..dp import GradBuckets, reduce_sum
+from ..dp import GradBuckets, reduce_sum, capture
 
 
 class FusedBertTrainer:
@@ -91,7 +91,7 @@ class FusedBertTrainer:
             self._launch(b_offset)          # warm up eagerly (hipFuncSetAttribute is not capturable), then capture
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with capture(self._graph):
                 self._launch(b_offset)
             return
         self._graph.replay()

@@ -105,3 +105,13 @@ def reduce_sum(t, group=None):
         import torch.distributed as dist
         dist.all_reduce(t, group=group)
     return t
+
+
+def capture(graph):
+    """torch.cuda.graph with capture_error_mode="thread_local".  The default ("global") makes EVERY thread's HIP calls illegal while the
+    step is being captured, and ProcessGroupNCCL's watchdog thread polls the events of earlier collectives with hipEventQuery whenever it
+    likes: a poll that lands inside the capture raises `operation not permitted when stream is capturing` in the watchdog, which takes
+    the process down (seen in tests/test_dp_nccl.py as soon as the steps got short enough for the race to hit).  Thread-local mode only
+    polices the capturing thread."""
+    import torch
+    return torch.cuda.graph(graph, capture_error_mode="thread_local")

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from .. import _lib, custom_ops, ops
-from ..dp import GradBuckets, reduce_sum
+from ..dp import GradBuckets, reduce_sum, capture
 from ..wide import Act, FlatModule, Tape, give
 from .model import REF_ORDER, param_table
 
@@ -324,7 +324,7 @@ class WideSasrecTrainer:
             self._launch(b_offset)
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with capture(self._graph):
                 self._launch(b_offset)
             return
         self._graph.replay()

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from .. import _lib, ops
-from ..dp import GradBuckets, reduce_sum
+from ..dp import GradBuckets, reduce_sum, capture
 from .model import WS_LOSS, WS_NORMS
 
 
@@ -157,7 +157,7 @@ class FusedTrainer:
             self._launch(B, b_offset)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with capture(g):
                 self._launch(B, b_offset)
             st["graph"], st["b_offset"] = g, b_offset
             return

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from ..dp import GradBuckets, reduce_sum
+from ..dp import GradBuckets, reduce_sum, capture
 
 
 class FusedStosaTrainer:
@@ -87,7 +87,7 @@ class FusedStosaTrainer:
             self._launch(b_offset)          # warm up eagerly (hipFuncSetAttribute is not capturable), then capture
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with capture(self._graph):
                 self._launch(b_offset)
             return
         self._graph.replay()
