@@ -121,6 +121,7 @@ ADT_DEVICE_INLINE void mark_dead_rows(int* sDead, const int* sKv, int L, int LP,
 
 template <int PREC, int HD, int MAXKT, int NW, bool CSK = false>
 __global__ __launch_bounds__(NW * 64) void k_attn_gen_fwd(AttnGenArgs ga) {
+  adt_prefetch_kernargs<sizeof(AttnGenArgs) <= 512 ? sizeof(AttnGenArgs) : 512>();      // every kernarg line in one scalar-cache round trip (adt_common.cuh)
   typedef Img<PREC> I;
   typedef typename I::E E;
   typedef typename I::F F;
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_gen_fwd(AttnGenArgs ga) {
 
 template <int PREC, int HD, int MAXKT, int NW>
 __global__ __launch_bounds__(NW * 64) void k_attn_gen_bwd(AttnGenArgs ga) {
+  adt_prefetch_kernargs<sizeof(AttnGenArgs) <= 512 ? sizeof(AttnGenArgs) : 512>();      // every kernarg line in one scalar-cache round trip (adt_common.cuh)
   typedef Img<PREC> I;
   typedef typename I::E E;
   typedef typename I::F F;
@@ -410,6 +412,7 @@ struct AttnChunkLds {
 
 template <int PREC, int HD, int MAXKT, int NCH, int NW>
 __global__ __launch_bounds__(NW * 64) void k_attn_gen_bwd_chunked(AttnGenArgs ga) {
+  adt_prefetch_kernargs<sizeof(AttnGenArgs) <= 512 ? sizeof(AttnGenArgs) : 512>();      // every kernarg line in one scalar-cache round trip (adt_common.cuh)
   typedef Img<PREC> I;
   typedef typename I::E E;
   typedef typename I::F F;

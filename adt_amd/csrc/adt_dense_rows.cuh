@@ -104,6 +104,7 @@ ADT_DEVICE_INLINE void rows_load_res(RowsRes<CH>& o, const DenseFwdArgs& a, int 
 
 template <int KB, int CH>
 __global__ __launch_bounds__(ROWS_NW * 64) void k_dense_fwd_rows(DenseFwdArgs a, int n_panels, int pc) {
+  adt_prefetch_kernargs<sizeof(DenseFwdArgs) <= 512 ? sizeof(DenseFwdArgs) : 512>();      // every kernarg line in one scalar-cache round trip (adt_common.cuh)
   constexpr int K = KB * 32, RS = K + 8, NW = ROWS_NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char rows_smem[];
   __bf16* sW = reinterpret_cast<__bf16*>(rows_smem);
@@ -262,6 +263,7 @@ ADT_DEVICE_INLINE void rows_load_old(RowsOld<CH>& o, const DenseBwdArgs& a, int 
 
 template <int NB, bool HAS_U>
 __global__ __launch_bounds__(ROWS_NW * 64) void k_dense_dx_rows(DenseBwdArgs a, int n_panels, int pc) {
+  adt_prefetch_kernargs<sizeof(DenseBwdArgs) <= 512 ? sizeof(DenseBwdArgs) : 512>();      // every kernarg line in one scalar-cache round trip (adt_common.cuh)
   constexpr int N = NB * 32, RS = N + 8, NW = ROWS_NW, CH = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char rows_smem[];
   __bf16* sWT = reinterpret_cast<__bf16*>(rows_smem);
@@ -332,6 +334,7 @@ constexpr size_t DW_LDS_BYTES = 2 * (size_t)(8 * DW_BN * 8 + 8 * DW_BK * 8) * si
 struct DwStage { float4 g[8]; float4 x[4]; };
 
 __global__ __launch_bounds__(DW_NTH) void k_dense_dw_rows(DenseBwdArgs a, int n_blocks, int k_blocks) {
+  adt_prefetch_kernargs<sizeof(DenseBwdArgs) <= 512 ? sizeof(DenseBwdArgs) : 512>();      // every kernarg line in one scalar-cache round trip (adt_common.cuh)
   extern __shared__ __attribute__((aligned(16))) unsigned char rows_smem[];
   __bf16* sG = reinterpret_cast<__bf16*>(rows_smem);                    // [2][8][DW_BN][8]
   __bf16* sX = sG + 2 * 8 * DW_BN * 8;                                  // [2][8][DW_BK][8]

@@ -343,6 +343,7 @@ struct DenseFwdArgs {
 
 template <int PREC, int BN>
 __global__ __launch_bounds__(GTH) void k_dense_fwd(DenseFwdArgs a) {
+  adt_prefetch_kernargs<sizeof(DenseFwdArgs) <= 512 ? sizeof(DenseFwdArgs) : 512>();      // every kernarg line in one scalar-cache round trip (adt_common.cuh)
   typedef typename GemmLds<PREC>::T LT;
   extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
   LT* sA = reinterpret_cast<LT*>(gemm_smem);
@@ -403,6 +404,7 @@ struct DenseBwdArgs {
 
 template <int PREC, int BN>
 __global__ __launch_bounds__(GTH) void k_dense_bwd_dx(DenseBwdArgs a) {
+  adt_prefetch_kernargs<sizeof(DenseBwdArgs) <= 512 ? sizeof(DenseBwdArgs) : 512>();      // every kernarg line in one scalar-cache round trip (adt_common.cuh)
   typedef typename GemmLds<PREC>::T LT;
   extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
   LT* sA = reinterpret_cast<LT*>(gemm_smem);
@@ -444,6 +446,7 @@ __global__ __launch_bounds__(GTH) void k_dense_bwd_dx(DenseBwdArgs a) {
 // ---- weight gradient: dW += G^T X, db += colsum(G); T split over blockIdx.z, partials added with atomics ------
 template <int PREC, int BN>
 __global__ __launch_bounds__(GTH) void k_dense_bwd_dw(DenseBwdArgs a) {
+  adt_prefetch_kernargs<sizeof(DenseBwdArgs) <= 512 ? sizeof(DenseBwdArgs) : 512>();      // every kernarg line in one scalar-cache round trip (adt_common.cuh)
   typedef typename GemmLds<PREC>::T LT;
   extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
   LT* sA = reinterpret_cast<LT*>(gemm_smem);

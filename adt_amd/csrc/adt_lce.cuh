@@ -115,6 +115,7 @@ ADT_DEVICE_INLINE bf16x8 lce_pack8(const f32x16& v, int base) {
 
 template <int KD, int MODE>
 __global__ __launch_bounds__(LCE_NTH) void k_lce(LceArgs a) {
+  adt_prefetch_kernargs<sizeof(LceArgs) <= 512 ? sizeof(LceArgs) : 512>();      // every kernarg line in one scalar-cache round trip (adt_common.cuh)
   using G = LceGeo<KD>;
   constexpr int NX = MODE == LCE_FWD ? 2 : 1;
   constexpr int XR = LCE_NW * 32 * NX;

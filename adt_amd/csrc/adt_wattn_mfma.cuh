@@ -150,6 +150,7 @@ ADT_DEVICE_INLINE float wm_prob(float x, bool masked, bool dead_row, float ref) 
 
 template <int PREC, int HD, int MAXKT>
 __global__ __launch_bounds__(WM_NW * 64) void k_wattn_mfma_fwd(WAttnArgs a) {
+  adt_prefetch_kernargs<sizeof(WAttnArgs) <= 512 ? sizeof(WAttnArgs) : 512>();      // every kernarg line in one scalar-cache round trip (adt_common.cuh)
   typedef WmShape<HD> S;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int L = a.L, Lp = (L + 31) / 32 * 32, nt16 = (L + 15) / 16, RST = Lp + 4;
@@ -272,6 +273,7 @@ ADT_DEVICE_INLINE void wm_pair_bwd(float x, bool masked, bool dead_row, float ls
 
 template <int PREC, int HD>
 __global__ __launch_bounds__(WM_NW * 64) void k_wattn_mfma_bwd(WAttnArgs a) {
+  adt_prefetch_kernargs<sizeof(WAttnArgs) <= 512 ? sizeof(WAttnArgs) : 512>();      // every kernarg line in one scalar-cache round trip (adt_common.cuh)
   typedef WmShape<HD> S;
   constexpr int KBV = (HD + 31) / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
