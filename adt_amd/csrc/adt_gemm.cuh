@@ -443,6 +443,82 @@ __global__ __launch_bounds__(GTH) void k_dense_bwd_dx(DenseBwdArgs a) {
   });
 }
 
+// ---- weight gradient of a 64 x 64 layer (bf16 operands): dW += G^T X, db += colsum(G) -------------------------------------------------
+// The tiled kernel below runs a 128 x 64 output tile in 32-row k-steps with a barrier pair per step; on a 64 x 64 layer it is one tile, so the
+// only parallelism is the T split, and 400-512 workgroups of two k-steps each spent their time on launch latency and on 4,096 atomics apiece
+// (33 us per call, 14 calls per STOSA-ADT step = 21 % of it).  Here a workgroup takes 128 rows per stage: G (with the epilogue's gradient
+// applied by GradSrc::at) and X go to two natural-order bf16 images, wave w computes output rows 16 w .. 16 w + 15 (four 16 x 16 tiles,
+// the G fragment shared) with both operands read through ds_read_b64_tr_b16, and the chunk count is chosen so that ~200 workgroups flush.
+constexpr int DW64_ROWS = 128, DW64_RS = 72, DW64_NTH = 256;
+typedef short dw64_s4 __attribute__((ext_vector_type(4)));
+typedef __bf16 dw64_b4 __attribute__((ext_vector_type(4)));
+ADT_DEVICE_INLINE bf16x8 dw64_trfrag(const __bf16* img, int row0, int col0, int c, int g) {     // feature col0 + c on the lane, 8 rows in slot order
+  const __bf16* p = img + (row0 + 4 * g + (c >> 2)) * DW64_RS + col0 + 4 * (c & 3);
+  union { struct { dw64_s4 a, b; } s; bf16x8 v; } u;
+  u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dw64_s4 __attribute__((address_space(3)))*)(p));
+  u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dw64_s4 __attribute__((address_space(3)))*)(p + 16 * DW64_RS));
+  return u.v;
+}
+__global__ __launch_bounds__(DW64_NTH) void k_dense_dw64(DenseBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) __bf16 sG[DW64_ROWS * DW64_RS];
+  __shared__ __attribute__((aligned(16))) __bf16 sX[DW64_ROWS * DW64_RS];
+  __shared__ float sB[16][64];
+  GradSrc G = a.G;
+  if (a.t_dev && G.T > *a.t_dev) G.T = *a.t_dev;
+  G.key = drop_key(G.drop);
+  const int t0 = blockIdx.x * a.t_chunk;
+  const int t1 = t0 + a.t_chunk < G.T ? t0 + a.t_chunk : G.T;
+  if (t0 >= t1) return;
+  G.T = t1;                                                // rows of the next chunk read as zeros
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int col4 = (threadIdx.x & 15) * 4, rsub = threadIdx.x >> 4;
+  f32x4 acc[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s0 = t0; s0 < t1; s0 += DW64_ROWS) {
+    float4 gv[DW64_ROWS / 16], xv[DW64_ROWS / 16];
+#pragma unroll
+    for (int i = 0; i < DW64_ROWS / 16; ++i) {
+      const int row = s0 + rsub + 16 * i;
+      xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < t1) xv[i] = *reinterpret_cast<const float4*>(a.X + (size_t)row * a.ldx + col4);
+    }
+#pragma unroll
+    for (int i = 0; i < DW64_ROWS / 16; ++i) gv[i] = G.at(s0 + rsub + 16 * i, col4);
+#pragma unroll
+    for (int i = 0; i < DW64_ROWS / 16; ++i) {
+      const int r = rsub + 16 * i;
+      bs[0] += gv[i].x; bs[1] += gv[i].y; bs[2] += gv[i].z; bs[3] += gv[i].w;
+      *reinterpret_cast<dw64_b4*>(sG + r * DW64_RS + col4) = dw64_b4{(__bf16)gv[i].x, (__bf16)gv[i].y, (__bf16)gv[i].z, (__bf16)gv[i].w};
+      *reinterpret_cast<dw64_b4*>(sX + r * DW64_RS + col4) = dw64_b4{(__bf16)xv[i].x, (__bf16)xv[i].y, (__bf16)xv[i].z, (__bf16)xv[i].w};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kp = 0; kp < DW64_ROWS / 32; ++kp) {
+      const bf16x8 fg = dw64_trfrag(sG, kp * 32, 16 * w, c, g);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg, dw64_trfrag(sX, kp * 32, 16 * kt, c, g), acc[kt], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(a.dW + (size_t)(16 * w + 4 * g + r) * a.lddw + 16 * kt + c, acc[kt][r]);
+  if (a.db) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sB[rsub][col4 + j] = bs[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += sB[i][threadIdx.x];
+      atomicAdd(a.db + threadIdx.x, t);
+    }
+  }
+}
+
 // ---- weight gradient: dW += G^T X, db += colsum(G); T split over blockIdx.z, partials added with atomics ------
 template <int PREC, int BN>
 __global__ __launch_bounds__(GTH) void k_dense_bwd_dw(DenseBwdArgs a) {
