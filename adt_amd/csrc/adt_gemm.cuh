@@ -449,6 +449,7 @@ __global__ __launch_bounds__(GTH) void k_dense_bwd_dx(DenseBwdArgs a) {
 // (33 us per call, 14 calls per STOSA-ADT step = 21 % of it).  Here a workgroup takes 128 rows per stage: G (with the epilogue's gradient
 // applied by GradSrc::at) and X go to two natural-order bf16 images, wave w computes output rows 16 w .. 16 w + 15 (four 16 x 16 tiles,
 // the G fragment shared) with both operands read through ds_read_b64_tr_b16, and the chunk count is chosen so that ~200 workgroups flush.
+// Layers of up to four 64 x 64 blocks (64 <-> 256 feed-forward layers) run one block per blockIdx.y.
 constexpr int DW64_ROWS = 128, DW64_RS = 72, DW64_NTH = 256;
 typedef short dw64_s4 __attribute__((ext_vector_type(4)));
 typedef __bf16 dw64_b4 __attribute__((ext_vector_type(4)));
@@ -470,6 +471,7 @@ __global__ __launch_bounds__(DW64_NTH) void k_dense_dw64(DenseBwdArgs a) {
   const int t1 = t0 + a.t_chunk < G.T ? t0 + a.t_chunk : G.T;
   if (t0 >= t1) return;
   G.T = t1;                                                // rows of the next chunk read as zeros
+  const int kblocks = a.K / 64, n0 = 64 * (blockIdx.y / kblocks), k0 = 64 * (blockIdx.y % kblocks);      // the 64 x 64 block of a wider layer
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int col4 = (threadIdx.x & 15) * 4, rsub = threadIdx.x >> 4;
   f32x4 acc[4];
@@ -482,10 +484,10 @@ __global__ __launch_bounds__(DW64_NTH) void k_dense_dw64(DenseBwdArgs a) {
     for (int i = 0; i < DW64_ROWS / 16; ++i) {
       const int row = s0 + rsub + 16 * i;
       xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < t1) xv[i] = *reinterpret_cast<const float4*>(a.X + (size_t)row * a.ldx + col4);
+      if (row < t1) xv[i] = *reinterpret_cast<const float4*>(a.X + (size_t)row * a.ldx + k0 + col4);
     }
 #pragma unroll
-    for (int i = 0; i < DW64_ROWS / 16; ++i) gv[i] = G.at(s0 + rsub + 16 * i, col4);
+    for (int i = 0; i < DW64_ROWS / 16; ++i) gv[i] = G.at(s0 + rsub + 16 * i, n0 + col4);
 #pragma unroll
     for (int i = 0; i < DW64_ROWS / 16; ++i) {
       const int r = rsub + 16 * i;
@@ -505,8 +507,8 @@ __global__ __launch_bounds__(DW64_NTH) void k_dense_dw64(DenseBwdArgs a) {
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(a.dW + (size_t)(16 * w + 4 * g + r) * a.lddw + 16 * kt + c, acc[kt][r]);
-  if (a.db) {
+    for (int r = 0; r < 4; ++r) atomicAdd(a.dW + (size_t)(n0 + 16 * w + 4 * g + r) * a.lddw + k0 + 16 * kt + c, acc[kt][r]);
+  if (a.db && k0 == 0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) sB[rsub][col4 + j] = bs[j];
     __syncthreads();
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(DW64_NTH) void k_dense_dw64(DenseBwdArgs a) {
       float t = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) t += sB[i][threadIdx.x];
-      atomicAdd(a.db + threadIdx.x, t);
+      atomicAdd(a.db + n0 + threadIdx.x, t);
     }
   }
 }

@@ -265,12 +265,12 @@ static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
     if (hipLaunchKernel((const void*)k_dense_dw_rows, dim3(xcd_grid(splits, tiles)), dim3(DW_NTH), kargs, DW_LDS_BYTES, s) != hipSuccess) return adt_set_error("dense dw rows: launch failed");
     a.dW = nullptr;
   }
-  if (a.dW && PREC == PREC_BF16 && g_rows_enabled && N == 64 && K == 64 && (a.ldx % 4) == 0 && aligned16(a.X) && (a.G.lddy % 4) == 0 && aligned16(a.G.dY)) {
+  if (a.dW && PREC == PREC_BF16 && g_rows_enabled && (N % 64) == 0 && (K % 64) == 0 && (N / 64) * (K / 64) <= 4 && (a.ldx % 4) == 0 && aligned16(a.X) && (a.G.lddy % 4) == 0 && aligned16(a.G.dY)) {
     // 64 x 64 layers: 128-row stages, ~200 workgroups (adt_gemm.cuh: k_dense_dw64)
     int chunk = ((T + 255) / 256 + DW64_ROWS - 1) / DW64_ROWS * DW64_ROWS;
     if (chunk < DW64_ROWS) chunk = DW64_ROWS;
     a.t_chunk = chunk;
-    hipLaunchKernelGGL(k_dense_dw64, dim3((T + chunk - 1) / chunk), dim3(DW64_NTH), 0, s, a);
+    hipLaunchKernelGGL(k_dense_dw64, dim3((T + chunk - 1) / chunk, (N / 64) * (K / 64)), dim3(DW64_NTH), 0, s, a);
     a.dW = nullptr;
   }
   if (a.dW) {

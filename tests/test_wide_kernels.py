@@ -38,7 +38,8 @@ def seed_tensor(seed):
 @pytest.mark.parametrize("T,K,N,act,p,resid", [(200, 64, 192, 0, 0.0, False), (130, 256, 100, 2, 0.0, True), (257, 128, 64, 3, 0.3, True),
                                               (64, 64, 1024, 2, 0.0, False), (300, 1024, 256, 0, 0.2, True), (77, 64, 36, 4, 0.0, False),
                                               (129, 96, 252, 1, 0.5, False), (333, 64, 64, 0, 0.3, True), (128, 64, 64, 3, 0.0, False),
-                                              (1000, 64, 64, 0, 0.5, True), (257, 64, 64, 2, 0.2, False)])      # 64 x 64: the stage kernel of the weight gradient (k_dense_dw64)
+                                              (1000, 64, 64, 0, 0.5, True), (257, 64, 64, 2, 0.2, False),
+                                              (300, 64, 256, 2, 0.3, False), (300, 256, 64, 0, 0.3, True), (190, 128, 128, 0, 0.0, False)])      # 64 x 64: the stage kernel of the weight gradient (k_dense_dw64)
 def test_dense_forward_backward(prec, T, K, N, act, p, resid):
     from adt_amd import ops
     r = np.random.RandomState(T + K + N)
