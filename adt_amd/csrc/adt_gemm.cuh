@@ -85,8 +85,13 @@ struct GradSrc {
       }
       if (act != ACT_NONE) {
         const float* u = U + (size_t)t * ldu + n;
+        if (lim == 4 && ((ldu | n) & 3) == 0 && (reinterpret_cast<uintptr_t>(U) & 15) == 0) {      // one 16-byte load instead of four scalar ones
+          const float4 uv = *reinterpret_cast<const float4*>(u);
+          v[0] *= act_grad(act, uv.x); v[1] *= act_grad(act, uv.y); v[2] *= act_grad(act, uv.z); v[3] *= act_grad(act, uv.w);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (j < lim) v[j] *= act_grad(act, u[j]);
+          for (int j = 0; j < 4; ++j) if (j < lim) v[j] *= act_grad(act, u[j]);
+        }
       }
     }
     return make_float4(v[0], v[1], v[2], v[3]);
