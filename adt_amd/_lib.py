@@ -98,6 +98,7 @@ SIGNATURES = {
     "adt_wdist_bpr": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _I, _P, _P, _P, _P]),
     "adt_wdist_full": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P]),
     "adt_dense_rows_enable": (_I, [_I]),
+    "adt_dense_workspace": (_I, [_P, _L]),
     "adt_dense_gradsrc": (_I, [_P, _I, _I, _I, _P, _F, _P, _U, _U, _I, _P, _I, _P, _I, _P, _P]),
     "adt_topk_masked": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "adt_sasrec_param_layout": (_L, [_CP, _P]),

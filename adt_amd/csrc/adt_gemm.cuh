@@ -526,6 +526,114 @@ __global__ __launch_bounds__(DW64_NTH) void k_dense_dw64(DenseBwdArgs a) {
   }
 }
 
+// ---- weight gradient of a 256 x 256 layer through private partials (bf16 operands) -------------------------------------------------------
+// At 256 x 256 the tiled kernel (and the 256 x 128-block one) is bound by its flush: every workgroup adds a 128 KB (256 KB) block to dW with
+// float atomics.  Here a workgroup owns the WHOLE 256 x 256 product of its token chunk: eight waves x (32 rows x 256 columns) = 128
+// accumulator registers per lane, 32-token stages, G and X as two bf16 LDS images in the dual-use layout of adt_lce.cuh (both operands of
+// v_mfma_f32_32x32x16_bf16 are read through ds_read_b64_tr_b16: the contraction runs over tokens), the next stage's rows requested before the
+// current one is multiplied.  The partial goes to the workspace in register order with plain 16-byte stores; k_dense_dw256_reduce folds the
+// partials into dW (32 per block, then one atomic per element: an 8-deep chain instead of a 256-deep one).
+constexpr int DWP_TS = 32, DWP_NTH = 512, DWP_IMG = 32 * 256 * 2;
+ADT_DEVICE_INLINE int dwp_off(int row, int ch) {          // byte offset of 16-byte chunk ch of row `row` (adt_lce.cuh: lce_off<256>)
+  return 4096 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+}
+__global__ __launch_bounds__(DWP_NTH) void k_dense_dw256(DenseBwdArgs a, float* part) {
+  adt_prefetch_kernargs<sizeof(DenseBwdArgs) <= 512 ? sizeof(DenseBwdArgs) : 512>();
+  __shared__ __attribute__((aligned(1024))) unsigned char sG[DWP_IMG];
+  __shared__ __attribute__((aligned(1024))) unsigned char sX[DWP_IMG];
+  __shared__ float sB[8][256];
+  GradSrc G = a.G;
+  if (a.t_dev && G.T > *a.t_dev) G.T = *a.t_dev;
+  G.key = drop_key(G.drop);
+  const int t0 = blockIdx.x * a.t_chunk;
+  const int t1 = t0 + a.t_chunk < G.T ? t0 + a.t_chunk : G.T;
+  G.T = t1 > t0 ? t1 : t0;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 5;
+  const int col4 = (threadIdx.x & 63) * 4, rsub = threadIdx.x >> 6;       // staging: 64 float4 per row, rows rsub + 8 i
+  int tb[2];
+  {
+    const int li = lane & 15, q = li >> 2, p = li & 3, gi = (lane >> 4) & 1;
+    tb[0] = 64 * (4 * h + q) + 16 * ((2 * gi + (p >> 1)) ^ h) + 8 * (p & 1);
+    tb[1] = 64 * (4 * h + q) + 16 * ((2 * gi + (p >> 1)) ^ (2 + h)) + 8 * (p & 1);
+  }
+  typedef float f32x16d __attribute__((ext_vector_type(16)));
+  f32x16d acc[8];
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[kt][e] = 0.f;
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 gv[4], xv[4];
+  auto request = [&](int s0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = s0 + rsub + 8 * i;
+      xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < t1) xv[i] = *reinterpret_cast<const float4*>(a.X + (size_t)row * a.ldx + col4);
+      gv[i] = G.at(row, col4);
+    }
+  };
+  if (t0 < t1) request(t0);
+  for (int s0 = t0; s0 < t1; s0 += DWP_TS) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rsub + 8 * i, o = dwp_off(r, col4 >> 3) + 8 * ((col4 >> 2) & 1);
+      bs[0] += gv[i].x; bs[1] += gv[i].y; bs[2] += gv[i].z; bs[3] += gv[i].w;
+      *reinterpret_cast<dw64_b4*>(sG + o) = dw64_b4{(__bf16)gv[i].x, (__bf16)gv[i].y, (__bf16)gv[i].z, (__bf16)gv[i].w};
+      *reinterpret_cast<dw64_b4*>(sX + o) = dw64_b4{(__bf16)xv[i].x, (__bf16)xv[i].y, (__bf16)xv[i].z, (__bf16)xv[i].w};
+    }
+    __syncthreads();
+    if (s0 + DWP_TS < t1) request(s0 + DWP_TS);           // in flight while this stage is multiplied
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      union { struct { dw64_s4 lo, hi; } p; bf16x8 v; } fa;
+      fa.p.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dw64_s4 __attribute__((address_space(3)))*)(sG + tb[0] + 4096 * (2 * ks) + 512 * w));
+      fa.p.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dw64_s4 __attribute__((address_space(3)))*)(sG + tb[1] + 4096 * (2 * ks + 1) + 512 * w));
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) {
+        union { struct { dw64_s4 lo, hi; } p; bf16x8 v; } fb;
+        fb.p.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dw64_s4 __attribute__((address_space(3)))*)(sX + tb[0] + 4096 * (2 * ks) + 512 * kt));
+        fb.p.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dw64_s4 __attribute__((address_space(3)))*)(sX + tb[1] + 4096 * (2 * ks + 1) + 512 * kt));
+        acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[kt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // partial in register order: float4 slot ((w * 8 + kt) * 4 + i) * 64 + lane of workgroup blockIdx.x
+  float4* dp = reinterpret_cast<float4*>(part) + (size_t)blockIdx.x * 16384 + (size_t)w * 8 * 4 * 64 + lane;
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dp[(kt * 4 + i) * 64] = make_float4(acc[kt][4 * i], acc[kt][4 * i + 1], acc[kt][4 * i + 2], acc[kt][4 * i + 3]);
+  if (a.db) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sB[rsub][col4 + j] = bs[j];
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t += sB[i][threadIdx.x];
+      if (t != 0.f) atomicAdd(a.db + threadIdx.x, t);
+    }
+  }
+}
+// dW[n][k] += sum over the workgroups' partials: block (slice, z) sums partials z * per .. of 256 float4 slots and adds its result with atomics
+__global__ __launch_bounds__(256) void k_dense_dw256_reduce(const float* part, int nwg, int per, float* dW, int lddw) {
+  const int slot = blockIdx.x * 256 + threadIdx.x;          // 0 .. 16383: ((w * 8 + kt) * 4 + i) * 64 + lane
+  const int z0 = blockIdx.y * per, z1 = z0 + per < nwg ? z0 + per : nwg;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = z0; z < z1; ++z) {
+    const float4 v = reinterpret_cast<const float4*>(part)[(size_t)z * 16384 + slot];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const int lane = slot & 63, i = (slot >> 6) & 3, kt = (slot >> 8) & 7, w = slot >> 11;
+  const int n = 32 * w + 8 * i + 4 * (lane >> 5), k = 32 * kt + (lane & 31);
+  atomicAdd(dW + (size_t)(n + 0) * lddw + k, s.x);
+  atomicAdd(dW + (size_t)(n + 1) * lddw + k, s.y);
+  atomicAdd(dW + (size_t)(n + 2) * lddw + k, s.z);
+  atomicAdd(dW + (size_t)(n + 3) * lddw + k, s.w);
+}
+
 // ---- weight gradient: dW += G^T X, db += colsum(G); T split over blockIdx.z, partials added with atomics ------
 template <int PREC, int BN>
 __global__ __launch_bounds__(GTH) void k_dense_bwd_dw(DenseBwdArgs a) {

@@ -116,6 +116,8 @@ static int gemm_launch(K kernel, size_t smem, int grid, hipStream_t s, const voi
 
 
 // ---- row-streaming kernels (adt_dense_rows.cuh): bf16 operands, contraction 64 / 128 / 256 ---------------------------------------
+static float* g_dense_ws = nullptr;      // scratch registered by the host (adt_dense_workspace): private partials of the 256 x 256 weight gradients
+static int64_t g_dense_ws_bytes = 0;
 static int g_rows_enabled = 1;      // adt_dense_rows_enable(0) routes everything to the tiled kernels (A/B measurements, tests)
 
 template <class KFn, class Args>
@@ -265,6 +267,21 @@ static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
     if (hipLaunchKernel((const void*)k_dense_dw_rows, dim3(xcd_grid(splits, tiles)), dim3(DW_NTH), kargs, DW_LDS_BYTES, s) != hipSuccess) return adt_set_error("dense dw rows: launch failed");
     a.dW = nullptr;
   }
+  if (a.dW && PREC == PREC_BF16 && g_rows_enabled && N == 256 && K == 256 && g_dense_ws && (a.ldx % 4) == 0 && aligned16(a.X) && (a.G.lddy % 4) == 0 &&
+      aligned16(a.G.dY)) {
+    // the whole 256 x 256 product per workgroup, private partials in the registered workspace + a reduce (adt_gemm.cuh: k_dense_dw256)
+    int nwg = (T + DWP_TS - 1) / DWP_TS;
+    if (nwg > 256) nwg = 256;
+    if ((int64_t)nwg * 262144 <= g_dense_ws_bytes) {
+      const int chunk = ((T + nwg - 1) / nwg + DWP_TS - 1) / DWP_TS * DWP_TS;
+      nwg = (T + chunk - 1) / chunk;
+      a.t_chunk = chunk;
+      hipLaunchKernelGGL(k_dense_dw256, dim3(nwg), dim3(DWP_NTH), 0, s, a, g_dense_ws);
+      const int per = 32;
+      hipLaunchKernelGGL(k_dense_dw256_reduce, dim3(64, (nwg + per - 1) / per), dim3(256), 0, s, (const float*)g_dense_ws, nwg, per, a.dW, a.lddw);
+      a.dW = nullptr;
+    }
+  }
   if (a.dW && PREC == PREC_BF16 && g_rows_enabled && (N % 64) == 0 && (K % 64) == 0 && (N / 64) * (K / 64) <= 4 && (a.ldx % 4) == 0 && aligned16(a.X) && (a.G.lddy % 4) == 0 && aligned16(a.G.dY)) {
     // 64 x 64 layers: 128-row stages, ~200 workgroups (adt_gemm.cuh: k_dense_dw64)
     int chunk = ((T + 255) / 256 + DW64_ROWS - 1) / DW64_ROWS * DW64_ROWS;
@@ -329,6 +346,12 @@ static int wattn_mfma_dispatch(int prec, bool bwd, const WAttnArgs& a, hipStream
 
 
 extern "C" {
+
+int adt_dense_workspace(void* ws, int64_t bytes) {
+  g_dense_ws = static_cast<float*>(ws);
+  g_dense_ws_bytes = ws ? bytes : 0;
+  return 0;
+}
 
 int adt_dense_rows_enable(int on) {
   const int was = g_rows_enabled;

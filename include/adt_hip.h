@@ -165,6 +165,10 @@ int adt_lce_fwd_bwd(const float* h, int ldh, const int32_t* rows, const int32_t*
  * allows (contraction 64/128/256 per chunk, N <= 1024), 0 = always the tiled kernels.  Returns the previous setting.  Results
  * agree to bf16 rounding either way; the switch exists for A/B measurements and tests. */
 int adt_dense_rows_enable(int on);
+/* Optional scratch for the dense backward: with at least 64 MiB registered (256 workgroups x 256 KiB), the weight gradient of a 256 x 256
+ * layer in bf16 mode runs through private per-workgroup partials + a reduce instead of a 128-256 KiB atomic flush per workgroup.  The
+ * library keeps the pointer (it allocates nothing itself); ws = NULL unregisters.  Results agree with the atomic path to summation order. */
+int adt_dense_workspace(void* ws, int64_t bytes);
 /* torch.nn.Linear with its surrounding elementwise ops, any K / N (bert4rec/model/modules.py:59-75,128-139,
  * bert.py:48-51,80-90; stosa/modules.py:199-212,477-487): Y = mask(R + dropout(act(X W^T + b))); W is N x K with row
  * stride ldw; U (optional) receives the pre-activation X W^T + b for the backward.  t_dev (optional, DEVICE int): only
