@@ -532,7 +532,8 @@ __global__ __launch_bounds__(DW64_NTH) void k_dense_dw64(DenseBwdArgs a) {
 // accumulator registers per lane, 32-token stages, G and X as two bf16 LDS images in the dual-use layout of adt_lce.cuh (both operands of
 // v_mfma_f32_32x32x16_bf16 are read through ds_read_b64_tr_b16: the contraction runs over tokens), the next stage's rows requested before the
 // current one is multiplied.  The partial goes to the workspace in register order with plain 16-byte stores; k_dense_dw256_reduce folds the
-// partials into dW (32 per block, then one atomic per element: an 8-deep chain instead of a 256-deep one).
+// partials into dW (32 per block, then one atomic per element: an 8-deep chain instead of a 256-deep one).  Layers of up to four 256 x 256
+// blocks (the 256 <-> 1024 feed-forward layers) run one block per blockIdx.y with the workgroups divided among the blocks.
 constexpr int DWP_TS = 32, DWP_NTH = 512, DWP_IMG = 32 * 256 * 2;
 ADT_DEVICE_INLINE int dwp_off(int row, int ch) {          // byte offset of 16-byte chunk ch of row `row` (adt_lce.cuh: lce_off<256>)
   return 4096 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
@@ -548,6 +549,7 @@ __global__ __launch_bounds__(DWP_NTH) void k_dense_dw256(DenseBwdArgs a, float* 
   const int t0 = blockIdx.x * a.t_chunk;
   const int t1 = t0 + a.t_chunk < G.T ? t0 + a.t_chunk : G.T;
   G.T = t1 > t0 ? t1 : t0;
+  const int kblocks = a.K / 256, n0 = 256 * (blockIdx.y / kblocks), k0 = 256 * (blockIdx.y % kblocks);      // the 256 x 256 block of a wider layer
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 5;
   const int col4 = (threadIdx.x & 63) * 4, rsub = threadIdx.x >> 6;       // staging: 64 float4 per row, rows rsub + 8 i
   int tb[2];
@@ -569,8 +571,8 @@ __global__ __launch_bounds__(DWP_NTH) void k_dense_dw256(DenseBwdArgs a, float* 
     for (int i = 0; i < 4; ++i) {
       const int row = s0 + rsub + 8 * i;
       xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < t1) xv[i] = *reinterpret_cast<const float4*>(a.X + (size_t)row * a.ldx + col4);
-      gv[i] = G.at(row, col4);
+      if (row < t1) xv[i] = *reinterpret_cast<const float4*>(a.X + (size_t)row * a.ldx + k0 + col4);
+      gv[i] = G.at(row, n0 + col4);
     }
   };
   if (t0 < t1) request(t0);
@@ -600,12 +602,12 @@ __global__ __launch_bounds__(DWP_NTH) void k_dense_dw256(DenseBwdArgs a, float* 
     __syncthreads();
   }
   // partial in register order: float4 slot ((w * 8 + kt) * 4 + i) * 64 + lane of workgroup blockIdx.x
-  float4* dp = reinterpret_cast<float4*>(part) + (size_t)blockIdx.x * 16384 + (size_t)w * 8 * 4 * 64 + lane;
+  float4* dp = reinterpret_cast<float4*>(part) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16384 + (size_t)w * 8 * 4 * 64 + lane;
 #pragma unroll
   for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
     for (int i = 0; i < 4; ++i) dp[(kt * 4 + i) * 64] = make_float4(acc[kt][4 * i], acc[kt][4 * i + 1], acc[kt][4 * i + 2], acc[kt][4 * i + 3]);
-  if (a.db) {
+  if (a.db && k0 == 0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) sB[rsub][col4 + j] = bs[j];
     __syncthreads();
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(DWP_NTH) void k_dense_dw256(DenseBwdArgs a, float* 
       float t = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) t += sB[i][threadIdx.x];
-      if (t != 0.f) atomicAdd(a.db + threadIdx.x, t);
+      if (t != 0.f) atomicAdd(a.db + n0 + threadIdx.x, t);
     }
   }
 }
