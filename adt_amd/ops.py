@@ -230,10 +230,15 @@ def dense_bwd(prec, dY, X, W, dW=None, db=None, dX=None, beta=False, act=ACT_NON
     """G = dY * mask * dropmask * act'(U); dX (+)= G W; dW += G^T X; db += colsum(G)."""
     T, N = dY.shape
     K = W.shape[1]
-    if dW is not None and N == 256 and K == 256 and prec == PREC_BF16 and dY.device not in _DENSE_WS:
-        # scratch for the private-partial weight gradient of 256 x 256 layers (adt_dense_workspace): one per device, kept for the process
-        ws = _DENSE_WS[dY.device] = torch.empty(64 << 20, device=dY.device, dtype=torch.uint8)
+    if dW is not None and N % 256 == 0 and K % 256 == 0 and prec == PREC_BF16 and _DENSE_WS.get("current") != dY.device:
+        # scratch for the private-partial weight gradients of 256-wide layers (adt_dense_workspace): one buffer per device, kept for the
+        # process; the library holds ONE pointer, so it is re-registered when the calls move to another device (one process per GPU is the
+        # normal case and registers once, before any graph capture: the trainers warm up eagerly)
+        ws = _DENSE_WS.get(dY.device)
+        if ws is None:
+            ws = _DENSE_WS[dY.device] = torch.empty(64 << 20, device=dY.device, dtype=torch.uint8)
         _lib.check(_lib.load().adt_dense_workspace(_p(ws), ws.numel()), "dense_workspace")
+        _DENSE_WS["current"] = dY.device
     _lib.check(_lib.load().adt_dense_bwd(prec, _p(_f32(dY)), _ld(dY), T, K, N, _p(mask_ids), float(p), _p(seed), site, row_offset, act, _p(U),
                                          _ld(U), _p(X), _ld(X), _p(_f32(W)), _ld(W), _p(dX), _ld(dX), int(beta), _p(dW), _ld(dW) if dW is not None else 0,
                                          _p(db), _p(t_dev), _stream()), "dense_bwd")
