@@ -636,6 +636,97 @@ __global__ __launch_bounds__(256) void k_dense_dw256_reduce(const float* part, i
   atomicAdd(dW + (size_t)(n + 3) * lddw + k, s.w);
 }
 
+// ---- input gradient of a 256 x 256 layer (bf16 operands): dX (+)= G W ------------------------------------------------------------------------
+// The LCE / k_dense_dw256 skeleton with the roles turned: the WEIGHT is the register-resident operand (wave w keeps W[:, 32 w .. 32 w + 31] as
+// sixteen B fragments, read once through ds_read_b64_tr_b16 from a staged image), the gradient streams through LDS in 32-token stages (one
+// bf16 image in the dual-use layout, row reads), the output tile is transposed (k on the lane, token on the accumulator rows: every store
+// instruction writes two 128-byte row segments).  The row-streaming kernel (adt_dense_rows.cuh) re-stages the 256 KB fp32 weight panel per
+// workgroup and holds two waves per SIMD with no overlap between loads, MFMAs and stores: 52 us per layer; this one is bound by its HBM bytes.
+__global__ __launch_bounds__(DWP_NTH) void k_dense_dx256(DenseBwdArgs a) {
+  adt_prefetch_kernargs<sizeof(DenseBwdArgs) <= 512 ? sizeof(DenseBwdArgs) : 512>();
+  __shared__ __attribute__((aligned(1024))) unsigned char sG[DWP_IMG];
+  __shared__ __attribute__((aligned(1024))) unsigned char sW[DWP_IMG];
+  GradSrc G = a.G;
+  if (a.t_dev && G.T > *a.t_dev) G.T = *a.t_dev;
+  G.key = drop_key(G.drop);
+  const int t0 = blockIdx.x * a.t_chunk;
+  const int t1 = t0 + a.t_chunk < G.T ? t0 + a.t_chunk : G.T;
+  if (t0 >= t1) return;
+  G.T = t1;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int col4 = (threadIdx.x & 63) * 4, rsub = threadIdx.x >> 6;
+  float4 gv[4];
+  auto request = [&](int s0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gv[i] = G.at(s0 + rsub + 8 * i, col4);
+  };
+  request(t0);                                             // in flight during the weight prologue
+  // W^T fragments: element j of lane (k = 32 w + r, h) of step ks is W[16 ks + 8 h + j][k] -- the natural slot order of the row-read A operand
+  bf16x8 wf[16];
+  {
+    const int li = lane & 15, q = li >> 2, p = li & 3, gi = (lane >> 4) & 1;
+    int tbn[2];
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) tbn[j2] = 4096 * h + 64 * (4 * j2 + q) + 16 * ((2 * gi + (p >> 1)) ^ ((2 * h + j2) & 3)) + 8 * (p & 1);
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rr = rsub + 8 * i;
+        const float4 wv = *reinterpret_cast<const float4*>(a.W + (size_t)(32 * pass + rr) * a.ldw + col4);
+        *reinterpret_cast<dw64_b4*>(sW + dwp_off(rr, col4 >> 3) + 8 * ((col4 >> 2) & 1)) = dw64_b4{(__bf16)wv.x, (__bf16)wv.y, (__bf16)wv.z, (__bf16)wv.w};
+      }
+      __syncthreads();
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) {
+        union { struct { dw64_s4 lo, hi; } p; bf16x8 v; } f;
+        f.p.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dw64_s4 __attribute__((address_space(3)))*)(sW + tbn[0] + 8192 * sk + 512 * w));
+        f.p.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dw64_s4 __attribute__((address_space(3)))*)(sW + tbn[1] + 8192 * sk + 512 * w));
+        wf[2 * pass + sk] = f.v;
+      }
+      __syncthreads();
+    }
+  }
+  int rb[2];
+  {
+    const int v = (r >> 2) & 3;
+    rb[0] = 4096 * (r >> 3) + 64 * (r & 7) + 16 * (h ^ v);
+    rb[1] = 4096 * (r >> 3) + 64 * (r & 7) + 16 * ((2 + h) ^ v);
+  }
+  typedef float f32x16x __attribute__((ext_vector_type(16)));
+  for (int s0 = t0; s0 < t1; s0 += DWP_TS) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = rsub + 8 * i;
+      *reinterpret_cast<dw64_b4*>(sG + dwp_off(rr, col4 >> 3) + 8 * ((col4 >> 2) & 1)) = dw64_b4{(__bf16)gv[i].x, (__bf16)gv[i].y, (__bf16)gv[i].z, (__bf16)gv[i].w};
+    }
+    __syncthreads();
+    if (s0 + DWP_TS < t1) request(s0 + DWP_TS);
+    f32x16x acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(sG + rb[ks & 1] + 512 * (ks >> 1)), wf[ks], acc, 0, 0, 0);
+    if (a.beta) {                                          // all sixteen old values first: interleaved with the stores they would be sixteen
+      float old[16];                                       // serial round trips (the compiler cannot prove that the rows do not alias)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int t = s0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        old[e] = t < t1 ? a.dX[(size_t)t * a.lddx + 32 * w + r] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] += old[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int t = s0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (t < t1) a.dX[(size_t)t * a.lddx + 32 * w + r] = acc[e];
+    }
+    __syncthreads();
+  }
+}
+
 // ---- weight gradient: dW += G^T X, db += colsum(G); T split over blockIdx.z, partials added with atomics ------
 template <int PREC, int BN>
 __global__ __launch_bounds__(GTH) void k_dense_bwd_dw(DenseBwdArgs a) {

@@ -222,6 +222,17 @@ template <int PREC>
 static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
   DenseBwdArgs a = a0;
   const int T = a.G.T, N = a.G.N, K = a.K;
+  if (PREC == PREC_BF16 && g_rows_enabled && a.dX && N == 256 && K == 256 && (a.ldw % 4) == 0 && aligned16(a.W) && (a.G.lddy % 4) == 0 && aligned16(a.G.dY) &&
+      (a.G.act == ACT_NONE || ((a.G.ldu % 4) == 0 && aligned16(a.G.U))) && getenv("ADT_DX256") == nullptr) {
+    // 256 x 256: weight in registers, gradient tiles through LDS, transposed output (adt_gemm.cuh: k_dense_dx256)
+    int nwg = (T + DWP_TS - 1) / DWP_TS;
+    if (nwg > 256) nwg = 256;
+    const int chunk = ((T + nwg - 1) / nwg + DWP_TS - 1) / DWP_TS * DWP_TS;
+    DenseBwdArgs d = a;
+    d.t_chunk = chunk;
+    hipLaunchKernelGGL(k_dense_dx256, dim3((T + chunk - 1) / chunk), dim3(DWP_NTH), 0, s, d);
+    a.dX = nullptr;
+  }
   if (PREC == PREC_BF16 && rows_dx_ok(a)) {
     if (launch_dense_dx_rows(a, s)) return -1;
     a.dX = nullptr;
