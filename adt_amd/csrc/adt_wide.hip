@@ -254,6 +254,25 @@ static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
     if (K > 64) { if (gemm_launch(k_dense_bwd_dx<PREC, 128>, gemm_lds_bytes<PREC, 128>(), grid, s, &a, done[0])) return -1; }
     else if (gemm_launch(k_dense_bwd_dx<PREC, 64>, gemm_lds_bytes<PREC, 64>(), grid, s, &a, done[1])) return -1;
   }
+  if (a.dW && PREC == PREC_BF16 && g_rows_enabled && (N % 256) == 0 && (K % 256) == 0 && (N / 256) * (K / 256) <= 4 && g_dense_ws && (a.ldx % 4) == 0 &&
+      aligned16(a.X) && (a.G.lddy % 4) == 0 && aligned16(a.G.dY)) {
+    // the whole 256 x 256 product (of each 256 x 256 block) per workgroup, private partials in the registered workspace + a reduce
+    // (adt_gemm.cuh: k_dense_dw256); 256 workgroups in all
+    const int blocks = (N / 256) * (K / 256), kblocks = K / 256;
+    int nwg = (T + DWP_TS - 1) / DWP_TS;
+    if (nwg > 256 / blocks) nwg = 256 / blocks;
+    if ((int64_t)nwg * blocks * 262144 <= g_dense_ws_bytes) {
+      const int chunk = ((T + nwg - 1) / nwg + DWP_TS - 1) / DWP_TS * DWP_TS;
+      nwg = (T + chunk - 1) / chunk;
+      a.t_chunk = chunk;
+      hipLaunchKernelGGL(k_dense_dw256, dim3(nwg, blocks), dim3(DWP_NTH), 0, s, a, g_dense_ws);
+      const int per = nwg >= 128 ? 32 : 16;
+      for (int b = 0; b < blocks; ++b)
+        hipLaunchKernelGGL(k_dense_dw256_reduce, dim3(64, (nwg + per - 1) / per), dim3(256), 0, s, (const float*)(g_dense_ws + (size_t)b * nwg * 65536), nwg, per,
+                           a.dW + (size_t)(256 * (b / kblocks)) * a.lddw + 256 * (b % kblocks), a.lddw);
+      a.dW = nullptr;
+    }
+  }
   // the 256 x 128-block kernel pays off from four output blocks on (N = 768: 127 us vs 225 us tiled); at two blocks (256 x 256)
   // its 32 K atomics per workgroup cost what the deeper stages save (84 us vs 77 us)
   if (a.dW && PREC == PREC_BF16 && g_rows_enabled && ((N + DW_BN - 1) / DW_BN) * ((K + DW_BK - 1) / DW_BK) >= 4 && (N % 4) == 0 && (K % 4) == 0 && (a.ldx % 4) == 0 &&
@@ -277,25 +296,6 @@ static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
     void* kargs[] = {&args, &nb, &kb};
     if (hipLaunchKernel((const void*)k_dense_dw_rows, dim3(xcd_grid(splits, tiles)), dim3(DW_NTH), kargs, DW_LDS_BYTES, s) != hipSuccess) return adt_set_error("dense dw rows: launch failed");
     a.dW = nullptr;
-  }
-  if (a.dW && PREC == PREC_BF16 && g_rows_enabled && (N % 256) == 0 && (K % 256) == 0 && (N / 256) * (K / 256) <= 4 && g_dense_ws && (a.ldx % 4) == 0 &&
-      aligned16(a.X) && (a.G.lddy % 4) == 0 && aligned16(a.G.dY)) {
-    // the whole 256 x 256 product (of each 256 x 256 block) per workgroup, private partials in the registered workspace + a reduce
-    // (adt_gemm.cuh: k_dense_dw256); 256 workgroups in all
-    const int blocks = (N / 256) * (K / 256), kblocks = K / 256;
-    int nwg = (T + DWP_TS - 1) / DWP_TS;
-    if (nwg > 256 / blocks) nwg = 256 / blocks;
-    if ((int64_t)nwg * blocks * 262144 <= g_dense_ws_bytes) {
-      const int chunk = ((T + nwg - 1) / nwg + DWP_TS - 1) / DWP_TS * DWP_TS;
-      nwg = (T + chunk - 1) / chunk;
-      a.t_chunk = chunk;
-      hipLaunchKernelGGL(k_dense_dw256, dim3(nwg, blocks), dim3(DWP_NTH), 0, s, a, g_dense_ws);
-      const int per = nwg >= 128 ? 32 : 16;
-      for (int b = 0; b < blocks; ++b)
-        hipLaunchKernelGGL(k_dense_dw256_reduce, dim3(64, (nwg + per - 1) / per), dim3(256), 0, s, (const float*)(g_dense_ws + (size_t)b * nwg * 65536), nwg, per,
-                           a.dW + (size_t)(256 * (b / kblocks)) * a.lddw + 256 * (b % kblocks), a.lddw);
-      a.dW = nullptr;
-    }
   }
   if (a.dW && PREC == PREC_BF16 && g_rows_enabled && (N % 64) == 0 && (K % 64) == 0 && (N / 64) * (K / 64) <= 4 && (a.ldx % 4) == 0 && aligned16(a.X) && (a.G.lddy % 4) == 0 && aligned16(a.G.dY)) {
     // 64 x 64 layers: 128-row stages, ~200 workgroups (adt_gemm.cuh: k_dense_dw64)
