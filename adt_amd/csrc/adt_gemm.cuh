@@ -642,10 +642,11 @@ __global__ __launch_bounds__(256) void k_dense_dw256_reduce(const float* part, i
 // bf16 image in the dual-use layout, row reads), the output tile is transposed (k on the lane, token on the accumulator rows: every store
 // instruction writes two 128-byte row segments).  The row-streaming kernel (adt_dense_rows.cuh) re-stages the 256 KB fp32 weight panel per
 // workgroup and holds two waves per SIMD with no overlap between loads, MFMAs and stores: 52 us per layer; this one is bound by its HBM bytes.
+template <int NB>      // N = 256 NB (the contraction: NB <= 3 keeps the 16 NB weight fragments in registers); K = 256 gridDim.y
 __global__ __launch_bounds__(DWP_NTH) void k_dense_dx256(DenseBwdArgs a) {
   adt_prefetch_kernargs<sizeof(DenseBwdArgs) <= 512 ? sizeof(DenseBwdArgs) : 512>();
-  __shared__ __attribute__((aligned(1024))) unsigned char sG[DWP_IMG];
-  __shared__ __attribute__((aligned(1024))) unsigned char sW[DWP_IMG];
+  extern __shared__ __attribute__((aligned(1024))) unsigned char dx_smem[];      // NB gradient images; image 0 doubles as the weight staging image
+  unsigned char* sG = dx_smem;
   GradSrc G = a.G;
   if (a.t_dev && G.T > *a.t_dev) G.T = *a.t_dev;
   G.key = drop_key(G.drop);
@@ -653,40 +654,43 @@ __global__ __launch_bounds__(DWP_NTH) void k_dense_dx256(DenseBwdArgs a) {
   const int t1 = t0 + a.t_chunk < G.T ? t0 + a.t_chunk : G.T;
   if (t0 >= t1) return;
   G.T = t1;
+  const int k0 = 256 * blockIdx.y;                         // this workgroup's 256 output columns
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int col4 = (threadIdx.x & 63) * 4, rsub = threadIdx.x >> 6;
-  float4 gv[4];
+  float4 gv[NB][4];
   auto request = [&](int s0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) gv[i] = G.at(s0 + rsub + 8 * i, col4);
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gv[nb][i] = G.at(s0 + rsub + 8 * i, 256 * nb + col4);
   };
-  request(t0);                                             // in flight during the weight prologue
-  // W^T fragments: element j of lane (k = 32 w + r, h) of step ks is W[16 ks + 8 h + j][k] -- the natural slot order of the row-read A operand
-  bf16x8 wf[16];
+  // W^T fragments: element j of lane (k = k0 + 32 w + r, h) of step ks is W[16 ks + 8 h + j][k] -- the natural slot order of the row-read A operand
+  bf16x8 wf[16 * NB];
   {
     const int li = lane & 15, q = li >> 2, p = li & 3, gi = (lane >> 4) & 1;
     int tbn[2];
 #pragma unroll
     for (int j2 = 0; j2 < 2; ++j2) tbn[j2] = 4096 * h + 64 * (4 * j2 + q) + 16 * ((2 * gi + (p >> 1)) ^ ((2 * h + j2) & 3)) + 8 * (p & 1);
 #pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
+    for (int pass = 0; pass < 8 * NB; ++pass) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int rr = rsub + 8 * i;
-        const float4 wv = *reinterpret_cast<const float4*>(a.W + (size_t)(32 * pass + rr) * a.ldw + col4);
-        *reinterpret_cast<dw64_b4*>(sW + dwp_off(rr, col4 >> 3) + 8 * ((col4 >> 2) & 1)) = dw64_b4{(__bf16)wv.x, (__bf16)wv.y, (__bf16)wv.z, (__bf16)wv.w};
+        const float4 wv = *reinterpret_cast<const float4*>(a.W + (size_t)(32 * pass + rr) * a.ldw + k0 + col4);
+        *reinterpret_cast<dw64_b4*>(sG + dwp_off(rr, col4 >> 3) + 8 * ((col4 >> 2) & 1)) = dw64_b4{(__bf16)wv.x, (__bf16)wv.y, (__bf16)wv.z, (__bf16)wv.w};
       }
       __syncthreads();
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk) {
         union { struct { dw64_s4 lo, hi; } p; bf16x8 v; } f;
-        f.p.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dw64_s4 __attribute__((address_space(3)))*)(sW + tbn[0] + 8192 * sk + 512 * w));
-        f.p.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dw64_s4 __attribute__((address_space(3)))*)(sW + tbn[1] + 8192 * sk + 512 * w));
+        f.p.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dw64_s4 __attribute__((address_space(3)))*)(sG + tbn[0] + 8192 * sk + 512 * w));
+        f.p.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dw64_s4 __attribute__((address_space(3)))*)(sG + tbn[1] + 8192 * sk + 512 * w));
         wf[2 * pass + sk] = f.v;
       }
       __syncthreads();
     }
   }
+  request(t0);
   int rb[2];
   {
     const int v = (r >> 2) & 3;
@@ -696,24 +700,29 @@ __global__ __launch_bounds__(DWP_NTH) void k_dense_dx256(DenseBwdArgs a) {
   typedef float f32x16x __attribute__((ext_vector_type(16)));
   for (int s0 = t0; s0 < t1; s0 += DWP_TS) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rr = rsub + 8 * i;
-      *reinterpret_cast<dw64_b4*>(sG + dwp_off(rr, col4 >> 3) + 8 * ((col4 >> 2) & 1)) = dw64_b4{(__bf16)gv[i].x, (__bf16)gv[i].y, (__bf16)gv[i].z, (__bf16)gv[i].w};
-    }
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rr = rsub + 8 * i;
+        *reinterpret_cast<dw64_b4*>(sG + DWP_IMG * nb + dwp_off(rr, col4 >> 3) + 8 * ((col4 >> 2) & 1)) =
+            dw64_b4{(__bf16)gv[nb][i].x, (__bf16)gv[nb][i].y, (__bf16)gv[nb][i].z, (__bf16)gv[nb][i].w};
+      }
     __syncthreads();
     if (s0 + DWP_TS < t1) request(s0 + DWP_TS);
     f32x16x acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(sG + rb[ks & 1] + 512 * (ks >> 1)), wf[ks], acc, 0, 0, 0);
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(sG + DWP_IMG * nb + rb[ks & 1] + 512 * (ks >> 1)), wf[16 * nb + ks], acc, 0, 0, 0);
     if (a.beta) {                                          // all sixteen old values first: interleaved with the stores they would be sixteen
       float old[16];                                       // serial round trips (the compiler cannot prove that the rows do not alias)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int t = s0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        old[e] = t < t1 ? a.dX[(size_t)t * a.lddx + 32 * w + r] : 0.f;
+        old[e] = t < t1 ? a.dX[(size_t)t * a.lddx + k0 + 32 * w + r] : 0.f;
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] += old[e];
@@ -721,7 +730,7 @@ __global__ __launch_bounds__(DWP_NTH) void k_dense_dx256(DenseBwdArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int t = s0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (t < t1) a.dX[(size_t)t * a.lddx + 32 * w + r] = acc[e];
+      if (t < t1) a.dX[(size_t)t * a.lddx + k0 + 32 * w + r] = acc[e];
     }
     __syncthreads();
   }

@@ -222,15 +222,22 @@ template <int PREC>
 static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
   DenseBwdArgs a = a0;
   const int T = a.G.T, N = a.G.N, K = a.K;
-  if (PREC == PREC_BF16 && g_rows_enabled && a.dX && N == 256 && K == 256 && (a.ldw % 4) == 0 && aligned16(a.W) && (a.G.lddy % 4) == 0 && aligned16(a.G.dY) &&
-      (a.G.act == ACT_NONE || ((a.G.ldu % 4) == 0 && aligned16(a.G.U))) && getenv("ADT_DX256") == nullptr) {
-    // 256 x 256: weight in registers, gradient tiles through LDS, transposed output (adt_gemm.cuh: k_dense_dx256)
+  if (PREC == PREC_BF16 && g_rows_enabled && a.dX && (N % 256) == 0 && N <= 768 && K == 256 && (a.ldw % 4) == 0 && aligned16(a.W) &&
+      (a.G.lddy % 4) == 0 && aligned16(a.G.dY) && (a.G.act == ACT_NONE || ((a.G.ldu % 4) == 0 && aligned16(a.G.U))) && getenv("ADT_DX256") == nullptr) {
+    // contraction 256 / 512 / 768 into 256 columns: weight in registers, gradient tiles through LDS, transposed output (adt_gemm.cuh:
+    // k_dense_dx256; wider outputs -- K = 1024 as four column blocks -- measured neutral against the row-streaming kernel and stay there)
+    const int NB = N / 256, kblocks = K / 256;
     int nwg = (T + DWP_TS - 1) / DWP_TS;
-    if (nwg > 256) nwg = 256;
+    const int cap = 256 / (kblocks > 2 ? 2 : 1);
+    if (nwg > cap) nwg = cap;
     const int chunk = ((T + nwg - 1) / nwg + DWP_TS - 1) / DWP_TS * DWP_TS;
     DenseBwdArgs d = a;
     d.t_chunk = chunk;
-    hipLaunchKernelGGL(k_dense_dx256, dim3((T + chunk - 1) / chunk), dim3(DWP_NTH), 0, s, d);
+    const dim3 grid((T + chunk - 1) / chunk, kblocks);
+    const size_t smem = (size_t)DWP_IMG * NB;
+    if (NB == 1) hipLaunchKernelGGL(k_dense_dx256<1>, grid, dim3(DWP_NTH), smem, s, d);
+    else if (NB == 2) hipLaunchKernelGGL(k_dense_dx256<2>, grid, dim3(DWP_NTH), smem, s, d);
+    else hipLaunchKernelGGL(k_dense_dx256<3>, grid, dim3(DWP_NTH), smem, s, d);
     a.dX = nullptr;
   }
   if (PREC == PREC_BF16 && rows_dx_ok(a)) {

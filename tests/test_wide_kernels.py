@@ -41,7 +41,8 @@ def seed_tensor(seed):
                                               (1000, 64, 64, 0, 0.5, True), (257, 64, 64, 2, 0.2, False),
                                               (300, 64, 256, 2, 0.3, False), (300, 256, 64, 0, 0.3, True), (190, 128, 128, 0, 0.0, False),
                                               (300, 256, 256, 0, 0.2, True), (1000, 256, 256, 2, 0.0, False), (33, 256, 256, 0, 0.0, False),
-                                              (260, 256, 1024, 2, 0.2, False), (300, 1024, 256, 0, 0.2, True), (130, 256, 512, 0, 0.0, False)])   # 256 x 256: private partials      # 64 x 64: the stage kernel of the weight gradient (k_dense_dw64)
+                                              (260, 256, 1024, 2, 0.2, False), (300, 1024, 256, 0, 0.2, True), (130, 256, 512, 0, 0.0, False),
+                                              (150, 256, 768, 0, 0.0, False), (97, 512, 768, 0, 0.2, True)])      # packed in-projections: contraction 768 in the input gradient   # 256 x 256: private partials      # 64 x 64: the stage kernel of the weight gradient (k_dense_dw64)
 def test_dense_forward_backward(prec, T, K, N, act, p, resid):
     from adt_amd import ops
     r = np.random.RandomState(T + K + N)
