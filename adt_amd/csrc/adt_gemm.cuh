@@ -636,6 +636,103 @@ __global__ __launch_bounds__(256) void k_dense_dw256_reduce(const float* part, i
   atomicAdd(dW + (size_t)(n + 3) * lddw + k, s.w);
 }
 
+// ---- forward of a layer with K = 256, N a multiple of 256 (bf16 operands): Y = mask(R + R2 + dropout(act(X W^T + b))) -------------------------
+// The skeleton of k_dense_dx256 below: wave w of column block blockIdx.y keeps W[n0 + 32 w .. + 31][:] as sixteen B fragments (staged through
+// LDS in eight coalesced passes, pass p holds wave p's rows), the activations stream through LDS in 32-token stages, the output tile is
+// transposed (n on the lane, token on the accumulator rows) and the epilogue of k_dense_fwd runs on it -- same order of operations, same
+// dropout indices.  The epilogue is specialised at compile time (EPI bit 0: residuals / row mask, bit 1: dropout, bit 2: activation / U): the
+// generic form held 234 registers and per-element branches and was slower than the row-streaming kernel.
+template <int EPI>
+__global__ __launch_bounds__(DWP_NTH) void k_dense_fwd256(DenseFwdArgs a, int t_chunk) {
+  adt_prefetch_kernargs<sizeof(DenseFwdArgs) <= 512 ? sizeof(DenseFwdArgs) : 512>();
+  __shared__ __attribute__((aligned(1024))) unsigned char sX[DWP_IMG];
+  const int T = (a.t_dev && *a.t_dev < a.T) ? *a.t_dev : a.T;
+  const int t0 = blockIdx.x * t_chunk;
+  const int t1 = t0 + t_chunk < T ? t0 + t_chunk : T;
+  if (t0 >= t1) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int col4 = (threadIdx.x & 63) * 4, rsub = threadIdx.x >> 6;
+  const int col = 256 * blockIdx.y + 32 * w + r;           // this lane's output column
+  int rb[2];
+  {
+    const int v = (r >> 2) & 3;
+    rb[0] = 4096 * (r >> 3) + 64 * (r & 7) + 16 * (h ^ v);
+    rb[1] = 4096 * (r >> 3) + 64 * (r & 7) + 16 * ((2 + h) ^ v);
+  }
+  bf16x8 wf[16];
+  for (int pass = 0; pass < 8; ++pass) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = rsub + 8 * i;
+      const float4 wv = *reinterpret_cast<const float4*>(a.W + (size_t)(256 * blockIdx.y + 32 * pass + rr) * a.ldw + col4);
+      *reinterpret_cast<dw64_b4*>(sX + dwp_off(rr, col4 >> 3) + 8 * ((col4 >> 2) & 1)) = dw64_b4{(__bf16)wv.x, (__bf16)wv.y, (__bf16)wv.z, (__bf16)wv.w};
+    }
+    __syncthreads();
+    if (pass == w) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) wf[ks] = *reinterpret_cast<const bf16x8*>(sX + rb[ks & 1] + 512 * (ks >> 1));
+    }
+    __syncthreads();
+  }
+  float4 xv[4];
+  auto request = [&](int s0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = s0 + rsub + 8 * i;
+      xv[i] = *reinterpret_cast<const float4*>(a.X + (size_t)(row < t1 ? row : t1 - 1) * a.ldx + col4);      // rows past the chunk: never stored
+    }
+  };
+  request(t0);
+  const float bias = a.b ? a.b[col] : 0.f;
+  const uint32_t key = (EPI & 2) ? drop_key(a.drop) : 0u;
+  typedef float f32x16y __attribute__((ext_vector_type(16)));
+  for (int s0 = t0; s0 < t1; s0 += DWP_TS) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = rsub + 8 * i;
+      *reinterpret_cast<dw64_b4*>(sX + dwp_off(rr, col4 >> 3) + 8 * ((col4 >> 2) & 1)) = dw64_b4{(__bf16)xv[i].x, (__bf16)xv[i].y, (__bf16)xv[i].z, (__bf16)xv[i].w};
+    }
+    __syncthreads();
+    if (s0 + DWP_TS < t1) request(s0 + DWP_TS);
+    f32x16y acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = bias;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(sX + rb[ks & 1] + 512 * (ks >> 1)), wf[ks], acc, 0, 0, 0);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {                 // eight elements at a time: the loads of a half first, then its arithmetic and stores
+      float rs[8];
+      int keep[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { rs[q] = 0.f; keep[q] = 1; }
+      if constexpr ((EPI & 1) != 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int e = 8 * half + q, row = s0 + (e & 3) + 8 * (e >> 2) + 4 * h, rc = row < t1 ? row : t1 - 1;
+          if (a.R) rs[q] = a.R[(size_t)rc * a.ldr + col];
+          if (a.R2) rs[q] += a.R2[(size_t)rc * a.ldr2 + col];
+          if (a.ids) keep[q] = a.ids[rc];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = 8 * half + q, row = s0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row >= t1) continue;
+        float v = acc[e];
+        if constexpr ((EPI & 4) != 0) {
+          if (a.U) a.U[(size_t)row * a.ldu + col] = v;
+          v = act_apply(a.act, v);
+        }
+        if constexpr ((EPI & 2) != 0) v = adt_keep(key, (uint32_t)(row + a.row_offset) * (uint32_t)a.N + (uint32_t)col, a.drop.thr) ? v * a.drop.scale : 0.f;
+        if constexpr ((EPI & 1) != 0) { v += rs[q]; if (keep[q] == 0) v = 0.f; }
+        a.Y[(size_t)row * a.ldy + col] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- input gradient of a 256 x 256 layer (bf16 operands): dX (+)= G W ------------------------------------------------------------------------
 // The LCE / k_dense_dw256 skeleton with the roles turned: the WEIGHT is the register-resident operand (wave w keeps W[:, 32 w .. 32 w + 31] as
 // sixteen B fragments, read once through ds_read_b64_tr_b16 from a staged image), the gradient streams through LDS in 32-token stages (one

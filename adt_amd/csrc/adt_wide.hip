@@ -118,7 +118,13 @@ static int gemm_launch(K kernel, size_t smem, int grid, hipStream_t s, const voi
 // ---- row-streaming kernels (adt_dense_rows.cuh): bf16 operands, contraction 64 / 128 / 256 ---------------------------------------
 static float* g_dense_ws = nullptr;      // scratch registered by the host (adt_dense_workspace): private partials of the 256 x 256 weight gradients
 static int64_t g_dense_ws_bytes = 0;
-static int g_rows_enabled = 1;      // adt_dense_rows_enable(0) routes everything to the tiled kernels (A/B measurements, tests)
+static int g_rows_enabled = 1;
+// ADT_STAGE256=0 in the environment keeps the 256-wide forward / input-gradient stage kernels (k_dense_fwd256, k_dense_dx256) off: A/B runs
+static bool stage_kernels_on() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("ADT_STAGE256"); on = (e && atoi(e) == 0) ? 0 : 1; }
+  return on != 0;
+}      // adt_dense_rows_enable(0) routes everything to the tiled kernels (A/B measurements, tests)
 
 template <class KFn, class Args>
 static int rows_launch(KFn kernel, const Args& a, int n_panels, int pc, int contraction, int T, hipStream_t s, bool& attr_done) {
@@ -207,6 +213,29 @@ static int launch_dense_dx_rows(const DenseBwdArgs& a0, hipStream_t s) {
 
 template <int PREC>
 static int launch_dense_fwd(const DenseFwdArgs& a0, hipStream_t s) {
+  const bool fwd256_plain = !(a0.R || a0.R2 || a0.ids) && !a0.drop.thr && a0.act == ACT_NONE && !a0.U;      // the packed in-projections
+  if (PREC == PREC_BF16 && g_rows_enabled && a0.K == 256 && (a0.N == 256 || (fwd256_plain && (a0.N % 256) == 0 && a0.N <= 768)) &&
+      (a0.ldx % 4) == 0 && aligned16(a0.X) && (a0.ldw % 4) == 0 && aligned16(a0.W) && stage_kernels_on()) {
+    // 256 x 256: weight rows in registers, activations through LDS, transposed output, compile-time epilogue (adt_gemm.cuh: k_dense_fwd256)
+    const int T = a0.T;
+    int nwg = (T + DWP_TS - 1) / DWP_TS;
+    const int cap = a0.N > 256 ? 512 / (a0.N / 256) : 256;
+    if (nwg > cap) nwg = cap;
+    const int chunk = ((T + nwg - 1) / nwg + DWP_TS - 1) / DWP_TS * DWP_TS;
+    const dim3 grid((T + chunk - 1) / chunk, a0.N / 256);
+    const int epi = ((a0.R || a0.R2 || a0.ids) ? 1 : 0) | (a0.drop.thr ? 2 : 0) | ((a0.act != ACT_NONE || a0.U) ? 4 : 0);
+    switch (epi) {
+      case 0: hipLaunchKernelGGL(k_dense_fwd256<0>, grid, dim3(DWP_NTH), 0, s, a0, chunk); break;
+      case 1: hipLaunchKernelGGL(k_dense_fwd256<1>, grid, dim3(DWP_NTH), 0, s, a0, chunk); break;
+      case 2: hipLaunchKernelGGL(k_dense_fwd256<2>, grid, dim3(DWP_NTH), 0, s, a0, chunk); break;
+      case 3: hipLaunchKernelGGL(k_dense_fwd256<3>, grid, dim3(DWP_NTH), 0, s, a0, chunk); break;
+      case 4: hipLaunchKernelGGL(k_dense_fwd256<4>, grid, dim3(DWP_NTH), 0, s, a0, chunk); break;
+      case 5: hipLaunchKernelGGL(k_dense_fwd256<5>, grid, dim3(DWP_NTH), 0, s, a0, chunk); break;
+      case 6: hipLaunchKernelGGL(k_dense_fwd256<6>, grid, dim3(DWP_NTH), 0, s, a0, chunk); break;
+      default: hipLaunchKernelGGL(k_dense_fwd256<7>, grid, dim3(DWP_NTH), 0, s, a0, chunk); break;
+    }
+    return 0;
+  }
   if (PREC == PREC_BF16 && rows_fwd_ok(a0)) return launch_dense_fwd_rows(a0, s);
   DenseFwdArgs a = a0;
   a.nt_n = a.N > 64 ? (a.N + 127) / 128 : 1;
@@ -223,7 +252,7 @@ static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
   DenseBwdArgs a = a0;
   const int T = a.G.T, N = a.G.N, K = a.K;
   if (PREC == PREC_BF16 && g_rows_enabled && a.dX && (N % 256) == 0 && N <= 768 && K == 256 && (a.ldw % 4) == 0 && aligned16(a.W) &&
-      (a.G.lddy % 4) == 0 && aligned16(a.G.dY) && (a.G.act == ACT_NONE || ((a.G.ldu % 4) == 0 && aligned16(a.G.U))) && getenv("ADT_DX256") == nullptr) {
+      (a.G.lddy % 4) == 0 && aligned16(a.G.dY) && (a.G.act == ACT_NONE || ((a.G.ldu % 4) == 0 && aligned16(a.G.U))) && stage_kernels_on()) {
     // contraction 256 / 512 / 768 into 256 columns: weight in registers, gradient tiles through LDS, transposed output (adt_gemm.cuh:
     // k_dense_dx256; wider outputs -- K = 1024 as four column blocks -- measured neutral against the row-streaming kernel and stay there)
     const int NB = N / 256, kblocks = K / 256;
