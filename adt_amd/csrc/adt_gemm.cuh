@@ -641,11 +641,12 @@ __global__ __launch_bounds__(256) void k_dense_dw256_reduce(const float* part, i
 // LDS in eight coalesced passes, pass p holds wave p's rows), the activations stream through LDS in 32-token stages, the output tile is
 // transposed (n on the lane, token on the accumulator rows) and the epilogue of k_dense_fwd runs on it -- same order of operations, same
 // dropout indices.  The epilogue is specialised at compile time (EPI bit 0: residuals / row mask, bit 1: dropout, bit 2: activation / U): the
-// generic form held 234 registers and per-element branches and was slower than the row-streaming kernel.
+// generic form held 234 registers and per-element branches and was slower than the row-streaming kernel.  Y, U, R, R2: 16-byte aligned rows.
 template <int EPI>
 __global__ __launch_bounds__(DWP_NTH) void k_dense_fwd256(DenseFwdArgs a, int t_chunk) {
   adt_prefetch_kernargs<sizeof(DenseFwdArgs) <= 512 ? sizeof(DenseFwdArgs) : 512>();
   __shared__ __attribute__((aligned(1024))) unsigned char sX[DWP_IMG];
+  __shared__ __attribute__((aligned(16))) float sT[32 * 260];
   const int T = (a.t_dev && *a.t_dev < a.T) ? *a.t_dev : a.T;
   const int t0 = blockIdx.x * t_chunk;
   const int t1 = t0 + t_chunk < T ? t0 + t_chunk : T;
@@ -700,34 +701,50 @@ __global__ __launch_bounds__(DWP_NTH) void k_dense_fwd256(DenseFwdArgs a, int t_
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(sX + rb[ks & 1] + 512 * (ks >> 1)), wf[ks], acc, 0, 0, 0);
+    if constexpr (EPI == 0) {                              // plain linear layer: straight from the accumulators (two 128-byte row segments per store)
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {                 // eight elements at a time: the loads of a half first, then its arithmetic and stores
-      float rs[8];
-      int keep[8];
+      for (int e = 0; e < 16; ++e) {
+        const int row = s0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < t1) a.Y[(size_t)row * a.ldy + col] = acc[e];
+      }
+    } else {
+    // the tile crosses LDS once (fp32 [32][260]) so that the epilogue runs on ROWS: 16-byte loads of the residuals, one dropout hash per four
+    // columns (adt_keep4), 16-byte stores of U and Y -- on the transposed accumulators it was 4-byte accesses and one hash per element
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { rs[q] = 0.f; keep[q] = 1; }
+    for (int e = 0; e < 16; ++e) sT[((e & 3) + 8 * (e >> 2) + 4 * h) * 260 + 32 * w + r] = acc[e];
+    __syncthreads();
+    const int colg = 256 * blockIdx.y + col4;
+    float4 rv[4], r2v[4];
+    int kp[4];
+    if constexpr ((EPI & 1) != 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = s0 + rsub + 8 * i, rc = row < t1 ? row : t1 - 1;
+        rv[i] = a.R ? *reinterpret_cast<const float4*>(a.R + (size_t)rc * a.ldr + colg) : make_float4(0.f, 0.f, 0.f, 0.f);
+        r2v[i] = a.R2 ? *reinterpret_cast<const float4*>(a.R2 + (size_t)rc * a.ldr2 + colg) : make_float4(0.f, 0.f, 0.f, 0.f);
+        kp[i] = a.ids ? a.ids[rc] : 1;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rl = rsub + 8 * i, row = s0 + rl;
+      if (row >= t1) continue;
+      float4 v = *reinterpret_cast<const float4*>(sT + rl * 260 + col4);
+      if constexpr ((EPI & 4) != 0) {
+        if (a.U) *reinterpret_cast<float4*>(a.U + (size_t)row * a.ldu + colg) = v;
+        v.x = act_apply(a.act, v.x); v.y = act_apply(a.act, v.y); v.z = act_apply(a.act, v.z); v.w = act_apply(a.act, v.w);
+      }
+      if constexpr ((EPI & 2) != 0) {
+        const uint32_t bits = adt_keep4(key, (uint32_t)(row + a.row_offset) * (uint32_t)a.N + (uint32_t)colg, a.drop.thr);
+        v.x = (bits & 1u) ? v.x * a.drop.scale : 0.f; v.y = (bits & 2u) ? v.y * a.drop.scale : 0.f;
+        v.z = (bits & 4u) ? v.z * a.drop.scale : 0.f; v.w = (bits & 8u) ? v.w * a.drop.scale : 0.f;
+      }
       if constexpr ((EPI & 1) != 0) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int e = 8 * half + q, row = s0 + (e & 3) + 8 * (e >> 2) + 4 * h, rc = row < t1 ? row : t1 - 1;
-          if (a.R) rs[q] = a.R[(size_t)rc * a.ldr + col];
-          if (a.R2) rs[q] += a.R2[(size_t)rc * a.ldr2 + col];
-          if (a.ids) keep[q] = a.ids[rc];
-        }
+        v.x += rv[i].x + r2v[i].x; v.y += rv[i].y + r2v[i].y; v.z += rv[i].z + r2v[i].z; v.w += rv[i].w + r2v[i].w;
+        if (kp[i] == 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int e = 8 * half + q, row = s0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row >= t1) continue;
-        float v = acc[e];
-        if constexpr ((EPI & 4) != 0) {
-          if (a.U) a.U[(size_t)row * a.ldu + col] = v;
-          v = act_apply(a.act, v);
-        }
-        if constexpr ((EPI & 2) != 0) v = adt_keep(key, (uint32_t)(row + a.row_offset) * (uint32_t)a.N + (uint32_t)col, a.drop.thr) ? v * a.drop.scale : 0.f;
-        if constexpr ((EPI & 1) != 0) { v += rs[q]; if (keep[q] == 0) v = 0.f; }
-        a.Y[(size_t)row * a.ldy + col] = v;
-      }
+      *reinterpret_cast<float4*>(a.Y + (size_t)row * a.ldy + colg) = v;
+    }
     }
     __syncthreads();
   }
