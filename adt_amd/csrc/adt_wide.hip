@@ -213,12 +213,11 @@ static int launch_dense_dx_rows(const DenseBwdArgs& a0, hipStream_t s) {
 
 template <int PREC>
 static int launch_dense_fwd(const DenseFwdArgs& a0, hipStream_t s) {
-  const bool fwd256_plain = !(a0.R || a0.R2 || a0.ids) && !a0.drop.thr && a0.act == ACT_NONE && !a0.U;      // the packed in-projections
-  if (PREC == PREC_BF16 && g_rows_enabled && a0.K == 256 && (a0.N == 256 || (fwd256_plain && (a0.N % 256) == 0 && a0.N <= 768)) &&
+  if (PREC == PREC_BF16 && g_rows_enabled && a0.K == 256 && (a0.N % 256) == 0 && a0.N <= 1024 &&
       (a0.ldx % 4) == 0 && aligned16(a0.X) && (a0.ldw % 4) == 0 && aligned16(a0.W) && (a0.ldy % 4) == 0 && aligned16(a0.Y) &&
       (!a0.U || ((a0.ldu % 4) == 0 && aligned16(a0.U))) && (!a0.R || ((a0.ldr % 4) == 0 && aligned16(a0.R))) && (!a0.R2 || ((a0.ldr2 % 4) == 0 && aligned16(a0.R2))) &&
       stage_kernels_on()) {
-    // 256 x 256: weight rows in registers, activations through LDS, transposed output, compile-time epilogue (adt_gemm.cuh: k_dense_fwd256)
+    // K = 256, N = 256 .. 1024: weight rows in registers, activations through LDS, compile-time epilogue on rows (adt_gemm.cuh: k_dense_fwd256)
     const int T = a0.T;
     int nwg = (T + DWP_TS - 1) / DWP_TS;
     const int cap = a0.N > 256 ? 512 / (a0.N / 256) : 256;
