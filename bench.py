@@ -158,6 +158,7 @@ def roofline_probe(model, trainer, B, seq_per_s, batch):
     if os.path.exists(pmc):
         traffic = round(json.load(open(pmc))["traffic_bytes"])
     step_bytes = 2.4e6
+    logits_entry = lce_probe(dev)
     return {"bound": "hbm", "kernel": "k_seqtt_dec_fwd (fused decoder-layer forward)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_us": round(us_dec, 2),
             "algorithmic_bytes_per_launch": dec_bytes,
@@ -171,10 +172,42 @@ def roofline_probe(model, trainer, B, seq_per_s, batch):
                  "achieved_TFLOPs": round(fl_fwd / (us_fwd * 1e-6) / 1e12, 2), "mfma_util": round(fl_fwd / (us_fwd * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)},
                 {"kernel": "k_seq_attn_bwd (standalone attention backward, C ABI)", "bound": "mfma", "avg_launch_us": round(us_bwd, 2),
                  "flops_per_launch": int(2.5 * fl_fwd), "achieved_TFLOPs": round(2.5 * fl_fwd / (us_bwd * 1e-6) / 1e12, 2),
-                 "mfma_util": round(2.5 * fl_fwd / (us_bwd * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)}],
+                 "mfma_util": round(2.5 * fl_fwd / (us_bwd * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)}] + ([logits_entry] if logits_entry else []),
             "step": {"bytes_per_sequence_ideal": step_bytes, "achieved_GBps": round(seq_per_s * step_bytes / 1e9, 1),
                      "frac": round(seq_per_s * step_bytes / 1e9 / HBM_PEAK_GBS, 4),
                      "mfma_util": round(seq_per_s * 250e6 / 1e12 / MFMA_PEAK_TFLOPS, 4)}}
+
+
+def lce_probe(dev):
+    """The MFMA-bound product north_star names besides attention: BERT4Rec-ADT's all-item logits + cross-entropy at BASELINE config 3's shape
+    (V + 100 = 26,844 items, d = 256, 5,921 masked rows of a 256 x 200 batch: the mean of the synthetic ml-20m batches), the fused forward +
+    backward of adt_lce_fwd_bwd timed with HIP events on the launch stream.  FLOPs: the five 2 M V d products it executes (forward scores,
+    score recompute + gradient product for dh and for dE); `useful` counts the three a materialising implementation needs."""
+    try:
+        import torch
+        from adt_amd import ops
+        T, V, K, M = 51200, 26844, 256, 5921
+        g = torch.Generator(device="cpu").manual_seed(5)
+        h = torch.randn(T, K, generator=g).to(dev)
+        E = (torch.randn(V, K, generator=g) / K ** 0.5).to(dev)
+        b = torch.zeros(V, device=dev)
+        rows = torch.zeros(T, dtype=torch.int32)
+        rows[:M] = torch.sort(torch.randperm(T, generator=g)[:M]).values.to(torch.int32)
+        lab = torch.zeros(T, dtype=torch.int32)
+        lab[:M] = torch.randint(1, V, (M,), generator=g).to(torch.int32)
+        rows, lab = rows.to(dev), lab.to(dev)
+        m_dev = torch.tensor([M], device=dev, dtype=torch.int32)
+        inv = torch.tensor([1.0 / M], device=dev)
+        loss64 = torch.zeros(64, device=dev)
+        dh, dE, db = torch.zeros(T, K, device=dev), torch.zeros(V, K, device=dev), torch.zeros(V, device=dev)
+        us = _time_us(lambda: ops.lce_fwd_bwd(h, rows, lab, T, m_dev, E, b, inv, loss64, dh, dE, db), reps=10)
+        one = 2.0 * M * V * K
+        return {"kernel": "adt_lce_fwd_bwd (BERT4Rec-ADT all-item logits + CE, fused forward + backward, config-3 shape: 5,921 rows x 26,844 items x 256)",
+                "bound": "mfma", "avg_launch_us": round(us, 1), "flops_per_launch": int(5 * one), "achieved_TFLOPs": round(5 * one / (us * 1e-6) / 1e12, 1),
+                "mfma_util": round(5 * one / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4), "useful_TFLOPs": round(3 * one / (us * 1e-6) / 1e12, 1)}
+    except Exception as e:       # a measurement extra: never fails the bench line
+        print("bench.py: lce probe skipped (%s)" % e, file=sys.stderr)
+        return None
 
 
 def self_launch(n):
