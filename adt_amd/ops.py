@@ -225,20 +225,26 @@ def dense_fwd(prec, X, W, b=None, act=ACT_NONE, save_u=False, p=0.0, seed=None, 
 _DENSE_WS = {}
 
 
+def _ensure_dense_ws(device):
+    """Scratch of the 256-wide stage kernels (adt_dense_workspace: private partials of the weight gradients): one 64 MiB buffer per device, kept for the process.  The library holds ONE pointer, so it is re-registered
+    when the calls move to another device (one process per GPU is the normal case and registers once, before any graph capture: the
+    trainers warm up eagerly)."""
+    if _DENSE_WS.get("current") == device:
+        return
+    ws = _DENSE_WS.get(device)
+    if ws is None:
+        ws = _DENSE_WS[device] = torch.empty(64 << 20, device=device, dtype=torch.uint8)
+    _lib.check(_lib.load().adt_dense_workspace(_p(ws), ws.numel()), "dense_workspace")
+    _DENSE_WS["current"] = device
+
+
 def dense_bwd(prec, dY, X, W, dW=None, db=None, dX=None, beta=False, act=ACT_NONE, U=None, p=0.0, seed=None, site=0, row_offset=0,
               mask_ids=None, t_dev=None):
     """G = dY * mask * dropmask * act'(U); dX (+)= G W; dW += G^T X; db += colsum(G)."""
     T, N = dY.shape
     K = W.shape[1]
-    if dW is not None and N % 256 == 0 and K % 256 == 0 and prec == PREC_BF16 and _DENSE_WS.get("current") != dY.device:
-        # scratch for the private-partial weight gradients of 256-wide layers (adt_dense_workspace): one buffer per device, kept for the
-        # process; the library holds ONE pointer, so it is re-registered when the calls move to another device (one process per GPU is the
-        # normal case and registers once, before any graph capture: the trainers warm up eagerly)
-        ws = _DENSE_WS.get(dY.device)
-        if ws is None:
-            ws = _DENSE_WS[dY.device] = torch.empty(64 << 20, device=dY.device, dtype=torch.uint8)
-        _lib.check(_lib.load().adt_dense_workspace(_p(ws), ws.numel()), "dense_workspace")
-        _DENSE_WS["current"] = dY.device
+    if dW is not None and N % 256 == 0 and K % 256 == 0 and prec == PREC_BF16:
+        _ensure_dense_ws(dY.device)
     _lib.check(_lib.load().adt_dense_bwd(prec, _p(_f32(dY)), _ld(dY), T, K, N, _p(mask_ids), float(p), _p(seed), site, row_offset, act, _p(U),
                                          _ld(U), _p(X), _ld(X), _p(_f32(W)), _ld(W), _p(dX), _ld(dX), int(beta), _p(dW), _ld(dW) if dW is not None else 0,
                                          _p(db), _p(t_dev), _stream()), "dense_bwd")
