@@ -33,7 +33,9 @@ def init_from_env(backend="nccl"):
     if world == 1 and not force:
         return None, 0, 1, local
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 2000))
+    # a pid-derived port only makes sense for the 1-rank group (ADT_FORCE_DP): with world > 1 every rank must agree on the port, so an
+    # unset MASTER_PORT (a manual launch without torchrun) falls back to torch's fixed default
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 2000) if world == 1 else "29500")
     if backend == "nccl":
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))

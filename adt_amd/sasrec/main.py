@@ -186,6 +186,9 @@ def main(argv=None):
             t_test, auc_test = U.evaluate_loader(model, test_ds.batches(args.eval_batch_size), args, "test", ks, process_group=pg)
             t_valid, auc_valid = U.evaluate_loader(model, val_ds.batches(args.eval_batch_size), args, "val", ks, process_group=pg)
             model.train()
+            # trainer.loss() sum-reduces the per-rank loss slots when world > 1: EVERY rank calls it (a collective issued by rank 0
+            # alone would pair with the other ranks' next gradient all-reduce)
+            last_loss = float(trainer.loss()) if trainer is not None else None
             if rank == 0:
                 for k in ks:
                     print("epoch: %d, time: %f, valid (NDCG@%d: %.4f, HR@%d: %.4f, AUC: %s), test (NDCG@%d: %.4f, HR@%d: %.4f, AUC: %s)"
@@ -193,7 +196,7 @@ def main(argv=None):
                 print(json.dumps({"epoch": epoch + 1, "train_seconds": T, "sequences_per_sec": nseq / max(T, 1e-9),
                                   "valid": {"ndcg10": t_valid[0][10], "hr10": t_valid[1][10], "auc": auc_valid},
                                   "test": {"ndcg10": t_test[0][10], "hr10": t_test[1][10], "auc": auc_test},
-                                  "loss": float(trainer.loss()) if trainer is not None else None}), flush=True)
+                                  "loss": last_loss}), flush=True)
                 logf.write(str(t_valid) + " " + str(t_test) + "\n")
                 logf.flush()
             if auc_valid >= best["score"]:     # model selection by valid AUC (sasrec/main.py:194-200)

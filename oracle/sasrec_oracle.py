@@ -107,6 +107,40 @@ def init_params(cfg, seed=0, dtype=np.float32):
 
 # ----------------------------------------------------------------------------------------------
 # primitives
+_OPERANDS = [None]
+
+
+def bf16_round(x):
+    """float32 -> nearest bfloat16 (ties to even), returned as float32: what `(__bf16)x` does in the kernels."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    u = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return u.view(np.float32)
+
+
+class operands:
+    """`with operands("bf16"):` -- every MATRIX product below rounds both operands to bfloat16 first and accumulates in fp32,
+    the arithmetic of the MFMA path's bf16 mode.  Everything else (LayerNorm, softmax statistics, dropout,
+    residuals, head classifier, logits, losses) stays fp32, as in the kernels.  Default (None): plain fp32, the reference's
+    arithmetic.  Used by the GPU tests to hold the bf16 kernels to a tighter bound than fp32-vs-bf16 rounding noise allows."""
+
+    def __init__(self, mode):
+        assert mode in (None, "bf16")
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = _OPERANDS[0]
+        _OPERANDS[0] = self.mode
+
+    def __exit__(self, *exc):
+        _OPERANDS[0] = self.prev
+
+
+def _mm(a, b):
+    if _OPERANDS[0] == "bf16":
+        return bf16_round(a) @ bf16_round(b)
+    return a @ b
+
+
 def _dropout(x, p, seed, site, idx):
     """y = x * keep / (1 - drop_prob(p)); keep from the shared hash RNG (oracle/rng.py: 8-bit thresholds)."""
     if p <= 0.0:
@@ -144,14 +178,14 @@ def layer_norm_bwd(dy, cache, w):
 
 
 def linear(x, w, b):
-    return x @ w.T + b
+    return _mm(x, w.T) + b
 
 
 def linear_bwd(dy, x, w):
     n = w.shape[0]
     dy2 = dy.reshape(-1, n)
     x2 = x.reshape(-1, w.shape[1])
-    return dy @ w, dy2.T @ x2, dy2.sum(0)
+    return _mm(dy, w), _mm(dy2.T, x2), dy2.sum(0)
 
 
 def embed(ids, E, P, p, seed, site, b_offset=0):
@@ -174,7 +208,7 @@ def attention(q, k, v, H, causal, p, seed, site, b_offset=0, key_keep=None):
     qh = q.reshape(B, L, H, hd).transpose(0, 2, 1, 3) / q.dtype.type(math.sqrt(hd))
     kh = k.reshape(B, L, H, hd).transpose(0, 2, 1, 3)
     vh = v.reshape(B, L, H, hd).transpose(0, 2, 1, 3)
-    s = qh @ kh.transpose(0, 1, 3, 2)  # (B,H,L,L)
+    s = _mm(qh, kh.transpose(0, 1, 3, 2))  # (B,H,L,L)
     if causal:
         s = np.where(np.tril(np.ones((L, L), dtype=bool))[None, None], s, -np.inf).astype(q.dtype)
     if key_keep is not None:  # key-padding variant (bert4rec); not used by sasrec
@@ -190,7 +224,7 @@ def attention(q, k, v, H, causal, p, seed, site, b_offset=0, key_keep=None):
         pd, keep = _dropout(pr, p, seed, site, idx)
     else:
         pd, keep = pr, None
-    o = (pd @ vh).transpose(0, 2, 1, 3).reshape(B, L, d)
+    o = _mm(pd, vh).transpose(0, 2, 1, 3).reshape(B, L, d)
     return o, (qh, kh, vh, pr, pd, keep, p, lse)
 
 
@@ -199,15 +233,15 @@ def attention_bwd(do, cache, H):
     B, _, L, hd = qh.shape
     d = H * hd
     doh = do.reshape(B, L, H, hd).transpose(0, 2, 1, 3)
-    dvh = pd.transpose(0, 1, 3, 2) @ doh
-    dpd = doh @ vh.transpose(0, 1, 3, 2)
+    dvh = _mm(pd.transpose(0, 1, 3, 2), doh)
+    dpd = _mm(doh, vh.transpose(0, 1, 3, 2))
     if keep is not None:
         dpr = dpd * keep * pr.dtype.type(1.0 / (1.0 - rng.drop_prob(p)))
     else:
         dpr = dpd
     ds = pr * (dpr - (dpr * pr).sum(-1, keepdims=True))
-    dqh = (ds @ kh) / qh.dtype.type(math.sqrt(hd))
-    dkh = ds.transpose(0, 1, 3, 2) @ qh  # qh already carries the 1/sqrt(hd)
+    dqh = _mm(ds, kh) / qh.dtype.type(math.sqrt(hd))
+    dkh = _mm(ds.transpose(0, 1, 3, 2), qh)  # qh already carries the 1/sqrt(hd)
     unh = lambda t: t.transpose(0, 2, 1, 3).reshape(B, L, d)
     return unh(dqh), unh(dkh), unh(dvh)
 

@@ -44,9 +44,12 @@ def main():
     ap.add_argument("--deterministic", action="store_true",
                     help="dropout 0, numpy initial weights oracle.sasrec_oracle.init_params(cfg, 23) and seeded batches from "
                          "adt_amd.sasrec.utils.WarpDataset.epoch_batches: the HIP run (tools/gpu_ndcg_run.py --deterministic) sees the same")
+    ap.add_argument("--seed", type=int, default=23, help="the reference's set_rng_seed value (init, batch order, dropout); the data file and "
+                                                         "the frozen evaluation candidates stay at seed 23, so every seed ranks the same items")
+    ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
-    torch.set_num_threads(8)
+    torch.set_num_threads(a.threads)
     import model as ref_model
     import utils as ref_utils
 
@@ -65,7 +68,7 @@ def main():
 
     # reference's seeding (sasrec/main.py:60-66, :71)
     import random
-    random.seed(23); np.random.seed(23); torch.manual_seed(23)
+    random.seed(a.seed); np.random.seed(a.seed); torch.manual_seed(a.seed)
     model = ref_model.SASRecADT(usernum, itemnum, args)
     for _, p in model.named_parameters():
         try:
@@ -94,7 +97,7 @@ def main():
         evals[mode] = [((torch.from_numpy(u), torch.from_numpy(s), torch.from_numpy(c.astype(np.int64))), torch.from_numpy(l))
                        for (u, s, c), l in ed.batches(512)]
 
-    log = {"deterministic": bool(a.deterministic), "preset": a.preset, "users": usernum, "items": itemnum, "hidden": a.hidden, "maxlen": a.maxlen, "evals": [], "loss": []}
+    log = {"seed": a.seed, "deterministic": bool(a.deterministic), "preset": a.preset, "users": usernum, "items": itemnum, "hidden": a.hidden, "maxlen": a.maxlen, "evals": [], "loss": []}
     t0 = time.time()
     for epoch in range(a.epochs):
         tot, nb = 0.0, 0
