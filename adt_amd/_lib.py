@@ -116,6 +116,7 @@ SIGNATURES = {
     "adt_sasrec_loss_seed": (_I, [_CP, _P, _P, _I, _P, _P, _P]),
     "adt_sasrec_loss_seed_nz": (_I, [_CP, _P, _P, _I, _P, _P, _P]),
     "adt_sasrec_step_begin": (_I, [_CP, _P, _I, _P, _U, _P, _P, _P, _L, _P, _P]),
+    "adt_sasrec_step_begin_ring": (_I, [_CP, _P, _I, _P, _U, _P, _L, _I, _P, _P, _P, _P, _P, _L, _P, _P]),
     "adt_sasrec_backward": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _U, _I, _P]),
     "adt_sasrec_predict": (_I, [_CP, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
 }

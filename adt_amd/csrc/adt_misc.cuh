@@ -523,9 +523,27 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* x, size_t n, float* 
 struct StepBeginArgs {
   uint32_t* seed; uint32_t inc; float* norms_dst; const float* norms_src; float* loss; int nloss; float* scal; float* G; size_t n;
   const float* E; size_t nE;
+  // optional id ring (adt_sasrec_step_begin_ring): slot (state[0] % nslots) of `ring` -- nslots blocks of slot_ints int32 in pinned HOST
+  // memory (read over PCIe by this kernel: no copy engine, no cross-queue wait between the copy and the step) or in HBM -- is copied to
+  // ids_dst (n_ints int32, a multiple of 4; its last four words are the loss normalisers, which then replace norms_src).  The last block
+  // to finish bumps state[0] and publishes the new count to *consumed (pinned host word the producer polls before it refills a slot).
+  const int32_t* ring; size_t slot_ints; int nslots; int32_t* ids_dst; size_t n_ints; uint32_t* state; uint32_t* consumed;
 };
 __global__ __launch_bounds__(256) void k_step_begin(StepBeginArgs a) {
   __shared__ float sbuf[4];
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const int32_t* slot = nullptr;
+  v4i idv[2];
+  size_t n16 = 0;
+  if (a.ring) {      // requests first: the PCIe round trips run under the zero-fill and the ||E||^2 sums below
+    slot = a.ring + (size_t)(a.state[0] % (uint32_t)a.nslots) * a.slot_ints;
+    n16 = a.n_ints / 4;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x + (size_t)u * gridDim.x * 256;
+      idv[u] = i < n16 ? __builtin_nontemporal_load(reinterpret_cast<const v4i*>(slot) + i) : v4i{0, 0, 0, 0};
+    }
+  }
   const size_t n4 = a.n / 4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
     reinterpret_cast<float4*>(a.G)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -539,8 +557,29 @@ __global__ __launch_bounds__(256) void k_step_begin(StepBeginArgs a) {
     if (threadIdx.x < 64) a.scal[128 + threadIdx.x] = 0.f;
     for (int i = threadIdx.x; i < a.nloss; i += 256) a.loss[i] = 0.f;
   } else if (blockIdx.x == 65) {
-    if (threadIdx.x < 4 && a.norms_dst) a.norms_dst[threadIdx.x] = a.norms_src[threadIdx.x];
+    const float* nsrc = slot ? reinterpret_cast<const float*>(slot + a.n_ints - 4) : a.norms_src;
+    if (threadIdx.x < 4 && a.norms_dst) a.norms_dst[threadIdx.x] = nsrc[threadIdx.x];
     if (threadIdx.x == 4 && a.seed) *a.seed += a.inc;
+  }
+  if (a.ring) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x + (size_t)u * gridDim.x * 256;
+      if (i < n16) reinterpret_cast<v4i*>(a.ids_dst)[i] = idv[u];
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x + (size_t)2 * gridDim.x * 256; i < n16; i += (size_t)gridDim.x * 256)      // larger batches
+      reinterpret_cast<v4i*>(a.ids_dst)[i] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(slot) + i);
+    __syncthreads();      // every thread of the block has its slot words in registers / stored: the block is done with the slot
+    if (threadIdx.x == 0) {
+      __threadfence();
+      if (atomicAdd(a.state + 1, 1u) == gridDim.x - 1) {      // the last block: every block has read state[0] and its part of the slot
+        a.state[1] = 0u;
+        const uint32_t c = a.state[0] + 1u;
+        a.state[0] = c;
+        __threadfence_system();
+        if (a.consumed) __hip_atomic_store(a.consumed, c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 

@@ -437,6 +437,18 @@ int adt_sasrec_step_begin(const adt_sasrec_cfg* c, float* ws, int B, uint32_t* s
                                (int64_t)(c->item_num + 1) * c->hidden, st);
 }
 
+int adt_sasrec_step_begin_ring(const adt_sasrec_cfg* c, float* ws, int B, uint32_t* seed, uint32_t seed_inc, const int32_t* ring, int64_t slot_ints,
+                               int nslots, int32_t* ids_dst, uint32_t* state, uint32_t* consumed, const float* P, float* G, int64_t n, float* scal,
+                               void* st) {
+  CK(check_cfg(c));
+  Layout lo;
+  make_layout(c, &lo);
+  WS w;
+  make_ws(c, B, &w);
+  return adt_step_begin_ring_launch(seed, seed_inc, ws + w.norms, ws + w.loss, 64 * (2 + 2 * c->num_layers), scal, G, n, P + lo.item(),
+                                    (int64_t)(c->item_num + 1) * c->hidden, ring, slot_ints, nslots, ids_dst, 4 * (int64_t)w.T + 4, state, consumed, st);
+}
+
 static int loss_seed_impl(const adt_sasrec_cfg* c, float* ws, const int32_t* pos, int B, const float* lambdas1, const float* lambdas2,
                           bool zero_loss, void* st);
 int adt_sasrec_loss_seed(const adt_sasrec_cfg* c, float* ws, const int32_t* pos, int B, const float* lambdas1,

@@ -81,7 +81,8 @@ def set_rng_seed(seed):
 def main(argv=None):
     args = parse_args(argv)
     from ..dp import global_norms, init_from_env, shard_bounds, skip_batch
-    pg, rank, world, local = init_from_env("nccl")     # torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE
+    # torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE; ADT_DIST_BACKEND=gloo lets several ranks share one GPU (tests)
+    pg, rank, world, local = init_from_env(os.environ.get("ADT_DIST_BACKEND", "nccl"))
     if args.device == "cuda":
         args.device = "cuda:%d" % local
     out_dir = args.dataset + "_" + args.train_dir
@@ -143,13 +144,20 @@ def main(argv=None):
             raise SystemExit("--loop reference is the single-process loop of sasrec/main.py; data-parallel runs use --loop fused")
         bce = torch.nn.BCEWithLogitsLoss()
         opt = torch.optim.Adam(model.parameters(), lr=args.lr, betas=(0.9, 0.98))
+    feeder = None
+    if isinstance(trainer, FusedTrainer) and warp._native is not None and os.environ.get("ADT_FEEDER", "1") != "0":
+        from .trainer import RingFeeder
+        feeder = RingFeeder(trainer, warp, rank, world)
     best = dict(score=0.0, epoch=0, valid=None, test=None, auc_valid=0.0, auc_test=0.0)
     T, t0, nseq = 0.0, time.time(), 0
     rng = np.random.RandomState(23)   # every rank draws the same global batches and takes its own shard
     for epoch in range(epoch_start - 1, args.num_epochs):
         if args.inference_only:
             break
-        for u, seq, dec, pos, neg in warp.epoch_batches(args.batch_size, rng):
+        if feeder is not None:       # native sampler -> pinned ring slots two steps ahead; one graph launch per step on this thread
+            for n in feeder.epoch(args.batch_size, rng):
+                nseq += n
+        for u, seq, dec, pos, neg in (() if feeder is not None else warp.epoch_batches(args.batch_size, rng)):
             if pg is not None:   # contiguous shard of the global batch (every rank draws the same batch: same seed)
                 if skip_batch(len(u), world):
                     continue        # a trailing batch with fewer sequences than ranks: dropped on every rank alike

@@ -172,6 +172,13 @@ class SASRecADT(torch.nn.Module):
                                                   _ptr(self.flat), _ptr(self.flat_grad), self.flat_grad.numel(), _ptr(scal), self._stream()),
                    "sasrec_step_begin")
 
+    def run_step_begin_ring(self, B, ring, slot_ints, nslots, ids_dst, state, consumed, scal, seed_inc=0x9E3779B1):
+        """run_step_begin that first fetches the packed id batch of ring slot (state[0] % nslots) into ids_dst (adt_sasrec_step_begin_ring);
+        `ring` / `consumed` are pinned host tensors (read / written by the kernel over PCIe) or device tensors."""
+        _lib.check(self.lib.adt_sasrec_step_begin_ring(ctypes.byref(self.cfg), _ptr(self.workspace(B)), B, _ptr(self._seed), seed_inc, _ptr(ring),
+                                                       slot_ints, nslots, _ptr(ids_dst), _ptr(state), _ptr(consumed), _ptr(self.flat),
+                                                       _ptr(self.flat_grad), self.flat_grad.numel(), _ptr(scal), self._stream()), "sasrec_step_begin_ring")
+
     def run_loss_seed(self, pos, B, lambdas1, lambdas2, zero_loss=True):
         nl = self.num_layers
         l1 = (ctypes.c_float * nl)(*[float(x) for x in lambdas1])

@@ -88,14 +88,10 @@ class WarpDataset:
     def _init_native(self):
         """CSR copy of the histories for libadt_host.so (adt_amd/csrc/adt_hostdata.cpp).  When the library has not been
         built the numpy sampler below is used: same semantics, ~100x slower."""
-        import ctypes
-        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc", "libadt_host.so")
-        if not os.path.exists(path):
+        from .. import _hostlib
+        if not _hostlib.available():
             return
-        lib = ctypes.CDLL(path)
-        P, I = ctypes.c_void_p, ctypes.c_int
-        lib.adt_host_sample_batch.restype = I
-        lib.adt_host_sample_batch.argtypes = [P, P, P, I, I, I, ctypes.c_uint64, P, P, P, P, I]
+        lib = _hostlib.load()
         off = np.zeros(self.usernum + 2, np.int64)
         for u in range(1, self.usernum + 1):
             off[u + 1] = off[u] + len(self.user_train.get(u, []))
@@ -145,9 +141,8 @@ class WarpDataset:
             lib, off, items = self._native
             us = np.ascontiguousarray(users, dtype=np.int32)
             out = [np.empty((B, L), np.int32) for _ in range(4)]
-            self._calls += 1
-            seed = int(rng.randint(0, 2 ** 31 - 1)) * 2654435761 + self._calls
-            rc = lib.adt_host_sample_batch(off.ctypes.data, items.ctypes.data, us.ctypes.data, B, L, self.itemnum, seed & (2 ** 64 - 1),
+            seed = self.next_seed(rng)
+            rc = lib.adt_host_sample_batch(off.ctypes.data, items.ctypes.data, us.ctypes.data, B, L, self.itemnum, seed,
                                            out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, out[3].ctypes.data, 1)   # 1 thread: 0.2 ms / 256-sequence batch
             if rc != 0:
                 raise RuntimeError("adt_host_sample_batch failed")
@@ -160,8 +155,8 @@ class WarpDataset:
             _, seq[b], dec[b], pos[b], neg[b] = self.sample_data(u, rng)
         return np.asarray(users), seq, dec, pos, neg
 
-    def epoch_batches(self, batch_size, rng=np.random, shuffle=True, drop_last=False):
-        """One epoch = usernum samples (sasrec/utils.py:316-317), shuffled like DataLoader(shuffle=True)."""
+    def epoch_users(self, batch_size, rng=np.random, shuffle=True, drop_last=False):
+        """The user ids of every batch of one epoch = usernum samples (sasrec/utils.py:316-317), shuffled like DataLoader(shuffle=True)."""
         order = np.arange(self.usernum)
         if shuffle:
             rng.shuffle(order)
@@ -175,7 +170,33 @@ class WarpDataset:
                 while len(self._hist(u)) < 1:
                     u = rng.randint(1, self.usernum + 1)
                 users.append(u)
+            yield users
+
+    def epoch_batches(self, batch_size, rng=np.random, shuffle=True, drop_last=False):
+        for users in self.epoch_users(batch_size, rng, shuffle, drop_last):
             yield self.sample_batch(users, rng)
+
+    # ---- in-place sampling for the trainer's pinned id ring (adt_amd/sasrec/trainer.py: RingFeeder) --------------------------------
+    def next_seed(self, rng=np.random):
+        """The per-batch seed of the native sampler, drawn exactly as sample_batch() draws it."""
+        self._calls += 1
+        return (int(rng.randint(0, 2 ** 31 - 1)) * 2654435761 + self._calls) & (2 ** 64 - 1)
+
+    def sample_rows_into(self, users, seed, out, b0=0):
+        """Rows [b0, b0 + len(users)) of a global batch, written straight into the four (B, L) int32 arrays `out` (views of a ring slot).
+        Native sampler only; callable from a producer thread (the C call releases the GIL)."""
+        lib, off, items = self._native
+        us = np.ascontiguousarray(users, dtype=np.int32)
+        rc = lib.adt_host_sample_rows(off.ctypes.data, items.ctypes.data, us.ctypes.data, len(us), b0, self.maxlen, self.itemnum, seed,
+                                      out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, out[3].ctypes.data, 1)
+        if rc != 0:
+            raise RuntimeError("adt_host_sample_rows failed")
+
+    def count_targets(self, users):
+        """Number of positions with a target in the batch of `users` (the BCE normaliser, sasrec/main.py:150-153), without sampling it."""
+        lib, off, _ = self._native
+        us = np.ascontiguousarray(users, dtype=np.int32)
+        return int(lib.adt_host_count_targets(off.ctypes.data, us.ctypes.data, len(us), self.maxlen))
 
 
 class PopularSampler:

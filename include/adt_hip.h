@@ -361,6 +361,16 @@ int adt_sasrec_loss_seed(const adt_sasrec_cfg* cfg, float* ws, const int32_t* po
  * adt_sasrec_loss_seed_nz (adt_sasrec_loss_seed without its loss-slot fill) and adt_clip_adam_pre. */
 int adt_sasrec_step_begin(const adt_sasrec_cfg* cfg, float* ws, int B, uint32_t* seed, uint32_t seed_inc, const float* norms_src,
                           const float* params, float* grads, int64_t n, float* scal, void* stream);
+/* adt_sasrec_step_begin that also FETCHES the step's id batch (sasrec/main.py:144-145: the batch the DataLoader hands the loop becomes device
+ * tensors at model.py:34,37,40,53).  `ring` holds nslots blocks of slot_ints int32 each, in pinned HOST memory (the kernel reads it over
+ * PCIe: no copy-engine transfer, no cross-queue wait between "copy" and "step") or in HBM; one block is the packed batch
+ * [seq | dec | pos | neg] (4 B L ids) + the three loss normalisers as float bits + a zero word.  Slot (state[0] % nslots) is copied to
+ * ids_dst (4 B L + 4 int32) and its normalisers go to NORMS; then state[0] += 1 and, if `consumed` is not NULL, the new count is stored to
+ * *consumed (a pinned host word the producer polls before it refills a slot: a slot written for step k is free once *consumed > k).
+ * `state` = two zero-initialised device uint32 (step count, block ticket).  slot_ints a multiple of 4, >= 4 B L + 4. */
+int adt_sasrec_step_begin_ring(const adt_sasrec_cfg* cfg, float* ws, int B, uint32_t* seed, uint32_t seed_inc, const int32_t* ring,
+                               int64_t slot_ints, int nslots, int32_t* ids_dst, uint32_t* state, uint32_t* consumed, const float* params,
+                               float* grads, int64_t n, float* scal, void* stream);
 int adt_sasrec_loss_seed_nz(const adt_sasrec_cfg* cfg, float* ws, const int32_t* pos, int B, const float* lambdas1,
                             const float* lambdas2, void* stream);
 /* reverse pass: consumes the G_* buffers (destroyed), accumulates into `grads` (same layout as params).

@@ -15,7 +15,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 
-def run(preset, epochs, eval_every, seed, precision, hidden=64, maxlen=200, data=None, deterministic=False):
+def run(preset, epochs, eval_every, seed, precision, hidden=64, maxlen=200, data=None, deterministic=False, device="cuda:0"):
     """deterministic: dropout 0, the numpy initial weights oracle.sasrec_oracle.init_params(cfg, 23) and the seeded batches of
     WarpDataset.epoch_batches(256, RandomState(1000 + epoch)) -- what tools/ref_train_ndcg.py --deterministic gave the reference."""
     import torch
@@ -30,7 +30,7 @@ def run(preset, epochs, eval_every, seed, precision, hidden=64, maxlen=200, data
     class A:
         pass
     a = A()
-    a.device, a.num_heads, a.maxlen, a.num_layers, a.hidden_units, a.dropout, a.precision = "cuda:0", 2, maxlen, 2, hidden, (0.0 if deterministic else 0.5), precision
+    a.device, a.num_heads, a.maxlen, a.num_layers, a.hidden_units, a.dropout, a.precision = device, 2, maxlen, 2, hidden, (0.0 if deterministic else 0.5), precision
     torch.manual_seed(seed)
     np.random.seed(seed)
     if hidden != 64:       # the template width (d = 256) runs on the general kernels, as adt_amd/sasrec/main.py routes it
