@@ -76,3 +76,7 @@ def main():
     t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     print("device ring: %.4f ms/step (host %.4f)" % ((time.perf_counter() - t0) / n * 1e3, t_host / n * 1e3))
+
+
+if __name__ == "__main__":
+    main()
