@@ -41,6 +41,8 @@ def init_from_env(backend="nccl"):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
+        if torch.cuda.device_count() > 0:      # gloo ranks may share a GPU (the one-GPU test box): fold the local rank onto the devices present
+            local = local % torch.cuda.device_count()
     return dist.group.WORLD, rank, world, local
 
 
