@@ -78,6 +78,21 @@ def build_model(device, prec):
     return m
 
 
+def _cpu_share():
+    """Threads for the CPU baseline: the cores this process may use -- its affinity mask, capped by a cgroup CPU quota when one is set
+    (a one-GPU lease of a shared host gets a share of its cores) -- or ADT_CPU_THREADS."""
+    if os.environ.get("ADT_CPU_THREADS"):
+        return int(os.environ["ADT_CPU_THREADS"])
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline():
     """The CPU restatement of the identical train step (oracle/csrc/adt_cpu.cpp -> libadt_cpu.so: C++17 / OpenMP, fp32, one task per user
     sequence; pinned to the reference's golden vectors by tests/test_cpu_restatement.py) timed on this host's cores on a bounded sample of the
@@ -87,7 +102,7 @@ def cpu_baseline():
     from oracle import cpu_restatement as cr
     from oracle import sasrec_oracle as so
     cfg = so.Cfg(CFG["item_num"], CFG["maxlen"], CFG["hidden_units"], CFG["num_heads"], CFG["num_layers"], CFG["dropout"])
-    m = cr.CpuSasrec(CFG["item_num"], CFG["maxlen"], CFG["hidden_units"], CFG["num_heads"], CFG["num_layers"], CFG["dropout"])
+    m = cr.CpuSasrec(CFG["item_num"], CFG["maxlen"], CFG["hidden_units"], CFG["num_heads"], CFG["num_layers"], CFG["dropout"], threads=_cpu_share())
     m.load_params(so.init_params(cfg, 0))
     B = CFG["batch"]
     batch = synth_batches(1, B, CFG["maxlen"], CFG["item_num"], 5)[0]
