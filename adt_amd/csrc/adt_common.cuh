@@ -98,6 +98,22 @@ __host__ __device__ __forceinline__ uint32_t adt_keep4(uint32_t key, uint32_t id
          ((h >> 24) >= thr ? 8u : 0u);
 }
 
+// The same four decisions WITHOUT compares: bit 8r + 7 of the result is set iff byte r of h >= thr (1 <= thr <= 255; the other bits
+// are scratch).  byte >= thr <=> the 8-bit sum byte + (256 - thr) carries out = majority(byte's bit 7, the constant's bit 7, the carry
+// out of the low seven bits); three bit operations for the four bytes (the last is one v_bitop3_b32), no VCC round trips.
+// clo = ((256 - thr) & 0x7F) * 0x01010101, chi = ((256 - thr) & 0x80) * 0x01010101 (adt_keep7_consts).
+__host__ __device__ __forceinline__ uint32_t adt_keep7(uint32_t h, uint32_t clo, uint32_t chi) {
+  const uint32_t lo = (h & 0x7F7F7F7Fu) + clo;
+  return (h & lo) | (chi & (h | lo));
+}
+__host__ __device__ __forceinline__ void adt_keep7_consts(uint32_t thr, uint32_t& clo, uint32_t& chi) {
+  const uint32_t c = 256u - thr;
+  clo = (c & 0x7Fu) * 0x01010101u;
+  chi = (c & 0x80u) * 0x01010101u;
+}
+// bits 7, 15, 23, 31 of a keep7 word gathered into a nibble (bit r = keep of byte r): the four products land on distinct bits 28 .. 31
+__host__ __device__ __forceinline__ uint32_t adt_keep7_nibble(uint32_t k7) { return ((k7 & 0x80808080u) * 0x00204081u) >> 28; }
+
 struct DropCfg {
   const uint32_t* seed;  // device scalar (changes every step; lives in device memory so a captured graph replays)
   uint32_t site;

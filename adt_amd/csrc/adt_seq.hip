@@ -15,14 +15,14 @@ static int seq_check(const char* what) {
   return 0;
 }
 
-static int seq_launch(const void* fn, size_t smem, bool& attr_done, int grid, const void* args_ptr, hipStream_t s, const char* what) {
+static int seq_launch(const void* fn, size_t smem, bool& attr_done, int grid, const void* args_ptr, hipStream_t s, const char* what, int nwaves = SQ_NW) {
   if (!attr_done) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return adt_set_error("%s: hipFuncSetAttribute(%zu)", what, smem);
     attr_done = true;
   }
   void* kargs[] = {const_cast<void*>(args_ptr)};
-  if (hipLaunchKernel(fn, dim3(grid), dim3(SQ_NW * 64), kargs, smem, s) != hipSuccess) return adt_set_error("%s: launch failed", what);
+  if (hipLaunchKernel(fn, dim3(grid), dim3(nwaves * 64), kargs, smem, s) != hipSuccess) return adt_set_error("%s: launch failed", what);
   return seq_check(what);
 }
 
@@ -97,7 +97,7 @@ static unsigned long long* seq_stamp_buffer(bool for_attention) {      // ADT_SE
   if (st < 0) {
     const char* e = getenv("ADT_SEQ_STAMPS");
     st = e ? atoi(e) : 0;
-    if (st && hipMalloc(&g_stamps, 8 * 16 * sizeof(unsigned long long)) != hipSuccess) st = 0;
+    if (st && hipMalloc(&g_stamps, 16 * 16 * sizeof(unsigned long long)) != hipSuccess) st = 0;
   }
   return (st == (for_attention ? 2 : 1)) ? g_stamps : nullptr;
 }
@@ -125,9 +125,9 @@ int adt_launch_seq_enc_fwd(int hd, const SeqFwdArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (seq_use_tt(args)) {
     const size_t smem_tt = SeqTtLds<6>::bytes;
-    if (hd == 64) return seq_launch((const void*)k_seqtt_enc_fwd<64>, smem_tt, done_tt[0], a.B, &args, s, "seqtt_enc_fwd<64>");
-    if (hd == 32) return seq_launch((const void*)k_seqtt_enc_fwd<32>, smem_tt, done_tt[1], a.B, &args, s, "seqtt_enc_fwd<32>");
-    if (hd == 16) return seq_launch((const void*)k_seqtt_enc_fwd<16>, smem_tt, done_tt[2], a.B, &args, s, "seqtt_enc_fwd<16>");
+    if (hd == 64) return seq_launch((const void*)k_seqtt_enc_fwd<64>, smem_tt, done_tt[0], a.B, &args, s, "seqtt_enc_fwd<64>", TQ_FWD_NW);
+    if (hd == 32) return seq_launch((const void*)k_seqtt_enc_fwd<32>, smem_tt, done_tt[1], a.B, &args, s, "seqtt_enc_fwd<32>", TQ_FWD_NW);
+    if (hd == 16) return seq_launch((const void*)k_seqtt_enc_fwd<16>, smem_tt, done_tt[2], a.B, &args, s, "seqtt_enc_fwd<16>", TQ_FWD_NW);
   }
   const size_t smem = SeqFwdLds<6>::bytes;
   if (hd == 64) return seq_launch((const void*)k_seq_enc_fwd<64, 2>, smem, done[0], a.B, &args, s, "seq_enc_fwd<64>");
@@ -144,9 +144,9 @@ int adt_launch_seq_dec_fwd(int hd, const SeqFwdArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (seq_use_tt(args)) {
     const size_t smem_tt = SeqTtLds<5>::bytes;
-    if (hd == 64) return seq_launch((const void*)k_seqtt_dec_fwd<64>, smem_tt, done_tt[0], a.B, &args, s, "seqtt_dec_fwd<64>");
-    if (hd == 32) return seq_launch((const void*)k_seqtt_dec_fwd<32>, smem_tt, done_tt[1], a.B, &args, s, "seqtt_dec_fwd<32>");
-    if (hd == 16) return seq_launch((const void*)k_seqtt_dec_fwd<16>, smem_tt, done_tt[2], a.B, &args, s, "seqtt_dec_fwd<16>");
+    if (hd == 64) return seq_launch((const void*)k_seqtt_dec_fwd<64>, smem_tt, done_tt[0], a.B, &args, s, "seqtt_dec_fwd<64>", TQ_FWD_NW);
+    if (hd == 32) return seq_launch((const void*)k_seqtt_dec_fwd<32>, smem_tt, done_tt[1], a.B, &args, s, "seqtt_dec_fwd<32>", TQ_FWD_NW);
+    if (hd == 16) return seq_launch((const void*)k_seqtt_dec_fwd<16>, smem_tt, done_tt[2], a.B, &args, s, "seqtt_dec_fwd<16>", TQ_FWD_NW);
   }
   const size_t smem = SeqFwdLds<5>::bytes;
   if (hd == 64) return seq_launch((const void*)k_seq_dec_fwd<64>, smem, done[0], a.B, &args, s, "seq_dec_fwd<64>");

@@ -10,7 +10,8 @@ namespace adt {
 
 #define TQ_STAMP(k) do { if (a.stamps && blockIdx.x == 0 && lane == 0) a.stamps[w * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 
-constexpr int TQ_NW = 8;                       // waves per workgroup
+constexpr int TQ_NW = 8;                       // waves per workgroup of the backward kernels that share tq_tile
+constexpr int TQ_FWD_NW = 12;                  // forward kernels: 12 waves = 3 per SIMD (<= 168 VGPRs): the 13 tiles of L = 200 are one per wave but one (tq_tile12)
 constexpr int TQ_MAXKT = 14;                   // 16-token tiles per sequence: L <= 224
 constexpr int TQ_LP = TQ_MAXKT * 16;
 
@@ -86,10 +87,20 @@ ADT_DEVICE_INLINE void tq_store_y(const SeqFwdArgs& a, size_t row, TT y, bool va
 // w + 4 share a SIMD, and with the straight order (tile w for w < n-8) SIMD 0 carried causal weight 13+9+1+5 = 28 of 91 at n = 13
 // against 20 for SIMD 3 -- its waves finished the attention phases 5k cycles after the others (profiles/r02_stamps_fwd.txt);
 // the snake gives 24 / 23 / 22 / 22.
-ADT_DEVICE_INLINE int tq_tile(int s, int w, int ntiles) {
-  if (s == 0) return ntiles - 1 - w;
-  const int t = ntiles - 2 * TQ_NW + w;
+ADT_DEVICE_INLINE int tq_tile(int s, int w, int ntiles, int nw = TQ_NW) {
+  if (s == 0) return ntiles - 1 - w;          // < 0: no tile for this wave in this slot
+  const int t = ntiles - 2 * nw + w;
   return t >= 0 ? t : -1;
+}
+// Forward kernels, 12 waves: waves w, w + 4 and w + 8 share a SIMD, and the attention phase is bound by each SIMD's vector-instruction
+// issue (profiles/r03_stamps_fwd12.txt: with tile 12 - w on wave w, SIMD 0 carried causal weight 13 + 9 + 5 = 27 of 91 against 19 on
+// SIMD 3 and its waves left the phase 7k cycles after the others).  The tiles, heaviest first (j = 0 is tile ntiles - 1), are dealt to the
+// four SIMD classes in snake order 0 1 2 3 3 2 1 0 0 1 2 3 3 ..: wave w takes round k = w / 4 in slot 0 and waves 8 .. 11 take round 3 in
+// slot 1 -- 24 / 23 / 22 / 22 at 13 tiles.
+ADT_DEVICE_INLINE int tq_tile12(int s, int w, int ntiles) {
+  const int cl = w & 3, k = s == 0 ? (w >> 2) : ((w >> 2) == 2 ? 3 : 4);
+  const int j = 4 * k + ((k & 1) ? 3 - cl : cl);
+  return (k < 4 && j < ntiles) ? ntiles - 1 - j : -1;
 }
 
 // slot-ordered packed image of the 64 x 64 block at W (adt_seq.hip: k_pack_wimg writes it at + 2 images, transposed at + 3)
@@ -106,13 +117,16 @@ ADT_DEVICE_INLINE const uint4* tq_img_src(const SeqFwdArgs& a, const float* W, b
 // one weight image per statement, in named registers: the array-of-registers form (tq_img_load) was kept in scratch by the compiler in
 // these two kernels, with a wait for the loads right behind their issue
 // (the tail load is unconditional -- lanes without a tail chunk re-read their first chunk: a load inside `if (tq_tail)` drew a vmcnt(0) behind it)
-#define TQ_IMG_LOAD(k, Wk) const uint4* tqp##k = tq_img_src(a, Wk, false); const uint4 tqr##k = tqp##k[threadIdx.x]; \
-  const uint4 tqt##k = tqp##k[tq_tail ? threadIdx.x + TQ_NW * 64 : threadIdx.x];
-#define TQ_IMG_STORE(k, dstk) reinterpret_cast<uint4*>(dstk)[threadIdx.x] = tqr##k; if (tq_tail) reinterpret_cast<uint4*>(dstk)[threadIdx.x + TQ_NW * 64] = tqt##k;
+// (TQW = the kernel's wave count; an image is TQ_CH 16-byte chunks: with more threads than chunks the surplus threads re-read chunk 0 and store nothing)
+constexpr int TQ_CH = TT_WIMG * 2 / 16;
+#define TQ_IMG_LOAD(k, Wk) const uint4* tqp##k = tq_img_src(a, Wk, false); const uint4 tqr##k = tqp##k[tq_body ? threadIdx.x : 0]; \
+  const uint4 tqt##k = tqp##k[tq_tail ? threadIdx.x + TQW * 64 : 0];
+#define TQ_IMG_STORE(k, dstk) if (tq_body) reinterpret_cast<uint4*>(dstk)[threadIdx.x] = tqr##k; if (tq_tail) reinterpret_cast<uint4*>(dstk)[threadIdx.x + TQW * 64] = tqt##k;
 
+template <int NTHREADS>
 ADT_DEVICE_INLINE void tq_zero(__bf16* p, size_t nbytes) {
   uint4* q = reinterpret_cast<uint4*>(p);
-  for (int i = threadIdx.x; i < (int)(nbytes / 16); i += TQ_NW * 64) q[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = threadIdx.x; i < (int)(nbytes / 16); i += NTHREADS) q[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // layer input of this lane's token: a load, or the embedding gather x = dropout(E[id] * sqrt(d) + P[l]) * (id != 0)   (model.py:34-41).
@@ -209,7 +223,8 @@ ADT_DEVICE_INLINE TT tq_ffn(const SeqFwdArgs& a, const float* vec, const __bf16*
 
 // ---- encoder layer: weight images 0 Wq, 1 Wk, 2 Wv, 3 out_proj, 4 conv1, 5 conv2 ------------------------------------------------
 template <int HD>
-__global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
+__global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
+  constexpr int TQW = TQ_FWD_NW;
   adt_prefetch_kernargs<(sizeof(SeqFwdArgs) + 63) / 64 * 64 <= 512 ? sizeof(SeqFwdArgs) : 512>();      // adt_common.cuh
   constexpr int H = 64 / HD, KB = (HD + 31) / 32, NF = H * KB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -224,25 +239,26 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
     if (!a.x) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int tile = tq_tile(s, w, ntiles), l = tile * 16 + c;
+        const int tile = tq_tile12(s, w, ntiles), l = tile * 16 + c;
         idr[s] = tt_load_id(a.ids, b * L + l, tile >= 0 && l < L);
       }
     }
-    const bool tq_tail = threadIdx.x < TT_WIMG * 2 / 16 - TQ_NW * 64;        // the last 64 chunks of an image: the first wave (wave-uniform)
+    const bool tq_body = TQW * 64 <= TQ_CH || threadIdx.x < TQ_CH;
+    const bool tq_tail = (int)threadIdx.x < TQ_CH - TQW * 64;        // chunks beyond the first TQW * 64 (wave-uniform: whole waves)
     TQ_IMG_LOAD(0, a.Win) TQ_IMG_LOAD(1, a.Win + 4096) TQ_IMG_LOAD(2, a.Win + 8192) TQ_IMG_LOAD(3, a.Wo) TQ_IMG_LOAD(4, a.W1) TQ_IMG_LOAD(5, a.W2)
-    const TqVecRegs vr = tq_vec_load<TQ_NW * 64>(a, H, HD);
+    const TqVecRegs vr = tq_vec_load<TQW * 64>(a, H, HD);
     if (a.drop.thr) seedv = *a.drop.seed;     // behind the image requests: read first, its round trip preceded every other load of the kernel
 #pragma unroll
     for (int s = 0; s < 2; ++s) {             // the layer input of both tiles, in flight while the images are stored
-      const int tile = tq_tile(s, w, ntiles), l = tile * 16 + c;
+      const int tile = tq_tile12(s, w, ntiles), l = tile * 16 + c;
       xr[s] = tq_x_request(a, b * L + l, l, tile >= 0 && l < L, idr[s], g);
     }
     TQ_STAMP(11);
-    tq_zero(lds.sK, 2 * SeqTtLds<6>::ibytes);
+    tq_zero<TQW * 64>(lds.sK, 2 * SeqTtLds<6>::ibytes);
     TQ_STAMP(12);
     TQ_IMG_STORE(0, lds.w[0]) TQ_IMG_STORE(1, lds.w[1]) TQ_IMG_STORE(2, lds.w[2]) TQ_IMG_STORE(3, lds.w[3]) TQ_IMG_STORE(4, lds.w[4]) TQ_IMG_STORE(5, lds.w[5])
     TQ_STAMP(13);
-    tq_vec_store<TQ_NW * 64>(lds.vec, vr);
+    tq_vec_store<TQW * 64>(lds.vec, vr);
     TQ_STAMP(14);
   }
   __syncthreads();
@@ -253,7 +269,7 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
   TT xn[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+    const int tile = tq_tile12(s, w, ntiles);
     if (tile >= 0) tq_pre_tile<HD, true>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[s], xn[s], xr[s]);
     TQ_STAMP(2 + s);
   }
@@ -261,7 +277,7 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
   TQ_STAMP(4);
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+    const int tile = tq_tile12(s, w, ntiles);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
@@ -317,7 +333,8 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) {
 // ---- decoder layer: set A: 0 Wq, 1 Wk, 2 Wv (slf_attn), 3 slf out_proj, 4 enc_attn Wq ; set B: 0 enc_attn Wk, 1 Wv, 2 enc_attn out_proj,
 // 3 conv1, 4 conv2 -------------------------------------------------------------------------------------------------------------------
 template <int HD>
-__global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
+__global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
+  constexpr int TQW = TQ_FWD_NW;
   adt_prefetch_kernargs<(sizeof(SeqFwdArgs) + 63) / 64 * 64 <= 512 ? sizeof(SeqFwdArgs) : 512>();      // adt_common.cuh
   constexpr int H = 64 / HD, KB = (HD + 31) / 32, NF = H * KB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -325,28 +342,29 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
   SeqTtLds<5> lds(smem_raw);
   const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16;
   uint32_t seedv = 0u;
-  const bool tq_tail = threadIdx.x < TT_WIMG * 2 / 16 - TQ_NW * 64;        // the last 64 chunks of an image: the first wave (wave-uniform)
+  const bool tq_body = TQW * 64 <= TQ_CH || threadIdx.x < TQ_CH;
+  const bool tq_tail = (int)threadIdx.x < TQ_CH - TQW * 64;        // chunks beyond the first TQW * 64 (wave-uniform: whole waves)
   TqX xr[2];
   {
     int idr[2] = {0, 0};                      // ids first, layer inputs of both tiles behind the images (see k_seqtt_enc_fwd)
     if (!a.x) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int tile = tq_tile(s, w, ntiles), l = tile * 16 + c;
+        const int tile = tq_tile12(s, w, ntiles), l = tile * 16 + c;
         idr[s] = tt_load_id(a.ids, b * L + l, tile >= 0 && l < L);
       }
     }
     TQ_IMG_LOAD(0, a.Win) TQ_IMG_LOAD(1, a.Win + 4096) TQ_IMG_LOAD(2, a.Win + 8192) TQ_IMG_LOAD(3, a.Wo) TQ_IMG_LOAD(4, a.Win2)
-    const TqVecRegs vr = tq_vec_load<TQ_NW * 64>(a, H, HD);
+    const TqVecRegs vr = tq_vec_load<TQW * 64>(a, H, HD);
     if (a.drop.thr) seedv = *a.drop.seed;     // behind the image requests (see k_seqtt_enc_fwd)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int tile = tq_tile(s, w, ntiles), l = tile * 16 + c;
+      const int tile = tq_tile12(s, w, ntiles), l = tile * 16 + c;
       xr[s] = tq_x_request(a, b * L + l, l, tile >= 0 && l < L, idr[s], g);
     }
-    tq_zero(lds.sK, 2 * SeqTtLds<5>::ibytes);
+    tq_zero<TQW * 64>(lds.sK, 2 * SeqTtLds<5>::ibytes);
     TQ_IMG_STORE(0, lds.w[0]) TQ_IMG_STORE(1, lds.w[1]) TQ_IMG_STORE(2, lds.w[2]) TQ_IMG_STORE(3, lds.w[3]) TQ_IMG_STORE(4, lds.w[4])
-    tq_vec_store<TQ_NW * 64>(lds.vec, vr);
+    tq_vec_store<TQW * 64>(lds.vec, vr);
   }
   __syncthreads();
   const uint32_t key0 = adt_site_key(seedv, a.site_emb), key1 = adt_site_key(seedv, a.site1), key2 = adt_site_key(seedv, a.site2);
@@ -356,14 +374,14 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
   // self attention: D = LN(x); q, k, v = D Win^T + b                                                    (sasrec/modules.py:668-670)
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+    const int tile = tq_tile12(s, w, ntiles);
     if (tile >= 0) tq_pre_tile<HD, false>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[s], dn[s], xr[s]);
   }
   __syncthreads();
   // a1 = out_proj(o1) ; q2 = a1 Wq2^T + b : the cross attention's queries replace the self attention's in the registers
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+    const int tile = tq_tile12(s, w, ntiles);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
@@ -385,7 +403,7 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
   // cross attention keys / values from the encoder's log_feats: [k2, v2] = f Wkv^T + b              (memory = log_feats, model.py:69-70)
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+    const int tile = tq_tile12(s, w, ntiles);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
@@ -412,7 +430,7 @@ __global__ __launch_bounds__(TQ_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) {
   // a2 = out_proj(o2) ; y = (D + a2 + FFN(a2)) * mask                                                (sasrec/modules.py:673-676)
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+    const int tile = tq_tile12(s, w, ntiles);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;

@@ -331,6 +331,33 @@ ADT_DEVICE_INLINE bf16x8 tt_trfrag(const __bf16* img, int row0, int col0, int c,
 // pre-multiplied by log2(e) / sqrt(hd).  One sweep: all score tiles stay in registers (the workgroup owns a CU: 256 VGPRs per wave),
 // so the MFMAs of the sweep are independent and issue back to back, and the exponentials form one long independent stream.
 // Output: o[nt] = O^T rows (features 16 nt + 4g + r of this head), column = query c; log-sum-exp and dropout keep bits to HBM.
+// v_max3_f32 / v_cvt_pk_bf16_f32 on two fp32 sources as single instructions: hipcc forms neither from the scalar expressions here (it kept
+// v_max_f32 pairs, and converted every probability on its own -- v_cvt_pk(x, 0) -- to select the dropped ones on the 16-bit results and
+// v_perm the pairs together: 1.5 instructions per element instead of 0.5)
+ADT_DEVICE_INLINE float tt_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+ADT_DEVICE_INLINE uint32_t tt_cvt_pk(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// x where bit POS of k is set, else +0.0: v_bfe_i32 (all-ones / zero) + v_and_b32 on the fp32 bits.  One asm statement: as C++ hipcc turns
+// `x & sext(bit)` back into v_and + v_cmp + v_cndmask (and a VCC wait state), and between two asm statements it pads the dependent pair with s_nop
+template <int POS>
+ADT_DEVICE_INLINE float tt_keep_if_bit(float x, uint32_t k) {
+  float r;
+  asm("v_bfe_i32 %0, %1, %3, 1\n\tv_and_b32 %0, %0, %2" : "=&v"(r) : "v"(k), "v"(x), "n"(POS));
+  return r;
+}
+ADT_DEVICE_INLINE bf16x8 tt_pack_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+  union { tt_u4 u; bf16x8 b; } x;
+  x.u = tt_u4{w0, w1, w2, w3};
+  return x.b;
+}
+
 template <int HD, int MAXKT>
 ADT_DEVICE_INLINE void tt_attn_tile(const __bf16* sK, const __bf16* sV, const bf16x8* fq, int kcol, int vcol, int qt, int L, int bh,
                                     uint32_t bh_rng, const DropCfg& drop, uint32_t key_rng, float* lse, uint32_t* mask, int lane,
@@ -341,7 +368,6 @@ ADT_DEVICE_INLINE void tt_attn_tile(const __bf16* sK, const __bf16* sV, const bf
   f32x4 s[MAXKT];
 #pragma unroll
   for (int kt = 0; kt < MAXKT; ++kt) {
-    s[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     if (kt < nkt) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -352,14 +378,21 @@ ADT_DEVICE_INLINE void tt_attn_tile(const __bf16* sK, const __bf16* sV, const bf
         for (int r = 0; r < 4; ++r) acc[r] = (4 * g + r <= c) ? acc[r] : -INFINITY;
       }
       s[kt] = acc;
+    } else {
+      s[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     }
   }
   float m = -INFINITY;
 #pragma unroll
-  for (int kt = 0; kt < MAXKT; ++kt) m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+  for (int kt = 0; kt < MAXKT; ++kt) m = tt_max3(tt_max3(m, s[kt][0], s[kt][1]), s[kt][2], s[kt][3]);
   m = tt_colmax(m);
-  const uint32_t idx_q = (bh_rng * (uint32_t)L + (uint32_t)q) * (uint32_t)L;      // a multiple of 4: L % 4 == 0 on this path, so a
-                                                                                  // register quad of keys shares one hash word
+  // dropout: element (query q, key j) has index idx_q + j with idx_q a multiple of 4 (L % 4 == 0 on this path), so the register quad of
+  // keys 16 kt + 4 g .. + 3 shares the hash word (idx_q >> 2) + 4 kt + g.  Per quad: one hash, three bit operations for the four keep
+  // flags (adt_keep7); per element: a sign-extending bit-field extract and an AND on the fp32 bits -- no compare / select pairs and no
+  // multiply (the 1 / (1 - p) factor goes into the final normalisation).
+  const uint32_t word_q = ((bh_rng * (uint32_t)L + (uint32_t)q) * (uint32_t)L >> 2) + (uint32_t)g;
+  uint32_t clo = 0u, chi = 0u;
+  if (drop.thr) adt_keep7_consts(drop.thr, clo, chi);
   float sum = 0.f;
   uint32_t mw[MAXKT / 2];
 #pragma unroll
@@ -369,30 +402,33 @@ ADT_DEVICE_INLINE void tt_attn_tile(const __bf16* sK, const __bf16* sV, const bf
 #pragma unroll
   for (int kp = 0; kp < MAXKT / 2; ++kp) {
     if (2 * kp < nkt) {
-      f32x4 pv[2];
+      uint32_t k7[2] = {0x80808080u, 0x80808080u};
+      if (drop.thr) {            // wave-uniform; the second tile of the last pair may lie beyond the causal range: its scores are -inf
+#pragma unroll
+        for (int t = 0; t < 2; ++t) k7[t] = adt_keep7(adt_hash32((word_q + (uint32_t)(4 * (2 * kp + t))) ^ key_rng), clo, chi);
+        mw[kp] = (adt_keep7_nibble(k7[0]) | (adt_keep7_nibble(k7[1]) << 16)) << (4 * g);
+      }
+      float pe[2][4];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const int kt = 2 * kp + t;
-        uint32_t bits = 15u;
-        if (drop.thr && kt < nkt) {
-          bits = adt_keep4(key_rng, idx_q + (uint32_t)(16 * kt + 4 * g), drop.thr);
-          mw[kp] |= bits << (16 * t + 4 * g);
-        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(s[kt][r] - m);      // exp2(-inf) = 0 for masked / absent keys
+          const float e = __builtin_amdgcn_exp2f(s[2 * kp + t][r] - m);      // exp2(-inf) = 0 for masked / absent keys
           sum += e;
-          pv[t][r] = ((bits >> r) & 1u) ? e * drop.scale : 0.f;
+          pe[t][r] = e;
         }
+#define TT_KEEP(r) pe[t][r] = tt_keep_if_bit<8 * (r) + 7>(pe[t][r], k7[t])
+        TT_KEEP(0); TT_KEEP(1); TT_KEEP(2); TT_KEEP(3);
+#undef TT_KEEP
       }
-      const bf16x8 fp = tt_pack(pv[0], pv[1]);
+      const bf16x8 fp = tt_pack_words(tt_cvt_pk(pe[0][0], pe[0][1]), tt_cvt_pk(pe[0][2], pe[0][3]), tt_cvt_pk(pe[1][0], pe[1][1]), tt_cvt_pk(pe[1][2], pe[1][3]));
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) o[nt] = mfma_bf16(o[nt], tt_trfrag(sV, kp * 32, vcol + nt * 16, c, g), fp);
     }
   }
   sum = tt_colsum(sum);
   if (g == 0 && q < L) lse[(size_t)bh * L + q] = (m + __builtin_amdgcn_logf(sum)) * 0.6931471805599453f;   // natural log of sum exp(score)
-  const float inv = 1.0f / sum;
+  const float inv = drop.scale / sum;          // drop.scale = 1 without dropout
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) o[nt] *= inv;
   if (mask && drop.thr) {
@@ -405,6 +441,117 @@ ADT_DEVICE_INLINE void tt_attn_tile(const __bf16* sK, const __bf16* sV, const bf
       dst[1] = make_uint4(ow[4], ow[5], ow[6], ow[7]);
     }
   }
+}
+
+// The same attention as two ROLLED sweeps over the key tiles, ALL heads of the query tile per iteration (the default; -DADT_ATTN_UNROLLED
+// restores the form above): sweep 1 takes the row maxima, sweep 2 recomputes the scores of a pair of key tiles (KB more MFMAs per tile and
+// head: the matrix pipe is idle most of the time here), exponentiates and multiplies by V.  The unrolled form keeps all 14 score tiles in
+// registers and is ~100 KB of straight-line code per kernel, every instruction executed once per wave: with twelve waves at different
+// places of it, instruction fetch and each wave's own read -> MFMA -> exp -> MFMA latency chain paced the phase, not the vector ALU
+// (profiles/r03_stamps_fwd12.txt: 14k cycles for a wave whose instruction stream issues in 7k).  Here the loop body is ~150 instructions and the
+// H heads are independent chains inside it.  Keep-bit words go to HBM per key pair (words of pairs beyond the causal range are not
+// written: no reader looks at them).  Returns the TT tile (features x queries) of all heads.
+template <int HD>
+ADT_DEVICE_INLINE TT tt_attn_heads_loop(const __bf16* sK, const __bf16* sV, const bf16x8* fq, int qt, int L, int b, uint32_t b_offset, const DropCfg& drop,
+                                        uint32_t key_rng, float* lse, uint32_t* mask, int c, int g) {
+  constexpr int H = 64 / HD, NT = HD / 16, KB = (HD + 31) / 32;
+  const int q = qt * 16 + c;
+  const __bf16* kbase = sK + c * TT_RS + 8 * g;                 // key row 16 kt + c of head h: + kt * 16 * TT_RS + kcol(h)
+  float m[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) m[h] = -INFINITY;
+#pragma unroll 2
+  for (int kt = 0; kt < qt; ++kt) {                              // tiles below the diagonal: every key precedes every query of the tile
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const int kcol = HD == 16 ? 32 * (h >> 1) : h * HD;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) acc = mfma_bf16(acc, *reinterpret_cast<const bf16x8*>(kbase + kt * 16 * TT_RS + kcol + 32 * kb), fq[h * KB + kb]);
+      m[h] = tt_max3(tt_max3(m[h], acc[0], acc[1]), acc[2], acc[3]);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const int kcol = HD == 16 ? 32 * (h >> 1) : h * HD;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) acc = mfma_bf16(acc, *reinterpret_cast<const bf16x8*>(kbase + qt * 16 * TT_RS + kcol + 32 * kb), fq[h * KB + kb]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m[h] = fmaxf(m[h], (4 * g + r <= c) ? acc[r] : -INFINITY);
+    m[h] = tt_colmax(m[h]);
+  }
+  // dropout: see tt_attn_tile.  Head h of sequence b is row (b * H + h) of the (B H, L, L) probability tensor
+  const uint32_t bh0 = (uint32_t)(b * H) + b_offset * (uint32_t)H;
+  uint32_t word_q[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) word_q[h] = (((bh0 + (uint32_t)h) * (uint32_t)L + (uint32_t)q) * (uint32_t)L >> 2) + (uint32_t)g;
+  uint32_t clo = 0u, chi = 0u;
+  if (drop.thr) adt_keep7_consts(drop.thr, clo, chi);
+  uint32_t* mrow = (mask && drop.thr && q < L) ? mask + ((size_t)(b * H) * L + q) * 8 : nullptr;      // head h: + h * L * 8
+  float sum[H];
+  TT o;
+#pragma unroll
+  for (int h = 0; h < H; ++h) sum[h] = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) o.v[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int npair = (qt + 2) >> 1;
+#pragma unroll 1
+  for (int kp = 0; kp < npair; ++kp) {
+    const bool edge = 2 * kp + 1 >= qt;      // wave-uniform: the last pair holds the diagonal tile and, for even qt, a tile beyond it
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const int kcol = HD == 16 ? 32 * (h >> 1) : h * HD;
+      f32x4 s[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+          s[t] = mfma_bf16(s[t], *reinterpret_cast<const bf16x8*>(kbase + (2 * kp + t) * 16 * TT_RS + kcol + 32 * kb), fq[h * KB + kb]);
+      }
+      if (edge) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int kt = 2 * kp + t;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[t][r] = (kt < qt || (kt == qt && 4 * g + r <= c)) ? s[t][r] : -INFINITY;
+        }
+      }
+      uint32_t k7[2] = {0x80808080u, 0x80808080u};
+      if (drop.thr) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) k7[t] = adt_keep7(adt_hash32((word_q[h] + (uint32_t)(4 * (2 * kp + t))) ^ key_rng), clo, chi);
+        const uint32_t ow = tt_color((adt_keep7_nibble(k7[0]) | (adt_keep7_nibble(k7[1]) << 16)) << (4 * g));
+        if (g == 0 && mrow) mrow[(size_t)h * L * 8 + kp] = ow;
+      }
+      float pe[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(s[t][r] - m[h]);      // exp2(-inf) = 0 for masked keys
+          sum[h] += e;
+          pe[t][r] = e;
+        }
+#define TT_KEEP(r) pe[t][r] = tt_keep_if_bit<8 * (r) + 7>(pe[t][r], k7[t])
+        TT_KEEP(0); TT_KEEP(1); TT_KEEP(2); TT_KEEP(3);
+#undef TT_KEEP
+      }
+      const bf16x8 fp = tt_pack_words(tt_cvt_pk(pe[0][0], pe[0][1]), tt_cvt_pk(pe[0][2], pe[0][3]), tt_cvt_pk(pe[1][0], pe[1][1]), tt_cvt_pk(pe[1][2], pe[1][3]));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) o.v[h * NT + nt] = mfma_bf16(o.v[h * NT + nt], tt_trfrag(sV, kp * 32, h * HD + nt * 16, c, g), fp);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const float st = tt_colsum(sum[h]);
+    if (g == 0 && q < L) lse[(size_t)(b * H + h) * L + q] = (m[h] + __builtin_amdgcn_logf(st)) * 0.6931471805599453f;   // natural log of sum exp(score)
+    const float inv = drop.scale / st;          // drop.scale = 1 without dropout
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) o.v[h * NT + nt] *= inv;
+  }
+  return o;
 }
 
 // query operands of every head from a TT q tile (scaled): fq[h * KB + kb]
@@ -429,6 +576,9 @@ ADT_DEVICE_INLINE TT tt_attn_heads(const __bf16* sK, const __bf16* sV, const bf1
                                    DropCfg drop, uint32_t site, uint32_t seedv, float* lse, uint32_t* mask, int lane, int c, int g) {
   constexpr int H = 64 / HD, NT = HD / 16, KB = (HD + 31) / 32;
   const uint32_t key_rng = drop.thr ? adt_site_key(seedv, site) : 0u;
+#ifndef ADT_ATTN_UNROLLED
+  return tt_attn_heads_loop<HD>(sK, sV, fq, tile, L, b, b_offset, drop, key_rng, lse, mask, c, g);
+#else
   TT o;
 #pragma unroll
   for (int h = 0; h < H; ++h) {
@@ -441,6 +591,7 @@ ADT_DEVICE_INLINE TT tt_attn_heads(const __bf16* sK, const __bf16* sV, const bf1
     for (int nt = 0; nt < NT; ++nt) o.v[h * NT + nt] = oh[nt];
   }
   return o;
+#endif
 }
 
 }  // namespace adt

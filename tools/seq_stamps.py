@@ -27,9 +27,10 @@ for _ in range(3):
     else:
         m.run_forward(*ids, 256, True)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 128)()
-rc = _lib.load().adt_seq_stamps_read(buf, 128)
-t = np.array(list(buf), dtype=np.int64).reshape(8, 16)
+NWV = 12 if MODE == "fwd" else 8          # waves per workgroup of the stamped kernel
+buf = (ctypes.c_ulonglong * 256)()
+rc = _lib.load().adt_seq_stamps_read(buf, 256)
+t = np.array(list(buf), dtype=np.int64).reshape(16, 16)[:NWV]
 print("rc", rc)
 t0 = t[:, 0].min()
 names = ["start", "staged", "pre0", "pre1", "barrier", "attn0", "oproj0", "ffn0", "attn1", "oproj1", "ffn1"]
@@ -40,5 +41,5 @@ if MODE == "post":      # k_seqtt_post_bwd<., true> (encoder), last launch of th
 print("wave " + " ".join("%8s" % n for n in names))
 if MODE == "fwd":
     print("prologue (issue loads, zero-fill, image stores, vector stores):", [[int(t[w, k] - t0) for k in (11, 12, 13, 14)] for w in (0, 4)])
-for w in range(8):
+for w in range(NWV):
     print("%4d " % w + " ".join("%8d" % (t[w, k] - t0 if t[w, k] else -1) for k in range(len(names))))
