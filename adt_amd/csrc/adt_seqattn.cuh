@@ -45,109 +45,145 @@ ADT_DEVICE_INLINE bf16x8 sab_rowfrag(const __bf16* img, int row, int h, int kb, 
 // MODE: 0 no dropout, 1 keep bits saved by the forward, 2 keep decisions recomputed from the hash RNG -- a compile-time choice: as
 // run-time branches inside the element loops the three variants cost ~100 branch instructions per key-tile pair.
 //
-// pass A: query tile qt on the lane (q = 16 qt + c), keys on the accumulator rows.  fq / fdo: this lane's query and dO rows of head h in
-// slot order (fq pre-scaled by log2(e)/sqrt(hd)); lse_q in the log2 domain; mrow: the 8 keep-bit words of query q (MODE 1).
+// Dropout scale: the dO operands / image CARRY the factor 1 / (1 - p) (the callers scale them once when they build them), so
+// dp = dO V^T arrives scaled, a dropped element is an AND with its keep bit (v_bfe_i32 + v_and_b32, no compare / select / multiply) and
+// the probabilities that multiply dO for dV stay unscaled.  delta = rowsum(dO * O) is taken from the UNSCALED dO by the callers.
+//
+// Only the pair of key (query) tiles that holds the diagonal tile needs the per-element causal mask: it is peeled out of the loops
+// (as `if (edge)` inside them the compiler if-converted it into two selects per element of EVERY pair).
+
+// p where bit `pos` (a lane variable) of `word` is set, else +0.0 (one statement: see tt_keep_if_bit; p comes from v_exp_f32, never from an MFMA)
+ADT_DEVICE_INLINE float sab_keep1(float p, uint32_t word, uint32_t pos) {
+  float r;
+  asm("v_bfe_i32 %0, %1, %2, 1\n\tv_and_b32 %0, %0, %3" : "=&v"(r) : "v"(word), "v"(pos), "v"(p));
+  return r;
+}
+
+// pass A: query tile qt on the lane (q = 16 qt + c), keys on the accumulator rows.  fq / fdo: this lane's query and (scaled) dO rows of head h
+// in slot order (fq pre-scaled by log2(e)/sqrt(hd)); lse_q in the log2 domain; mrow: the 8 keep-bit words of query q (MODE 1).
 // Result: dq[nt] = rows (features 16 nt + 4g + r of the head) x column (query c) of dS K, NOT yet multiplied by 1/sqrt(hd).
+template <int HD, int MODE, bool EDGE>
+ADT_DEVICE_INLINE void sab_pair_a(const __bf16* sK, const __bf16* sV, const bf16x8* fq, const bf16x8* fdo, float lse_q, float delta_q, const uint32_t* mrow,
+                                  int kp, int qt, int h, const DropCfg& drop, uint32_t key_rng, uint32_t idx_q, int c, int g, f32x4 (&dq)[HD / 16]) {
+  constexpr int NT = HD / 16, KB = (HD + 31) / 32;
+  f32x4 s[2], dp[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int kt = 2 * kp + t;
+    s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dp[t] = s[t];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {          // rows beyond the causal range are zero-filled or masked below
+      s[t] = mfma_bf16(s[t], sab_rowfrag<HD>(sK, kt * 16 + c, h, kb, g), fq[kb]);
+      dp[t] = mfma_bf16(dp[t], sab_rowfrag<HD>(sV, kt * 16 + c, h, kb, g), fdo[kb]);
+    }
+  }
+  uint32_t mword = 0u;
+  if constexpr (MODE == 1) mword = mrow[kp] >> (4 * g);
+  // dS = P o (keep o dP - delta) = (keep o P) o dP - P delta: the keep bit is applied to P (a v_exp result), dP stays an ordinary operand
+  f32x4 ds[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int kt = 2 * kp + t;
+    float p[4], pk[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p[r] = __builtin_amdgcn_exp2f(s[t][r] - lse_q);
+      if constexpr (EDGE) p[r] = (kt < qt || (kt == qt && 4 * g + r <= c)) ? p[r] : 0.f;
+      pk[r] = p[r];
+      if constexpr (MODE == 2) pk[r] = adt_keep(key_rng, idx_q + (uint32_t)(kt * 16 + 4 * g + r), drop.thr) ? p[r] : 0.f;
+    }
+    if constexpr (MODE == 1) {
+      if (t == 0) {
+        pk[0] = tt_keep_if_bit<0>(p[0], mword); pk[1] = tt_keep_if_bit<1>(p[1], mword); pk[2] = tt_keep_if_bit<2>(p[2], mword); pk[3] = tt_keep_if_bit<3>(p[3], mword);
+      } else {
+        pk[0] = tt_keep_if_bit<16>(p[0], mword); pk[1] = tt_keep_if_bit<17>(p[1], mword); pk[2] = tt_keep_if_bit<18>(p[2], mword); pk[3] = tt_keep_if_bit<19>(p[3], mword);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ds[t][r] = pk[r] * dp[t][r] - p[r] * delta_q;
+  }
+  const bf16x8 fds = tt_pack(ds[0], ds[1]);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) dq[nt] = mfma_bf16(dq[nt], tt_trfrag(sK, kp * 32, h * HD + nt * 16, c, g), fds);
+}
+
 template <int HD, int MODE>
 ADT_DEVICE_INLINE void sab_pass_a(const __bf16* sK, const __bf16* sV, const bf16x8* fq, const bf16x8* fdo, float lse_q, float delta_q,
                                   const uint32_t* mrow, int qt, int h, const DropCfg& drop, uint32_t key_rng, uint32_t idx_q, int c, int g,
                                   f32x4 (&dq)[HD / 16]) {
-  constexpr int NT = HD / 16, KB = (HD + 31) / 32;
-  const int nkt = qt + 1;
+  constexpr int NT = HD / 16;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) dq[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nfull = qt >> 1;                    // pairs strictly below the diagonal tile; pair nfull holds it (and, for even qt, a tile beyond it)
 #pragma unroll 2
-  for (int kp = 0; 2 * kp < nkt; ++kp) {
-    f32x4 s[2], dp[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int kt = 2 * kp + t;
-      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dp[t] = s[t];
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {          // rows beyond the causal range are zero-filled or masked below
-        s[t] = mfma_bf16(s[t], sab_rowfrag<HD>(sK, kt * 16 + c, h, kb, g), fq[kb]);
-        dp[t] = mfma_bf16(dp[t], sab_rowfrag<HD>(sV, kt * 16 + c, h, kb, g), fdo[kb]);
-      }
-    }
-    uint32_t mword = 0u;
-    if constexpr (MODE == 1) mword = mrow[kp] >> (4 * g);
-    f32x4 ds[2];
-    const bool edge = 2 * kp + 1 >= qt;          // the pair touches the diagonal tile (or lies beyond it): per-element mask
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int kt = 2 * kp + t;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float p = __builtin_amdgcn_exp2f(s[t][r] - lse_q);
-        if (edge) p = (kt < qt || (kt == qt && 4 * g + r <= c)) ? p : 0.f;
-        float d = dp[t][r];
-        if constexpr (MODE == 1) d = ((mword >> (16 * t + r)) & 1u) ? d * drop.scale : 0.f;
-        if constexpr (MODE == 2) d = adt_keep(key_rng, idx_q + (uint32_t)(kt * 16 + 4 * g + r), drop.thr) ? d * drop.scale : 0.f;
-        ds[t][r] = p * (d - delta_q);
-      }
-    }
-    const bf16x8 fds = tt_pack(ds[0], ds[1]);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) dq[nt] = mfma_bf16(dq[nt], tt_trfrag(sK, kp * 32, h * HD + nt * 16, c, g), fds);
-  }
+  for (int kp = 0; kp < nfull; ++kp) sab_pair_a<HD, MODE, false>(sK, sV, fq, fdo, lse_q, delta_q, mrow, kp, qt, h, drop, key_rng, idx_q, c, g, dq);
+  sab_pair_a<HD, MODE, true>(sK, sV, fq, fdo, lse_q, delta_q, mrow, nfull, qt, h, drop, key_rng, idx_q, c, g, dq);
 }
 
 // pass B: key tile kt on the lane (key = 16 kt + c), queries on the accumulator rows.  fk / fv: this lane's key and value rows of head h;
 // lse_h / del_h: the head's per-query log2-domain log-sum-exp (+inf for padded queries) and delta; sM_h: [rows][8] keep bits (MODE 1).
-// Results: dk = dS^T Q (carries the Q image's factor log2(e)/sqrt(hd)), dv = P'^T dO; rows = features, column = key c.
+// Results: dk = dS^T Q (carries the Q image's factor log2(e)/sqrt(hd)), dv = P'^T dO (the dO image carries 1 / (1 - p)); rows = features, column = key c.
+template <int HD, int MODE, bool EDGE>
+ADT_DEVICE_INLINE void sab_pair_b(const __bf16* sQ, const __bf16* sdO, const bf16x8* fk, const bf16x8* fv, const float* lse_h, const float* del_h,
+                                  const uint32_t* sM_h, int qp, int kt, int h, const DropCfg& drop, uint32_t key_rng, uint32_t idx_bh, int L, int c, int g,
+                                  f32x4 (&dk)[HD / 16], f32x4 (&dv)[HD / 16]) {
+  constexpr int NT = HD / 16, KB = (HD + 31) / 32;
+  const int key = kt * 16 + c;
+  f32x4 s[2], dp[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int qt = 2 * qp + t;
+    s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dp[t] = s[t];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      s[t] = mfma_bf16(s[t], sab_rowfrag<HD>(sQ, qt * 16 + c, h, kb, g), fk[kb]);
+      dp[t] = mfma_bf16(dp[t], sab_rowfrag<HD>(sdO, qt * 16 + c, h, kb, g), fv[kb]);
+    }
+  }
+  f32x4 pv[2], ds[2];
+  const uint32_t bitpos = (uint32_t)(16 * (kt & 1) + c);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int qt = 2 * qp + t;
+    const float4 lse4 = *reinterpret_cast<const float4*>(lse_h + qt * 16 + 4 * g);      // +inf for padded queries -> p = 0
+    const float4 del4 = *reinterpret_cast<const float4*>(del_h + qt * 16 + 4 * g);
+    const float lq[4] = {lse4.x, lse4.y, lse4.z, lse4.w}, dq4[4] = {del4.x, del4.y, del4.z, del4.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = qt * 16 + 4 * g + r;
+      float p = __builtin_amdgcn_exp2f(s[t][r] - lq[r]);
+      if constexpr (EDGE) p = (qt > kt || (qt == kt && c <= 4 * g + r)) ? p : 0.f;
+      float pk = p;
+      if constexpr (MODE == 1) pk = sab_keep1(p, sM_h[(size_t)qq * 8 + (kt >> 1)], bitpos);
+      if constexpr (MODE == 2) pk = adt_keep(key_rng, (idx_bh + (uint32_t)qq) * (uint32_t)L + (uint32_t)key, drop.thr) ? p : 0.f;
+      pv[t][r] = pk;
+      ds[t][r] = pk * dp[t][r] - p * dq4[r];          // dS = (keep o P) o dP - P delta
+    }
+  }
+  const bf16x8 fp = tt_pack(pv[0], pv[1]), fds = tt_pack(ds[0], ds[1]);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    dv[nt] = mfma_bf16(dv[nt], tt_trfrag(sdO, qp * 32, h * HD + nt * 16, c, g), fp);
+    dk[nt] = mfma_bf16(dk[nt], tt_trfrag(sQ, qp * 32, h * HD + nt * 16, c, g), fds);
+  }
+}
+
 template <int HD, int MODE>
 ADT_DEVICE_INLINE void sab_pass_b(const __bf16* sQ, const __bf16* sdO, const bf16x8* fk, const bf16x8* fv, const float* lse_h, const float* del_h,
                                   const uint32_t* sM_h, int kt, int nqt, int h, const DropCfg& drop, uint32_t key_rng, uint32_t idx_bh, int L,
                                   int c, int g, f32x4 (&dk)[HD / 16], f32x4 (&dv)[HD / 16]) {
-  constexpr int NT = HD / 16, KB = (HD + 31) / 32;
-  const int key = kt * 16 + c;
+  constexpr int NT = HD / 16;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     dk[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     dv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  const int q0 = kt >> 1;                       // the pair that holds the diagonal tile (and, for odd kt, the tile above it, fully masked)
+  sab_pair_b<HD, MODE, true>(sQ, sdO, fk, fv, lse_h, del_h, sM_h, q0, kt, h, drop, key_rng, idx_bh, L, c, g, dk, dv);
 #pragma unroll 2
-  for (int qp = kt / 2; 2 * qp < nqt; ++qp) {
-    f32x4 s[2], dp[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int qt = 2 * qp + t;
-      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dp[t] = s[t];
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        s[t] = mfma_bf16(s[t], sab_rowfrag<HD>(sQ, qt * 16 + c, h, kb, g), fk[kb]);
-        dp[t] = mfma_bf16(dp[t], sab_rowfrag<HD>(sdO, qt * 16 + c, h, kb, g), fv[kb]);
-      }
-    }
-    f32x4 pv[2], ds[2];
-    const bool edge = 2 * qp <= kt;               // the pair holds the diagonal tile (and, for odd kt, the tile below it)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int qt = 2 * qp + t;
-      const float4 lse4 = *reinterpret_cast<const float4*>(lse_h + qt * 16 + 4 * g);      // +inf for padded queries -> p = 0
-      const float4 del4 = *reinterpret_cast<const float4*>(del_h + qt * 16 + 4 * g);
-      const float lq[4] = {lse4.x, lse4.y, lse4.z, lse4.w}, dq4[4] = {del4.x, del4.y, del4.z, del4.w};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qq = qt * 16 + 4 * g + r;
-        float p = __builtin_amdgcn_exp2f(s[t][r] - lq[r]);
-        if (edge) p = (qt > kt || (qt == kt && c <= 4 * g + r)) ? p : 0.f;
-        float ks = 1.0f;
-        if constexpr (MODE == 1) ks = ((sM_h[(size_t)qq * 8 + (kt >> 1)] >> (16 * (kt & 1) + c)) & 1u) ? drop.scale : 0.f;
-        if constexpr (MODE == 2) ks = adt_keep(key_rng, (idx_bh + (uint32_t)qq) * (uint32_t)L + (uint32_t)key, drop.thr) ? drop.scale : 0.f;
-        pv[t][r] = p * ks;
-        ds[t][r] = p * (dp[t][r] * ks - dq4[r]);
-      }
-    }
-    const bf16x8 fp = tt_pack(pv[0], pv[1]), fds = tt_pack(ds[0], ds[1]);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      dv[nt] = mfma_bf16(dv[nt], tt_trfrag(sdO, qp * 32, h * HD + nt * 16, c, g), fp);
-      dk[nt] = mfma_bf16(dk[nt], tt_trfrag(sQ, qp * 32, h * HD + nt * 16, c, g), fds);
-    }
-  }
+  for (int qp = q0 + 1; 2 * qp < nqt; ++qp) sab_pair_b<HD, MODE, false>(sQ, sdO, fk, fv, lse_h, del_h, sM_h, qp, kt, h, drop, key_rng, idx_bh, L, c, g, dk, dv);
 }
 
 template <int HD, int MODE>
@@ -220,7 +256,7 @@ __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
     }
     float part = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { part += d[j] * o[j]; q[j] *= qmul; }
+    for (int j = 0; j < 8; ++j) { part += d[j] * o[j]; q[j] *= qmul; d[j] *= a.drop.scale; }      // the dO image carries 1 / (1 - p): see sab_pass_a
     *reinterpret_cast<bf16x8*>(sQ + r * TT_RS + c8) = pack8(q);
     *reinterpret_cast<bf16x8*>(sK + r * TT_RS + c8) = pack8(k);
     *reinterpret_cast<bf16x8*>(sV + r * TT_RS + c8) = pack8(v);

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     tt_put_rows(img1, l, v, valid, g);
     const TT& dO = doa[s];
     const TT& o = oa[s];
-    sb_frags<HD>(dO, 1.0f, fdo[s]);
+    sb_frags<HD>(dO, a.drop.scale, fdo[s]);          // the dO operands / image carry 1 / (1 - p) (adt_seqattn.cuh: sab_pass_a); delta below does not
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       float part = 0.f;

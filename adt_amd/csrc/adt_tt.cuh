@@ -331,33 +331,30 @@ ADT_DEVICE_INLINE bf16x8 tt_trfrag(const __bf16* img, int row0, int col0, int c,
 // pre-multiplied by log2(e) / sqrt(hd).  One sweep: all score tiles stay in registers (the workgroup owns a CU: 256 VGPRs per wave),
 // so the MFMAs of the sweep are independent and issue back to back, and the exponentials form one long independent stream.
 // Output: o[nt] = O^T rows (features 16 nt + 4g + r of this head), column = query c; log-sum-exp and dropout keep bits to HBM.
-// v_max3_f32 / v_cvt_pk_bf16_f32 on two fp32 sources as single instructions: hipcc forms neither from the scalar expressions here (it kept
-// v_max_f32 pairs, and converted every probability on its own -- v_cvt_pk(x, 0) -- to select the dropped ones on the 16-bit results and
-// v_perm the pairs together: 1.5 instructions per element instead of 0.5)
+// INLINE ASM AND MFMA RESULTS.  On gfx950 the wait states between a v_mfma and a vector instruction that reads its result are the
+// COMPILER's job, and its hazard recognizer does not look inside asm statements: an asm that consumes an accumulator register straight
+// from an MFMA reads it before the matrix pipe has written it -- silently, and differently from run to run (found by the data-parallel
+// determinism test: a v_max3_f32 asm on raw score registers made the forward differ by 2e-3 between two identical launches).  Every asm
+// helper below therefore takes only values that an ordinary (compiler-visible) vector instruction has produced.
+//
+// max of a score quad into a running maximum: the two pair maxima are plain fmaxf on the MFMA results (compiler-managed), v_max3_f32
+// folds them in (hipcc does not form v_max3 from nested fmaxf here): 3 instructions per quad instead of 4
 ADT_DEVICE_INLINE float tt_max3(float a, float b, float c) {
   float r;
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
-ADT_DEVICE_INLINE uint32_t tt_cvt_pk(float lo, float hi) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
+ADT_DEVICE_INLINE float tt_max_quad(float m, const f32x4& acc) { return tt_max3(m, fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])); }
 // x where bit POS of k is set, else +0.0: v_bfe_i32 (all-ones / zero) + v_and_b32 on the fp32 bits.  One asm statement: as C++ hipcc turns
-// `x & sext(bit)` back into v_and + v_cmp + v_cndmask (and a VCC wait state), and between two asm statements it pads the dependent pair with s_nop
+// `x & sext(bit)` back into v_and + v_cmp + v_cndmask (and a VCC wait state), and between two asm statements it pads the dependent pair with s_nop.
+// x must come from an ordinary vector instruction (here: v_exp_f32 -- the v_bfe in front of the v_and is the one instruction a reader of a
+// transcendental result must stay behind), never straight from an MFMA: see above
 template <int POS>
 ADT_DEVICE_INLINE float tt_keep_if_bit(float x, uint32_t k) {
   float r;
   asm("v_bfe_i32 %0, %1, %3, 1\n\tv_and_b32 %0, %0, %2" : "=&v"(r) : "v"(k), "v"(x), "n"(POS));
   return r;
 }
-ADT_DEVICE_INLINE bf16x8 tt_pack_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
-  union { tt_u4 u; bf16x8 b; } x;
-  x.u = tt_u4{w0, w1, w2, w3};
-  return x.b;
-}
-
 template <int HD, int MAXKT>
 ADT_DEVICE_INLINE void tt_attn_tile(const __bf16* sK, const __bf16* sV, const bf16x8* fq, int kcol, int vcol, int qt, int L, int bh,
                                     uint32_t bh_rng, const DropCfg& drop, uint32_t key_rng, float* lse, uint32_t* mask, int lane,
@@ -384,7 +381,7 @@ ADT_DEVICE_INLINE void tt_attn_tile(const __bf16* sK, const __bf16* sV, const bf
   }
   float m = -INFINITY;
 #pragma unroll
-  for (int kt = 0; kt < MAXKT; ++kt) m = tt_max3(tt_max3(m, s[kt][0], s[kt][1]), s[kt][2], s[kt][3]);
+  for (int kt = 0; kt < MAXKT; ++kt) m = tt_max_quad(m, s[kt]);
   m = tt_colmax(m);
   // dropout: element (query q, key j) has index idx_q + j with idx_q a multiple of 4 (L % 4 == 0 on this path), so the register quad of
   // keys 16 kt + 4 g .. + 3 shares the hash word (idx_q >> 2) + 4 kt + g.  Per quad: one hash, three bit operations for the four keep
@@ -421,7 +418,7 @@ ADT_DEVICE_INLINE void tt_attn_tile(const __bf16* sK, const __bf16* sV, const bf
         TT_KEEP(0); TT_KEEP(1); TT_KEEP(2); TT_KEEP(3);
 #undef TT_KEEP
       }
-      const bf16x8 fp = tt_pack_words(tt_cvt_pk(pe[0][0], pe[0][1]), tt_cvt_pk(pe[0][2], pe[0][3]), tt_cvt_pk(pe[1][0], pe[1][1]), tt_cvt_pk(pe[1][2], pe[1][3]));
+      const bf16x8 fp = tt_pack(f32x4{pe[0][0], pe[0][1], pe[0][2], pe[0][3]}, f32x4{pe[1][0], pe[1][1], pe[1][2], pe[1][3]});
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) o[nt] = mfma_bf16(o[nt], tt_trfrag(sV, kp * 32, vcol + nt * 16, c, g), fp);
     }
@@ -468,7 +465,7 @@ ADT_DEVICE_INLINE TT tt_attn_heads_loop(const __bf16* sK, const __bf16* sV, cons
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) acc = mfma_bf16(acc, *reinterpret_cast<const bf16x8*>(kbase + kt * 16 * TT_RS + kcol + 32 * kb), fq[h * KB + kb]);
-      m[h] = tt_max3(tt_max3(m[h], acc[0], acc[1]), acc[2], acc[3]);
+      m[h] = tt_max_quad(m[h], acc);
     }
   }
 #pragma unroll
@@ -538,7 +535,7 @@ ADT_DEVICE_INLINE TT tt_attn_heads_loop(const __bf16* sK, const __bf16* sV, cons
         TT_KEEP(0); TT_KEEP(1); TT_KEEP(2); TT_KEEP(3);
 #undef TT_KEEP
       }
-      const bf16x8 fp = tt_pack_words(tt_cvt_pk(pe[0][0], pe[0][1]), tt_cvt_pk(pe[0][2], pe[0][3]), tt_cvt_pk(pe[1][0], pe[1][1]), tt_cvt_pk(pe[1][2], pe[1][3]));
+      const bf16x8 fp = tt_pack(f32x4{pe[0][0], pe[0][1], pe[0][2], pe[0][3]}, f32x4{pe[1][0], pe[1][1], pe[1][2], pe[1][3]});
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) o.v[h * NT + nt] = mfma_bf16(o.v[h * NT + nt], tt_trfrag(sV, kp * 32, h * HD + nt * 16, c, g), fp);
     }
