@@ -1,33 +1,40 @@
 """GPU: ranking parity with the reference on the same split.  The reference (PyTorch CPU, fp32) was trained for 30
-epochs on the seeded synthetic ml-1m-shaped file (tools/ref_train_ndcg.py; 53 minutes on 8 cores) and scored on
-candidate sets frozen with RandomState(23); tests/golden/ref_ndcg_ml1m.json holds its NDCG@10 / HR@10 / AUC at epochs
-10, 20 and 30.  Here the HIP path (bf16 MFMA operands, dropout 0.5, fused trainer) trains on the same file with the
-same hyper-parameters and is scored on the same candidates.  Tolerance: NDCG@10 within 0.02 abs and HR@10 within
-0.03 abs at every checkpoint.  (North star: +-0.01 or the seed spread, whichever is larger.  Measured against the
-reference's single seed: 3 HIP seeds with the numpy batch sampler were 0.0002..0.009 away in NDCG@10 at epoch 30
-(profiles/r01_ndcg_ml1m_synth_ours.json), 4 seeds with the native sampler 0.001..0.014
-(profiles/r01_ndcg_ml1m_synth_ours_native_sampler.json); the curve still rises ~0.006 per epoch at epoch 30 and float
-atomics make even a fixed seed move by ~0.002 between runs.)"""
+epochs on the seeded synthetic ml-1m-shaped file with THREE seeds (tools/ref_train_ndcg.py --seed 23 / 24 / 25; ~55 minutes each on the
+build container's cores) and scored on candidate sets frozen with RandomState(23); tests/golden/ref_ndcg_ml1m{,_s24,_s25}.json hold
+its NDCG@10 / HR@10 / AUC at epochs 10, 20 and 30.  Here the HIP path (bf16 MFMA operands, dropout 0.5, fused trainer, HIP graph) trains
+three seeds on the same file with the same hyper-parameters and is scored on the same candidates.
+
+Tolerance (north_star / SURVEY 8d): the mean over the HIP seeds lies within max(0.01, 2 sigma) of the mean over the reference seeds,
+sigma = the reference's own sample standard deviation over its three seeds at that checkpoint, for NDCG@10 and HR@10 on validation and
+test.  At epoch 30 sigma is 0.003 (NDCG@10) / 0.003-0.005 (HR@10), so the bound there is the stated +-0.01; epoch 20 sits on the steep
+part of the curve (reference sigma 0.009-0.014) and gets its 2 sigma."""
 import json
 import os
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+REF_SEEDS = {23: "ref_ndcg_ml1m.json", 24: "ref_ndcg_ml1m_s24.json", 25: "ref_ndcg_ml1m_s25.json"}
 
 
 def test_ndcg_hr_match_reference_on_same_split(golden_dir):
     from tools.gpu_ndcg_run import run
     from adt_amd.sasrec import synth
-    ref = json.load(open(os.path.join(golden_dir, "ref_ndcg_ml1m.json")))
+    refs = [json.load(open(os.path.join(golden_dir, f))) for f in REF_SEEDS.values()]
     data = synth.generate("ml1m", 23)
-    ours = run("ml1m", 30, 10, seed=23, precision="bf16", data=data)
-    assert [e["epoch"] for e in ours["evals"]] == [e["epoch"] for e in ref["evals"]] == [10, 20, 30]
-    for eo, er in zip(ours["evals"], ref["evals"]):
+    ours = [run("ml1m", 30, 10, seed=s, precision="bf16", data=data) for s in REF_SEEDS]
+    for r in refs + ours:
+        assert [e["epoch"] for e in r["evals"]] == [10, 20, 30]
+    for i, epoch in enumerate((10, 20, 30)):
         for mode in ("val", "test"):
-            assert abs(eo[mode]["ndcg10"] - er[mode]["ndcg10"]) <= 0.02, (eo["epoch"], mode, eo[mode], er[mode])
-            assert abs(eo[mode]["hr10"] - er[mode]["hr10"]) <= 0.03, (eo["epoch"], mode, eo[mode], er[mode])
-    assert ours["evals"][-1]["test"]["ndcg10"] > 0.25     # the model actually learned the sequential structure
+            for k in ("ndcg10", "hr10"):
+                rv = np.array([r["evals"][i][mode][k] for r in refs])
+                ov = np.array([o["evals"][i][mode][k] for o in ours])
+                tol = max(0.01, 2.0 * rv.std(ddof=1))
+                assert abs(ov.mean() - rv.mean()) <= tol, (epoch, mode, k, ov, rv, tol)
+    assert min(o["evals"][-1]["test"]["ndcg10"] for o in ours) > 0.25     # the model actually learned the sequential structure
 
 
 def test_template_width_ndcg_matches_reference(golden_dir):
