@@ -121,6 +121,19 @@ SIGNATURES = {
     "adt_sasrec_predict": (_I, [_CP, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
 }
 
+def dropout_rate(p, what="dropout"):
+    """The rate a kernel actually applies for a requested dropout probability: drop decisions compare one random BYTE with the threshold
+    round(256 p), so the rate is round(256 p) / 256 (0.5 -> 0.5, 0.2 -> 0.19922, 0.3 -> 0.30078; survivors are scaled by the inverse of the
+    quantised keep rate, so the mask stays unbiased) and is capped at 255 / 256.  A p > 0 that would quantise to ZERO (p < 1/512) is an
+    error instead of a silent `dropout off`.  Returns float(p) unchanged: the quantisation happens in adt_make_drop / oracle.rng.threshold."""
+    p = float(p)
+    if not 0.0 <= p < 1.0:
+        raise ValueError("%s = %r: need 0 <= p < 1" % (what, p))
+    if p > 0.0 and int(p * 256.0 + 0.5) == 0:
+        raise ValueError("%s = %g is below the 8-bit resolution of the dropout RNG (1/512): it would silently disable dropout; use 0 or >= 0.002" % (what, p))
+    return p
+
+
 _lib = None
 
 

@@ -82,7 +82,7 @@ class BertModel(FlatModule):
         self.usernum, self.itemnum = usernum, itemnum
         self.maxlen, self.num_heads, self.num_layers = args.maxlen, args.num_heads, args.num_layers
         self.hidden_units, self.inner_units = args.hidden_units, (args.inner_units if inner_units is None else inner_units)
-        self.dropout, self.attention_dropout = float(args.dropout), float(args.attention_dropout)
+        self.dropout, self.attention_dropout = _lib.dropout_rate(args.dropout, "dropout"), _lib.dropout_rate(args.attention_dropout, "attention_dropout")
         self.vocab = itemnum + 100 if vocab is None else vocab          # bert4rec/model/bert.py:20 (the supernet: itemnum + 2)
         self.ldv = (self.vocab + 3) // 4 * 4
         self.use_lce = os.environ.get("ADT_LCE", "1") != "0"            # fused all-item logits + CE where the shape allows (bf16, d 128 / 256)
@@ -296,7 +296,7 @@ class BertModel(FlatModule):
         rows_p[:M] = rows
         lab_p = np.zeros(cap, np.int32)
         lab_p[:M] = flat[rows]
-        nv = float(max(M, 1) if n_valid_global is None else n_valid_global)
+        nv = float(max(M if n_valid_global is None else n_valid_global, 1))      # a batch with no masked position: CE term 0, never 1/0
         return {"B": B, "src": self.ids(src), "dec": self.ids(dec), "rows": self.ids(rows_p), "labels": self.ids(lab_p),
                 "M": torch.tensor([M], device=self.dev, dtype=torch.int32), "M_host": M,
                 "inv_count": torch.tensor([1.0 / nv], device=self.dev, dtype=torch.float32)}

@@ -53,8 +53,13 @@ class FusedBertTrainer:
         st["norms"] = torch.tensor([0.0, float(norms_scale * T * m.hidden_units), float(norms_scale * T * m.num_heads)], device=m.dev,
                                    dtype=torch.float32)
         cap = int(np.ceil(self.mcap_frac * T))
-        if st["M_host"] > cap:
-            raise ValueError("batch has %d masked rows, more than the capacity %d (mcap_frac=%g)" % (st["M_host"], cap, self.mcap_frac))
+        over = st["M_host"] > cap
+        if self.world > 1:      # every rank must reach the same decision, or the ranks that go on hang in the gradient all-reduce
+            t = torch.tensor([1.0 if over else 0.0], device=m.dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.pg)
+            over = bool(t.item() > 0)
+        if over:
+            raise ValueError("a rank's shard has more masked rows than the capacity %d (this rank: %d; mcap_frac=%g)" % (cap, st["M_host"], self.mcap_frac))
         return st
 
     def _launch(self, b_offset):

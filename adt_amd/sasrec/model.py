@@ -80,7 +80,7 @@ class SASRecADT(torch.nn.Module):
         if self.dev.type != "cuda":
             raise _lib.AdtError("SASRecADT (adt_amd) needs a GPU device, got %r" % (args.device,))
         self.num_heads, self.maxlen, self.num_layers = args.num_heads, args.maxlen, args.num_layers
-        self.hidden_units, self.dropout = args.hidden_units, float(args.dropout)
+        self.hidden_units, self.dropout = args.hidden_units, _lib.dropout_rate(args.dropout, "dropout")
         self.args = args
         prec = getattr(args, "precision", "bf16")
         self.cfg = _lib.SasrecCfg(item_num, args.maxlen, args.hidden_units, args.num_heads, args.num_layers,

@@ -45,7 +45,7 @@ class SASRecADTWide(FlatModule):
         super().__init__()
         self.user_num, self.item_num = user_num, item_num
         self.num_heads, self.maxlen, self.num_layers = args.num_heads, args.maxlen, args.num_layers
-        self.hidden_units, self.dropout = args.hidden_units, float(args.dropout)
+        self.hidden_units, self.dropout = args.hidden_units, _lib.dropout_rate(args.dropout, "dropout")
         self.args = args
         self.prec = {"f32": ops.PREC_F32, "fp32": ops.PREC_F32, "bf16": ops.PREC_BF16}[getattr(args, "precision", "bf16")]
         d, H = self.hidden_units, self.num_heads

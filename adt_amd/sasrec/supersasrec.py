@@ -57,7 +57,7 @@ class SuperSASRecModel(FlatModule):
         super().__init__()
         self.usernum, self.itemnum = usernum, itemnum
         self.num_heads, self.maxlen, self.num_layers = args.num_heads, args.maxlen, args.num_layers
-        self.hidden_units, self.dropout = args.hidden_units, float(args.dropout)
+        self.hidden_units, self.dropout = args.hidden_units, _lib.dropout_rate(args.dropout, "dropout")
         self.rec_choice, self.ind_choice = np.asarray(rec_choice, np.float64), np.asarray(ind_choice, np.float64)
         self.block = len(self.rec_choice) * len(self.ind_choice)
         self.prec = {"f32": ops.PREC_F32, "fp32": ops.PREC_F32, "bf16": ops.PREC_BF16}[getattr(args, "precision", "bf16")]

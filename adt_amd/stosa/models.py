@@ -85,7 +85,7 @@ class DisenDistSAModel(FlatModule):
         self.args = args
         self.item_size, self.maxlen, self.hidden_units = args.item_size, args.maxlen, args.hidden_units
         self.num_heads, self.num_layers = args.num_heads, args.num_layers
-        self.dropout, self.attention_dropout = float(args.dropout), float(args.attention_dropout)
+        self.dropout, self.attention_dropout = _lib.dropout_rate(args.dropout, "dropout"), _lib.dropout_rate(args.attention_dropout, "attention_dropout")
         self.prec = {"f32": ops.PREC_F32, "fp32": ops.PREC_F32, "bf16": ops.PREC_BF16}[getattr(args, "precision", "bf16")]
         d, H = self.hidden_units, self.num_heads
         if d % 64 or (d // H) not in (16, 32, 64):

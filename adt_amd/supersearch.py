@@ -179,14 +179,8 @@ class EvolutionSearch:
                 cand[i] = min(1 - 1e-10, max(1e-10, cand[i] + self.scale_factor * (c2[i] - c3[i])))
         return cand
 
-    def _score_chunk(self, cands):
-        """Marks and scores the not yet visited candidates of a chunk together; returns the fresh ones in order."""
-        fresh = []
-        for c in cands:
-            info = self.vis_dict.setdefault(str(c), {})
-            if "visited" not in info:
-                info["visited"] = True
-                fresh.append(c)
+    def _score_batch(self, fresh):
+        """Scores candidates (already marked visited) in one batched supernet pass."""
         if fresh:
             for c, metrics in zip(fresh, self.evaluate(fresh)):
                 self.vis_dict[str(c)].update(metrics)
@@ -195,13 +189,26 @@ class EvolutionSearch:
         return fresh
 
     def propose(self, random_func, dest, quota, max_iter):
-        """Fill `dest` up to `quota` with fresh scored candidates from random_func."""
+        """Fill `dest` up to `quota` with fresh scored candidates from random_func -- the reference's `stack_random_cand` + `check_cand` loop
+        (sasrec/evolution.py:162-170, 192-206): proposals are drawn ten at a time (the same random call order), walked in order, one
+        `max_iter` each, and a proposal is visited (and scored) only if the walk reaches it before the quota is full -- the rest of the last
+        chunk stays unvisited, exactly as the reference's lazy generator leaves it.  What differs is only WHEN the scores are computed: the
+        proposals the walk consumes from a chunk are scored together in one batched pass (they do not influence each other's scores)."""
         while len(dest) < quota and max_iter > 0:
-            n = min(self.chunk, max_iter)
-            max_iter -= n
-            for c in self._score_chunk([random_func() for _ in range(n)]):
-                if len(dest) < quota:
-                    dest.append(c)
+            chunk = [random_func() for _ in range(self.chunk)]
+            for c in chunk:
+                self.vis_dict.setdefault(str(c), {})
+            take, need = [], quota - len(dest)
+            for c in chunk:
+                if max_iter <= 0 or len(take) >= need:
+                    break
+                max_iter -= 1
+                info = self.vis_dict[str(c)]
+                if "visited" in info:
+                    continue
+                info["visited"] = True
+                take.append(c)
+            dest.extend(self._score_batch(take))
         return dest
 
     def get_random(self):

@@ -60,3 +60,59 @@ def test_search_is_deterministic_given_the_seeds():
     b = _run(9)[1]
     assert a == b
     assert _run(9, chunk=1)[1] != [] and len(_run(9, chunk=1)[2]) >= len(_run(9)[2])      # chunk = 1 is the reference's one-at-a-time granularity
+
+
+def test_propose_visits_exactly_what_the_reference_generator_consumes():
+    """`propose` against a line-by-line restatement of the reference's lazy loop (sasrec/evolution.py:162-170 stack_random_cand,
+    :139-160 check_cand, :192-206 get_random): same destination list, same visited set (proposals of the last chunk that the walk never
+    reached stay unvisited and unscored), same number of random calls -- with duplicates inside a chunk and already-visited proposals."""
+    pool = [[round(0.1 * (i % 7) + 0.01, 3), round(0.05 * (i % 5) + 0.02, 3)] for i in range(40)]      # plenty of duplicates
+
+    def make(seed):
+        r = random.Random(seed)
+        return lambda: list(pool[r.randrange(len(pool))])
+
+    def score(c):
+        return 1.0 - (c[0] - 0.3) ** 2 - (c[1] - 0.1) ** 2
+
+    for seed, quota, max_iter in ((1, 7, 400), (2, 3, 400), (3, 12, 9), (4, 5, 400)):
+        # reference semantics, one candidate at a time
+        vis, dest, calls, f = {}, [], 0, make(seed)
+        vis[str(pool[0])] = {"visited": True, "auc": score(pool[0])}          # something visited before the call
+        it = max_iter
+
+        def gen():
+            nonlocal calls
+            while True:
+                cands = [f() for _ in range(10)]
+                calls += 10
+                for c in cands:
+                    vis.setdefault(str(c), {})
+                for c in cands:
+                    yield c
+        g = gen()
+        while len(dest) < quota and it > 0:
+            it -= 1
+            c = next(g)
+            info = vis[str(c)]
+            if "visited" in info:
+                continue
+            info["visited"] = True
+            info["auc"] = score(c)
+            dest.append(c)
+        # batched implementation
+        ncalls = [0]
+        f2 = make(seed)
+
+        def rf():
+            ncalls[0] += 1
+            return f2()
+        s = EvolutionSearch(1, lambda cs: [{"auc": score(c)} for c in cs], "auc", select_num=2, population_num=quota, m_prob=0.3, crossover_num=1,
+                            mutation_num=1, scale_factor=0.5, chunk=10)
+        s.vis_dict[str(pool[0])] = {"visited": True, "auc": score(pool[0])}
+        got = s.propose(rf, [], quota, max_iter)
+        assert got == dest, (seed, got, dest)
+        assert ncalls[0] == calls
+        assert {k for k, v in s.vis_dict.items() if "visited" in v} == {k for k, v in vis.items() if "visited" in v}
+        assert set(s.vis_dict) == set(vis)
+        assert all(abs(s.vis_dict[k]["auc"] - vis[k]["auc"]) < 1e-15 for k, v in vis.items() if "auc" in v)
