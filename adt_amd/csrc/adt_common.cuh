@@ -123,6 +123,25 @@ struct DropCfg {
 
 __device__ __forceinline__ uint32_t drop_key(const DropCfg& d) { return d.thr ? adt_site_key(*d.seed, d.site) : 0u; }
 
+// LDS-DMA: 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4), no VGPR in between.  lds_dst: WAVE-UNIFORM LDS
+// byte address of the 1 KiB piece; the hardware adds lane * 16.  Issued from inline asm (hipcc would put vmcnt(0) in front of every ds_read
+// that follows a visible global_load_lds).  The request counts in vmcnt like any load (in issue order), and the compiler does not know
+// about it: wait with adt_wait_vm0() before the barrier that publishes the LDS bytes.
+__device__ __forceinline__ void adt_glds16(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void adt_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// one contiguous block of `bytes` (a multiple of 1,024) global -> LDS, the 1 KiB pieces dealt round-robin to the NW waves of the workgroup
+template <int NW>
+__device__ __forceinline__ void adt_glds_block(const void* gsrc, const void* lds_dst, int bytes) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t dst = (uint32_t)(uintptr_t)lds_dst;       // generic pointer to LDS: the low 32 bits are the LDS byte address
+  for (int p = w; p * 1024 < bytes; p += NW)
+    adt_glds16(reinterpret_cast<const unsigned char*>(gsrc) + p * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(dst + p * 1024));
+}
+
 // ---------------------------------------------------------------------------------------------
 // reductions
 __device__ __forceinline__ float wave_sum(float v) {

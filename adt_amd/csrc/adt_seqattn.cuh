@@ -14,7 +14,13 @@
 
 namespace adt {
 
-constexpr int SAB_NW = 8;
+constexpr int SAB_NW = 16;      // 16 waves = 4 per SIMD (the kernel needs <= 128 VGPRs): with 13 tiles at L = 200 every wave owns at most one tile per pass
+// Tile of wave w in a pass whose tiles are sorted heaviest-first (index j = 0 the heaviest): waves w, w + 4, w + 8, w + 12 share a SIMD and
+// the passes are bound by each SIMD's instruction issue, so the tiles are dealt to the four SIMD classes in snake order (see tq_tile12)
+ADT_DEVICE_INLINE int sab_rank16(int w) {
+  const int cl = w & 3, k = w >> 2;
+  return 4 * k + ((k & 1) ? 3 - cl : cl);
+}
 
 __host__ __device__ inline int sab_rows(int L) { return (L + 31) / 32 * 32; }       // image rows: whole tile pairs
 __host__ __device__ inline size_t sab_lds_bytes(int L, int H) {
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
 
   // ---- pass A: dQ (a wave owns query tile qt, keys on the accumulator rows) -----------------------------------------------------
   for (int rnd = 0; rnd * NW < nqt; ++rnd) {
-    const int tix = rnd * NW + ((rnd & 1) ? NW - 1 - w : w);       // snake order, heaviest causal tile first
+    const int tix = rnd * NW + sab_rank16(w);                      // heaviest causal tile first, balanced over the SIMDs
     if (tix >= nqt) continue;
     const int qt = nqt - 1 - tix;
     const int q = qt * 16 + c;
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
   SAB_STAMP(3);
   // ---- pass B: dK, dV (a wave owns key tile kt, queries on the accumulator rows) ---------------------------------------------
   for (int rnd = 0; rnd * NW < nqt; ++rnd) {
-    const int kt = rnd * NW + ((rnd & 1) ? NW - 1 - w : w);        // key tile 0 is the heaviest under the causal mask
+    const int kt = rnd * NW + sab_rank16(w);                       // key tile 0 is the heaviest under the causal mask
     if (kt >= nqt) continue;
     const int key = kt * 16 + c;
 #pragma unroll 1

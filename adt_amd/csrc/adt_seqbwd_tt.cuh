@@ -225,49 +225,62 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   // first: their LDS stores then wait for nothing but themselves, while the weight images and the activations stream behind them.
   // (Requested after the big loads, their stores waited for every byte in front of them: the prologue took 21.7k cycles.)
   constexpr int MI = (H * R * 2 + NW * 64 - 1) / (NW * 64), LI = (H * R + NW * 64 - 1) / (NW * 64);
-  uint4 mreg[MI];
+  tt_u4 mreg[MI];
   float lreg[LI];
+  // every load of the prologue is UNCONDITIONAL (lanes without an element read a block of zeros / a clamped index): `if (valid) x = *p`
+  // compiles to a branch with the wait for the load inside it, and six such loads were six serial memory round trips before the first
+  // activation load was even issued (12k of the 18.6k prologue cycles, profiles/r03_stamps_attn_pre_bwd.txt)
+  typedef const tt_u4 __attribute__((address_space(1))) * gu4;
+  typedef const float __attribute__((address_space(1))) * gf1;
   if constexpr (MODE == 1) {
     adt_static_for<MI>([&](auto k) {
       const int i = threadIdx.x + k * NW * 64, hr = i >> 1, h = hr / R, r = hr - h * R;
-      mreg[k] = make_uint4(0u, 0u, 0u, 0u);
-      if (i < H * R * 2 && r < L) mreg[k] = reinterpret_cast<const uint4*>(a.mask + ((size_t)(b * H + h) * L + r) * 8)[i & 1];
+      const bool ok = i < H * R * 2 && r < L;
+      const gu4 p = ok ? (gu4)(a.mask + ((size_t)(b * H + h) * L + r) * 8) + (i & 1) : (gu4)tt_zero_row;
+      mreg[k] = *p;
     });
   }
   adt_static_for<LI>([&](auto k) {
     const int i = threadIdx.x + k * NW * 64, h = i / R, r = i - h * R;
-    lreg[k] = (i < H * R && r < L) ? a.lse[(size_t)(b * H + h) * L + r] * 1.4426950408889634f : INFINITY;
+    const bool ok = i < H * R && r < L;
+    const float v = *(ok ? (gf1)(a.lse + (size_t)(b * H + h) * L + r) : (gf1)tt_zero_row);
+    lreg[k] = ok ? v * 1.4426950408889634f : INFINITY;
   });
   float vreg = 0.f;
   {
     const int t = threadIdx.x;
-    if (t < 64) vreg = a.gamma[t];
-    else if (t < 128) vreg = a.beta[t - 64];
-    else if (t < 320) vreg = a.bin[t - 128];
+    const gf1 p = t < 64 ? (gf1)(a.gamma + t) : t < 128 ? (gf1)(a.beta + (t - 64)) : t < 320 ? (gf1)(a.bin + (t - 128)) : (gf1)tt_zero_row;
+    vreg = *p;
   }
   const __bf16* wsrc = reinterpret_cast<const __bf16*>(a.wp_img) + 6 * (a.Win - a.wp_base);
   const __bf16* const src6[6] = {wsrc + 2 * WPACK_IMG, wsrc + 6 * 4096 + 2 * WPACK_IMG, wsrc + 12 * 4096 + 2 * WPACK_IMG,
                                  wsrc + 3 * WPACK_IMG, wsrc + 6 * 4096 + 3 * WPACK_IMG, wsrc + 12 * 4096 + 3 * WPACK_IMG};
-  const SbImgRegs<6> wr = sb_img_load<6>(src6);
+  // Weight images (9 KiB each, plain copies of the pre-packed images) by LDS-DMA: no staging registers (the register-staged form held 48
+  // VGPRs through the prologue and forced the activation loads into their branching form).  The prologue is a BANDWIDTH burst -- all 256
+  // workgroups pull their inputs at once, ~11 B per cycle and CU (MI355X_MICROARCH.md; 200 KB per workgroup took the 18.6k cycles of
+  // profiles/r03_stamps_attn_pre_bwd.txt) -- so only what phase P1 needs is requested in front of the first barrier: the small tables, the
+  // three plain images and x.  dO, O and the three transposed images (needed from the end of P1 / in P5) are requested behind the barrier
+  // and stream while P1 computes.
+#pragma unroll
+  for (int k = 0; k < 3; ++k) adt_glds_block<NW>(src6[k], wimg + k * TT_WIMG, TT_WIMG * 2);
   TT xa[2], doa[2], oa[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile(s, w, ntiles);
     const int l = tile * 16 + c, row = b * L + l;
-    const bool valid = tile >= 0 && l < L;
-    xa[s] = tt_load_if(a.x + (size_t)row * 64, valid, g);            // branching loads here: see tt_load_if
-    doa[s] = tt_load_if(a.dO + (size_t)row * 64, valid, g);
-    oa[s] = tt_load_saved_if(a.o, row, valid, g, a.saved_bf16);
+    xa[s] = tt_load(a.x + (size_t)row * 64, tile >= 0 && l < L, g);               // unconditional (address-select) loads: all in flight together
   }
+  SB_STAMP(11);
   // ---- P0: zeroed token images, then the tables and the weight images land in LDS ------------------------------------------------
   {
     uint4* z = reinterpret_cast<uint4*>(img0);
     for (int i = threadIdx.x; i < (int)((2 * Lds::ibytes + 64) / 16); i += NW * 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
     if (threadIdx.x < 320) sRed[threadIdx.x] = 0.f;
+    SB_STAMP(12);
     if constexpr (MODE == 1) {
       adt_static_for<MI>([&](auto k) {
         const int i = threadIdx.x + k * NW * 64;
-        if (i < H * R * 2) reinterpret_cast<uint4*>(sM + (size_t)(i >> 1) * 8)[i & 1] = mreg[k];
+        if (i < H * R * 2) reinterpret_cast<tt_u4*>(sM + (size_t)(i >> 1) * 8)[i & 1] = mreg[k];
       });
     }
     adt_static_for<LI>([&](auto k) {
@@ -275,10 +288,22 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
       if (i < H * R) { sLse[i] = lreg[k]; sDelta[i] = 0.f; }
     });
     if (threadIdx.x < 320) sVec[threadIdx.x] = vreg;
-    sb_img_store<6>(wimg, wr);
+    SB_STAMP(13);
+    adt_wait_vm0();          // the LDS-DMA of the weight images (and everything requested before it) has landed
+    SB_STAMP(14);
   }
   __syncthreads();
   SB_STAMP(1);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    const int l = tile * 16 + c, row = b * L + l;
+    const bool valid = tile >= 0 && l < L;
+    doa[s] = tt_load(a.dO + (size_t)row * 64, valid, g);
+    oa[s] = tt_load_saved(a.o, row, valid, g, a.saved_bf16);
+  }
+#pragma unroll
+  for (int k = 3; k < 6; ++k) adt_glds_block<NW>(src6[k], wimg + k * TT_WIMG, TT_WIMG * 2);      // waited for in front of the barrier behind pass A
   const float qmul = a.scale * 1.4426950408889634f;
   const uint32_t key_rng = drop_key(a.drop);
   // ---- P1: recompute LN + in-projection; operands to registers, K / V images ------------------------------------------------------
@@ -339,6 +364,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
       for (int nt = 0; nt < NT; ++nt) dq[s].v[h * NT + nt] = t[nt] * a.scale;
     }
   }
+  adt_wait_vm0();            // the transposed weight images (LDS-DMA issued at the start of P1) have landed: published by this barrier
   __syncthreads();
   SB_STAMP(3);
   // ---- P3: Q / dO images, then pass B (dK, dV) with own key and value rows from registers ----------------------------------------------

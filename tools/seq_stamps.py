@@ -39,6 +39,8 @@ if MODE == "attn":
 if MODE == "post":      # k_seqtt_post_bwd<., true> (encoder), last launch of the step
     names = ["start", "issued", "staged", "loadsA", "slot0A", "endA", "bar", "dW2", "bar", "endB", "dW1", "bar", "endC", "dWo", "end"]
 print("wave " + " ".join("%8s" % n for n in names))
+if MODE == "attn":
+    print("prologue (loads issued, zero-fill done, small tables stored, images stored):", [[int(t[w, k] - t0) for k in (11, 12, 13, 14)] for w in (0, 4)])
 if MODE == "fwd":
     print("prologue (issue loads, zero-fill, image stores, vector stores):", [[int(t[w, k] - t0) for k in (11, 12, 13, 14)] for w in (0, 4)])
 for w in range(NWV):
