@@ -489,6 +489,19 @@ static int loss_seed_impl(const adt_sasrec_cfg* c, float* ws, const int32_t* pos
   return 0;
 }
 
+// Measurement hook (bench.py's roofline probe; not part of include/adt_hip.h): HIP events recorded on the launch stream right before and right
+// after ONE launch inside adt_sasrec_backward -- which = 1: the fused attention-block backward (k_seqtt_attn_pre_bwd) of encoder layer `layer`;
+// which = 2: the same kernel's decoder instantiation for decoder layer `layer`; 0 switches the hook off.
+static int g_time_which = 0, g_time_layer = 0;
+static hipEvent_t g_time_ev0 = nullptr, g_time_ev1 = nullptr;
+extern "C" int adt_debug_time_launch(int which, int layer, void* ev_start, void* ev_stop) {
+  g_time_which = which; g_time_layer = layer; g_time_ev0 = (hipEvent_t)ev_start; g_time_ev1 = (hipEvent_t)ev_stop;
+  return 0;
+}
+static inline void time_mark(int which, int layer, bool start, void* st) {
+  if (g_time_which == which && g_time_layer == layer && g_time_ev0 && g_time_ev1) (void)hipEventRecord(start ? g_time_ev0 : g_time_ev1, (hipStream_t)st);
+}
+
 int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float* ws, const int32_t* seq,
                         const int32_t* dec, const int32_t* pos, const int32_t* neg, int B, int training,
                         const uint32_t* seed, uint32_t b_offset, int phase, void* st) {
@@ -604,7 +617,9 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.gx = gx; a.acc = i > 0 ? 1 : 0; a.dWin = gsinw; a.dbin = gsinb; a.dgamma = Gq + lo.dec(i, D_LNW); a.dbeta = Gq + lo.dec(i, D_LNB);
         a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride; a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack; a.saved_bf16 = lean;
         a.part = PART(i, PS_D_SIN); a.part_stride = (size_t)w.part_stride;
+        time_mark(2, i, true, st);
         const int rc = adt_launch_seq_attn_pre_bwd(hd, 1, a, st);
+        time_mark(2, i, false, st);
         if (rc < 0) return rc;
         if (rc != 0 && lean) return adt_set_error("backward: the lean forward needs the fused attention-block backward (L=%d hd=%d)", L, hd);
         fused_blk = rc == 0;
@@ -680,7 +695,9 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.gx = gx; a.acc = 1; a.dWin = ginw; a.dbin = ginb; a.dgamma = Gq + lo.enc(i, E_LN1W); a.dbeta = Gq + lo.enc(i, E_LN1B);
         a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride; a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack; a.saved_bf16 = lean;
         a.part = PART(i, PS_E_IN); a.part_stride = (size_t)w.part_stride;
+        time_mark(1, i, true, st);
         const int rc = adt_launch_seq_attn_pre_bwd(hd, 0, a, st);
+        time_mark(1, i, false, st);
         if (rc < 0) return rc;
         if (rc != 0 && lean) return adt_set_error("backward: the lean forward needs the fused attention-block backward (L=%d hd=%d)", L, hd);
         fused_blk = rc == 0;

@@ -30,10 +30,12 @@ static bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 // ---- masked attention dispatch ---------------------------------------------------------------------------------
 template <int PREC, int HD, int MAXKT, bool CSK = false>
 static int launch_attn_gen(bool bwd, const AttnGenArgs& a, hipStream_t s) {
-  constexpr int NW = 8;
+  // bf16 operands: the forward (<= 106 VGPRs at every head size) and the backward at head size <= 64 (<= 124) fit the 128-register budget of
+  // 16 waves = 4 per SIMD: one query / key tile per wave at L = 200 instead of two, and twice the waves to cover each other's LDS and MFMA latency
+  constexpr int NWF = PREC == PREC_BF16 ? 16 : 8, NWB = (PREC == PREC_BF16 && HD <= 64) ? 16 : 8;
   const size_t smem = bwd ? AttnGenLds<PREC, HD, MAXKT>::bwd_bytes : AttnGenLds<PREC, HD, MAXKT>::fwd_bytes;
   if (smem > 160 * 1024) return adt_set_error("masked attention: L=%d hd=%d prec=%d needs %zu B of LDS (> 160 KB)", a.a.L, HD, PREC, smem);
-  const void* fn = bwd ? (const void*)k_attn_gen_bwd<PREC, HD, MAXKT, NW> : (const void*)k_attn_gen_fwd<PREC, HD, MAXKT, NW, CSK>;
+  const void* fn = bwd ? (const void*)k_attn_gen_bwd<PREC, HD, MAXKT, NWB> : (const void*)k_attn_gen_fwd<PREC, HD, MAXKT, NWF, CSK>;
   static bool done[2] = {false, false};
   if (!done[bwd ? 1 : 0]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -42,7 +44,7 @@ static int launch_attn_gen(bool bwd, const AttnGenArgs& a, hipStream_t s) {
   }
   AttnGenArgs args = a;
   void* kargs[] = {&args};
-  if (hipLaunchKernel(fn, dim3(a.a.B * a.a.H), dim3(NW * 64), kargs, smem, s) != hipSuccess) return adt_set_error("masked attention: launch failed");
+  if (hipLaunchKernel(fn, dim3(a.a.B * a.a.H), dim3((bwd ? NWB : NWF) * 64), kargs, smem, s) != hipSuccess) return adt_set_error("masked attention: launch failed");
   return check_launch(bwd ? "attn_masked_bwd" : "attn_masked_fwd");
 }
 

@@ -135,15 +135,43 @@ def _time_us(fn, reps=20, warm=3):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
+def _time_in_step(model, trainer, batch, which, layer, reps=12):
+    """Duration (us, median) of ONE launch inside a real training step, in its own context: the C library records two HIP events on the launch
+    stream right around that launch (adt_debug_time_launch) while complete eager steps run."""
+    import ctypes
+    import torch
+    lib = model.lib
+    lib.adt_debug_time_launch.restype = ctypes.c_int
+    lib.adt_debug_time_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    graph = trainer.use_graph
+    trainer.use_graph = False
+    ts = []
+    try:
+        for _ in range(reps + 2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); e1.record()          # creates the underlying hipEvents
+            torch.cuda.synchronize()
+            lib.adt_debug_time_launch(which, layer, ctypes.c_void_p(e0.cuda_event), ctypes.c_void_p(e1.cuda_event))
+            trainer.step(*batch)
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3)
+    finally:
+        lib.adt_debug_time_launch(0, 0, None, None)
+        trainer.use_graph = graph
+    return sorted(ts[2:])[len(ts[2:]) // 2]
+
+
 def roofline_probe(model, trainer, B, seq_per_s, batch):
-    """`roofline` of the bench line.  The object itself describes the DOMINANT kernel of the step -- the fused decoder-layer forward
-    k_seqtt_dec_fwd (one workgroup per sequence; the largest share of the step in profiles/r02_kernel_stats.csv): algorithmic bytes
-    per launch = tokens x (x 256 + log_feats 256 + y 256 fp32; o1, a1, q2, o2, a2, u 6 x 128 and k2|v2 256 bf16; 2 H log-sum-exp floats;
-    2 H x 32 B of dropout keep bits; 4 B id) / its average launch duration, measured live with HIP events on the launch stream by
-    launching that one kernel on the workspace of a completed forward (adt_sasrec_probe_dec_layer_fwd).  `kernels` adds what north_star
-    asks for by name: achieved HBM GB/s of the embedding gather and MFMA utilisation of the attention kernels (causal-aware FLOPs,
-    SURVEY 8d: 4*L(L+1)/2*hd per (b,h) forward, 2.5x that backward), measured on the standalone C-ABI kernels; `step` is SURVEY 8d's
-    step-level figure, sequences/s x 2.4 MB of ideal fused-step traffic against the HBM peak."""
+    """`roofline` of the bench line.  The object itself describes the kernel with the LARGEST share of the step -- the fused attention-block
+    backward k_seqtt_attn_pre_bwd (one workgroup per sequence; four launches per step, 26 % of it in profiles/r03_kernel_stats.csv).
+    Algorithmic bytes per launch = tokens x (x 256 + dO 256 + residual-path gradient 256 + gx read 256 + gx write 256 fp32; O 128 bf16;
+    H log-sum-exp floats; H x 32 B of dropout keep bits) + 3 x 16 KB of private weight-gradient partials per sequence, divided by its launch
+    duration measured live with HIP events recorded by the library right around that launch inside complete training steps
+    (adt_debug_time_launch; the committed rocprofv3 average is used instead when it is the larger, i.e. the conservative, figure).
+    `kernels` adds the fused decoder-layer forward (the round-2 dominant kernel), and what north_star asks for by name: achieved HBM GB/s of
+    the embedding gather and MFMA utilisation of the attention kernels (causal-aware FLOPs, SURVEY 8d: 4*L(L+1)/2*hd per (b,h) forward,
+    2.5x that backward; counter-based matrix-pipe busy fractions: profiles/r03_mfma.json) on the standalone C-ABI kernels; `step` is
+    SURVEY 8d's step-level figure, sequences/s x 2.4 MB of ideal fused-step traffic against the HBM peak."""
     import torch
     from adt_amd import ops
     L, d, H = CFG["maxlen"], CFG["hidden_units"], CFG["num_heads"]
@@ -152,9 +180,16 @@ def roofline_probe(model, trainer, B, seq_per_s, batch):
     dev = model.dev
     prec, p, sd = model.cfg.prec, CFG["dropout"], model._seed
     ids4 = [model._ids(a) for a in batch]
+    # dominant kernel: in-step duration of the encoder instantiation, layer 1 (the first encoder block of the backward)
+    us_bwd_blk = _time_in_step(model, trainer, batch, 1, CFG["num_layers"] - 1)
+    us_prof = _profile_avg_us("k_seqtt_attn_pre_bwd<32, 1, false>")
+    us_used = max(us_bwd_blk, us_prof or 0.0)
+    blk_bytes = T * (5 * 256 + 128 + H * 4 + H * 32) + B * 3 * 16384
+    blk_flops = T * 9 * 2 * d * d + B * H * 10 * (L * (L + 1) // 2) * hd      # 3 recomputed + 3 weight-gradient + 3 input-gradient 64x64 products per token; five causal score-sized products per head
+    achieved = blk_bytes / (us_used * 1e-6) / 1e9
+    # the fused decoder-layer forward: back-to-back relaunches, and in context (a whole forward before every timed launch)
     model.run_forward(*ids4, B, True)
-    us_dec_iso = _time_us(lambda: model.probe_dec_layer_forward(ids4[1], B, 1))      # back-to-back relaunches: warm caches, the optimistic figure
-    # in context: a whole forward (which leaves the caches as the step does) before every timed launch, HIP events around that one launch
+    us_dec_iso = _time_us(lambda: model.probe_dec_layer_forward(ids4[1], B, 1))
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
     for e0, e1 in pairs:
         model.run_forward(*ids4, B, True)
@@ -163,9 +198,8 @@ def roofline_probe(model, trainer, B, seq_per_s, batch):
         e1.record()
     torch.cuda.synchronize()
     us_dec = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in pairs)[len(pairs) // 2]
-    # the committed rocprofv3 --kernel-trace --stats average of the same kernel inside the step, when it is the larger one (the conservative figure)
-    us_prof = _profile_avg_us("k_seqtt_dec_fwd")
-    us_used = max(us_dec, us_prof or 0.0)
+    us_dec_prof = _profile_avg_us("k_seqtt_dec_fwd")
+    us_dec_used = max(us_dec, us_dec_prof or 0.0)
     dec_bytes = T * (3 * 256 + 6 * 128 + 256 + 2 * H * 4 + 2 * H * 32 + 4)
     dec_flops = T * 10 * 2 * d * d + 2 * B * H * 4 * (L * (L + 1) // 2) * hd      # ten 64x64 products per token + two causal attentions
     qkv = torch.randn(T, 3 * d, device=dev)
@@ -178,35 +212,54 @@ def roofline_probe(model, trainer, B, seq_per_s, batch):
     ids = torch.randint(1, CFG["item_num"] + 1, (T,), device=dev, dtype=torch.int32)
     E, Pt = model.flat[:(CFG["item_num"] + 1) * d].view(-1, d), model.flat[model.offsets[1]:model.offsets[1] + L * d].view(L, d)
     us_emb = _time_us(lambda: ops.embed_fwd(ids, E, Pt, L, p, sd, 1, 0))
-    achieved = dec_bytes / (us_used * 1e-6) / 1e9
     fl_fwd = B * H * 4 * (L * (L + 1) // 2) * hd           # QK^T and PV, causal half
     emb_bytes = T * (4 + d * 4 + d * 4)                     # id + fp32 table row + fp32 output row (positional table stays in cache)
     # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes of this same command,
     # corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py): a profiler measurement, committed under profiles/
-    traffic = None
-    for name in ("r03_dec_fwd_pmc.json", "r02_dec_fwd_pmc.json"):
+    traffic = dec_traffic = None
+    for name, key in (("r03_attn_pre_bwd_pmc.json", "blk"), ("r03_dec_fwd_pmc.json", "dec"), ("r02_dec_fwd_pmc.json", "dec")):
         pmc = os.path.join(REPO, "profiles", name)
         if os.path.exists(pmc):
-            traffic = round(json.load(open(pmc))["traffic_bytes"])
-            break
+            if key == "blk" and traffic is None:
+                traffic = round(json.load(open(pmc))["traffic_bytes"])
+            if key == "dec" and dec_traffic is None:
+                dec_traffic = round(json.load(open(pmc))["traffic_bytes"])
     step_bytes = 2.4e6
     logits_entry = lce_probe(dev)
-    return {"bound": "hbm", "kernel": "k_seqtt_dec_fwd (fused decoder-layer forward)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+    mfma_pmc = {}
+    try:
+        mfma_pmc = json.load(open(os.path.join(REPO, "profiles", "r03_mfma.json")))["runs"]["flagship"]
+    except Exception:
+        pass
+
+    def busy(name):
+        for k, e in mfma_pmc.items():
+            if k.startswith(name):
+                return round(e.get("mfma_busy_frac", 0.0), 4)
+        return None
+    return {"bound": "hbm", "kernel": "k_seqtt_attn_pre_bwd (fused attention-block backward, encoder instantiation; the largest share of the step)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_us": round(us_used, 2),
-            "avg_launch_us_in_context": round(us_dec, 2), "avg_launch_us_back_to_back": round(us_dec_iso, 2), "avg_launch_us_rocprof": us_prof,
+            "avg_launch_us_in_step": round(us_bwd_blk, 2), "avg_launch_us_rocprof": us_prof,
             "traffic_source": "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.py): a committed measurement, not taken in this run",
-            "algorithmic_bytes_per_launch": dec_bytes,
-            "mfma": {"flops_per_launch": dec_flops, "achieved_TFLOPs": round(dec_flops / (us_used * 1e-6) / 1e12, 2),
-                     "mfma_util": round(dec_flops / (us_used * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+            "algorithmic_bytes_per_launch": blk_bytes,
+            "mfma": {"flops_per_launch": blk_flops, "achieved_TFLOPs": round(blk_flops / (us_used * 1e-6) / 1e12, 2),
+                     "mfma_util": round(blk_flops / (us_used * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4), "mfma_busy_frac_pmc": busy("k_seqtt_attn_pre_bwd<32, 1, false>")},
             "kernels": [
+                {"kernel": "k_seqtt_dec_fwd (fused decoder-layer forward)", "bound": "hbm", "avg_launch_us": round(us_dec_used, 2),
+                 "avg_launch_us_in_context": round(us_dec, 2), "avg_launch_us_back_to_back": round(us_dec_iso, 2), "avg_launch_us_rocprof": us_dec_prof,
+                 "algorithmic_bytes_per_launch": dec_bytes, "achieved_GBps": round(dec_bytes / (us_dec_used * 1e-6) / 1e9, 1),
+                 "frac": round(dec_bytes / (us_dec_used * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": dec_traffic, "flops_per_launch": dec_flops,
+                 "mfma_util": round(dec_flops / (us_dec_used * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4), "mfma_busy_frac_pmc": busy("k_seqtt_dec_fwd")},
                 {"kernel": "k_embed_fwd (item + positional gather, dropout, pad mask)", "bound": "hbm", "avg_launch_us": round(us_emb, 2),
                  "algorithmic_bytes_per_launch": emb_bytes, "achieved_GBps": round(emb_bytes / (us_emb * 1e-6) / 1e9, 1),
                  "frac": round(emb_bytes / (us_emb * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
                 {"kernel": "k_attn_fwd (standalone attention, C ABI)", "bound": "mfma", "avg_launch_us": round(us_fwd, 2), "flops_per_launch": fl_fwd,
-                 "achieved_TFLOPs": round(fl_fwd / (us_fwd * 1e-6) / 1e12, 2), "mfma_util": round(fl_fwd / (us_fwd * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+                 "achieved_TFLOPs": round(fl_fwd / (us_fwd * 1e-6) / 1e12, 2), "mfma_util": round(fl_fwd / (us_fwd * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                 "mfma_busy_frac_pmc": busy("k_attn_fwd_bf16")},
                 {"kernel": "k_seq_attn_bwd (standalone attention backward, C ABI)", "bound": "mfma", "avg_launch_us": round(us_bwd, 2),
                  "flops_per_launch": int(2.5 * fl_fwd), "achieved_TFLOPs": round(2.5 * fl_fwd / (us_bwd * 1e-6) / 1e12, 2),
-                 "mfma_util": round(2.5 * fl_fwd / (us_bwd * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)}] + ([logits_entry] if logits_entry else []),
+                 "mfma_util": round(2.5 * fl_fwd / (us_bwd * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4), "mfma_busy_frac_pmc": busy("k_seq_attn_bwd")}] + ([logits_entry] if logits_entry else []),
             "step": {"bytes_per_sequence_ideal": step_bytes, "achieved_GBps": round(seq_per_s * step_bytes / 1e9, 1),
                      "frac": round(seq_per_s * step_bytes / 1e9 / HBM_PEAK_GBS, 4),
                      "mfma_util": round(seq_per_s * 250e6 / 1e12 / MFMA_PEAK_TFLOPS, 4)}}

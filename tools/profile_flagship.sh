@@ -6,6 +6,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/r03/f -o fetch -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-ndcg > gpurun_out/r03/f_log.txt 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/r03/w -o write -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-ndcg > gpurun_out/r03/w_log.txt 2>&1 || exit 1
 python tools/pmc_traffic.py gpurun_out/r03/f/fetch_counter_collection.csv gpurun_out/r03/w/write_counter_collection.csv k_seqtt_dec_fwd gpurun_out/r03/r03_dec_fwd_pmc.json
+python tools/pmc_traffic.py gpurun_out/r03/f/fetch_counter_collection.csv gpurun_out/r03/w/write_counter_collection.csv "k_seqtt_attn_pre_bwd<32, 1, false>" gpurun_out/r03/r03_attn_pre_bwd_pmc.json
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d gpurun_out/r03/sq -o sq -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-ndcg > gpurun_out/r03/sq_log.txt 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d gpurun_out/r03/sq_lce -o sq -- python3 tools/bench_lce.py > gpurun_out/r03/sq_lce_log.txt 2>&1 || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d gpurun_out/r03/sq_bert -o sq -- python3 tools/bench_wide.py bert --steps 4 > gpurun_out/r03/sq_bert_log.txt 2>&1 || exit 1
