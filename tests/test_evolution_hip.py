@@ -35,7 +35,9 @@ def test_sasrec_evolution(tmp_path, monkeypatch):
     assert "V_NDCG" in recs[0] and os.path.exists(tmp_path / "checkpoint" / "super.pth")
     st = s.search_state
     assert st.batches < st.evaluated          # several candidates per validation pass
-    assert s.eval_stats["layer_calls"] < s.eval_stats["layer_copies"] or s.eval_stats["layer_calls"] < 8 * st.evaluated
+    # candidates of one pass that select the same layer share its evaluation; with the reference's lazy consumption of proposals the
+    # passes of this tiny search hold ~3 candidates, so sharing may be zero here: never MORE calls than one per (candidate, selected layer)
+    assert s.eval_stats["layer_calls"] <= s.eval_stats["layer_copies"]
 
 
 def test_bert_evolution(tmp_path, monkeypatch):
