@@ -225,13 +225,13 @@ int adt_launch_seq_post_bwd(int hd, int enc, const BwdChainArgs& a, void* stream
   const int slot = (hd == 64 ? 0 : hd == 32 ? 2 : 4) + (enc ? 1 : 0);
   BwdChainArgs args = a;
   args.stamps = enc ? seq_stamp_buffer_post() : nullptr;
-  return seq_launch(fns[slot], SeqPostLds<3>::bytes, done[slot], a.B, &args, (hipStream_t)stream, "seqtt_post_bwd");
+  return seq_launch(fns[slot], SeqPostLds<3>::bytes, done[slot], a.B, &args, (hipStream_t)stream, "seqtt_post_bwd", SP_NW);
 }
 
 int adt_launch_seq_mid_bwd(int hd, const BwdChainArgs& a, void* stream) {
   if (!seq_post_ok(a, hd)) return 1;
   static bool done = false;
-  return seq_launch((const void*)k_seqtt_mid_bwd, SeqPostLds<4>::bytes, done, a.B, &a, (hipStream_t)stream, "seqtt_mid_bwd");
+  return seq_launch((const void*)k_seqtt_mid_bwd, SeqPostLds<4>::bytes, done, a.B, &a, (hipStream_t)stream, "seqtt_mid_bwd", SP_NW);
 }
 
 // ---- sum of the per-workgroup weight-gradient partials (adt_seqbwd_tt.cuh: sb_dw_tiles) --------------------------------------------

@@ -123,34 +123,39 @@ ADT_DEVICE_INLINE TT tt_ln_bwd(const TT& dy, const TTLn& st, const float* gamma,
 // 2-layer model.  part != nullptr: this workgroup's PRIVATE 4,096-float partial of the block, written with plain 256-byte stores in
 // register order -- element ((tile * 4 + r) * 64 + lane), tile = 4 nt + kt -- and summed over the workgroups, in a fixed order, by
 // k_dwpart_reduce (adt_seq.hip).  Nothing is zeroed and the sum does not depend on timing.
-template <int NP>
+template <int NP, int NW = SB_NW>
 ADT_DEVICE_INLINE void sb_dw_tiles(const __bf16* sG, const __bf16* sX, float* dW, float* part, int w, int c, int g) {
+  // NW = 8: wave w computes output tiles (nt0, kt) and (nt0 + 2, kt), nt0 = w >> 2, kt = w & 3 (they share the X fragments);
+  // NW = 16: wave w computes tile (w >> 2, w & 3) alone.  Either way tile 4 nt + kt of the partial layout is w (and w + 8).
+  constexpr bool TWO = NW == 8;
   const int kt = w & 3, nt0 = w >> 2;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int kp = 0; kp < NP; ++kp) {
     const bf16x8 fx = tt_trfrag(sX, kp * 32, 16 * kt, c, g);
     acc0 = mfma_bf16(acc0, tt_trfrag(sG, kp * 32, 16 * nt0, c, g), fx);
-    acc1 = mfma_bf16(acc1, tt_trfrag(sG, kp * 32, 16 * (nt0 + 2), c, g), fx);
+    if (TWO) acc1 = mfma_bf16(acc1, tt_trfrag(sG, kp * 32, 16 * (nt0 + 2), c, g), fx);
   }
   if (part) {
     const int lane = 16 * g + c;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       part[(w * 4 + r) * 64 + lane] = acc0[r];              // tile 4 nt0 + kt == w
-      part[((w + 8) * 4 + r) * 64 + lane] = acc1[r];
+      if (TWO) part[((w + 8) * 4 + r) * 64 + lane] = acc1[r];
     }
     return;
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     atomicAdd(dW + (16 * nt0 + 4 * g + r) * 64 + 16 * kt + c, acc0[r]);
-    atomicAdd(dW + (16 * (nt0 + 2) + 4 * g + r) * 64 + 16 * kt + c, acc1[r]);
+    if (TWO) atomicAdd(dW + (16 * (nt0 + 2) + 4 * g + r) * 64 + 16 * kt + c, acc1[r]);
   }
 }
+template <int NW = SB_NW>
 ADT_DEVICE_INLINE void sb_dw_product16(const __bf16* sG, const __bf16* sX, int npair, float* dW, float* part, int w, int c, int g) {
-  if (npair <= 4) sb_dw_tiles<4>(sG, sX, dW, part, w, c, g);
-  else sb_dw_tiles<SB_R / 32>(sG, sX, dW, part, w, c, g);
+  static_assert(NW == 8 || NW == 16, "8 waves (two output tiles each) or 16 (one each)");
+  if (npair <= 4) sb_dw_tiles<4, NW>(sG, sX, dW, part, w, c, g);
+  else sb_dw_tiles<SB_R / 32, NW>(sG, sX, dW, part, w, c, g);
 }
 // bias gradients (column sums of G over the tokens): per-lane sums of the tiles a wave holds, reduced over the 16 tokens of a lane row,
 // added to a 64-float LDS vector; the workgroup adds the vector to the global accumulator once, at its end

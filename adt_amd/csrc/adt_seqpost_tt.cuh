@@ -30,24 +30,30 @@ ADT_DEVICE_INLINE void sp_replica(BwdChainArgs& a) {
     if (*ptrs[i]) *ptrs[i] += off;
 }
 
-// transposed slot-ordered images (the operand of dX^T = W^T dY^T) of N weights: the global loads
-template <int N>
-ADT_DEVICE_INLINE SbImgRegs<N> sp_wload(const BwdChainArgs& a, const float* const (&W)[N]) {
-  const __bf16* src[N];
+// transposed slot-ordered images (the operand of dX^T = W^T dY^T) of N weights, global -> LDS by LDS-DMA (no staging registers; the caller
+// waits with adt_wait_vm0() in front of the barrier that publishes them)
+template <int N, int NW>
+ADT_DEVICE_INLINE void sp_wdma(const BwdChainArgs& a, const float* const (&W)[N], __bf16* wimg) {
 #pragma unroll
-  for (int j = 0; j < N; ++j) src[j] = reinterpret_cast<const __bf16*>(a.wp_img) + 6 * (W[j] - a.wp_base) + 3 * WPACK_IMG;
-  return sb_img_load<N>(src);
+  for (int j = 0; j < N; ++j)
+    adt_glds_block<NW>(reinterpret_cast<const __bf16*>(a.wp_img) + 6 * (W[j] - a.wp_base) + 3 * WPACK_IMG, wimg + j * TT_WIMG, TT_WIMG * 2);
 }
+template <int NW>
 ADT_DEVICE_INLINE void sp_zero_images(__bf16* img0) {
   constexpr size_t ibytes = (size_t)SB_R * TT_RS * 2;
   uint4* z = reinterpret_cast<uint4*>(img0);
-  for (int i = threadIdx.x; i < (int)((2 * ibytes + 64) / 16); i += SB_NW * 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = threadIdx.x; i < (int)((2 * ibytes + 64) / 16); i += NW * 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
 }
+// Wave count of the token-chain backward kernels.  Every tile costs the same here (no causal weights), so with 13 tiles at L = 200 the eight-wave
+// form is paced by the five waves that own two tiles; sixteen waves (<= 128 VGPRs, one tile slot per wave) give every tile its own wave and
+// four waves per SIMD to cover each other's LDS and MFMA latency.
+constexpr int SP_NW = 8;
+constexpr int SP_NS = (14 + SP_NW - 1) / SP_NW;          // tile slots per wave (L <= 224)
 
 template <int HD, bool ENC>
-__global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
+__global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   adt_prefetch_kernargs<(sizeof(BwdChainArgs) + 63) / 64 * 64 <= 512 ? sizeof(BwdChainArgs) : 512>();      // adt_common.cuh
-  constexpr int H = 64 / HD, NT = HD / 16, NW = SB_NW;
+  constexpr int H = 64 / HD, NT = HD / 16, NW = SP_NW, NS = SP_NS;
   typedef SeqPostLds<3> Lds;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* wimg = reinterpret_cast<__bf16*>(smem_raw);                       // conv2^T, conv1^T, out_proj^T
@@ -64,13 +70,13 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   // every workgroup of the launch runs the same phases at the same time: the activations of phase A are requested right behind the
   // weight images, so that HBM streams them while the prologue runs (requested at the top of phase A they arrived ~8k cycles after it)
   const float* const ws3[3] = {a.W0, a.W1, a.W2};
-  const SbImgRegs<3> wr = sp_wload<3>(a, ws3);
-  TT dy[2];
-  TTSaved uraw[2], hreq[2];                              // requested here, converted where they are first needed (tt_saved_value)
-  int idv[2];
+  sp_wdma<3, NW>(a, ws3, wimg);
+  TT dy[NS];
+  TTSaved uraw[NS], hreq[NS];                            // requested here, converted where they are first needed (tt_saved_value)
+  int idv[NS];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+  for (int s = 0; s < NS; ++s) {
+    const int tile = tq_tile(s, w, ntiles, NW);
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = tile >= 0 && l < L;
     dy[s] = tt_load(a.gy + (size_t)row * 64, valid, g);
@@ -80,16 +86,16 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   }
   if (a.gy_scale != 0.f) {                                 // after every load of the prologue has been issued: a use is a wait
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) dy[s].v[nt] *= a.gy_scale;
   }
   {
-    sp_zero_images(img0);
+    sp_zero_images<NW>(img0);
     if (threadIdx.x < 448) sRed[threadIdx.x] = 0.f;
     if (ENC) { tt_stage_vec<NW * 64>(sVec, a.gamma, 64); tt_stage_vec<NW * 64>(sVec + 64, a.beta, 64); }
     if (cls) tt_stage_vec<NW * 64>(sVec + 128, a.Ws, 64);
-    sb_img_store<3>(wimg, wr);
+    adt_wait_vm0();
   }
   const uint32_t seedv = a.drop.thr ? *a.drop.seed : 0u;
   const uint32_t key1 = adt_site_key(seedv, a.site1), key2 = adt_site_key(seedv, a.site2);
@@ -97,11 +103,11 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   __syncthreads();
   SB_STAMP(2);
   // ---- A: masked upstream gradient through dropout2 and conv2 ; dW(conv2) = df^T u ----------------------------------------------------
-  TT dt[2];
+  TT dt[NS];
   TT bsum = tt_zero();
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+  for (int s = 0; s < NS; ++s) {
+    const int tile = tq_tile(s, w, ntiles, NW);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
@@ -127,18 +133,18 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   SB_STAMP(5);
   __syncthreads();
   SB_STAMP(6);
-  sb_dw_product16(img0, img1, npair, a.dW0, a.part[0] ? a.part[0] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
+  sb_dw_product16<NW>(img0, img1, npair, a.dW0, a.part[0] ? a.part[0] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
   SB_STAMP(7);
   __syncthreads();
   SB_STAMP(8);
   // ---- B: conv1 ; encoder: forward_layernorm backward -> dh ; dW(conv1) = dt^T LN2(h) (decoder: dt^T a2) --------------------------------
-  TT dh[2];
-  TTSaved oreq[2];
+  TT dh[NS];
+  TTSaved oreq[NS];
   TT dgm = tt_zero(), dbt = tt_zero();
   bsum = tt_zero();
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+  for (int s = 0; s < NS; ++s) {
+    const int tile = tq_tile(s, w, ntiles, NW);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   sb_colsum_flush(sRed + 320, bsum, c, g);
   SB_STAMP(9);
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dW1, a.part[1] ? a.part[1] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
+  sb_dw_product16<NW>(img0, img1, npair, a.dW1, a.part[1] ? a.part[1] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
   SB_STAMP(10);
   __syncthreads();
   SB_STAMP(11);
@@ -177,8 +183,8 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
       for (int r = 0; r < 4; ++r) dws[cc][nt][r] = 0.f;
   }
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+  for (int s = 0; s < NS; ++s) {
+    const int tile = tq_tile(s, w, ntiles, NW);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   sb_colsum_flush(sRed + 384, bsum, c, g);
   SB_STAMP(12);
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dW2, a.part[2] ? a.part[2] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
+  sb_dw_product16<NW>(img0, img1, npair, a.dW2, a.part[2] ? a.part[2] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
   SB_STAMP(13);
   if (ENC) {
     // per-lane partials over this wave's tokens -> workgroup sums in LDS -> one atomic per element
@@ -257,9 +263,9 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
 
 // W0 = enc_attn Wq, W1 = slf_attn.out_proj, W2 = enc_attn Wk, W3 = enc_attn Wv ; dqkv = dq2 (ld lddqkv), xin = a1, o = o1, dkv2 (B*L x 128),
 // f = log_feats ; out0 = dO1, out1 = d log_feats (acc1: add to what is there)
-__global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
+__global__ __launch_bounds__(SP_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
   adt_prefetch_kernargs<(sizeof(BwdChainArgs) + 63) / 64 * 64 <= 512 ? sizeof(BwdChainArgs) : 512>();      // adt_common.cuh
-  constexpr int NW = SB_NW;
+  constexpr int NW = SP_NW, NS = SP_NS;
   typedef SeqPostLds<4> Lds;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* wimg = reinterpret_cast<__bf16*>(smem_raw);
@@ -270,28 +276,28 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
   const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16, npair = (L + 31) / 32;
   sp_replica(a);
   const float* const ws4[4] = {a.W0, a.W1, a.W2, a.W3};
-  const SbImgRegs<4> wr = sp_wload<4>(a, ws4);
-  TT dqa[2];
-  TTSaved a1req[2], oreq[2];             // phase A's activations are requested right behind the weight images (see k_seqtt_post_bwd)
+  sp_wdma<4, NW>(a, ws4, wimg);
+  TT dqa[NS];
+  TTSaved a1req[NS], oreq[NS];             // phase A's activations are requested right behind the weight images (see k_seqtt_post_bwd)
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+  for (int s = 0; s < NS; ++s) {
+    const int tile = tq_tile(s, w, ntiles, NW);
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = tile >= 0 && l < L;
     dqa[s] = tt_load(a.dqkv + (size_t)row * a.lddqkv, valid, g);
     a1req[s] = tt_saved_request(a.xin, row, valid, g, a.saved_bf16);
     oreq[s] = tt_saved_request(a.o, row, valid, g, a.saved_bf16);
   }
-  sp_zero_images(img0);
+  sp_zero_images<NW>(img0);
   if (threadIdx.x < 256) sRed[threadIdx.x] = 0.f;
-  sb_img_store<4>(wimg, wr);
+  adt_wait_vm0();
   __syncthreads();
   // ---- A: cross-attention query projection: da1 = dq2 Wq ; dWq = dq2^T a1 ----------------------------------------------------------
-  TT da1[2];
+  TT da1[NS];
   TT bsum = tt_zero();
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+  for (int s = 0; s < NS; ++s) {
+    const int tile = tq_tile(s, w, ntiles, NW);
     if (tile < 0) continue;
     const int l = tile * 16 + c;
     const bool valid = l < L;
@@ -302,14 +308,14 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
   }
   sb_colsum_flush(sRed, bsum, c, g);
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dW0, a.part[0] ? a.part[0] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
+  sb_dw_product16<NW>(img0, img1, npair, a.dW0, a.part[0] ? a.part[0] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
   __syncthreads();
   // ---- B: self-attention out_proj: dO1 = da1 Wo1 ; dWo1 = da1^T o1 --------------------------------------------------------------------
-  TT dk[2], fx[2];
+  TT dk[NS], fx[NS];
   bsum = tt_zero();
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+  for (int s = 0; s < NS; ++s) {
+    const int tile = tq_tile(s, w, ntiles, NW);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
@@ -322,14 +328,14 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
   }
   sb_colsum_flush(sRed + 64, bsum, c, g);
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dW1, a.part[1] ? a.part[1] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
+  sb_dw_product16<NW>(img0, img1, npair, a.dW1, a.part[1] ? a.part[1] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
   __syncthreads();
   // ---- C: cross-attention keys: df = dk2 Wk ; dWk = dk2^T f -----------------------------------------------------------------------------
-  TT df[2], dv[2];
+  TT df[NS], dv[NS];
   bsum = tt_zero();
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+  for (int s = 0; s < NS; ++s) {
+    const int tile = tq_tile(s, w, ntiles, NW);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
@@ -341,13 +347,13 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
   }
   sb_colsum_flush(sRed + 128, bsum, c, g);
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dW2, a.part[2] ? a.part[2] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
+  sb_dw_product16<NW>(img0, img1, npair, a.dW2, a.part[2] ? a.part[2] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
   __syncthreads();
   // ---- D: cross-attention values (the X image still holds f) --------------------------------------------------------------------------
   bsum = tt_zero();
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+  for (int s = 0; s < NS; ++s) {
+    const int tile = tq_tile(s, w, ntiles, NW);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
   }
   sb_colsum_flush(sRed + 192, bsum, c, g);
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dW3, a.part[3] ? a.part[3] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
+  sb_dw_product16<NW>(img0, img1, npair, a.dW3, a.part[3] ? a.part[3] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
   {
     const int t = threadIdx.x;
     float* const dst[4] = {a.db0, a.db1, a.db2, a.db3};
