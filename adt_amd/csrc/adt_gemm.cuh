@@ -620,7 +620,10 @@ __global__ __launch_bounds__(DWP_NTH) void k_dense_dw256(DenseBwdArgs a, float* 
   }
 }
 // dW[n][k] += sum over the workgroups' partials: block (slice, z) sums partials z * per .. of 256 float4 slots and adds its result with atomics
-__global__ __launch_bounds__(256) void k_dense_dw256_reduce(const float* part, int nwg, int per, float* dW, int lddw) {
+// (blockIdx.z = the 256 x 256 block of a wider layer: its partials start at part + z * nwg * 65536, its corner of dW is (256 (z / kblocks), 256 (z % kblocks)))
+__global__ __launch_bounds__(256) void k_dense_dw256_reduce(const float* part, int nwg, int per, float* dW, int lddw, int kblocks) {
+  part += (size_t)blockIdx.z * nwg * 65536;
+  dW += (size_t)(256 * (blockIdx.z / kblocks)) * lddw + 256 * (blockIdx.z % kblocks);
   const int slot = blockIdx.x * 256 + threadIdx.x;          // 0 .. 16383: ((w * 8 + kt) * 4 + i) * 64 + lane
   const int z0 = blockIdx.y * per, z1 = z0 + per < nwg ? z0 + per : nwg;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);

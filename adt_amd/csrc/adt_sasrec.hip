@@ -113,6 +113,63 @@ void make_ws(const adt_sasrec_cfg* c, int B, WS* w) {
 
 #define CK(call) do { int _r = (call); if (_r) return _r; } while (0)
 
+// Side stream of the backward pass.  The chain kernels are one workgroup per CU and serial by data dependence; the scatter / fold kernels
+// beside them (item-table gradient of the logits, decoder input embedding gradient, the ordered sums of the weight-gradient partials) depend
+// on little and are bound by memory-side atomics or HBM, so they run on a second stream under the chain kernels: fork = an event recorded on
+// the caller's stream that the side stream waits for, join = the reverse.  Inside a stream capture both become edges of the graph.  The
+// stream and its events are created on the first call that is not being captured (creating them is not a capturable operation); until then,
+// and with ADT_SIDE_STREAM=0, everything stays on the caller's stream.
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork_ev[3] = {nullptr, nullptr, nullptr}, join_ev[3] = {nullptr, nullptr, nullptr};
+};
+// ADT_SIDE_STREAM: bit 0 the logits' item rows, bit 1 the decoder's embedding gradient + partial sums, bit 2 the encoder's partial sums
+// (default 7, 0 = everything on the caller's stream)
+int side_sites() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("ADT_SIDE_STREAM"); on = e ? (atoi(e) & 7) : 7; }
+  return on;
+}
+SideStream* side_stream(hipStream_t main) {
+  static SideStream g[16];
+  if (!side_sites()) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  SideStream* sd = &g[dev];
+  if (sd->s) return sd;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(main, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  for (int i = 0; i < 3; ++i)
+    if (hipEventCreateWithFlags(&sd->fork_ev[i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sd->join_ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  sd->s = s;
+  return sd;
+}
+// fork in two halves: side_mark records the point of the caller's stream the side work depends on, side_enter makes the side stream wait
+// for it and returns the stream to enqueue the side work on (the caller's stream when there is no side stream).  The caller enqueues its
+// OWN next kernel between the two: in a captured graph the branch whose node is created first stays on the queue of the parent node, and
+// a chain kernel that hops queues pays the cross-queue signal (5-11 us, profiles/r03_side_stream_timeline.txt).
+int side_mark(SideStream* sd, int k, void* main) {
+  if (!sd) return 0;
+  if (hipEventRecord(sd->fork_ev[k], (hipStream_t)main) != hipSuccess) return adt_set_error("backward: side-stream fork %d failed", k);
+  return 0;
+}
+int side_enter(SideStream* sd, int k, void* main, void** out) {
+  *out = main;
+  if (!sd) return 0;
+  if (hipStreamWaitEvent(sd->s, sd->fork_ev[k], 0) != hipSuccess) return adt_set_error("backward: side-stream fork %d failed", k);
+  *out = sd->s;
+  return 0;
+}
+int side_join(SideStream* sd, int k, void* main) {
+  if (!sd) return 0;
+  if (hipEventRecord(sd->join_ev[k], sd->s) != hipSuccess || hipStreamWaitEvent((hipStream_t)main, sd->join_ev[k], 0) != hipSuccess)
+    return adt_set_error("backward: side-stream join %d failed", k);
+  return 0;
+}
+
 int check_cfg(const adt_sasrec_cfg* c) {
   if (c->hidden != 64) return adt_set_error("sasrec: hidden=%d unsupported in this build (64)", c->hidden);
   if (c->num_heads < 1 || c->hidden % c->num_heads) return adt_set_error("sasrec: bad num_heads");
@@ -533,12 +590,24 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   const bool parts = w.part_stride > 0 && adt_seq_partials(prec, L, d, hd) != 0;
   auto PART = [&](int layer, int slot) { return parts ? ws + w.part + (int64_t)(16 * layer + slot) * 4096 : nullptr; };
   const char* const no_fallback = "backward: shape L=%d hd=%d left the per-sequence kernels although the partial-gradient path was chosen";
+  SideStream* const sd = side_stream((hipStream_t)st);
+  int dec_side = 0;      // the decoder's embedding gradient + partial sums on the side stream: 1 marked, 2 enqueued
+  bool dec_parts_done = false;
   if (phase == 0 || phase == 1) {
     // d log_feats (overwrites g_f) and item-table rows of pos/neg      (sasrec/model.py:72-76)
     // item-table replicas and parameter replicas are adjacent in the workspace: one fill
     if (w.prep != w.rep + NREP * w.rep_stride) return adt_set_error("workspace layout: replica areas not adjacent");
-    if (adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride + (size_t)NREPP * w.prep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
-    CK(adt_logits_bwd_scatter(f, d, P + lo.item(), pos, neg, ws + w.g_pos, ws + w.g_neg, T, d, gf, d, ws + w.rep, NREP, w.rep_stride, st));
+    // The item-table rows of the logits (and d log_feats, first read by the reverse of the cross-attention projections) go to the side
+    // stream: they run under the first two decoder kernels, which only need the parameter replicas zeroed.
+    int logits_side = 0;      // 1: marked, to be enqueued behind the first chain kernel ; 2: enqueued, to be joined
+    if (sd && (side_sites() & 1)) {
+      CK(side_mark(sd, 0, st));
+      if (adt::zero_f32_async(ws + w.prep, (size_t)NREPP * w.prep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
+      logits_side = 1;
+    } else {
+      if (adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride + (size_t)NREPP * w.prep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
+      CK(adt_logits_bwd_scatter(f, d, P + lo.item(), pos, neg, ws + w.g_pos, ws + w.g_neg, T, d, gf, d, ws + w.rep, NREP, w.rep_stride, st));
+    }
     for (int i = nl - 1; i >= 0; --i) {
       float* gy = ws + w.g_dec_x + (i + 1) * Td;      // d loss / d (output of decoder layer i), complete
       float* gx = ws + w.g_dec_x + i * Td;            // accumulates d / d (input of layer i)
@@ -568,6 +637,13 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         if (rc && parts) return adt_set_error(no_fallback, L, hd);
         if (rc) CK(adt_launch_bwdchain(prec, 1, a, st));
       }
+      if (logits_side == 1) {
+        void* s2 = nullptr;
+        CK(side_enter(sd, 0, st, &s2));
+        if (adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride, (hipStream_t)s2)) return adt_set_error("replica zero");
+        CK(adt_logits_bwd_scatter(f, d, P + lo.item(), pos, neg, ws + w.g_pos, ws + w.g_neg, T, d, gf, d, ws + w.rep, NREP, w.rep_stride, s2));
+        logits_side = 2;
+      }
       // cross attention core: dq2 -> s5, dkv2 -> s4
       if (lean) {
         const uint16_t* kvb = reinterpret_cast<const uint16_t*>(kv2);      // rows of 128 bf16: k2 | v2
@@ -577,6 +653,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         CK(adt_attn_bwd(prec, q2, d, kv2, 2 * d, kv2 + d, 2 * d, o2, d, lse2, s1, d, B, H, L, hd, 1, p, seed, dec_site(i, 1), b_offset,
                         s5, d, s4, 2 * d, s4 + d, 2 * d, reinterpret_cast<const uint32_t*>(base + w.d_mask2), st));
       }
+      if (logits_side == 2) { CK(side_join(sd, 0, st)); logits_side = 0; }      // d log_feats is complete from here on
       int mid_rc = 1;
       if (use_seq) {   // both projections' reverse in one launch per sequence (adt_seqpost_tt.cuh)
         adt::BwdChainArgs a = BA(dec, 0.f, nullptr);
@@ -640,17 +717,37 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       }
     }
     // decoder input embedding (sasrec/model.py:53-59)
-    CK(adt_embed_bwd_rep(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
-    if (phase == 1) {  // two-phase (data-parallel) use: fold what has been scattered so far, the replicas restart at zero
+    // The decoder's input embedding gradient and the sum of the decoder blocks' partials need nothing from the encoder chain: in a
+    // one-phase backward they run on the side stream under it (joined in front of the last fold); in the two-phase form the sum runs
+    // beside the embedding gradient.  k_dwpart_reduce adds with atomics and k_replica_reduce2 read-modify-writes the same range of G:
+    // the fold always comes behind the join.
+    if (phase == 0 && sd && (side_sites() & 2)) {
+      CK(side_mark(sd, 1, st));
+      dec_side = 1;                      // enqueued behind the first kernel of the encoder phase
+    } else if (phase == 0) {
+      CK(adt_embed_bwd_rep(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
+    } else {
+      void* s2 = nullptr;
+      CK(side_mark(sd, 1, st));
+      CK(adt_embed_bwd_rep(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
+      CK(side_enter(sd, 1, st, &s2));
+      if (parts) CK(reduce_partials(c, lo, w, G, ws, false, true, s2));
+      CK(side_join(sd, 1, st));
       CK(adt_replica_reduce2(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, NREP, w.rep_stride, G + dec_begin, Gq + dec_begin,
                              lo.total - dec_begin, NREPP, w.prep_stride, st));
-      if (parts) CK(reduce_partials(c, lo, w, G, ws, false, true, st));
     }
   }
   if (phase == 0 || phase == 2) {
     // last_layernorm: g_enc_x[nl] = LN'(g_f)
     CK(adt_layernorm_bwd_rep(gf, d, ws + w.enc_x + nl * Td, d, P + lo.lnl_w(), LN_EPS, T, d, ws + w.g_enc_x + nl * Td, d, 0,
                              Gq + lo.lnl_w(), Gq + lo.lnl_b(), NREPP, w.prep_stride, st));
+    if (dec_side == 1) {
+      void* s2 = nullptr;
+      CK(side_enter(sd, 1, st, &s2));
+      CK(adt_embed_bwd_rep(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, s2));
+      if (parts) { CK(reduce_partials(c, lo, w, G, ws, false, true, s2)); dec_parts_done = true; }
+      dec_side = 2;
+    }
     for (int i = nl - 1; i >= 0; --i) {
       float* gy = ws + w.g_enc_x + (i + 1) * Td;
       float* gx = ws + w.g_enc_x + i * Td;     // already holds the reconstruction seed for enc_in[i]
@@ -718,10 +815,19 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       }
     }
     if (phase == 2 && adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
-    CK(adt_embed_bwd_rep(seq, ws + w.g_enc_x, T, L, d, p, seed, SITE_EMB_SEQ, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
+    if (dec_side == 2) { CK(side_join(sd, 1, st)); dec_side = 0; }
+    // the sum of the encoder blocks' partials runs beside the embedding gradient ; the fold (read-modify-write of the same range) behind both
+    {
+      SideStream* const sd2 = (side_sites() & 4) ? sd : nullptr;
+      void* s2 = nullptr;
+      CK(side_mark(sd2, 2, st));
+      CK(adt_embed_bwd_rep(seq, ws + w.g_enc_x, T, L, d, p, seed, SITE_EMB_SEQ, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
+      CK(side_enter(sd2, 2, st, &s2));
+      if (parts) CK(reduce_partials(c, lo, w, G, ws, true, phase == 0 && !dec_parts_done, s2));
+      CK(side_join(sd2, 2, st));
+    }
     CK(adt_replica_reduce2(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, NREP, w.rep_stride, G + lo.posw(), Gq + lo.posw(),
                            (phase == 0 ? lo.total : dec_begin) - lo.posw(), NREPP, w.prep_stride, st));
-    if (parts) CK(reduce_partials(c, lo, w, G, ws, true, phase == 0, st));
   }
   return 0;
 }

@@ -123,18 +123,45 @@ ADT_DEVICE_INLINE TT tt_ln_bwd(const TT& dy, const TTLn& st, const float* gamma,
 // 2-layer model.  part != nullptr: this workgroup's PRIVATE 4,096-float partial of the block, written with plain 256-byte stores in
 // register order -- element ((tile * 4 + r) * 64 + lane), tile = 4 nt + kt -- and summed over the workgroups, in a fixed order, by
 // k_dwpart_reduce (adt_seq.hip).  Nothing is zeroed and the sum does not depend on timing.
+// Bias gradient.  bred != nullptr: the column sums of G over the tokens (the bias gradient of the same layer) come out of the same
+// fragments: the two waves with kt == 0 multiply their G fragments by a fragment of ones as well (14 more MFMAs on two waves) and store the
+// 64 sums to bred[0..64) (LDS) -- every column of such a product holds sum_t G[t][n].  The sums are those of the bf16 image rows, like the
+// weight gradient beside them.  (Per-lane fp32 sums + a 16-lane DPP reduction of 16 registers + LDS atomics, sb_colsum_flush, cost every
+// wave ~1.1k cycles per layer on the critical path in front of the product's barrier: profiles/r03_stamps_attn_pre_bwd.txt.)
+template <int NP, int NW, bool BIAS>
+ADT_DEVICE_INLINE void sb_dw_accumulate(const __bf16* sG, const __bf16* sX, int kt, int nt0, int c, int g, f32x4& acc0, f32x4& acc1, f32x4& b0, f32x4& b1) {
+  constexpr bool TWO = NW == 8;
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+#pragma unroll
+  for (int kp = 0; kp < NP; ++kp) {
+    const bf16x8 fx = tt_trfrag(sX, kp * 32, 16 * kt, c, g);
+    const bf16x8 g0 = tt_trfrag(sG, kp * 32, 16 * nt0, c, g);
+    acc0 = mfma_bf16(acc0, g0, fx);
+    if (BIAS) b0 = mfma_bf16(b0, g0, ones);
+    if (TWO) {
+      const bf16x8 g1 = tt_trfrag(sG, kp * 32, 16 * (nt0 + 2), c, g);
+      acc1 = mfma_bf16(acc1, g1, fx);
+      if (BIAS) b1 = mfma_bf16(b1, g1, ones);
+    }
+  }
+}
 template <int NP, int NW = SB_NW>
-ADT_DEVICE_INLINE void sb_dw_tiles(const __bf16* sG, const __bf16* sX, float* dW, float* part, int w, int c, int g) {
+ADT_DEVICE_INLINE void sb_dw_tiles(const __bf16* sG, const __bf16* sX, float* dW, float* part, float* bred, int w, int c, int g) {
   // NW = 8: wave w computes output tiles (nt0, kt) and (nt0 + 2, kt), nt0 = w >> 2, kt = w & 3 (they share the X fragments);
   // NW = 16: wave w computes tile (w >> 2, w & 3) alone.  Either way tile 4 nt + kt of the partial layout is w (and w + 8).
   constexpr bool TWO = NW == 8;
   const int kt = w & 3, nt0 = w >> 2;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kp = 0; kp < NP; ++kp) {
-    const bf16x8 fx = tt_trfrag(sX, kp * 32, 16 * kt, c, g);
-    acc0 = mfma_bf16(acc0, tt_trfrag(sG, kp * 32, 16 * nt0, c, g), fx);
-    if (TWO) acc1 = mfma_bf16(acc1, tt_trfrag(sG, kp * 32, 16 * (nt0 + 2), c, g), fx);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+  if (bred != nullptr && kt == 0) {
+    sb_dw_accumulate<NP, NW, true>(sG, sX, kt, nt0, c, g, acc0, acc1, b0, b1);
+    if (c == 0) {
+      *reinterpret_cast<f32x4*>(bred + 16 * nt0 + 4 * g) = b0;             // rows 4 g + r of the tile, any column
+      if (TWO) *reinterpret_cast<f32x4*>(bred + 16 * (nt0 + 2) + 4 * g) = b1;
+    }
+  } else {
+    sb_dw_accumulate<NP, NW, false>(sG, sX, kt, nt0, c, g, acc0, acc1, b0, b1);
   }
   if (part) {
     const int lane = 16 * g + c;
@@ -152,10 +179,10 @@ ADT_DEVICE_INLINE void sb_dw_tiles(const __bf16* sG, const __bf16* sX, float* dW
   }
 }
 template <int NW = SB_NW>
-ADT_DEVICE_INLINE void sb_dw_product16(const __bf16* sG, const __bf16* sX, int npair, float* dW, float* part, int w, int c, int g) {
+ADT_DEVICE_INLINE void sb_dw_product16(const __bf16* sG, const __bf16* sX, int npair, float* dW, float* part, float* bred, int w, int c, int g) {
   static_assert(NW == 8 || NW == 16, "8 waves (two output tiles each) or 16 (one each)");
-  if (npair <= 4) sb_dw_tiles<4, NW>(sG, sX, dW, part, w, c, g);
-  else sb_dw_tiles<SB_R / 32, NW>(sG, sX, dW, part, w, c, g);
+  if (npair <= 4) sb_dw_tiles<4, NW>(sG, sX, dW, part, bred, w, c, g);
+  else sb_dw_tiles<SB_R / 32, NW>(sG, sX, dW, part, bred, w, c, g);
 }
 // bias gradients (column sums of G over the tokens): per-lane sums of the tiles a wave holds, reduced over the 16 tokens of a lane row,
 // added to a 64-float LDS vector; the workgroup adds the vector to the global accumulator once, at its end
@@ -382,8 +409,19 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     sb_put_frags<HD>(img1, l, fdo[s], l < L, g);
   }
   __syncthreads();
+  TT xk[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
+    if (s == 1) {
+      // x is read once more for P4 and P5 (its registers were needed by the attention passes); requested here, behind slot 0 of pass B
+      // (whose operand registers are free by now), the rows arrive while slot 1 is swept instead of stalling P4 (3.4-6.2k cycles)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int tile2 = tq_tile(s2, w, ntiles);
+        const int l2 = tile2 * 16 + c;
+        xk[s2] = tt_load(a.x + (size_t)(b * L + l2) * 64, tile2 >= 0 && l2 < L, g);
+      }
+    }
     const int tile = tq_tile(s, w, ntiles);
     if (tile < 0) continue;
 #pragma unroll
@@ -401,18 +439,8 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   }
   __syncthreads();
   SB_STAMP(4);
-  // x is read once more here for P4 and P5 (its registers were needed by the attention passes) instead of three times; prefetching the
-  // residual-path gradient and the accumulated gx as well overflowed the register file (118-140 spills)
-  TT xk[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
-    const int l = tile * 16 + c, row = b * L + l;
-    xk[s] = tt_load_if(a.x + (size_t)row * 64, tile >= 0 && l < L, g);
-  }
   // ---- P4: in-projection weight / bias gradients: three products over all tokens ------------------------------------------------------
   {
-    TT sq = tt_zero(), sk = tt_zero(), sv = tt_zero();
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int tile = tq_tile(s, w, ntiles);
@@ -421,12 +449,22 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
       const bool valid = l < L;
       tt_put_rows(img0, l, dq[s], valid, g);
       tt_put_rows(img1, l, tt_ln_apply(tt_ln_stats(xk[s], a.ln_eps).xhat, vgamma, vbeta, g), valid, g);     // q always reads LN(x)
-      if (valid) { tt_add(sq, dq[s]); tt_add(sk, dk[s]); tt_add(sv, dv[s]); }
     }
-    sb_colsum_flush(sRed + 128, sq, c, g); sb_colsum_flush(sRed + 192, sk, c, g); sb_colsum_flush(sRed + 256, sv, c, g);
+    SB_STAMP(7);
   }
+  SB_STAMP(8);
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dWin, part, w, c, g);
+  // P5's inputs are requested here, in front of the three products (as loads inside P5 each was a fully exposed round trip: two waves
+  // per SIMD do not hide one): the residual-path gradient of both slots now, the accumulated gx one slot ahead of its use
+  TT resa[2], gxo[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = tq_tile(s, w, ntiles);
+    const int l = tile * 16 + c;
+    resa[s] = tt_load(a.dres + (size_t)(b * L + l) * 64, tile >= 0 && l < L, g);
+  }
+  sb_dw_product16(img0, img1, npair, a.dWin, part, sRed + 128, w, c, g);
+  SB_STAMP(9);
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -438,7 +476,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     if (!DEC) tt_put_rows(img1, l, xk[s], valid, g);                  // encoder: k, v read the raw x
   }
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dWin + 4096, part ? part + 4096 : nullptr, w, c, g);
+  sb_dw_product16(img0, img1, npair, a.dWin + 4096, part ? part + 4096 : nullptr, sRed + 192, w, c, g);
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -448,26 +486,34 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     tt_put_rows(img0, l, dv[s], l < L, g);
   }
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dWin + 8192, part ? part + 8192 : nullptr, w, c, g);
+  sb_dw_product16(img0, img1, npair, a.dWin + 8192, part ? part + 8192 : nullptr, sRed + 256, w, c, g);
   SB_STAMP(5);
   // ---- P5: gradient of the block input ----------------------------------------------------------------------------------------
   TT dgm = tt_zero(), dbt = tt_zero();
+  auto gx_request = [&](int s) {
+    const int tile = tq_tile(s, w, ntiles);
+    const int l = tile * 16 + c;
+    gxo[s] = tt_load(a.gx + (size_t)(b * L + l) * 64, a.acc && tile >= 0 && l < L, g);
+  };
+  gx_request(0);
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile(s, w, ntiles);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
+    if (s == 0) gx_request(1);
     const TTLn st = tt_ln_stats(xk[s], a.ln_eps);
     TT dn = tt_gemm(tt_bfrags(dq[s]), wimg + 3 * TT_WIMG, c, g);
     TT dkv = tt_gemm(tt_bfrags(dk[s]), wimg + 4 * TT_WIMG, c, g);
     tt_add(dkv, tt_gemm(tt_bfrags(dv[s]), wimg + 5 * TT_WIMG, c, g));
-    TT res = tt_load_if(a.dres + (size_t)row * 64, valid, g);
+    TT res = resa[s];
     if (DEC && (!valid || a.ids[row] == 0)) res = tt_zero();
     if (DEC && a.dres_scale != 0.f) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) res.v[nt] *= a.dres_scale;
     }
+    if (s == 0) SB_STAMP(10);
     tt_add(dn, res);
     TT dx;
     if (!DEC) {
@@ -479,9 +525,10 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     }
     if (valid) {
       float* dst = a.gx + (size_t)row * 64;
-      if (a.acc) tt_add(dx, tt_load_if(dst, true, g));
+      tt_add(dx, gxo[s]);                               // zeros unless a.acc
       tt_store(dst, dx, true, g);
     }
+    if (s == 0) SB_STAMP(15);
   }
   // LayerNorm gamma / beta gradients: per-lane partials over this wave's tokens -> workgroup sums in LDS -> one atomic per feature
 #pragma unroll

@@ -104,7 +104,6 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   SB_STAMP(2);
   // ---- A: masked upstream gradient through dropout2 and conv2 ; dW(conv2) = df^T u ----------------------------------------------------
   TT dt[NS];
-  TT bsum = tt_zero();
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int tile = tq_tile(s, w, ntiles, NW);
@@ -118,7 +117,6 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
     tt_dropout(gyv, key2, a.drop, (uint32_t)row + a.row_offset, g);         // the forward's keep decisions and scale, applied to the gradient
     tt_put_rows(img0, l, gyv, valid, g);
     tt_put_rows(img1, l, u, valid, g);
-    tt_add(bsum, gyv);                                                      // zero for absent and padded tokens
     TT t = tt_gemm(tt_bfrags(gyv), wimg, c, g);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -129,11 +127,10 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
     dt[s] = t;
     if (s == 0) SB_STAMP(4);
   }
-  sb_colsum_flush(sRed + 256, bsum, c, g);
   SB_STAMP(5);
   __syncthreads();
   SB_STAMP(6);
-  sb_dw_product16<NW>(img0, img1, npair, a.dW0, a.part[0] ? a.part[0] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
+  sb_dw_product16<NW>(img0, img1, npair, a.dW0, a.part[0] ? a.part[0] + (size_t)blockIdx.x * a.part_stride : nullptr, sRed + 256, w, c, g);
   SB_STAMP(7);
   __syncthreads();
   SB_STAMP(8);
@@ -141,7 +138,6 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   TT dh[NS];
   TTSaved oreq[NS];
   TT dgm = tt_zero(), dbt = tt_zero();
-  bsum = tt_zero();
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int tile = tq_tile(s, w, ntiles, NW);
@@ -151,7 +147,6 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
     oreq[s] = tt_saved_request(a.o, row, valid, g, a.saved_bf16);           // consumed in C
     const TT hraw_s = tt_saved_value(hreq[s], a.saved_bf16);
     tt_put_rows(img0, l, dt[s], valid, g);
-    tt_add(bsum, dt[s]);
     TT d = tt_gemm(tt_bfrags(dt[s]), wimg + TT_WIMG, c, g);
     tt_add(d, dy[s]);                                                       // the residual around the feed-forward
     if (ENC) {
@@ -164,15 +159,13 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
       dh[s] = d;                                                            // gradient wrt a2 (the Dn residual is handled by the pre chain)
     }
   }
-  sb_colsum_flush(sRed + 320, bsum, c, g);
   SB_STAMP(9);
   __syncthreads();
-  sb_dw_product16<NW>(img0, img1, npair, a.dW1, a.part[1] ? a.part[1] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
+  sb_dw_product16<NW>(img0, img1, npair, a.dW1, a.part[1] ? a.part[1] + (size_t)blockIdx.x * a.part_stride : nullptr, sRed + 320, w, c, g);
   SB_STAMP(10);
   __syncthreads();
   SB_STAMP(11);
   // ---- C: out_proj ; dW(out_proj) = dh^T o ; encoder: head classifier reverse joins dO ---------------------------------------------------
-  bsum = tt_zero();
   float dws[H][NT][4], dbs_acc[H];
 #pragma unroll
   for (int cc = 0; cc < H; ++cc) {
@@ -191,7 +184,6 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
     const TT oraw_s = tt_saved_value(oreq[s], a.saved_bf16);
     tt_put_rows(img0, l, dh[s], valid, g);
     tt_put_rows(img1, l, oraw_s, valid, g);
-    if (valid) tt_add(bsum, dh[s]);
     TT dO = tt_gemm(tt_bfrags(dh[s]), wimg + 2 * TT_WIMG, c, g);
     if (cls) {
       // z[h][cc] = o_h . Ws[cc] + bs[cc], rec = log_softmax_cc(z): dz = drec - exp(rec) * sum_cc drec ; dO_h += dz Ws ; dWs += dz^T o_h ; dbs += dz
@@ -223,10 +215,9 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
     }
     tt_store((ENC ? a.out1 : a.out0) + (size_t)row * 64, dO, valid, g);
   }
-  sb_colsum_flush(sRed + 384, bsum, c, g);
   SB_STAMP(12);
   __syncthreads();
-  sb_dw_product16<NW>(img0, img1, npair, a.dW2, a.part[2] ? a.part[2] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
+  sb_dw_product16<NW>(img0, img1, npair, a.dW2, a.part[2] ? a.part[2] + (size_t)blockIdx.x * a.part_stride : nullptr, sRed + 384, w, c, g);
   SB_STAMP(13);
   if (ENC) {
     // per-lane partials over this wave's tokens -> workgroup sums in LDS -> one atomic per element
@@ -294,7 +285,6 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
   __syncthreads();
   // ---- A: cross-attention query projection: da1 = dq2 Wq ; dWq = dq2^T a1 ----------------------------------------------------------
   TT da1[NS];
-  TT bsum = tt_zero();
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int tile = tq_tile(s, w, ntiles, NW);
@@ -304,15 +294,12 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
     tt_put_rows(img0, l, dqa[s], valid, g);
     tt_put_rows(img1, l, tt_saved_value(a1req[s], a.saved_bf16), valid, g);
     da1[s] = tt_gemm(tt_bfrags(dqa[s]), wimg, c, g);
-    tt_add(bsum, dqa[s]);                                                   // zero rows for absent tokens (loaded as zeros)
   }
-  sb_colsum_flush(sRed, bsum, c, g);
   __syncthreads();
-  sb_dw_product16<NW>(img0, img1, npair, a.dW0, a.part[0] ? a.part[0] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
+  sb_dw_product16<NW>(img0, img1, npair, a.dW0, a.part[0] ? a.part[0] + (size_t)blockIdx.x * a.part_stride : nullptr, sRed, w, c, g);
   __syncthreads();
   // ---- B: self-attention out_proj: dO1 = da1 Wo1 ; dWo1 = da1^T o1 --------------------------------------------------------------------
   TT dk[NS], fx[NS];
-  bsum = tt_zero();
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int tile = tq_tile(s, w, ntiles, NW);
@@ -323,16 +310,13 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
     fx[s] = tt_load(a.f + (size_t)row * 64, valid, g);
     tt_put_rows(img0, l, da1[s], valid, g);
     tt_put_rows(img1, l, tt_saved_value(oreq[s], a.saved_bf16), valid, g);
-    tt_add(bsum, da1[s]);
     tt_store(a.out0 + (size_t)row * 64, tt_gemm(tt_bfrags(da1[s]), wimg + TT_WIMG, c, g), valid, g);
   }
-  sb_colsum_flush(sRed + 64, bsum, c, g);
   __syncthreads();
-  sb_dw_product16<NW>(img0, img1, npair, a.dW1, a.part[1] ? a.part[1] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
+  sb_dw_product16<NW>(img0, img1, npair, a.dW1, a.part[1] ? a.part[1] + (size_t)blockIdx.x * a.part_stride : nullptr, sRed + 64, w, c, g);
   __syncthreads();
   // ---- C: cross-attention keys: df = dk2 Wk ; dWk = dk2^T f -----------------------------------------------------------------------------
-  TT df[NS], dv[NS];
-  bsum = tt_zero();
+  TT df[NS], dv[NS], acc1v[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int tile = tq_tile(s, w, ntiles, NW);
@@ -340,17 +324,15 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
     dv[s] = tt_load(a.dkv2 + (size_t)row * 128 + 64, valid, g);
+    acc1v[s] = tt_load(a.out1 + (size_t)row * 64, valid && a.acc1, g);       // consumed in D (requested there it was an exposed round trip)
     tt_put_rows(img0, l, dk[s], valid, g);
     tt_put_rows(img1, l, fx[s], valid, g);
-    tt_add(bsum, dk[s]);
     df[s] = tt_gemm(tt_bfrags(dk[s]), wimg + 2 * TT_WIMG, c, g);
   }
-  sb_colsum_flush(sRed + 128, bsum, c, g);
   __syncthreads();
-  sb_dw_product16<NW>(img0, img1, npair, a.dW2, a.part[2] ? a.part[2] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
+  sb_dw_product16<NW>(img0, img1, npair, a.dW2, a.part[2] ? a.part[2] + (size_t)blockIdx.x * a.part_stride : nullptr, sRed + 128, w, c, g);
   __syncthreads();
   // ---- D: cross-attention values (the X image still holds f) --------------------------------------------------------------------------
-  bsum = tt_zero();
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int tile = tq_tile(s, w, ntiles, NW);
@@ -358,15 +340,14 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a) {
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
     tt_put_rows(img0, l, dv[s], valid, g);
-    tt_add(bsum, dv[s]);
     tt_add(df[s], tt_gemm(tt_bfrags(dv[s]), wimg + 3 * TT_WIMG, c, g));
     float* dst = a.out1 + (size_t)row * 64;
-    if (a.acc1) tt_add(df[s], tt_load(dst, valid, g));
+    tt_add(df[s], acc1v[s]);                                                // zeros unless a.acc1
     tt_store(dst, df[s], valid, g);
   }
-  sb_colsum_flush(sRed + 192, bsum, c, g);
   __syncthreads();
-  sb_dw_product16<NW>(img0, img1, npair, a.dW3, a.part[3] ? a.part[3] + (size_t)blockIdx.x * a.part_stride : nullptr, w, c, g);
+  sb_dw_product16<NW>(img0, img1, npair, a.dW3, a.part[3] ? a.part[3] + (size_t)blockIdx.x * a.part_stride : nullptr, sRed + 192, w, c, g);
+  __syncthreads();          // the last product's bias sums
   {
     const int t = threadIdx.x;
     float* const dst[4] = {a.db0, a.db1, a.db2, a.db3};

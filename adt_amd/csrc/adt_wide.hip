@@ -306,9 +306,7 @@ static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
       a.t_chunk = chunk;
       hipLaunchKernelGGL(k_dense_dw256, dim3(nwg, blocks), dim3(DWP_NTH), 0, s, a, g_dense_ws);
       const int per = nwg >= 128 ? 32 : 16;
-      for (int b = 0; b < blocks; ++b)
-        hipLaunchKernelGGL(k_dense_dw256_reduce, dim3(64, (nwg + per - 1) / per), dim3(256), 0, s, (const float*)(g_dense_ws + (size_t)b * nwg * 65536), nwg, per,
-                           a.dW + (size_t)(256 * (b / kblocks)) * a.lddw + 256 * (b % kblocks), a.lddw);
+      hipLaunchKernelGGL(k_dense_dw256_reduce, dim3(64, (nwg + per - 1) / per, blocks), dim3(256), 0, s, (const float*)g_dense_ws, nwg, per, a.dW, a.lddw, kblocks);
       a.dW = nullptr;
     }
   }

@@ -41,6 +41,8 @@ if MODE == "post":      # k_seqtt_post_bwd<., true> (encoder), last launch of th
 print("wave " + " ".join("%8s" % n for n in names))
 if MODE == "attn":
     print("prologue (loads issued, zero-fill done, small tables stored, images stored):", [[int(t[w, k] - t0) for k in (11, 12, 13, 14)] for w in (0, 4)])
+if MODE == "attn":
+    print("P4/P5 detail (rows put, colsums flushed, product 1 done, P5 slot-0 products issued, slot 0 stored):", [[int(t[w, k] - t0) for k in (7, 8, 9, 10, 15)] for w in (0, 4)])
 if MODE == "fwd":
     print("prologue (issue loads, zero-fill, image stores, vector stores):", [[int(t[w, k] - t0) for k in (11, 12, 13, 14)] for w in (0, 4)])
 for w in range(NWV):
