@@ -73,14 +73,27 @@ __global__ __launch_bounds__(256) void k_item_scatter(ScatterArgs a) {
 }
 
 // dst[i] += sum_r rep[r * stride + i]  (float4 granularity; n multiple of 4)
+// sum of the nrep replica values of one float4 slot.  Eight loads are in flight at a time: with the plain `for (r < nrep) s += rep[r]` loop
+// (runtime trip count, not unrolled) every load was its own round trip -- 16 serial round trips made the 20 MB fold of a training step an
+// 11.6 us kernel (profiles/r03_kernel_stats.csv).
+__device__ __forceinline__ float4 replica_sum4(const float* rep, size_t stride, int nrep, float4 s) {
+  int r = 0;
+  for (; r + 8 <= nrep; r += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(rep + (size_t)(r + u) * stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  for (; r < nrep; ++r) {
+    const float4 v = *reinterpret_cast<const float4*>(rep + (size_t)r * stride);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  return s;
+}
 __global__ __launch_bounds__(256) void k_replica_reduce(float* dst, const float* rep, size_t n, int nrep, size_t stride) {
   for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
-    float4 s = *reinterpret_cast<const float4*>(dst + i);
-    for (int r = 0; r < nrep; ++r) {
-      const float4 v = *reinterpret_cast<const float4*>(rep + (size_t)r * stride + i);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    *reinterpret_cast<float4*>(dst + i) = s;
+    *reinterpret_cast<float4*>(dst + i) = replica_sum4(rep + i, stride, nrep, *reinterpret_cast<const float4*>(dst + i));
   }
 }
 
@@ -94,12 +107,7 @@ __global__ __launch_bounds__(256) void k_replica_reduce2(RepReduce2Args a) {
   const size_t n = a.n[j], stride = a.stride[j];
   const int nrep = a.nrep[j];
   for (size_t i = ((size_t)bid * 256 + threadIdx.x) * 4; i < n; i += (size_t)nblk * 1024) {
-    float4 s = *reinterpret_cast<const float4*>(dst + i);
-    for (int r = 0; r < nrep; ++r) {
-      const float4 v = *reinterpret_cast<const float4*>(rep + (size_t)r * stride + i);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    *reinterpret_cast<float4*>(dst + i) = s;
+    *reinterpret_cast<float4*>(dst + i) = replica_sum4(rep + i, stride, nrep, *reinterpret_cast<const float4*>(dst + i));
   }
 }
 
@@ -549,8 +557,22 @@ __global__ __launch_bounds__(256) void k_step_begin(StepBeginArgs a) {
     reinterpret_cast<float4*>(a.G)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (blockIdx.x == 0 && threadIdx.x < (int)(a.n - n4 * 4)) a.G[n4 * 4 + threadIdx.x] = 0.f;
   if (blockIdx.x < 64) {
+    // 16-byte loads, four in flight (a scalar loop with a runtime trip count was 13 serial round trips at the ml-1m table: ~10 us)
     float acc = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.nE; i += (size_t)64 * 256) acc += a.E[i] * a.E[i];
+    const size_t nE4 = a.nE / 4, step = (size_t)64 * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * step < nE4; i += 4 * step) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const float4*>(a.E)[i + u * step];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
+    }
+    for (; i < nE4; i += step) {
+      const float4 v = reinterpret_cast<const float4*>(a.E)[i];
+      acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(a.nE - nE4 * 4)) { const float t = a.E[nE4 * 4 + threadIdx.x]; acc += t * t; }
     const float s = block_sum(acc, sbuf);
     if (threadIdx.x == 0) a.scal[64 + blockIdx.x] = s;
   } else if (blockIdx.x == 64) {
@@ -594,12 +616,26 @@ ADT_DEVICE_INLINE float sum64(const float* part, float* sbuf) {
   return r;
 }
 
+// Both optimizer kernels are a few dependent memory round trips long (1.3 MB of parameters at the flagship shape): the operands of a
+// thread's first element are requested BEFORE the reduction of the 64 partial sums, whose round trip they then share.
 __global__ __launch_bounds__(256) void k_wd_gradnorm(OptArgs a) {
   __shared__ float sbuf[4];
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const bool first = i < a.n;
+  float g0 = 0.f, p0 = 0.f;
+  if (first) { g0 = a.G[i]; if (i < a.nE) p0 = a.P[i]; }
   const float nrm = sqrtf(sum64(a.scal + 64, sbuf));
   const float coef = (a.wd != 0.f && nrm > 0.f) ? a.wd / nrm : 0.f;
   float acc = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+  if (first) {
+    float g = g0 * a.grad_scale;
+    if (i < a.nE) g += coef * p0;
+    a.G[i] = g;
+    acc += g * g;
+    i += stride;
+  }
+  for (; i < a.n; i += stride) {
     float g = a.G[i] * a.grad_scale;
     if (i < a.nE) g += coef * a.P[i];
     a.G[i] = g;
@@ -612,14 +648,28 @@ __global__ __launch_bounds__(256) void k_wd_gradnorm(OptArgs a) {
 
 __global__ __launch_bounds__(256) void k_adam(OptArgs a) {
   __shared__ float sbuf[4];
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const bool first = i < a.n;
+  float g0 = 0.f, p0 = 0.f, m0 = 0.f, v0 = 0.f;
+  if (first) { g0 = a.G[i]; p0 = a.P[i]; m0 = a.M[i]; v0 = a.Vv[i]; }
+  const float t = a.scal[2];
   const float gn2 = sum64(a.scal + 128, sbuf);
   if (blockIdx.x == 0 && threadIdx.x == 0) a.scal[1] = gn2;
   const float tn = sqrtf(gn2);
   const float coef = fminf(1.0f, a.clip / (tn + 1e-6f));
-  const float t = a.scal[2];
   const float bc1 = 1.0f - powf(a.b1, t), bc2 = 1.0f - powf(a.b2, t);
   const float step = a.lr / bc1, rs2 = 1.0f / sqrtf(bc2);
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+  if (first) {
+    const float g = g0 * coef + a.l2 * p0;
+    const float m = a.b1 * m0 + (1.0f - a.b1) * g;
+    const float v = a.b2 * v0 + (1.0f - a.b2) * g * g;
+    a.M[i] = m;
+    a.Vv[i] = v;
+    a.P[i] = p0 - step * m / (sqrtf(v) * rs2 + a.eps);
+    i += stride;
+  }
+  for (; i < a.n; i += stride) {
     const float g = a.G[i] * coef + a.l2 * a.P[i];
     const float m = a.b1 * a.M[i] + (1.0f - a.b1) * g;
     const float v = a.b2 * a.Vv[i] + (1.0f - a.b2) * g * g;

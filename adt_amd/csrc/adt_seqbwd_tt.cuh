@@ -25,7 +25,10 @@ template <int H>
 struct SeqBwdLds {
   static constexpr size_t wbytes = 6 * (size_t)TT_WIMG * 2, ibytes = (size_t)SB_R * TT_RS * 2;
   static constexpr size_t mbytes = (size_t)H * SB_R * 8 * 4, sbytes = 2 * (size_t)H * SB_R * 4, rbytes = (320 + 320) * 4;         // sRed: dgamma, dbeta, dbin ; sVec: gamma, beta, bin
-  static constexpr size_t bytes = wbytes + 2 * ibytes + 64 /* spill of the last row's ones-column read */ + mbytes + sbytes + rbytes;
+  // the three plain weight images (dead behind P1) lie at the END of the allocation: a third token image overlays them in P4
+  static constexpr size_t pbytes = ibytes + 64 > wbytes / 2 ? ibytes + 64 : wbytes / 2;
+  static constexpr size_t poff = wbytes / 2 + 2 * ibytes + 64 /* spill of the last row's ones-column read */ + mbytes + sbytes + rbytes;
+  static constexpr size_t bytes = poff + pbytes;
 };
 
 // operands of every head from a transposed tile, in the slot order sab_rowfrag reads image rows in: f[h * KB + kb]
@@ -234,10 +237,12 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   constexpr int H = 64 / HD, NT = HD / 16, KB = (HD + 31) / 32, NF = H * KB, NW = SB_NW, R = SB_R;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef SeqBwdLds<H> Lds;
-  __bf16* wimg = reinterpret_cast<__bf16*>(smem_raw);                       // 0..2 Wq, Wk, Wv (plain) ; 3..5 transposed
-  __bf16* img0 = reinterpret_cast<__bf16*>(smem_raw + Lds::wbytes);
-  __bf16* img1 = reinterpret_cast<__bf16*>(smem_raw + Lds::wbytes + Lds::ibytes);
-  uint32_t* sM = reinterpret_cast<uint32_t*>(smem_raw + Lds::wbytes + 2 * Lds::ibytes + 64);
+  __bf16* wtr = reinterpret_cast<__bf16*>(smem_raw);                        // Wq, Wk, Wv transposed (P5)
+  __bf16* wpl = reinterpret_cast<__bf16*>(smem_raw + Lds::poff);             // Wq, Wk, Wv plain (P1) ; behind P1: the third token image
+  __bf16* img2 = wpl;
+  __bf16* img0 = reinterpret_cast<__bf16*>(smem_raw + Lds::wbytes / 2);
+  __bf16* img1 = reinterpret_cast<__bf16*>(smem_raw + Lds::wbytes / 2 + Lds::ibytes);
+  uint32_t* sM = reinterpret_cast<uint32_t*>(smem_raw + Lds::wbytes / 2 + 2 * Lds::ibytes + 64);
   float* sLse = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(sM) + Lds::mbytes);
   float* sDelta = sLse + H * R;
   float* sRed = sDelta + H * R;                                              // dgamma, dbeta, dbin[192] of this workgroup
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   // three plain images and x.  dO, O and the three transposed images (needed from the end of P1 / in P5) are requested behind the barrier
   // and stream while P1 computes.
 #pragma unroll
-  for (int k = 0; k < 3; ++k) adt_glds_block<NW>(src6[k], wimg + k * TT_WIMG, TT_WIMG * 2);
+  for (int k = 0; k < 3; ++k) adt_glds_block<NW>(src6[k], wpl + k * TT_WIMG, TT_WIMG * 2);
   TT xa[2], doa[2], oa[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     oa[s] = tt_load_saved(a.o, row, valid, g, a.saved_bf16);
   }
 #pragma unroll
-  for (int k = 3; k < 6; ++k) adt_glds_block<NW>(src6[k], wimg + k * TT_WIMG, TT_WIMG * 2);      // waited for in front of the barrier behind pass A
+  for (int k = 3; k < 6; ++k) adt_glds_block<NW>(src6[k], wtr + (k - 3) * TT_WIMG, TT_WIMG * 2);      // waited for in front of the barrier behind pass A
   const float qmul = a.scale * 1.4426950408889634f;
   const uint32_t key_rng = drop_key(a.drop);
   // ---- P1: recompute LN + in-projection; operands to registers, K / V images ------------------------------------------------------
@@ -352,14 +357,14 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     const TTB bn = tt_bfrags(xn);
     TTB bx;
     if (!DEC) bx = tt_bfrags(x);
-    TT q = tt_gemm(bn, wimg, c, g);
+    TT q = tt_gemm(bn, wpl, c, g);
     tt_add_vec(q, vbin, g);
     sb_frags<HD>(q, qmul, fq[s]);
-    TT k = tt_gemm(DEC ? bn : bx, wimg + TT_WIMG, c, g);
+    TT k = tt_gemm(DEC ? bn : bx, wpl + TT_WIMG, c, g);
     tt_add_vec(k, vbin + 64, g);
     sb_frags<HD>(k, 1.0f, fk[s]);
     tt_put_rows(img0, l, k, valid, g);
-    TT v = tt_gemm(DEC ? bn : bx, wimg + 2 * TT_WIMG, c, g);
+    TT v = tt_gemm(DEC ? bn : bx, wpl + 2 * TT_WIMG, c, g);
     tt_add_vec(v, vbin + 128, g);
     sb_frags<HD>(v, 1.0f, fv[s]);
     tt_put_rows(img1, l, v, valid, g);
@@ -379,6 +384,10 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   }
   __syncthreads();
   SB_STAMP(2);
+  {                                              // the plain weight images are dead: their place becomes the third token image of P4 (rows beyond L stay zero)
+    uint4* z = reinterpret_cast<uint4*>(img2);
+    for (int i = threadIdx.x; i < (int)((Lds::ibytes + 64) / 16); i += NW * 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
   // ---- P2: pass A (dQ): keys / values from the images, own query and dO rows from registers ----------------------------------------
   TT dq[2], dk[2], dv[2];
 #pragma unroll
@@ -439,7 +448,10 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   }
   __syncthreads();
   SB_STAMP(4);
-  // ---- P4: in-projection weight / bias gradients: three products over all tokens ------------------------------------------------------
+  // ---- P4: in-projection weight / bias gradients: three products over all tokens, in two rounds on three token images ------------------
+  // round 1: G = dq (img0), dk (img2), X = LN(x) (img1): dWq -- and dWk in the decoder block, whose k reads LN(x) too
+  // round 2: G = dv (img0), X = the raw x in the encoder block (img1): dWv -- and the encoder's dWk = dk^T x
+  // (three rounds on two images were five barriers; dk waits in the place of the plain weight images, dead since P1)
   {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -448,13 +460,14 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
       const int l = tile * 16 + c;
       const bool valid = l < L;
       tt_put_rows(img0, l, dq[s], valid, g);
+      tt_put_rows(img2, l, dk[s], valid, g);
       tt_put_rows(img1, l, tt_ln_apply(tt_ln_stats(xk[s], a.ln_eps).xhat, vgamma, vbeta, g), valid, g);     // q always reads LN(x)
     }
     SB_STAMP(7);
   }
   SB_STAMP(8);
   __syncthreads();
-  // P5's inputs are requested here, in front of the three products (as loads inside P5 each was a fully exposed round trip: two waves
+  // P5's inputs are requested here, in front of the products (as loads inside P5 each was a fully exposed round trip: two waves
   // per SIMD do not hide one): the residual-path gradient of both slots now, the accumulated gx one slot ahead of its use
   TT resa[2], gxo[2];
 #pragma unroll
@@ -464,6 +477,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     resa[s] = tt_load(a.dres + (size_t)(b * L + l) * 64, tile >= 0 && l < L, g);
   }
   sb_dw_product16(img0, img1, npair, a.dWin, part, sRed + 128, w, c, g);
+  if (DEC) sb_dw_product16(img2, img1, npair, a.dWin + 4096, part ? part + 4096 : nullptr, sRed + 192, w, c, g);
   SB_STAMP(9);
   __syncthreads();
 #pragma unroll
@@ -472,20 +486,11 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     if (tile < 0) continue;
     const int l = tile * 16 + c;
     const bool valid = l < L;
-    tt_put_rows(img0, l, dk[s], valid, g);
+    tt_put_rows(img0, l, dv[s], valid, g);
     if (!DEC) tt_put_rows(img1, l, xk[s], valid, g);                  // encoder: k, v read the raw x
   }
   __syncthreads();
-  sb_dw_product16(img0, img1, npair, a.dWin + 4096, part ? part + 4096 : nullptr, sRed + 192, w, c, g);
-  __syncthreads();
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
-    if (tile < 0) continue;
-    const int l = tile * 16 + c;
-    tt_put_rows(img0, l, dv[s], l < L, g);
-  }
-  __syncthreads();
+  if (!DEC) sb_dw_product16(img2, img1, npair, a.dWin + 4096, part ? part + 4096 : nullptr, sRed + 192, w, c, g);
   sb_dw_product16(img0, img1, npair, a.dWin + 8192, part ? part + 8192 : nullptr, sRed + 256, w, c, g);
   SB_STAMP(5);
   // ---- P5: gradient of the block input ----------------------------------------------------------------------------------------
@@ -504,9 +509,9 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     const bool valid = l < L;
     if (s == 0) gx_request(1);
     const TTLn st = tt_ln_stats(xk[s], a.ln_eps);
-    TT dn = tt_gemm(tt_bfrags(dq[s]), wimg + 3 * TT_WIMG, c, g);
-    TT dkv = tt_gemm(tt_bfrags(dk[s]), wimg + 4 * TT_WIMG, c, g);
-    tt_add(dkv, tt_gemm(tt_bfrags(dv[s]), wimg + 5 * TT_WIMG, c, g));
+    TT dn = tt_gemm(tt_bfrags(dq[s]), wtr, c, g);
+    TT dkv = tt_gemm(tt_bfrags(dk[s]), wtr + TT_WIMG, c, g);
+    tt_add(dkv, tt_gemm(tt_bfrags(dv[s]), wtr + 2 * TT_WIMG, c, g));
     TT res = resa[s];
     if (DEC && (!valid || a.ids[row] == 0)) res = tt_zero();
     if (DEC && a.dres_scale != 0.f) {

@@ -97,7 +97,17 @@ ADT_DEVICE_INLINE int tq_tile(int s, int w, int ntiles, int nw = TQ_NW) {
 // SIMD 3 and its waves left the phase 7k cycles after the others).  The tiles, heaviest first (j = 0 is tile ntiles - 1), are dealt to the
 // four SIMD classes in snake order 0 1 2 3 3 2 1 0 0 1 2 3 3 ..: wave w takes round k = w / 4 in slot 0 and waves 8 .. 11 take round 3 in
 // slot 1 -- 24 / 23 / 22 / 22 at 13 tiles.
+// At 13 tiles (L = 200) one SIMD carries FOUR tiles, and most of a tile's cost does not depend on its position: in-projection, out_proj and
+// feed-forward are ~11k cycles per tile against ~1.1k per causal key tile in the attention (profiles/r03_stamps_fwd12.txt).  The snake gave
+// that SIMD tiles 9, 8, 1, 0 -- 66k of work against 55-57k on the others, and its wave with two tiles ended the kernel 5k cycles after
+// everyone else.  The table gives the four-tile SIMD the four lightest but one: 12 7 5 | 11 9 1 | 10 8 6 | 4 3 2 + 0 = 60 / 57 / 60 / 57.
 ADT_DEVICE_INLINE int tq_tile12(int s, int w, int ntiles) {
+  if (ntiles == 13) {
+    const int t13 = (0xC << 0) | (0xB << 4) | (0xA << 8) | (0x4 << 12) | (0x7 << 16) | (0x9 << 20) | (0x8 << 24) | (0x3 << 28);      // waves 0 .. 7
+    const int t13b = (0x5 << 0) | (0x1 << 4) | (0x6 << 8) | (0x2 << 12);                                                              // waves 8 .. 11
+    if (s == 0) return w < 8 ? (int)(((unsigned)t13 >> (4 * w)) & 15u) : ((t13b >> (4 * (w - 8))) & 15);
+    return w == 11 ? 0 : -1;
+  }
   const int cl = w & 3, k = s == 0 ? (w >> 2) : ((w >> 2) == 2 ? 3 : 4);
   const int j = 4 * k + ((k & 1) ? 3 - cl : cl);
   return (k < 4 && j < ntiles) ? ntiles - 1 - j : -1;
