@@ -190,12 +190,14 @@ __global__ __launch_bounds__(NW * 64) void k_attn_gen_fwd(AttnGenArgs ga) {
         const int kt = 2 * kp + t;
         f32x4 sc = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         if (kt < nkt) score(kt, sc);
+        // the quad's four keys are consecutive elements of probability row q: one hash for the four when L % 4 == 0
+        const uint32_t kbits = (a.drop.thr && kt < nkt) ? adt_keep4_any(key_rng, idx_q + (uint32_t)(kt * 16 + 4 * g), a.drop.thr, (L & 3) == 0) : 0u;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float e = __expf(sc[r] - m);        // exp(-inf) = 0 for absent keys
           sum += e;
           float p = e;
-          if (a.drop.thr) p = (kt < nkt && adt_keep(key_rng, idx_q + (uint32_t)(kt * 16 + 4 * g + r), a.drop.thr)) ? e * a.drop.scale : 0.f;
+          if (a.drop.thr) p = ((kbits >> r) & 1u) ? e * a.drop.scale : 0.f;
           pv[4 * t + r] = p;
         }
       }
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_gen_bwd(AttnGenArgs ga) {
             dp = I::mma(dp, rfrag_g<PREC, HD>(sR1, kt * 16 + c, kb, g), fdo[kb]);
           }
         }
+        const uint32_t kbits = a.drop.thr ? adt_keep4_any(key_rng, idx_q + (uint32_t)(kt * 16 + 4 * g), a.drop.thr, (L & 3) == 0) : 0u;      // see k_attn_gen_fwd
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + 4 * g + r;   // < LP
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_gen_bwd(AttnGenArgs ga) {
           const float sv = masked ? fill_q : s[r];
           const float p = (kt < nkt && key < L) ? __expf(sv - lse_q) : 0.f;
           float d = dp[r];
-          if (a.drop.thr) d = adt_keep(key_rng, idx_q + (uint32_t)key, a.drop.thr) ? d * a.drop.scale : 0.f;
+          if (a.drop.thr) d = ((kbits >> r) & 1u) ? d * a.drop.scale : 0.f;
           dsv[4 * t + r] = masked ? 0.f : p * (d - delta_q);
         }
       }
@@ -506,6 +509,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_gen_bwd_chunked(AttnGenArgs ga
               sacc = I::mma(sacc, rfrag_g<PREC, HD>(sR0, ktl * 16 + c, kb, g), fq[kb]);
               dp = I::mma(dp, rfrag_g<PREC, HD>(sR1, ktl * 16 + c, kb, g), fdo[kb]);
             }
+            const uint32_t kbits = a.drop.thr ? adt_keep4_any(key_rng, idx_q + (uint32_t)(r0 + ktl * 16 + 4 * g), a.drop.thr, (L & 3) == 0 && (r0 & 3) == 0) : 0u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int key = r0 + ktl * 16 + 4 * g + r;  // < LP
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_gen_bwd_chunked(AttnGenArgs ga
               const float sv = masked ? fill_q : sacc[r];
               const float p = key < L ? __expf(sv - lse_q) : 0.f;
               float d = dp[r];
-              if (a.drop.thr) d = adt_keep(key_rng, idx_q + (uint32_t)key, a.drop.thr) ? d * a.drop.scale : 0.f;
+              if (a.drop.thr) d = ((kbits >> r) & 1u) ? d * a.drop.scale : 0.f;
               dsv[4 * tt + r] = masked ? 0.f : p * (d - delta_q);
             }
           }

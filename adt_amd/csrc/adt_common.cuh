@@ -98,6 +98,14 @@ __host__ __device__ __forceinline__ uint32_t adt_keep4(uint32_t key, uint32_t id
          ((h >> 24) >= thr ? 8u : 0u);
 }
 
+// the keep bits of idx0 .. idx0 + 3 for ANY idx0: one hash when the quad is aligned (`aligned`: wave-uniform, e.g. L % 4 == 0 for the
+// L x L probability rows of an attention), four otherwise.  Same decisions as adt_keep per element.
+__host__ __device__ __forceinline__ uint32_t adt_keep4_any(uint32_t key, uint32_t idx0, uint32_t thr, bool aligned) {
+  if (aligned) return adt_keep4(key, idx0, thr);
+  return (adt_keep(key, idx0, thr) ? 1u : 0u) | (adt_keep(key, idx0 + 1u, thr) ? 2u : 0u) | (adt_keep(key, idx0 + 2u, thr) ? 4u : 0u) |
+         (adt_keep(key, idx0 + 3u, thr) ? 8u : 0u);
+}
+
 // The same four decisions WITHOUT compares: bit 8r + 7 of the result is set iff byte r of h >= thr (1 <= thr <= 255; the other bits
 // are scratch).  byte >= thr <=> the 8-bit sum byte + (256 - thr) carries out = majority(byte's bit 7, the constant's bit 7, the carry
 // out of the low seven bits); three bit operations for the four bytes (the last is one v_bitop3_b32), no VCC round trips.

@@ -590,7 +590,8 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   const bool parts = w.part_stride > 0 && adt_seq_partials(prec, L, d, hd) != 0;
   auto PART = [&](int layer, int slot) { return parts ? ws + w.part + (int64_t)(16 * layer + slot) * 4096 : nullptr; };
   const char* const no_fallback = "backward: shape L=%d hd=%d left the per-sequence kernels although the partial-gradient path was chosen";
-  SideStream* const sd = side_stream((hipStream_t)st);
+  // (one-phase backward only: the two-phase form belongs to the data-parallel step, whose capture already carries the collectives' stream)
+  SideStream* const sd = phase == 0 ? side_stream((hipStream_t)st) : nullptr;
   int dec_side = 0;      // the decoder's embedding gradient + partial sums on the side stream: 1 marked, 2 enqueued
   bool dec_parts_done = false;
   if (phase == 0 || phase == 1) {
