@@ -375,6 +375,31 @@ def test_lean_step_is_deterministic_and_ignores_workspace_garbage(L):
         assert float((grad - runs[0][1]).abs().max()) <= 2e-6 * float(runs[0][1].abs().max())
 
 
+def test_side_stream_matches_single_stream(tmp_path):
+    """The backward puts its scatter / fold kernels on a side stream under the chain kernels (adt_sasrec.hip: side_stream; in the captured
+    step they are parallel branches of the HIP graph).  Two processes run the same three steps at the flagship shape's L = 200 (eager
+    warm-up, capture, replay; learning rate 0: with bf16 operand rounding a 1e-9 difference in a weight can flip a rounding and move a
+    gradient by 1e-4, so the weights are held), one with everything on one stream (ADT_SIDE_STREAM=0): the forward tensors of the replayed
+    step are bit-equal, its gradients agree to the order of the fp32 atomic sums.  A missing dependency edge would show here as a
+    gradient read before its producer finished."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for name, val in (("single", "0"), ("side", "7")):
+        out = str(tmp_path / (name + ".npz"))
+        env = dict(os.environ, ADT_SIDE_STREAM=val)
+        subprocess.run([sys.executable, os.path.join(repo, "tools", "side_stream_arm.py"), out], check=True, env=env, timeout=300)
+        outs.append(np.load(out))
+    a, b = outs
+    for k in a.files:
+        assert np.isfinite(b[k]).all(), k
+        if k in ("grad", "loss"):
+            assert np.abs(a[k] - b[k]).max() <= 4e-6 * max(np.abs(a[k]).max(), 1e-30), (k, np.abs(a[k] - b[k]).max())
+        else:
+            assert np.array_equal(a[k], b[k]), (k, np.abs(a[k] - b[k]).max())
+
+
 def test_predict_and_rank_vs_reference_golden(golden_dir):
     z, cfg = load_golden(golden_dir, "sasrec_small_h4")
     P = {k[2:]: z[k] for k in z.files if k.startswith("w.")}
