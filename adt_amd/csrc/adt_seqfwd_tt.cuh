@@ -100,18 +100,29 @@ ADT_DEVICE_INLINE int tq_tile(int s, int w, int ntiles, int nw = TQ_NW) {
 // At 13 tiles (L = 200) one SIMD carries FOUR tiles, and most of a tile's cost does not depend on its position: in-projection, out_proj and
 // feed-forward are ~11k cycles per tile against ~1.1k per causal key tile in the attention (profiles/r03_stamps_fwd12.txt).  The snake gave
 // that SIMD tiles 9, 8, 1, 0 -- 66k of work against 55-57k on the others, and its wave with two tiles ended the kernel 5k cycles after
-// everyone else.  The table gives the four-tile SIMD the four lightest but one: 12 7 5 | 11 9 1 | 10 8 6 | 4 3 2 + 0 = 60 / 57 / 60 / 57.
+// everyone else.  Fitted to the stamps (a tile ~7.2k + 0.81k per causal key tile) the table deals 12 9 1 | 11 8 2 | 10 7 5 | 3 6 4 + 0:
+// 25 / 24 / 25 causal units on the three-tile SIMDs, 17 on the four-tile one.  The two tiles of one wave
+// are a serial chain, so they go to wave 3, the OLDEST wave of its SIMD (the issue arbiter prefers older waves: as the youngest, wave 11
+// finished its two tiles last even with the lightest load).
 ADT_DEVICE_INLINE int tq_tile12(int s, int w, int ntiles) {
   if (ntiles == 13) {
-    const int t13 = (0xC << 0) | (0xB << 4) | (0xA << 8) | (0x4 << 12) | (0x7 << 16) | (0x9 << 20) | (0x8 << 24) | (0x3 << 28);      // waves 0 .. 7
-    const int t13b = (0x5 << 0) | (0x1 << 4) | (0x6 << 8) | (0x2 << 12);                                                              // waves 8 .. 11
+    const int t13 = (0xC << 0) | (0xB << 4) | (0xA << 8) | (0x3 << 12) | (0x9 << 16) | (0x8 << 20) | (0x7 << 24) | (0x6 << 28);      // waves 0 .. 7
+    const int t13b = (0x1 << 0) | (0x2 << 4) | (0x5 << 8) | (0x4 << 12);                                                              // waves 8 .. 11
     if (s == 0) return w < 8 ? (int)(((unsigned)t13 >> (4 * w)) & 15u) : ((t13b >> (4 * (w - 8))) & 15);
-    return w == 11 ? 0 : -1;
+    return w == 3 ? 0 : -1;
   }
   const int cl = w & 3, k = s == 0 ? (w >> 2) : ((w >> 2) == 2 ? 3 : 4);
   const int j = 4 * k + ((k & 1) ? 3 - cl : cl);
   return (k < 4 && j < ntiles) ? ntiles - 1 - j : -1;
 }
+
+// The wave with two tiles used to run both in-projections in front of the barrier behind which every wave's attention starts: the other
+// eleven waited ~3k cycles for its second one (profiles/r03_stamps_fwd12.txt: pre1 17.0k against 11.5-14k).  At 13 tiles the k / v rows of
+// that second tile (tile 0, which every query attends to) are computed by wave 0 instead -- an oldest wave, done with its own tile first -- in
+// its idle slot 1; the owner computes the tile's query operands behind the barrier.
+constexpr int TQ_HELPER_WAVE = 0;
+ADT_DEVICE_INLINE int tq_helper_tile(int w, int ntiles) { return (ntiles == 13 && w == TQ_HELPER_WAVE) ? 0 : -1; }
+ADT_DEVICE_INLINE bool tq_split_second(int ntiles) { return ntiles == 13; }
 
 // slot-ordered packed image of the 64 x 64 block at W (adt_seq.hip: k_pack_wimg writes it at + 2 images, transposed at + 3)
 template <int NTHREADS>
@@ -171,20 +182,30 @@ ADT_DEVICE_INLINE TT tq_x_finish(const SeqFwdArgs& a, const TqX& r, int row, boo
 }
 
 // LayerNorm + packed in-projection of one tile: query operands to registers, k / v into the LDS images (and to HBM for the backward)
-template <int HD, bool ENC>
+// PART 0: everything.  The tile of the one wave that carries TWO tiles (13 tiles on 12 waves) is split: PART 1 = the k / v rows only, by a
+// helper wave in front of the barrier every wave's attention waits at; PART 2 = x / LN(x) stores and the query operands, by the owner behind
+// that barrier (tq_helper_tile).  Both recompute x and LN(x) from the same inputs (same hash dropout): identical values.
+template <int HD, bool ENC, int PART = 0>
 ADT_DEVICE_INLINE void tq_pre_tile(const SeqFwdArgs& a, const float* vec, const __bf16* wq, const __bf16* wk, const __bf16* wv, __bf16* sK, __bf16* sV,
                                    int tile, int b, uint32_t key0, float qmul, int c, int g,
                                    bf16x8 (&fq)[(64 / HD) * ((HD + 31) / 32)], TT& xn_out, const TqX& xr) {
   const int l = tile * 16 + c, row = b * a.L + l;
   const bool valid = l < a.L;
-  const TT x = tq_x_finish(a, xr, row, valid, key0, g);
+  TT x;
+  if (PART == 1) {
+    SeqFwdArgs a1 = a;
+    a1.x_out = nullptr;                            // the owner stores x
+    x = tq_x_finish(a1, xr, row, valid, key0, g);
+  } else {
+    x = tq_x_finish(a, xr, row, valid, key0, g);
+  }
   const TT xn = tt_layernorm(x, vec + SV_GAMMA, vec + SV_BETA, a.ln_eps, g);
-  if (a.xn) tt_store(a.xn + (size_t)row * 64, xn, valid, g);
-  xn_out = xn;
+  if (PART != 1 && a.xn) tt_store(a.xn + (size_t)row * 64, xn, valid, g);
+  if (PART != 1) xn_out = xn;
   const TTB bn = tt_bfrags(xn);
   TTB bx;
   if (ENC) bx = tt_bfrags(x);
-  {
+  if (PART != 1) {
     TT q = tt_gemm(bn, wq, c, g);
     tt_add_vec(q, vec + SV_BIN, g);
     if (a.qkv && valid) {
@@ -193,6 +214,7 @@ ADT_DEVICE_INLINE void tq_pre_tile(const SeqFwdArgs& a, const float* vec, const 
     }
     tt_qfrags<HD>(q, qmul, fq);
   }
+  if (PART == 2) return;
   {
     TT k = tt_gemm(ENC ? bx : bn, wk, c, g);
     tt_add_vec(k, vec + SV_BIN + 64, g);
@@ -244,47 +266,62 @@ __global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) 
   TQ_STAMP(0);
   uint32_t seedv = 0u;
   TqX xr[2];
+  const int htile = tq_helper_tile(w, ntiles);      // >= 0: this wave computes the k / v rows of that tile in its slot 1
+  const bool split2 = tq_split_second(ntiles);      // the owner of a second tile leaves its k / v rows to the helper
   {
     int idr[2] = {0, 0};                      // the ids first: vector-memory results return in issue order, and the gather's row loads wait for them
     if (!a.x) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int tile = tq_tile12(s, w, ntiles), l = tile * 16 + c;
+        const int tile = (s == 1 && htile >= 0) ? htile : tq_tile12(s, w, ntiles), l = tile * 16 + c;
         idr[s] = tt_load_id(a.ids, b * L + l, tile >= 0 && l < L);
       }
     }
     const bool tq_body = TQW * 64 <= TQ_CH || threadIdx.x < TQ_CH;
     const bool tq_tail = (int)threadIdx.x < TQ_CH - TQW * 64;        // chunks beyond the first TQW * 64 (wave-uniform: whole waves)
-    TQ_IMG_LOAD(0, a.Win) TQ_IMG_LOAD(1, a.Win + 4096) TQ_IMG_LOAD(2, a.Win + 8192) TQ_IMG_LOAD(3, a.Wo) TQ_IMG_LOAD(4, a.W1) TQ_IMG_LOAD(5, a.W2)
+    // only what the in-projection needs is requested in front of the first barrier (the prologue is a bandwidth burst: every workgroup of
+    // the launch pulls its inputs at once, ~11 B per cycle and CU); out_proj / conv1 / conv2 follow behind it by LDS-DMA
+    TQ_IMG_LOAD(0, a.Win) TQ_IMG_LOAD(1, a.Win + 4096) TQ_IMG_LOAD(2, a.Win + 8192)
     const TqVecRegs vr = tq_vec_load<TQW * 64>(a, H, HD);
     if (a.drop.thr) seedv = *a.drop.seed;     // behind the image requests: read first, its round trip preceded every other load of the kernel
 #pragma unroll
     for (int s = 0; s < 2; ++s) {             // the layer input of both tiles, in flight while the images are stored
-      const int tile = tq_tile12(s, w, ntiles), l = tile * 16 + c;
+      const int tile = (s == 1 && htile >= 0) ? htile : tq_tile12(s, w, ntiles), l = tile * 16 + c;
       xr[s] = tq_x_request(a, b * L + l, l, tile >= 0 && l < L, idr[s], g);
     }
     TQ_STAMP(11);
     tq_zero<TQW * 64>(lds.sK, 2 * SeqTtLds<6>::ibytes);
     TQ_STAMP(12);
-    TQ_IMG_STORE(0, lds.w[0]) TQ_IMG_STORE(1, lds.w[1]) TQ_IMG_STORE(2, lds.w[2]) TQ_IMG_STORE(3, lds.w[3]) TQ_IMG_STORE(4, lds.w[4]) TQ_IMG_STORE(5, lds.w[5])
+    TQ_IMG_STORE(0, lds.w[0]) TQ_IMG_STORE(1, lds.w[1]) TQ_IMG_STORE(2, lds.w[2])
     TQ_STAMP(13);
     tq_vec_store<TQW * 64>(lds.vec, vr);
     TQ_STAMP(14);
   }
   __syncthreads();
   TQ_STAMP(1);
+  adt_glds_block<TQW>(tq_img_src(a, a.Wo, false), lds.w[3], TT_WIMG * 2);
+  adt_glds_block<TQW>(tq_img_src(a, a.W1, false), lds.w[4], TT_WIMG * 2);
+  adt_glds_block<TQW>(tq_img_src(a, a.W2, false), lds.w[5], TT_WIMG * 2);
   const uint32_t key0 = adt_site_key(seedv, a.site_emb), key1 = adt_site_key(seedv, a.site1), key2 = adt_site_key(seedv, a.site2);
   const float qmul = a.scale * 1.4426950408889634f;          // scores in log2 units: the softmax is exp2
   bf16x8 fq[2][NF];
   TT xn[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile12(s, w, ntiles);
-    if (tile >= 0) tq_pre_tile<HD, true>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[s], xn[s], xr[s]);
-    TQ_STAMP(2 + s);
+  {
+    const int tile = tq_tile12(0, w, ntiles);
+    if (tile >= 0) tq_pre_tile<HD, true>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[0], xn[0], xr[0]);
+    TQ_STAMP(2);
+    const int tile1 = tq_tile12(1, w, ntiles);
+    if (htile >= 0) tq_pre_tile<HD, true, 1>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, htile, b, key0, qmul, c, g, fq[1], xn[1], xr[1]);
+    else if (tile1 >= 0 && !split2) tq_pre_tile<HD, true>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile1, b, key0, qmul, c, g, fq[1], xn[1], xr[1]);
+    TQ_STAMP(3);
   }
+  adt_wait_vm0();            // the three images requested behind the first barrier have landed: published by this one
   __syncthreads();
   TQ_STAMP(4);
+  {      // the owner's part of a split second tile, first (its layer-input registers die here, as they did in front of the barrier)
+    const int tile1 = tq_tile12(1, w, ntiles);
+    if (split2 && tile1 >= 0) tq_pre_tile<HD, true, 2>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile1, b, key0, qmul, c, g, fq[1], xn[1], xr[1]);
+  }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile12(s, w, ntiles);
@@ -355,39 +392,49 @@ __global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) 
   const bool tq_body = TQW * 64 <= TQ_CH || threadIdx.x < TQ_CH;
   const bool tq_tail = (int)threadIdx.x < TQ_CH - TQW * 64;        // chunks beyond the first TQW * 64 (wave-uniform: whole waves)
   TqX xr[2];
+  const int htile = tq_helper_tile(w, ntiles);      // see k_seqtt_enc_fwd: k / v rows (both attentions) of the two-tile wave's second tile
+  const bool split2 = tq_split_second(ntiles);
   {
     int idr[2] = {0, 0};                      // ids first, layer inputs of both tiles behind the images (see k_seqtt_enc_fwd)
     if (!a.x) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int tile = tq_tile12(s, w, ntiles), l = tile * 16 + c;
+        const int tile = (s == 1 && htile >= 0) ? htile : tq_tile12(s, w, ntiles), l = tile * 16 + c;
         idr[s] = tt_load_id(a.ids, b * L + l, tile >= 0 && l < L);
       }
     }
-    TQ_IMG_LOAD(0, a.Win) TQ_IMG_LOAD(1, a.Win + 4096) TQ_IMG_LOAD(2, a.Win + 8192) TQ_IMG_LOAD(3, a.Wo) TQ_IMG_LOAD(4, a.Win2)
+    TQ_IMG_LOAD(0, a.Win) TQ_IMG_LOAD(1, a.Win + 4096) TQ_IMG_LOAD(2, a.Win + 8192)      // out_proj and Wq2 follow behind the barrier (see k_seqtt_enc_fwd)
     const TqVecRegs vr = tq_vec_load<TQW * 64>(a, H, HD);
     if (a.drop.thr) seedv = *a.drop.seed;     // behind the image requests (see k_seqtt_enc_fwd)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int tile = tq_tile12(s, w, ntiles), l = tile * 16 + c;
+      const int tile = (s == 1 && htile >= 0) ? htile : tq_tile12(s, w, ntiles), l = tile * 16 + c;
       xr[s] = tq_x_request(a, b * L + l, l, tile >= 0 && l < L, idr[s], g);
     }
     tq_zero<TQW * 64>(lds.sK, 2 * SeqTtLds<5>::ibytes);
-    TQ_IMG_STORE(0, lds.w[0]) TQ_IMG_STORE(1, lds.w[1]) TQ_IMG_STORE(2, lds.w[2]) TQ_IMG_STORE(3, lds.w[3]) TQ_IMG_STORE(4, lds.w[4])
+    TQ_IMG_STORE(0, lds.w[0]) TQ_IMG_STORE(1, lds.w[1]) TQ_IMG_STORE(2, lds.w[2])
     tq_vec_store<TQW * 64>(lds.vec, vr);
   }
   __syncthreads();
+  adt_glds_block<TQW>(tq_img_src(a, a.Wo, false), lds.w[3], TT_WIMG * 2);
+  adt_glds_block<TQW>(tq_img_src(a, a.Win2, false), lds.w[4], TT_WIMG * 2);
   const uint32_t key0 = adt_site_key(seedv, a.site_emb), key1 = adt_site_key(seedv, a.site1), key2 = adt_site_key(seedv, a.site2);
   const float qmul = a.scale * 1.4426950408889634f;
   bf16x8 fq[2][NF];
   TT dn[2];
   // self attention: D = LN(x); q, k, v = D Win^T + b                                                    (sasrec/modules.py:668-670)
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile12(s, w, ntiles);
-    if (tile >= 0) tq_pre_tile<HD, false>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[s], dn[s], xr[s]);
+  {
+    const int tile = tq_tile12(0, w, ntiles), tile1 = tq_tile12(1, w, ntiles);
+    if (tile >= 0) tq_pre_tile<HD, false>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[0], dn[0], xr[0]);
+    if (htile >= 0) tq_pre_tile<HD, false, 1>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, htile, b, key0, qmul, c, g, fq[1], dn[1], xr[1]);
+    else if (tile1 >= 0 && !split2) tq_pre_tile<HD, false>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile1, b, key0, qmul, c, g, fq[1], dn[1], xr[1]);
   }
+  adt_wait_vm0();
   __syncthreads();
+  {
+    const int tile1 = tq_tile12(1, w, ntiles);
+    if (split2 && tile1 >= 0) tq_pre_tile<HD, false, 2>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile1, b, key0, qmul, c, g, fq[1], dn[1], xr[1]);
+  }
   // a1 = out_proj(o1) ; q2 = a1 Wq2^T + b : the cross attention's queries replace the self attention's in the registers
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -407,17 +454,23 @@ __global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) 
   }
   // weight set B is requested before the barrier ...
   TQ_IMG_LOAD(5, a.Win2 + 4096) TQ_IMG_LOAD(6, a.Win2 + 8192) TQ_IMG_LOAD(7, a.Wo2) TQ_IMG_LOAD(8, a.W1) TQ_IMG_LOAD(9, a.W2)
+  TT fa[2];                             // the encoder's log_feats rows of both tiles, behind the images (inside the tile loop each was an exposed round trip)
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = (s == 1 && split2) ? htile : tq_tile12(s, w, ntiles), l = tile * 16 + c;      // the helper projects the split tile's k2 / v2 as well
+    fa[s] = tt_load(a.f + (size_t)(b * L + l) * 64, tile >= 0 && l < L, g);
+  }
   __syncthreads();                      // every wave is done with the self-attention images and with weight set A
   TQ_IMG_STORE(5, lds.w[0]) TQ_IMG_STORE(6, lds.w[1]) TQ_IMG_STORE(7, lds.w[2]) TQ_IMG_STORE(8, lds.w[3]) TQ_IMG_STORE(9, lds.w[4])      // ... and lands after it
   __syncthreads();
   // cross attention keys / values from the encoder's log_feats: [k2, v2] = f Wkv^T + b              (memory = log_feats, model.py:69-70)
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile12(s, w, ntiles);
+    const int tile = (s == 1 && split2) ? htile : tq_tile12(s, w, ntiles);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
-    const TTB bf = tt_bfrags(tt_load(a.f + (size_t)row * 64, valid, g));
+    const TTB bf = tt_bfrags(fa[s]);
     TT k2 = tt_gemm(bf, lds.w[0], c, g);
     tt_add_vec(k2, lds.vec + SV_BIN2 + 64, g);
     TT v2 = tt_gemm(bf, lds.w[1], c, g);

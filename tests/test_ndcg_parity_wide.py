@@ -2,43 +2,58 @@
 fp32; imported read-only in the build container by tools/ref_train_wide.py) were trained for 20 epochs on the seeded synthetic
 "ml1m-small" set (1,200 users, 800 items) with the batches of tools/wide_parity_common.py; tests/golden/ref_ndcg_{bert,stosa}_small.json
 hold their metrics at epochs 10 and 20.  Here the HIP path (bf16 MFMA operands, hash dropout, fused trainer, HIP graph) trains on the
-same batches with the same hyper-parameters.  Tolerances (abs, stated per metric below) cover the run-to-run spread that dropout
-streams and float atomics cause on 1,200 evaluation users (one user = 0.0008 HR); the measured seed spread of the HIP path is in
-profiles/r01_ndcg_wide_ours.json."""
+same batches with the same hyper-parameters.  Both sides run THREE model seeds (reference: ref_ndcg_{bert,stosa}_small{,_s*}.json);
+the stated tolerance is max(0.01, 2 sigma of the reference's own seed spread) on the seed means, per metric and checkpoint (one user of the
+1,200 evaluation users is 0.0008 HR)."""
 import json
 import os
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
+BERT_REF = ("ref_ndcg_bert_small.json", "ref_ndcg_bert_small_s24.json", "ref_ndcg_bert_small_s25.json")          # model seeds 23, 24, 25
+STOSA_REF = ("ref_ndcg_stosa_small.json", "ref_ndcg_stosa_small_s43.json", "ref_ndcg_stosa_small_s44.json")      # model seeds 42, 43, 44
+
+
+def _three_seed_check(ours, refs, keys, floor=0.01):
+    """north_star / SURVEY 8(d): the mean over three HIP seeds lies within max(0.01, 2 sigma) of the mean over the three reference seeds,
+    sigma = the reference's own sample standard deviation at that checkpoint (tools/ref_train_wide.py <model> <seed>)."""
+    for r in refs + ours:
+        assert [e["epoch"] for e in r["evals"]] == [10, 20]
+    for i, epoch in enumerate((10, 20)):
+        for mode in ("val", "test"):
+            for k in keys:
+                rv = np.array([r["evals"][i][mode][k] for r in refs])
+                ov = np.array([o["evals"][i][mode][k] for o in ours])
+                tol = max(floor, 2.0 * rv.std(ddof=1))
+                assert abs(ov.mean() - rv.mean()) <= tol, (epoch, mode, k, ov, rv, tol)
+
+
 def test_bert_ranking_matches_reference(golden_dir):
     from tools.gpu_wide_ndcg_run import run_bert
-    ref = json.load(open(os.path.join(golden_dir, "ref_ndcg_bert_small.json")))
-    ours = run_bert(seed=23)
-    assert [e["epoch"] for e in ours["evals"]] == [e["epoch"] for e in ref["evals"]] == [10, 20]
-    for eo, er in zip(ours["evals"], ref["evals"]):
-        for mode in ("val", "test"):
-            assert abs(eo[mode]["ndcg10"] - er[mode]["ndcg10"]) <= 0.03, (eo["epoch"], mode, eo[mode], er[mode])
-            assert abs(eo[mode]["hr10"] - er[mode]["hr10"]) <= 0.04, (eo["epoch"], mode, eo[mode], er[mode])
-            assert abs(eo[mode]["auc"] - er[mode]["auc"]) <= 0.02, (eo["epoch"], mode, eo[mode], er[mode])
-    assert abs(ours["loss"][-1] - ref["loss"][-1]) <= 0.05 * ref["loss"][-1]
-    assert ours["evals"][-1]["test"]["ndcg10"] > 2 * 0.045          # far above the random ranker (NDCG@10 of 101 candidates ~ 0.045)
+    from tools import wide_parity_common as C
+    refs = [json.load(open(os.path.join(golden_dir, f))) for f in BERT_REF]
+    data = C.bert_data()
+    ours = [run_bert(seed=s, data=data) for s in (23, 24, 25)]
+    _three_seed_check(ours, refs, ("ndcg10", "hr10", "auc"))
+    rl = np.mean([r["loss"][-1] for r in refs])
+    assert abs(np.mean([o["loss"][-1] for o in ours]) - rl) <= 0.02 * rl
+    assert min(o["evals"][-1]["test"]["ndcg10"] for o in ours) > 2 * 0.045          # far above the random ranker (NDCG@10 of 101 candidates ~ 0.045)
 
 
 def test_stosa_ranking_matches_reference(golden_dir):
     from tools.gpu_wide_ndcg_run import run_stosa
-    ref = json.load(open(os.path.join(golden_dir, "ref_ndcg_stosa_small.json")))
-    ours = run_stosa(seed=42)
-    assert [e["epoch"] for e in ours["evals"]] == [e["epoch"] for e in ref["evals"]] == [10, 20]
-    for eo, er in zip(ours["evals"], ref["evals"]):
-        for mode in ("val", "test"):
-            assert abs(eo[mode]["ndcg10"] - er[mode]["ndcg10"]) <= 0.03, (eo["epoch"], mode, eo[mode], er[mode])
-            assert abs(eo[mode]["hit10"] - er[mode]["hit10"]) <= 0.04, (eo["epoch"], mode, eo[mode], er[mode])
-            assert abs(eo[mode]["mrr"] - er[mode]["mrr"]) <= 0.03, (eo["epoch"], mode, eo[mode], er[mode])
-    assert abs(ours["loss"][-1] - ref["loss"][-1]) <= 0.05 * ref["loss"][-1]
-    assert ours["evals"][-1]["test"]["ndcg10"] > 0.1               # full-sort over 800 items: random is ~0.006
+    from tools import wide_parity_common as C
+    refs = [json.load(open(os.path.join(golden_dir, f))) for f in STOSA_REF]
+    data = C.stosa_data()
+    ours = [run_stosa(seed=s, data=data) for s in (42, 43, 44)]
+    _three_seed_check(ours, refs, ("ndcg10", "hit10", "mrr"))
+    rl = np.mean([r["loss"][-1] for r in refs])
+    assert abs(np.mean([o["loss"][-1] for o in ours]) - rl) <= 0.05 * rl
+    assert min(o["evals"][-1]["test"]["ndcg10"] for o in ours) > 0.1               # full-sort over 800 items: random is ~0.006
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
