@@ -548,15 +548,22 @@ static int loss_seed_impl(const adt_sasrec_cfg* c, float* ws, const int32_t* pos
 
 // Measurement hook (bench.py's roofline probe; not part of include/adt_hip.h): HIP events recorded on the launch stream right before and right
 // after ONE launch inside adt_sasrec_backward -- which = 1: the fused attention-block backward (k_seqtt_attn_pre_bwd) of encoder layer `layer`;
-// which = 2: the same kernel's decoder instantiation for decoder layer `layer`; 0 switches the hook off.
+// which = 2: the same kernel's decoder instantiation for decoder layer `layer`; 3: see time_mark; 0 switches the hook off.
 static int g_time_which = 0, g_time_layer = 0;
 static hipEvent_t g_time_ev0 = nullptr, g_time_ev1 = nullptr;
 extern "C" int adt_debug_time_launch(int which, int layer, void* ev_start, void* ev_stop) {
   g_time_which = which; g_time_layer = layer; g_time_ev0 = (hipEvent_t)ev_start; g_time_ev1 = (hipEvent_t)ev_stop;
   return 0;
 }
+// which = 3: calibration -- BOTH events in front of the launch of which = 1 (nothing between them): what an event pair itself adds to an interval
 static inline void time_mark(int which, int layer, bool start, void* st) {
-  if (g_time_which == which && g_time_layer == layer && g_time_ev0 && g_time_ev1) (void)hipEventRecord(start ? g_time_ev0 : g_time_ev1, (hipStream_t)st);
+  if (!g_time_ev0 || !g_time_ev1 || g_time_layer != layer) return;
+  if (g_time_which == 3 && which == 1 && start) {
+    (void)hipEventRecord(g_time_ev0, (hipStream_t)st);
+    (void)hipEventRecord(g_time_ev1, (hipStream_t)st);
+  } else if (g_time_which == which) {
+    (void)hipEventRecord(start ? g_time_ev0 : g_time_ev1, (hipStream_t)st);
+  }
 }
 
 int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float* ws, const int32_t* seq,

@@ -167,7 +167,9 @@ def roofline_probe(model, trainer, B, seq_per_s, batch):
     Algorithmic bytes per launch = tokens x (x 256 + dO 256 + residual-path gradient 256 + gx read 256 + gx write 256 fp32; O 128 bf16;
     H log-sum-exp floats; H x 32 B of dropout keep bits) + 3 x 16 KB of private weight-gradient partials per sequence, divided by its launch
     duration measured live with HIP events recorded by the library right around that launch inside complete training steps
-    (adt_debug_time_launch; the committed rocprofv3 average is used instead when it is the larger, i.e. the conservative, figure).
+    (adt_debug_time_launch), net of what the event pair itself adds (the same two events recorded with nothing between them, at the same
+    place in the same steps: `event_pair_us`); the committed rocprofv3 average is used instead when it is the larger, i.e. the conservative,
+    figure.
     `kernels` adds the fused decoder-layer forward (the round-2 dominant kernel), and what north_star asks for by name: achieved HBM GB/s of
     the embedding gather and MFMA utilisation of the attention kernels (causal-aware FLOPs, SURVEY 8d: 4*L(L+1)/2*hd per (b,h) forward,
     2.5x that backward; counter-based matrix-pipe busy fractions: profiles/r03_mfma.json) on the standalone C-ABI kernels; `step` is
@@ -181,7 +183,9 @@ def roofline_probe(model, trainer, B, seq_per_s, batch):
     prec, p, sd = model.cfg.prec, CFG["dropout"], model._seed
     ids4 = [model._ids(a) for a in batch]
     # dominant kernel: in-step duration of the encoder instantiation, layer 1 (the first encoder block of the backward)
-    us_bwd_blk = _time_in_step(model, trainer, batch, 1, CFG["num_layers"] - 1)
+    us_bwd_raw = _time_in_step(model, trainer, batch, 1, CFG["num_layers"] - 1)
+    us_pair = _time_in_step(model, trainer, batch, 3, CFG["num_layers"] - 1)      # the same two events with no launch between them
+    us_bwd_blk = us_bwd_raw - us_pair
     us_prof = _profile_avg_us("k_seqtt_attn_pre_bwd<32, 1, false>")
     us_used = max(us_bwd_blk, us_prof or 0.0)
     blk_bytes = T * (5 * 256 + 128 + H * 4 + H * 32) + B * 3 * 16384
@@ -240,7 +244,8 @@ def roofline_probe(model, trainer, B, seq_per_s, batch):
     return {"bound": "hbm", "kernel": "k_seqtt_attn_pre_bwd (fused attention-block backward, encoder instantiation; the largest share of the step)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_us": round(us_used, 2),
-            "avg_launch_us_in_step": round(us_bwd_blk, 2), "avg_launch_us_rocprof": us_prof,
+            "avg_launch_us_in_step": round(us_bwd_blk, 2), "avg_launch_us_in_step_raw": round(us_bwd_raw, 2), "event_pair_us": round(us_pair, 2),
+            "avg_launch_us_rocprof": us_prof,
             "traffic_source": "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.py): a committed measurement, not taken in this run",
             "algorithmic_bytes_per_launch": blk_bytes,
             "mfma": {"flops_per_launch": blk_flops, "achieved_TFLOPs": round(blk_flops / (us_used * 1e-6) / 1e12, 2),
