@@ -563,20 +563,32 @@ int adt_clip_adam_pre(float* P, float* G, float* M, float* V, int64_t n, int64_t
   return check_launch("clip_adam_pre");
 }
 
+static void step_begin_extras(StepBeginArgs& a, float* Z, int64_t nz, const float* pack_base, void* pack_img, const int* pack_offs, int npack) {
+  a.Z = Z; a.nz = Z ? (size_t)nz : 0;
+  a.pk.base = pack_base; a.pk.img = reinterpret_cast<__bf16*>(pack_img); a.pk.n = (pack_base && pack_img && pack_offs) ? npack : 0;
+  for (int i = 0; i < a.pk.n; ++i) a.pk.off[i] = pack_offs[i];
+}
+
 int adt_step_begin_launch(uint32_t* seed, uint32_t inc, float* norms_dst, const float* norms_src, float* loss, int nloss, float* scal, float* G,
-                          int64_t n, const float* E, int64_t nE, void* stream) {
+                          int64_t n, const float* E, int64_t nE, float* Z, int64_t nz, const float* pack_base, void* pack_img, const int* pack_offs,
+                          int npack, void* stream) {
+  if (npack < 0 || npack > 256 || (nz & 3)) return adt_set_error("step_begin: %d weight blocks, %lld floats to zero", npack, (long long)nz);
   StepBeginArgs a{seed, inc, norms_dst, norms_src, loss, nloss, scal, G, (size_t)n, E, (size_t)nE, nullptr, 0, 0, nullptr, 0, nullptr, nullptr};
-  hipLaunchKernelGGL(k_step_begin, dim3(256), dim3(256), 0, (hipStream_t)stream, a);
+  step_begin_extras(a, Z, nz, pack_base, pack_img, pack_offs, npack);
+  hipLaunchKernelGGL(k_step_begin, dim3(256 + a.pk.n), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("step_begin");
 }
 
 int adt_step_begin_ring_launch(uint32_t* seed, uint32_t inc, float* norms_dst, float* loss, int nloss, float* scal, float* G, int64_t n, const float* E,
                                int64_t nE, const int32_t* ring, int64_t slot_ints, int nslots, int32_t* ids_dst, int64_t n_ints, uint32_t* state,
-                               uint32_t* consumed, void* stream) {
+                               uint32_t* consumed, float* Z, int64_t nz, const float* pack_base, void* pack_img, const int* pack_offs, int npack,
+                               void* stream) {
   if (!ring || !ids_dst || !state || nslots < 1 || n_ints < 4 || (n_ints & 3) || slot_ints < n_ints || (slot_ints & 3))
     return adt_set_error("step_begin_ring: ring %p, %d slots of %lld ints, %lld ints per step (multiples of 4)", (const void*)ring, nslots, (long long)slot_ints, (long long)n_ints);
+  if (npack < 0 || npack > 256 || (nz & 3)) return adt_set_error("step_begin_ring: %d weight blocks, %lld floats to zero", npack, (long long)nz);
   StepBeginArgs a{seed, inc, norms_dst, nullptr, loss, nloss, scal, G, (size_t)n, E, (size_t)nE, ring, (size_t)slot_ints, nslots, ids_dst, (size_t)n_ints, state, consumed};
-  hipLaunchKernelGGL(k_step_begin, dim3(256), dim3(256), 0, (hipStream_t)stream, a);
+  step_begin_extras(a, Z, nz, pack_base, pack_img, pack_offs, npack);
+  hipLaunchKernelGGL(k_step_begin, dim3(256 + a.pk.n), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("step_begin_ring");
 }
 

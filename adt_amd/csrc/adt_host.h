@@ -57,11 +57,14 @@ int adt_embed_bwd_rep(const int32_t* ids, const float* dX, int T, int L, int d, 
                       float* dP, float* rep, int nrep, int64_t rep_stride, void* stream);
 int adt_layernorm_bwd_rep(const float* dY, int lddy, const float* X, int ldx, const float* gamma, float eps, int T, int d, float* dX, int lddx,
                           int accumulate, float* dgamma, float* dbeta, int nrep, int64_t rep_stride, void* stream);
+// Z / nz: a second range to zero (or null) ; pack_*: npack 64 x 64 blocks at pack_base + pack_offs[i] packed into pack_img (adt_pack_wimg's work) or null
 int adt_step_begin_launch(uint32_t* seed, uint32_t inc, float* norms_dst, const float* norms_src, float* loss, int nloss, float* scal, float* G,
-                          int64_t n, const float* E, int64_t nE, void* stream);
+                          int64_t n, const float* E, int64_t nE, float* Z, int64_t nz, const float* pack_base, void* pack_img, const int* pack_offs,
+                          int npack, void* stream);
 int adt_step_begin_ring_launch(uint32_t* seed, uint32_t inc, float* norms_dst, float* loss, int nloss, float* scal, float* G, int64_t n, const float* E,
                                int64_t nE, const int32_t* ring, int64_t slot_ints, int nslots, int32_t* ids_dst, int64_t n_ints, uint32_t* state,
-                               uint32_t* consumed, void* stream);
+                               uint32_t* consumed, float* Z, int64_t nz, const float* pack_base, void* pack_img, const int* pack_offs, int npack,
+                               void* stream);
 int adt_loss_seeds(const float* pos_logits, const float* neg_logits, const int32_t* pos, int T, const float* norms, float* dpos, float* dneg,
                    float* loss_bce, int nmse, const float* const* A, const float* const* Bm, int64_t n, const float* lambdas, float* const* GA,
                    int accumulate_a, float* const* GB, float* const* loss_mse, int nnll, const float* const* rec, int n_rows, int H, float lambda2,

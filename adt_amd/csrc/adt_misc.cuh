@@ -2,6 +2,7 @@
 // clip + Adam.  HBM-bound integer/elementwise work: coalesced float4 accesses, no MFMA.
 #pragma once
 #include "adt_common.cuh"
+#include "adt_wave.cuh"
 
 namespace adt {
 
@@ -536,10 +537,17 @@ struct StepBeginArgs {
   // ids_dst (n_ints int32, a multiple of 4; its last four words are the loss normalisers, which then replace norms_src).  The last block
   // to finish bumps state[0] and publishes the new count to *consumed (pinned host word the producer polls before it refills a slot).
   const int32_t* ring; size_t slot_ints; int nslots; int32_t* ids_dst; size_t n_ints; uint32_t* state; uint32_t* consumed;
+  // optional extras of the model-level step (adt_sasrec_step_begin*): a second range to zero (the parameter-gradient replicas the backward
+  // chains flush into) and the bf16 weight images of the step (pk.n blocks, packed by the LAST pk.n workgroups of the grid: k_pack_wimg's
+  // work without its launch)
+  float* Z; size_t nz;
+  PackArgs pk;
 };
 __global__ __launch_bounds__(256) void k_step_begin(StepBeginArgs a) {
   __shared__ float sbuf[4];
   typedef int v4i __attribute__((ext_vector_type(4)));
+  const unsigned nblk = gridDim.x - (unsigned)a.pk.n;      // the workgroups of the step's own work ; the rest pack weight images
+  if (blockIdx.x >= nblk) { pack_wimg_block(a.pk, (int)(blockIdx.x - nblk)); return; }
   const int32_t* slot = nullptr;
   v4i idv[2];
   size_t n16 = 0;
@@ -548,14 +556,16 @@ __global__ __launch_bounds__(256) void k_step_begin(StepBeginArgs a) {
     n16 = a.n_ints / 4;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x + (size_t)u * gridDim.x * 256;
+      const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x + (size_t)u * nblk * 256;
       idv[u] = i < n16 ? __builtin_nontemporal_load(reinterpret_cast<const v4i*>(slot) + i) : v4i{0, 0, 0, 0};
     }
   }
   const size_t n4 = a.n / 4;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)nblk * 256)
     reinterpret_cast<float4*>(a.G)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (blockIdx.x == 0 && threadIdx.x < (int)(a.n - n4 * 4)) a.G[n4 * 4 + threadIdx.x] = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.nz / 4; i += (size_t)nblk * 256)      // nz: a multiple of 4
+    reinterpret_cast<float4*>(a.Z)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (blockIdx.x < 64) {
     // 16-byte loads, four in flight (a scalar loop with a runtime trip count was 13 serial round trips at the ml-1m table: ~10 us)
     float acc = 0.f;
@@ -586,15 +596,15 @@ __global__ __launch_bounds__(256) void k_step_begin(StepBeginArgs a) {
   if (a.ring) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x + (size_t)u * gridDim.x * 256;
+      const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x + (size_t)u * nblk * 256;
       if (i < n16) reinterpret_cast<v4i*>(a.ids_dst)[i] = idv[u];
     }
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x + (size_t)2 * gridDim.x * 256; i < n16; i += (size_t)gridDim.x * 256)      // larger batches
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x + (size_t)2 * nblk * 256; i < n16; i += (size_t)nblk * 256)      // larger batches
       reinterpret_cast<v4i*>(a.ids_dst)[i] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(slot) + i);
     __syncthreads();      // every thread of the block has its slot words in registers / stored: the block is done with the slot
     if (threadIdx.x == 0) {
       __threadfence();
-      if (atomicAdd(a.state + 1, 1u) == gridDim.x - 1) {      // the last block: every block has read state[0] and its part of the slot
+      if (atomicAdd(a.state + 1, 1u) == nblk - 1) {      // the last block: every block has read state[0] and its part of the slot
         a.state[1] = 0u;
         const uint32_t c = a.state[0] + 1u;
         a.state[0] = c;

@@ -197,9 +197,8 @@ adt::BwdChainArgs bwd_args(int T, int L, int B, const int32_t* ids, float p, con
 
 // bf16 mode: both LDS images of every 64 x 64 layer weight, written once per forward (the weights do not change until the
 // optimizer step that follows the backward), so that every kernel's weight staging is a plain copy
-int pack_weights(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const float* P, float* ws, void* st) {
+int pack_offsets(const adt_sasrec_cfg* c, const Layout& lo, int* offs) {      // float offsets from lo.posw() of the 64 x 64 blocks ; 0 blocks outside bf16 mode
   if (c->prec != ADT_PREC_BF16) return 0;
-  int offs[256];
   int n = 0;
   const int64_t base = lo.posw();
   const int dd = c->hidden * c->hidden;
@@ -211,7 +210,13 @@ int pack_weights(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const f
     offs[n++] = (int)(lo.dec(i, D_SOW) - base); offs[n++] = (int)(lo.dec(i, D_EOW) - base);
     offs[n++] = (int)(lo.dec(i, D_C1W) - base); offs[n++] = (int)(lo.dec(i, D_C2W) - base);
   }
-  return adt_pack_wimg(P + base, ws + w.wpack, offs, n, st);
+  return n;
+}
+int pack_weights(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const float* P, float* ws, void* st) {
+  int offs[256];
+  const int n = pack_offsets(c, lo, offs);
+  if (n == 0) return 0;
+  return adt_pack_wimg(P + lo.posw(), ws + w.wpack, offs, n, st);
 }
 
 // slot of a 64 x 64 block in a workgroup's partial area: the order of pack_weights
@@ -261,14 +266,14 @@ adt::SeqFwdArgs seq_args(int L, int B, int H, const int32_t* ids, float p, const
 // cross-attention k/v projections of every decoder layer when training_outputs)
 int encoder_forward(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const float* P, float* ws,
                     const int32_t* seq, const int32_t* pos, const int32_t* neg, float p, const uint32_t* seed,
-                    uint32_t b_offset, bool training_outputs, void* st) {
+                    uint32_t b_offset, bool training_outputs, void* st, bool packed = false) {
   const int T = (int)w.T, d = (int)w.d, H = (int)w.H, hd = d / H, L = (int)w.L, B = (int)w.B, prec = c->prec, nl = c->num_layers;
   const int64_t Td = up64(w.T * w.d);
   const uint32_t ro = b_offset * (uint32_t)L;
   const int dd = d * d;
   const bool use_seq = adt_seq_supported(prec, L, d, hd) != 0;
   const bool lean = training_outputs && adt_seq_lean(prec, L, d, hd) != 0;   // bf16 saved tensors, no LN(x) / qkv (the fused backward recomputes them)
-  CK(pack_weights(c, lo, w, P, ws, st));
+  if (!packed) CK(pack_weights(c, lo, w, P, ws, st));      // packed: adt_sasrec_step_begin* of this step wrote the images
   const float* wp_base = P + lo.posw();
   const void* wp_img = prec == ADT_PREC_BF16 ? (const void*)(ws + w.wpack) : nullptr;
   for (int i = 0; i < nl; ++i) {
@@ -416,9 +421,11 @@ int adt_sasrec_forward(const adt_sasrec_cfg* c, const float* P, float* ws, const
   make_ws(c, B, &w);
   const int T = (int)w.T, d = (int)w.d, H = (int)w.H, hd = d / H, L = (int)w.L, prec = c->prec;
   const int64_t Td = up64(w.T * w.d);
+  const bool packed = (training & 2) != 0;       // bit 1: the weight images were packed by adt_sasrec_step_begin* of this step
+  training &= 1;
   const float p = training ? c->dropout : 0.f;
   const uint32_t ro = b_offset * (uint32_t)L;
-  CK(encoder_forward(c, lo, w, P, ws, seq, pos, neg, p, seed, b_offset, true, st));
+  CK(encoder_forward(c, lo, w, P, ws, seq, pos, neg, p, seed, b_offset, true, st, packed));
   const float* f = ws + w.f;
   const int dd = d * d;
   const int B_ = (int)w.B;
@@ -490,8 +497,11 @@ int adt_sasrec_step_begin(const adt_sasrec_cfg* c, float* ws, int B, uint32_t* s
   make_layout(c, &lo);
   WS w;
   make_ws(c, B, &w);
+  int offs[256];
+  const int npack = pack_offsets(c, lo, offs);
   return adt_step_begin_launch(seed, seed_inc, ws + w.norms, norms_src, ws + w.loss, 64 * (2 + 2 * c->num_layers), scal, G, n, P + lo.item(),
-                               (int64_t)(c->item_num + 1) * c->hidden, st);
+                               (int64_t)(c->item_num + 1) * c->hidden, ws + w.prep, (int64_t)NREPP * w.prep_stride, P + lo.posw(), ws + w.wpack, offs,
+                               npack, st);
 }
 
 int adt_sasrec_step_begin_ring(const adt_sasrec_cfg* c, float* ws, int B, uint32_t* seed, uint32_t seed_inc, const int32_t* ring, int64_t slot_ints,
@@ -502,8 +512,11 @@ int adt_sasrec_step_begin_ring(const adt_sasrec_cfg* c, float* ws, int B, uint32
   make_layout(c, &lo);
   WS w;
   make_ws(c, B, &w);
+  int offs[256];
+  const int npack = pack_offsets(c, lo, offs);
   return adt_step_begin_ring_launch(seed, seed_inc, ws + w.norms, ws + w.loss, 64 * (2 + 2 * c->num_layers), scal, G, n, P + lo.item(),
-                                    (int64_t)(c->item_num + 1) * c->hidden, ring, slot_ints, nslots, ids_dst, 4 * (int64_t)w.T + 4, state, consumed, st);
+                                    (int64_t)(c->item_num + 1) * c->hidden, ring, slot_ints, nslots, ids_dst, 4 * (int64_t)w.T + 4, state, consumed,
+                                    ws + w.prep, (int64_t)NREPP * w.prep_stride, P + lo.posw(), ws + w.wpack, offs, npack, st);
 }
 
 static int loss_seed_impl(const adt_sasrec_cfg* c, float* ws, const int32_t* pos, int B, const float* lambdas1, const float* lambdas2,
@@ -597,6 +610,8 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   const bool parts = w.part_stride > 0 && adt_seq_partials(prec, L, d, hd) != 0;
   auto PART = [&](int layer, int slot) { return parts ? ws + w.part + (int64_t)(16 * layer + slot) * 4096 : nullptr; };
   const char* const no_fallback = "backward: shape L=%d hd=%d left the per-sequence kernels although the partial-gradient path was chosen";
+  const bool prep_zeroed = (phase & 4) != 0;      // bit 2: adt_sasrec_step_begin* of this step zeroed the parameter-gradient replicas
+  phase &= 3;
   // (one-phase backward only: the two-phase form belongs to the data-parallel step, whose capture already carries the collectives' stream)
   SideStream* const sd = phase == 0 ? side_stream((hipStream_t)st) : nullptr;
   int dec_side = 0;      // the decoder's embedding gradient + partial sums on the side stream: 1 marked, 2 enqueued
@@ -610,10 +625,10 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
     int logits_side = 0;      // 1: marked, to be enqueued behind the first chain kernel ; 2: enqueued, to be joined
     if (sd && (side_sites() & 1)) {
       CK(side_mark(sd, 0, st));
-      if (adt::zero_f32_async(ws + w.prep, (size_t)NREPP * w.prep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
+      if (!prep_zeroed && adt::zero_f32_async(ws + w.prep, (size_t)NREPP * w.prep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
       logits_side = 1;
     } else {
-      if (adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride + (size_t)NREPP * w.prep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
+      if (adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride + (prep_zeroed ? 0 : (size_t)NREPP * w.prep_stride), (hipStream_t)st)) return adt_set_error("replica zero");
       CK(adt_logits_bwd_scatter(f, d, P + lo.item(), pos, neg, ws + w.g_pos, ws + w.g_neg, T, d, gf, d, ws + w.rep, NREP, w.rep_stride, st));
     }
     for (int i = nl - 1; i >= 0; --i) {

@@ -27,36 +27,7 @@ static int seq_launch(const void* fn, size_t smem, bool& attr_done, int grid, co
 }
 
 // ---- pre-packed weight images (adt_wave.cuh: WPack) -----------------------------------------------------------------------------
-struct PackArgs {
-  const float* base;      // start of the packed parameter range
-  __bf16* img;
-  int n;
-  int off[256];           // float offsets (relative to base) of the 64 x 64 blocks
-};
-
-__global__ __launch_bounds__(256) void k_pack_wimg(PackArgs a) {
-  const int off = a.off[blockIdx.x];
-  const float* W = a.base + off;
-  __bf16* plain = a.img + 6 * (size_t)off;
-  __bf16* trans = plain + WPACK_IMG;
-  __bf16* splain = plain + 2 * WPACK_IMG;       // slot-ordered forms for the transposed chains (adt_tt.cuh): column 32 kb + 4 g' + q + 16 s
-  __bf16* strans = plain + 3 * WPACK_IMG;       // of a row sits at 32 kb + 8 g' + 4 s + q
-  for (int i = threadIdx.x; i < 64 * 16; i += 256) {
-    const int n = i >> 4, k4 = (i & 15) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(W + n * 64 + k4);
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    const int ns = (n & 32) + 8 * ((n >> 2) & 3) + 4 * ((n >> 4) & 1) + (n & 3);      // slot position of column n in a transposed row
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k4 + j;
-      const int ks = (k & 32) + 8 * ((k >> 2) & 3) + 4 * ((k >> 4) & 1) + (k & 3);
-      plain[n * 72 + k] = (__bf16)x[j];
-      trans[k * 72 + n] = (__bf16)x[j];
-      splain[n * 72 + ks] = (__bf16)x[j];
-      strans[k * 72 + ns] = (__bf16)x[j];
-    }
-  }
-}
+__global__ __launch_bounds__(256) void k_pack_wimg(PackArgs a) { pack_wimg_block(a, blockIdx.x); }      // adt_wave.cuh
 
 extern "C" int adt_pack_wimg(const float* base, void* img, const int* offs, int n, void* stream) {
   if (n < 1 || n > 256) return adt_set_error("pack_wimg: %d blocks", n);

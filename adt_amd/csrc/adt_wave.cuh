@@ -86,6 +86,39 @@ ADT_DEVICE_INLINE void stage_wimg(typename WImg<PREC>::T* img, const float* W, b
 // image (14,000 cycles for the six images of an encoder layer, measured with s_memtime stamps).  The block whose fp32 weights
 // start at `base + off` keeps its images at img + 6 * off (bf16 elements): plain first, transposed WPACK_IMG elements later.
 constexpr int WPACK_IMG = 64 * 72;
+
+// ---- pre-packed weight images: the 64 x 64 fp32 block at base + off as four bf16 images of 64 x 72 (plain, transposed, and their slot-ordered
+// forms for the transposed chains of adt_tt.cuh) at img + 6 * off.  One workgroup of 256 threads per block (k_pack_wimg, or the trailing
+// blocks of k_step_begin).
+struct PackArgs {
+  const float* base;      // start of the packed parameter range
+  __bf16* img;
+  int n;
+  int off[256];           // float offsets (relative to base) of the 64 x 64 blocks
+};
+__device__ __forceinline__ void pack_wimg_block(const PackArgs& a, int blk) {
+  const int off = a.off[blk];
+  const float* W = a.base + off;
+  __bf16* plain = a.img + 6 * (size_t)off;
+  __bf16* trans = plain + WPACK_IMG;
+  __bf16* splain = plain + 2 * WPACK_IMG;       // slot-ordered forms for the transposed chains (adt_tt.cuh): column 32 kb + 4 g' + q + 16 s
+  __bf16* strans = plain + 3 * WPACK_IMG;       // of a row sits at 32 kb + 8 g' + 4 s + q
+  for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+    const int n = i >> 4, k4 = (i & 15) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(W + n * 64 + k4);
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    const int ns = (n & 32) + 8 * ((n >> 2) & 3) + 4 * ((n >> 4) & 1) + (n & 3);      // slot position of column n in a transposed row
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k4 + j;
+      const int ks = (k & 32) + 8 * ((k >> 2) & 3) + 4 * ((k >> 4) & 1) + (k & 3);
+      plain[n * 72 + k] = (__bf16)x[j];
+      trans[k * 72 + n] = (__bf16)x[j];
+      splain[n * 72 + ks] = (__bf16)x[j];
+      strans[k * 72 + ns] = (__bf16)x[j];
+    }
+  }
+}
 struct WPack {
   const float* base;       // start of the packed parameter range (the positional table: everything after the item table)
   const __bf16* img;       // nullptr: not packed (fp32-exact mode, or a caller that did not pack)

@@ -156,10 +156,12 @@ class SASRecADT(torch.nn.Module):
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     # raw launches (no autograd); ids are device int32 tensors
-    def run_forward(self, seq, dec, pos, neg, B, training, b_offset=0):
+    def run_forward(self, seq, dec, pos, neg, B, training, b_offset=0, packed=False):
+        """packed: run_step_begin / run_step_begin_ring of THIS step already wrote the bf16 weight images (bit 1 of `training`)."""
         ws = self.workspace(B)
         _lib.check(self.lib.adt_sasrec_forward(ctypes.byref(self.cfg), _ptr(self.flat), _ptr(ws), _ptr(seq), _ptr(dec), _ptr(pos),
-                                               _ptr(neg), B, int(training), _ptr(self._seed), b_offset, self._stream()), "sasrec_forward")
+                                               _ptr(neg), B, int(bool(training)) | (2 if packed else 0), _ptr(self._seed), b_offset, self._stream()),
+                   "sasrec_forward")
 
     def probe_dec_layer_forward(self, dec, B, layer, training=True, b_offset=0):
         """Measurement hook: only the fused forward launch of decoder layer `layer`, on the workspace of a completed run_forward."""
@@ -167,7 +169,8 @@ class SASRecADT(torch.nn.Module):
                                                            int(training), _ptr(self._seed), b_offset, layer, self._stream()), "probe_dec_layer_fwd")
 
     def run_step_begin(self, B, norms_src, scal, seed_inc=0x9E3779B1):
-        """One launch: zero_grad, loss slots, normalisers, the dropout seed += seed_inc, ||E||^2 partials (adt_sasrec_step_begin)."""
+        """One launch: zero_grad, loss slots, normalisers, the dropout seed += seed_inc, ||E||^2 partials, the parameter-gradient replicas of
+        the backward zeroed and (bf16) the step's weight images packed (adt_sasrec_step_begin)."""
         _lib.check(self.lib.adt_sasrec_step_begin(ctypes.byref(self.cfg), _ptr(self.workspace(B)), B, _ptr(self._seed), seed_inc, _ptr(norms_src),
                                                   _ptr(self.flat), _ptr(self.flat_grad), self.flat_grad.numel(), _ptr(scal), self._stream()),
                    "sasrec_step_begin")
@@ -186,10 +189,11 @@ class SASRecADT(torch.nn.Module):
         fn = self.lib.adt_sasrec_loss_seed if zero_loss else self.lib.adt_sasrec_loss_seed_nz
         _lib.check(fn(ctypes.byref(self.cfg), _ptr(self.workspace(B)), _ptr(pos), B, l1, l2, self._stream()), "sasrec_loss_seed")
 
-    def run_backward(self, seq, dec, pos, neg, B, training, b_offset=0, phase=0):
+    def run_backward(self, seq, dec, pos, neg, B, training, b_offset=0, phase=0, prezeroed=False):
+        """prezeroed: run_step_begin / run_step_begin_ring of THIS step already zeroed the parameter-gradient replicas (bit 2 of `phase`)."""
         _lib.check(self.lib.adt_sasrec_backward(ctypes.byref(self.cfg), _ptr(self.flat), _ptr(self.flat_grad), _ptr(self.workspace(B)),
                                                 _ptr(seq), _ptr(dec), _ptr(pos), _ptr(neg), B, int(training), _ptr(self._seed),
-                                                b_offset, phase, self._stream()), "sasrec_backward")
+                                                b_offset, phase | (4 if prezeroed else 0), self._stream()), "sasrec_backward")
 
     # ------------------------------------------------------------------------------------------
     def forward(self, user_ids, log_seqs, dec_seqs, pos_seqs, neg_seqs):

@@ -93,15 +93,15 @@ class FusedTrainer:
             m.run_step_begin(B, self._norms_dev, self.scal)
         else:
             m.run_step_begin_ring(B, src[0], self._st["n_int"], src[1], self._devbuf, src[2], src[3], self.scal)
-        m.run_forward(seq, dec, pos, neg, B, True, b_offset)
+        m.run_forward(seq, dec, pos, neg, B, True, b_offset, packed=True)      # run_step_begin* above packed the weight images ...
         m.run_loss_seed(pos, B, self.lambdas1, self.lambdas2, zero_loss=False)
         if not self._buckets.active:
-            m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=0)
+            m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=0, prezeroed=True)      # ... and zeroed the parameter-gradient replicas
         else:
             # two buckets: the decoder bucket's all-reduce (RCCL, its own stream) overlaps the encoder's backward.
             # NOTE: phase 1 also scatters the decoder-input embedding rows, which live in the encoder bucket
             # (item/pos tables at flat offset 0) -- that bucket is reduced after phase 2, so nothing is lost.
-            m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=1)
+            m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=1, prezeroed=True)
             self._buckets.tail_ready()
             m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=2)
             self._buckets.finish()

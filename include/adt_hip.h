@@ -311,7 +311,8 @@ int64_t adt_sasrec_workspace_floats(const adt_sasrec_cfg* cfg, int B);
 #define ADT_WS_SCAL 13      /* 192 floats for adt_clip_adam                                                    */
 int64_t adt_sasrec_ws_offset(const adt_sasrec_cfg* cfg, int B, int what, int layer);
 
-/* SASRecADT.forward (sasrec/model.py:67-81).  ids are device int32 (B*L). training != 0 enables dropout. */
+/* SASRecADT.forward (sasrec/model.py:67-81).  ids are device int32 (B*L).  training bit 0 enables dropout; bit 1 (value 2): the bf16
+ * weight images of this step were already packed by adt_sasrec_step_begin / _ring (the forward then skips its own packing launch). */
 int adt_sasrec_forward(const adt_sasrec_cfg* cfg, const float* params, float* ws, const int32_t* seq,
                        const int32_t* dec, const int32_t* pos, const int32_t* neg, int B, int training,
                        const uint32_t* seed, uint32_t b_offset, void* stream);
@@ -357,8 +358,10 @@ int adt_sasrec_loss_seed(const adt_sasrec_cfg* cfg, float* ws, const int32_t* po
                          const float* lambdas2, void* stream);
 /* One launch for everything a training step (sasrec/main.py:146-173) does before its forward: grads[0..n) = 0 (optimizer.zero_grad), the loss
  * slots = 0, NORMS = norms_src[0..4), *seed += seed_inc (the per-step dropout stream), scal[128..192) = 0 and scal[64..128) = partial sums of
- * ||item table||^2 (the weight-decay term of adt_clip_adam_pre; the parameters do not change in between).  Pair it with
- * adt_sasrec_loss_seed_nz (adt_sasrec_loss_seed without its loss-slot fill) and adt_clip_adam_pre. */
+ * ||item table||^2 (the weight-decay term of adt_clip_adam_pre; the parameters do not change in between).  The same launch zeroes the
+ * parameter-gradient replicas the backward chains flush into and, in bf16 mode, packs the step's weight images (adt_pack_wimg's work):
+ * tell the forward (training | 2) and the backward (phase | 4) of the same step.  Pair it with adt_sasrec_loss_seed_nz
+ * (adt_sasrec_loss_seed without its loss-slot fill) and adt_clip_adam_pre. */
 int adt_sasrec_step_begin(const adt_sasrec_cfg* cfg, float* ws, int B, uint32_t* seed, uint32_t seed_inc, const float* norms_src,
                           const float* params, float* grads, int64_t n, float* scal, void* stream);
 /* adt_sasrec_step_begin that also FETCHES the step's id batch (sasrec/main.py:144-145: the batch the DataLoader hands the loop becomes device
@@ -375,7 +378,9 @@ int adt_sasrec_loss_seed_nz(const adt_sasrec_cfg* cfg, float* ws, const int32_t*
                             const float* lambdas2, void* stream);
 /* reverse pass: consumes the G_* buffers (destroyed), accumulates into `grads` (same layout as params).
  * phase: 0 = everything; 1 = logits + decoder stack only; 2 = last LN + encoder stack + embeddings (lets the
- * host overlap the gradient all-reduce of the decoder bucket with phase 2). */
+ * host overlap the gradient all-reduce of the decoder bucket with phase 2).  + 4: the parameter-gradient replicas were already zeroed by
+ * adt_sasrec_step_begin / _ring of this step.  With phase 0 the scatter / fold kernels run on a side stream of the library under the
+ * chain kernels (joined before the call returns its last launch; ADT_SIDE_STREAM=0 keeps everything on `stream`). */
 int adt_sasrec_backward(const adt_sasrec_cfg* cfg, const float* params, float* grads, float* ws,
                         const int32_t* seq, const int32_t* dec, const int32_t* pos, const int32_t* neg, int B,
                         int training, const uint32_t* seed, uint32_t b_offset, int phase, void* stream);
