@@ -192,6 +192,32 @@ ADT_DEVICE_INLINE void sab_pass_b(const __bf16* sQ, const __bf16* sdO, const bf1
   for (int qp = q0 + 1; 2 * qp < nqt; ++qp) sab_pair_b<HD, MODE, false>(sQ, sdO, fk, fv, lse_h, del_h, sM_h, qp, kt, h, drop, key_rng, idx_bh, L, c, g, dk, dv);
 }
 
+// pass B for ALL heads of a key tile in one sweep over the query pairs: the heads are independent chains (LDS reads -> MFMA -> exp -> MFMA),
+// and at two waves per SIMD one chain at a time leaves the wave waiting on its own latencies
+template <int HD, int MODE>
+ADT_DEVICE_INLINE void sab_pass_b_heads(const __bf16* sQ, const __bf16* sdO, const bf16x8* fk, const bf16x8* fv, const float* sLse, const float* sDelta,
+                                        const uint32_t* sM, int R, int kt, int nqt, const DropCfg& drop, uint32_t key_rng, uint32_t bh0, int L,
+                                        int c, int g, f32x4 (&dk)[64 / 16], f32x4 (&dv)[64 / 16]) {
+  constexpr int H = 64 / HD, NT = HD / 16, KB = (HD + 31) / 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    dk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int q0 = kt >> 1;
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+    sab_pair_b<HD, MODE, true>(sQ, sdO, fk + h * KB, fv + h * KB, sLse + h * R, sDelta + h * R, sM + (size_t)h * R * 8, q0, kt, h, drop, key_rng,
+                               (bh0 + (uint32_t)h) * (uint32_t)L, L, c, g, *reinterpret_cast<f32x4 (*)[NT]>(&dk[h * NT]), *reinterpret_cast<f32x4 (*)[NT]>(&dv[h * NT]));
+#pragma unroll 1
+  for (int qp = q0 + 1; 2 * qp < nqt; ++qp) {
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+      sab_pair_b<HD, MODE, false>(sQ, sdO, fk + h * KB, fv + h * KB, sLse + h * R, sDelta + h * R, sM + (size_t)h * R * 8, qp, kt, h, drop, key_rng,
+                                  (bh0 + (uint32_t)h) * (uint32_t)L, L, c, g, *reinterpret_cast<f32x4 (*)[NT]>(&dk[h * NT]), *reinterpret_cast<f32x4 (*)[NT]>(&dv[h * NT]));
+  }
+}
+
 template <int HD, int MODE>
 __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
   adt_prefetch_kernargs<(sizeof(AttnArgs) + 63) / 64 * 64 <= 512 ? sizeof(AttnArgs) : 512>();      // adt_common.cuh

@@ -227,6 +227,19 @@ ADT_DEVICE_INLINE void sb_img_store(__bf16* wimg, const SbImgRegs<N>& t) {
   }
 }
 
+// Key tile of slot s of wave w in pass B.  Pass A costs a query tile t its (t + 1) / 2 key-tile pairs, pass B costs a key tile t its
+// (13 - t) / 2 query-tile pairs: with ONE tile map (tq_tile) the SIMD with four tiles carried 18 of pass B's 49 pairs per head against
+// 10-11 on the others (pass A: 12-13 everywhere).  Pass B therefore has its own map, 13 / 12 / 12 / 12 pairs per SIMD -- its k / v operands
+// are read back from the K / V images (sab_rowfrag: the same bf16 values the own-tile registers held), and P5 reads dk / dv of its own
+// tile back from the token images P4 wrote (the same bf16 values tt_bfrags made of the registers).
+ADT_DEVICE_INLINE int sb_tile_b(int s, int w, int ntiles) {
+  if (ntiles != 13) return tq_tile(s, w, ntiles);
+  const int t0 = (0x0 << 0) | (0x1 << 4) | (0x2 << 8) | (0x3 << 12) | (0x7 << 16) | (0x5 << 20) | (0x6 << 24) | (0x4 << 28);      // slot 0 of waves 0 .. 7
+  const int t1 = (0xC << 12) | (0x8 << 16) | (0x9 << 20) | (0xA << 24) | (0xB << 28);                                             // slot 1 of waves 3 .. 7
+  if (s == 0) return (int)(((unsigned)t0 >> (4 * w)) & 15u);
+  return w >= 3 ? (int)(((unsigned)t1 >> (4 * w)) & 15u) : -1;
+}
+
 #define SB_STAMP(k) do { if (a.stamps && blockIdx.x == 0 && lane == 0) a.stamps[w * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // DEC = false: encoder block (q from LN(x), k / v from the raw x; the residual gradient joins at the LayerNorm output);
@@ -344,7 +357,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   const float qmul = a.scale * 1.4426950408889634f;
   const uint32_t key_rng = drop_key(a.drop);
   // ---- P1: recompute LN + in-projection; operands to registers, K / V images ------------------------------------------------------
-  bf16x8 fq[2][NF], fdo[2][NF], fk[2][NF], fv[2][NF];
+  bf16x8 fq[2][NF], fdo[2][NF];
   float delta[2][H];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -362,11 +375,9 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     sb_frags<HD>(q, qmul, fq[s]);
     TT k = tt_gemm(DEC ? bn : bx, wpl + TT_WIMG, c, g);
     tt_add_vec(k, vbin + 64, g);
-    sb_frags<HD>(k, 1.0f, fk[s]);
     tt_put_rows(img0, l, k, valid, g);
     TT v = tt_gemm(DEC ? bn : bx, wpl + 2 * TT_WIMG, c, g);
     tt_add_vec(v, vbin + 128, g);
-    sb_frags<HD>(v, 1.0f, fv[s]);
     tt_put_rows(img1, l, v, valid, g);
     const TT& dO = doa[s];
     const TT& o = oa[s];
@@ -405,6 +416,20 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
       for (int nt = 0; nt < NT; ++nt) dq[s].v[h * NT + nt] = t[nt] * a.scale;
     }
   }
+  // pass B's own key / value rows (its tile map differs from pass A's: sb_tile_b), from the K / V images while they are still there
+  bf16x8 fk[2][NF], fv[2][NF];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tile = sb_tile_b(s, w, ntiles);
+    const int row = (tile >= 0 ? tile : 0) * 16 + c;
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        fk[s][h * KB + kb] = sab_rowfrag<HD>(img0, row, h, kb, g);
+        fv[s][h * KB + kb] = sab_rowfrag<HD>(img1, row, h, kb, g);
+      }
+  }
   adt_wait_vm0();            // the transposed weight images (LDS-DMA issued at the start of P1) have landed: published by this barrier
   __syncthreads();
   SB_STAMP(3);
@@ -431,18 +456,16 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
         xk[s2] = tt_load(a.x + (size_t)(b * L + l2) * 64, tile2 >= 0 && l2 < L, g);
       }
     }
-    const int tile = tq_tile(s, w, ntiles);
+    const int tile = sb_tile_b(s, w, ntiles);
     if (tile < 0) continue;
+    {
+      f32x4 tk[4], tv[4];
+      sab_pass_b_heads<HD, MODE>(img0, img1, fk[s], fv[s], sLse, sDelta, sM, R, tile, ntiles, a.drop, key_rng,
+                                 (uint32_t)(b * H) + a.b_offset * (uint32_t)H, L, c, g, tk, tv);
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-      f32x4 tk[NT], tv[NT];
-      const uint32_t bh_rng = (uint32_t)(b * H + h) + a.b_offset * (uint32_t)H;
-      sab_pass_b<HD, MODE>(img0, img1, fk[s] + h * KB, fv[s] + h * KB, sLse + h * R, sDelta + h * R, sM + (size_t)h * R * 8, tile, ntiles, h, a.drop,
-                           key_rng, bh_rng * (uint32_t)L, L, c, g, tk, tv);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        dk[s].v[h * NT + nt] = tk[nt] * 0.6931471805599453f;        // the Q image carries log2(e) / sqrt(hd)
-        dv[s].v[h * NT + nt] = tv[nt];
+      for (int i = 0; i < 4; ++i) {
+        dk[s].v[i] = tk[i] * 0.6931471805599453f;        // the Q image carries log2(e) / sqrt(hd)
+        dv[s].v[i] = tv[i];
       }
     }
   }
@@ -460,8 +483,14 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
       const int l = tile * 16 + c;
       const bool valid = l < L;
       tt_put_rows(img0, l, dq[s], valid, g);
-      tt_put_rows(img2, l, dk[s], valid, g);
       tt_put_rows(img1, l, tt_ln_apply(tt_ln_stats(xk[s], a.ln_eps).xhat, vgamma, vbeta, g), valid, g);     // q always reads LN(x)
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {                // dk of pass B's tiles
+      const int tile = sb_tile_b(s, w, ntiles);
+      if (tile < 0) continue;
+      const int l = tile * 16 + c;
+      tt_put_rows(img2, l, dk[s], l < L, g);
     }
     SB_STAMP(7);
   }
@@ -486,8 +515,14 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     if (tile < 0) continue;
     const int l = tile * 16 + c;
     const bool valid = l < L;
-    tt_put_rows(img0, l, dv[s], valid, g);
     if (!DEC) tt_put_rows(img1, l, xk[s], valid, g);                  // encoder: k, v read the raw x
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {                  // dv of pass B's tiles
+    const int tile = sb_tile_b(s, w, ntiles);
+    if (tile < 0) continue;
+    const int l = tile * 16 + c;
+    tt_put_rows(img0, l, dv[s], l < L, g);
   }
   __syncthreads();
   if (!DEC) sb_dw_product16(img2, img1, npair, a.dWin + 4096, part ? part + 4096 : nullptr, sRed + 192, w, c, g);
@@ -510,8 +545,12 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     if (s == 0) gx_request(1);
     const TTLn st = tt_ln_stats(xk[s], a.ln_eps);
     TT dn = tt_gemm(tt_bfrags(dq[s]), wtr, c, g);
-    TT dkv = tt_gemm(tt_bfrags(dk[s]), wtr + TT_WIMG, c, g);
-    tt_add(dkv, tt_gemm(tt_bfrags(dv[s]), wtr + 2 * TT_WIMG, c, g));
+    // dk / dv of THIS tile were computed by pass B's owner of it: their bf16 rows are in the token images (img2: dk, img0: dv)
+    TTB bdk, bdv;
+    bdk.kb[0] = sab_rowfrag<32>(img2, l, 0, 0, g); bdk.kb[1] = sab_rowfrag<32>(img2, l, 1, 0, g);
+    bdv.kb[0] = sab_rowfrag<32>(img0, l, 0, 0, g); bdv.kb[1] = sab_rowfrag<32>(img0, l, 1, 0, g);
+    TT dkv = tt_gemm(bdk, wtr + TT_WIMG, c, g);
+    tt_add(dkv, tt_gemm(bdv, wtr + 2 * TT_WIMG, c, g));
     TT res = resa[s];
     if (DEC && (!valid || a.ids[row] == 0)) res = tt_zero();
     if (DEC && a.dres_scale != 0.f) {
