@@ -202,7 +202,7 @@ int adt_launch_seq_post_bwd(int hd, int enc, const BwdChainArgs& a, void* stream
 int adt_launch_seq_mid_bwd(int hd, const BwdChainArgs& a, void* stream) {
   if (!seq_post_ok(a, hd)) return 1;
   static bool done = false;
-  return seq_launch((const void*)k_seqtt_mid_bwd, SeqPostLds<4>::bytes, done, a.B, &a, (hipStream_t)stream, "seqtt_mid_bwd", SP_NW);
+  return seq_launch((const void*)k_seqtt_mid_bwd, SeqPostLds<4>::bytes, done, a.B, &a, (hipStream_t)stream, "seqtt_mid_bwd", SP_MID_NW);
 }
 
 // ---- sum of the per-workgroup weight-gradient partials (adt_seqbwd_tt.cuh: sb_dw_tiles) --------------------------------------------

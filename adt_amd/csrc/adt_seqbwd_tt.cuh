@@ -131,9 +131,10 @@ ADT_DEVICE_INLINE TT tt_ln_bwd(const TT& dy, const TTLn& st, const float* gamma,
 // 64 sums to bred[0..64) (LDS) -- every column of such a product holds sum_t G[t][n].  The sums are those of the bf16 image rows, like the
 // weight gradient beside them.  (Per-lane fp32 sums + a 16-lane DPP reduction of 16 registers + LDS atomics, sb_colsum_flush, cost every
 // wave ~1.1k cycles per layer on the critical path in front of the product's barrier: profiles/r03_stamps_attn_pre_bwd.txt.)
-template <int NP, int NW, bool BIAS>
-ADT_DEVICE_INLINE void sb_dw_accumulate(const __bf16* sG, const __bf16* sX, int kt, int nt0, int c, int g, f32x4& acc0, f32x4& acc1, f32x4& b0, f32x4& b1) {
-  constexpr bool TWO = NW == 8;
+// wave w computes output tile w (nt = w >> 2, kt = w & 3) and, when `two` (wave-uniform), also the tile (nt + step, kt) that shares its X fragments:
+// NW = 8: every wave, step 2 (tiles w and w + 8); NW = 12: waves 0 .. 3, step 3 (tiles w and w + 12); NW = 16: none.
+template <int NP, int STEP, bool BIAS>
+ADT_DEVICE_INLINE void sb_dw_accumulate(const __bf16* sG, const __bf16* sX, int kt, int nt0, bool two, int c, int g, f32x4& acc0, f32x4& acc1, f32x4& b0, f32x4& b1) {
   bf16x8 ones;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
@@ -143,8 +144,8 @@ ADT_DEVICE_INLINE void sb_dw_accumulate(const __bf16* sG, const __bf16* sX, int 
     const bf16x8 g0 = tt_trfrag(sG, kp * 32, 16 * nt0, c, g);
     acc0 = mfma_bf16(acc0, g0, fx);
     if (BIAS) b0 = mfma_bf16(b0, g0, ones);
-    if (TWO) {
-      const bf16x8 g1 = tt_trfrag(sG, kp * 32, 16 * (nt0 + 2), c, g);
+    if (STEP > 0 && two) {
+      const bf16x8 g1 = tt_trfrag(sG, kp * 32, 16 * (nt0 + STEP), c, g);
       acc1 = mfma_bf16(acc1, g1, fx);
       if (BIAS) b1 = mfma_bf16(b1, g1, ones);
     }
@@ -152,38 +153,37 @@ ADT_DEVICE_INLINE void sb_dw_accumulate(const __bf16* sG, const __bf16* sX, int 
 }
 template <int NP, int NW = SB_NW>
 ADT_DEVICE_INLINE void sb_dw_tiles(const __bf16* sG, const __bf16* sX, float* dW, float* part, float* bred, int w, int c, int g) {
-  // NW = 8: wave w computes output tiles (nt0, kt) and (nt0 + 2, kt), nt0 = w >> 2, kt = w & 3 (they share the X fragments);
-  // NW = 16: wave w computes tile (w >> 2, w & 3) alone.  Either way tile 4 nt + kt of the partial layout is w (and w + 8).
-  constexpr bool TWO = NW == 8;
+  constexpr int STEP = NW == 8 ? 2 : (NW == 12 ? 3 : 0);      // second tile of a wave: + STEP n-tiles = + NW tiles
   const int kt = w & 3, nt0 = w >> 2;
+  const bool two = NW == 8 || (NW == 12 && w < 4);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
   if (bred != nullptr && kt == 0) {
-    sb_dw_accumulate<NP, NW, true>(sG, sX, kt, nt0, c, g, acc0, acc1, b0, b1);
+    sb_dw_accumulate<NP, STEP, true>(sG, sX, kt, nt0, two, c, g, acc0, acc1, b0, b1);
     if (c == 0) {
       *reinterpret_cast<f32x4*>(bred + 16 * nt0 + 4 * g) = b0;             // rows 4 g + r of the tile, any column
-      if (TWO) *reinterpret_cast<f32x4*>(bred + 16 * (nt0 + 2) + 4 * g) = b1;
+      if (two) *reinterpret_cast<f32x4*>(bred + 16 * (nt0 + STEP) + 4 * g) = b1;
     }
   } else {
-    sb_dw_accumulate<NP, NW, false>(sG, sX, kt, nt0, c, g, acc0, acc1, b0, b1);
+    sb_dw_accumulate<NP, STEP, false>(sG, sX, kt, nt0, two, c, g, acc0, acc1, b0, b1);
   }
   if (part) {
     const int lane = 16 * g + c;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       part[(w * 4 + r) * 64 + lane] = acc0[r];              // tile 4 nt0 + kt == w
-      if (TWO) part[((w + 8) * 4 + r) * 64 + lane] = acc1[r];
+      if (two) part[((w + NW) * 4 + r) * 64 + lane] = acc1[r];
     }
     return;
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     atomicAdd(dW + (16 * nt0 + 4 * g + r) * 64 + 16 * kt + c, acc0[r]);
-    if (TWO) atomicAdd(dW + (16 * (nt0 + 2) + 4 * g + r) * 64 + 16 * kt + c, acc1[r]);
+    if (two) atomicAdd(dW + (16 * (nt0 + STEP) + 4 * g + r) * 64 + 16 * kt + c, acc1[r]);
   }
 }
 template <int NW = SB_NW>
 ADT_DEVICE_INLINE void sb_dw_product16(const __bf16* sG, const __bf16* sX, int npair, float* dW, float* part, float* bred, int w, int c, int g) {
-  static_assert(NW == 8 || NW == 16, "8 waves (two output tiles each) or 16 (one each)");
+  static_assert(NW == 8 || NW == 12 || NW == 16, "8 waves (two output tiles each), 12 (waves 0..3 two) or 16 (one each)");
   if (npair <= 4) sb_dw_tiles<4, NW>(sG, sX, dW, part, bred, w, c, g);
   else sb_dw_tiles<SB_R / 32, NW>(sG, sX, dW, part, bred, w, c, g);
 }
