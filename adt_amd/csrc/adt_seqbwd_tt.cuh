@@ -314,11 +314,13 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
 #pragma unroll
   for (int k = 0; k < 3; ++k) adt_glds_block<NW>(src6[k], wpl + k * TT_WIMG, TT_WIMG * 2);
   TT xa[2], doa[2], oa[2];
+  int idv[2] = {1, 1};                           // decoder block: the pad mask of the residual-path gradient in P5 (read there it was an exposed round trip)
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile(s, w, ntiles);
     const int l = tile * 16 + c, row = b * L + l;
     xa[s] = tt_load(a.x + (size_t)row * 64, tile >= 0 && l < L, g);               // unconditional (address-select) loads: all in flight together
+    if (DEC) idv[s] = tt_load_id(a.ids, row, tile >= 0 && l < L);
   }
   SB_STAMP(11);
   // ---- P0: zeroed token images, then the tables and the weight images land in LDS ------------------------------------------------
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     TT dkv = tt_gemm(bdk, wtr + TT_WIMG, c, g);
     tt_add(dkv, tt_gemm(bdv, wtr + 2 * TT_WIMG, c, g));
     TT res = resa[s];
-    if (DEC && (!valid || a.ids[row] == 0)) res = tt_zero();
+    if (DEC && (!valid || idv[s] == 0)) res = tt_zero();
     if (DEC && a.dres_scale != 0.f) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) res.v[nt] *= a.dres_scale;

@@ -268,15 +268,18 @@ __global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) 
   TqX xr[2];
   const int htile = tq_helper_tile(w, ntiles);      // >= 0: this wave computes the k / v rows of that tile in its slot 1
   const bool split2 = tq_split_second(ntiles);      // the owner of a second tile leaves its k / v rows to the helper
+  int idm[2] = {0, 0};                        // ids of this wave's OWN tiles (the pad mask of the layer output: read at the end of a tile it was an exposed round trip)
   {
     int idr[2] = {0, 0};                      // the ids first: vector-memory results return in issue order, and the gather's row loads wait for them
-    if (!a.x) {
+    if (!a.x) {                               // embedding layer: the gather's row addresses need the ids
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int tile = (s == 1 && htile >= 0) ? htile : tq_tile12(s, w, ntiles), l = tile * 16 + c;
-        idr[s] = tt_load_id(a.ids, b * L + l, tile >= 0 && l < L);
+        const int tile = tq_tile12(s, w, ntiles), l = tile * 16 + c;
+        idm[s] = tt_load_id(a.ids, b * L + l, tile >= 0 && l < L);
+        idr[s] = idm[s];
       }
-    }
+      if (htile >= 0) idr[1] = tt_load_id(a.ids, b * L + htile * 16 + c, htile * 16 + c < L);
+    }      // the helper's slot 1 is another wave's tile
     const bool tq_body = TQW * 64 <= TQ_CH || threadIdx.x < TQ_CH;
     const bool tq_tail = (int)threadIdx.x < TQ_CH - TQW * 64;        // chunks beyond the first TQW * 64 (wave-uniform: whole waves)
     // only what the in-projection needs is requested in front of the first barrier (the prologue is a bandwidth burst: every workgroup of
@@ -288,6 +291,13 @@ __global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) 
     for (int s = 0; s < 2; ++s) {             // the layer input of both tiles, in flight while the images are stored
       const int tile = (s == 1 && htile >= 0) ? htile : tq_tile12(s, w, ntiles), l = tile * 16 + c;
       xr[s] = tq_x_request(a, b * L + l, l, tile >= 0 && l < L, idr[s], g);
+    }
+    if (a.x) {                                // later layers: the ids are only the output's pad mask -- behind every other request
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int tile = tq_tile12(s, w, ntiles), l = tile * 16 + c;
+        idm[s] = tt_load_id(a.ids, b * L + l, tile >= 0 && l < L);
+      }
     }
     TQ_STAMP(11);
     tq_zero<TQW * 64>(lds.sK, 2 * SeqTtLds<6>::ibytes);
@@ -371,7 +381,7 @@ __global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) 
     const TT h2 = tt_layernorm(hh, lds.vec + SV_GAMMA2, lds.vec + SV_BETA2, a.ln_eps, g);
     TT y = tq_ffn(a, lds.vec, lds.w[4], lds.w[5], h2, key1, key2, row, valid, c, g);
     tt_add(y, h2);
-    if (!valid || a.ids[row] == 0) y = tt_zero();
+    if (!valid || idm[s] == 0) y = tt_zero();
     tq_store_y(a, row, y, valid, g);
     TQ_STAMP(7 + 3 * s);
   }
@@ -394,14 +404,17 @@ __global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) 
   TqX xr[2];
   const int htile = tq_helper_tile(w, ntiles);      // see k_seqtt_enc_fwd: k / v rows (both attentions) of the two-tile wave's second tile
   const bool split2 = tq_split_second(ntiles);
+  int idm[2] = {0, 0};                        // see k_seqtt_enc_fwd
   {
     int idr[2] = {0, 0};                      // ids first, layer inputs of both tiles behind the images (see k_seqtt_enc_fwd)
-    if (!a.x) {
+    if (!a.x) {                               // embedding layer: the gather's row addresses need the ids
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int tile = (s == 1 && htile >= 0) ? htile : tq_tile12(s, w, ntiles), l = tile * 16 + c;
-        idr[s] = tt_load_id(a.ids, b * L + l, tile >= 0 && l < L);
+        const int tile = tq_tile12(s, w, ntiles), l = tile * 16 + c;
+        idm[s] = tt_load_id(a.ids, b * L + l, tile >= 0 && l < L);
+        idr[s] = idm[s];
       }
+      if (htile >= 0) idr[1] = tt_load_id(a.ids, b * L + htile * 16 + c, htile * 16 + c < L);
     }
     TQ_IMG_LOAD(0, a.Win) TQ_IMG_LOAD(1, a.Win + 4096) TQ_IMG_LOAD(2, a.Win + 8192)      // out_proj and Wq2 follow behind the barrier (see k_seqtt_enc_fwd)
     const TqVecRegs vr = tq_vec_load<TQW * 64>(a, H, HD);
@@ -410,6 +423,13 @@ __global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) 
     for (int s = 0; s < 2; ++s) {
       const int tile = (s == 1 && htile >= 0) ? htile : tq_tile12(s, w, ntiles), l = tile * 16 + c;
       xr[s] = tq_x_request(a, b * L + l, l, tile >= 0 && l < L, idr[s], g);
+    }
+    if (a.x) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int tile = tq_tile12(s, w, ntiles), l = tile * 16 + c;
+        idm[s] = tt_load_id(a.ids, b * L + l, tile >= 0 && l < L);
+      }
     }
     tq_zero<TQW * 64>(lds.sK, 2 * SeqTtLds<5>::ibytes);
     TQ_IMG_STORE(0, lds.w[0]) TQ_IMG_STORE(1, lds.w[1]) TQ_IMG_STORE(2, lds.w[2])
@@ -505,7 +525,7 @@ __global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) 
     TT y = tq_ffn(a, lds.vec, lds.w[3], lds.w[4], a2, key1, key2, row, valid, c, g);
     tt_add(y, a2);
     tt_add(y, dn[s]);
-    if (!valid || a.ids[row] == 0) y = tt_zero();
+    if (!valid || idm[s] == 0) y = tt_zero();
     tq_store_y(a, row, y, valid, g);
   }
 }

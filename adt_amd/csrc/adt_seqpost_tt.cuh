@@ -137,6 +137,9 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   // ---- B: conv1 ; encoder: forward_layernorm backward -> dh ; dW(conv1) = dt^T LN2(h) (decoder: dt^T a2) --------------------------------
   TT dh[NS];
   TTSaved oreq[NS];
+  f32x4 drq[NS], rcq[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) drq[s] = rcq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   TT dgm = tt_zero(), dbt = tt_zero();
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
@@ -145,6 +148,14 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
     oreq[s] = tt_saved_request(a.o, row, valid, g, a.saved_bf16);           // consumed in C
+    if constexpr (H == 2) {                                                  // the head classifier's H x H values of this token, consumed in C
+      if (cls) {                                                             // (read there they were two exposed round trips per tile)
+        typedef const f32x4 __attribute__((address_space(1))) * gf4;
+        const size_t off = (size_t)(l * a.B + b) * (H * H);
+        drq[s] = *(valid ? (gf4)(a.drec + off) : (gf4)tt_zero_row);
+        rcq[s] = *(valid ? (gf4)(a.rec + off) : (gf4)tt_zero_row);
+      }
+    }
     const TT hraw_s = tt_saved_value(hreq[s], a.saved_bf16);
     tt_put_rows(img0, l, dt[s], valid, g);
     TT d = tt_gemm(tt_bfrags(dt[s]), wimg + TT_WIMG, c, g);
@@ -190,12 +201,18 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
       const size_t off = (size_t)(l * a.B + b) * (H * H);
 #pragma unroll
       for (int h = 0; h < H; ++h) {
-        float dz[H], sd = 0.f;
+        float dz[H], rcv[H], sd = 0.f;
+        if constexpr (H == 2) {
+          const float dr4[4] = {drq[s][0], drq[s][1], drq[s][2], drq[s][3]}, rc4[4] = {rcq[s][0], rcq[s][1], rcq[s][2], rcq[s][3]};
 #pragma unroll
-        for (int cc = 0; cc < H; ++cc) { dz[cc] = valid ? a.drec[off + h * H + cc] : 0.f; sd += dz[cc]; }
+          for (int cc = 0; cc < H; ++cc) { dz[cc] = valid ? dr4[h * H + cc] : 0.f; rcv[cc] = rc4[h * H + cc]; sd += dz[cc]; }
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < H; ++cc) { dz[cc] = valid ? a.drec[off + h * H + cc] : 0.f; rcv[cc] = valid ? a.rec[off + h * H + cc] : 0.f; sd += dz[cc]; }
+        }
 #pragma unroll
         for (int cc = 0; cc < H; ++cc) {
-          dz[cc] -= valid ? __expf(a.rec[off + h * H + cc]) * sd : 0.f;
+          dz[cc] -= valid ? __expf(rcv[cc]) * sd : 0.f;
           if (g == 0) dbs_acc[cc] += dz[cc];
         }
 #pragma unroll
