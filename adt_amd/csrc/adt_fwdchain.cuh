@@ -259,6 +259,14 @@ __global__ __launch_bounds__(NW * 64) void k_final_fwd(FwdChainArgs a) {
   __syncthreads();
   for (int tile = blockIdx.x * NW + w; tile < ntiles; tile += tstride) {
     const int row0 = tile * 16;
+    int ipr[4] = {0, 0, 0, 0}, inr[4] = {0, 0, 0, 0};      // the four rows' pos / neg ids, requested with the rows (read inside the loop below they were one more round trip in front of the table rows)
+    if (a.pos_logits) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + 4 * g + r;
+        if (row < a.T) { ipr[r] = a.pos[row]; inr[r] = a.neg[row]; }
+      }
+    }
     wave_fence();
     rows_to_scr(lds.scr, a.x, 64, row0, a.T, lane);
     wave_fence();
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(NW * 64) void k_final_fwd(FwdChainArgs a) {
         const int row = row0 + 4 * g + r;
         float sp = 0.f, sn = 0.f;
         if (row < a.T) {
-          const int ip = a.pos[row], in = a.neg[row];
+          const int ip = ipr[r], in = inr[r];
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
             sp += f.v[nt][r] * a.E[(size_t)ip * 64 + 16 * nt + c];
