@@ -612,8 +612,11 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   const char* const no_fallback = "backward: shape L=%d hd=%d left the per-sequence kernels although the partial-gradient path was chosen";
   const bool prep_zeroed = (phase & 4) != 0;      // bit 2: adt_sasrec_step_begin* of this step zeroed the parameter-gradient replicas
   phase &= 3;
-  // (one-phase backward only: the two-phase form belongs to the data-parallel step, whose capture already carries the collectives' stream)
-  SideStream* const sd = phase == 0 ? side_stream((hipStream_t)st) : nullptr;
+  // (one-phase backward by default: the two-phase form belongs to the data-parallel step, whose capture already carries the collectives'
+  // stream; there the side stream measured 0.692 against 0.699 ms on a 1-rank RCCL group and is opt-in: ADT_SIDE_STREAM_DP=1)
+  static int dp_on = -1;
+  if (dp_on < 0) { const char* e = getenv("ADT_SIDE_STREAM_DP"); dp_on = (e && atoi(e) != 0) ? 1 : 0; }
+  SideStream* const sd = (phase == 0 || dp_on) ? side_stream((hipStream_t)st) : nullptr;
   int dec_side = 0;      // the decoder's embedding gradient + partial sums on the side stream: 1 marked, 2 enqueued
   bool dec_parts_done = false;
   if (phase == 0 || phase == 1) {
