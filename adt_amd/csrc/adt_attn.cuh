@@ -34,6 +34,9 @@ struct AttnArgs {
   uint32_t* mask;             // optional (B*H*L x 8 words): dropout keep bits written by the bf16 forward, read by its backward
   unsigned long long* stamps; // timing experiments only (ADT_SEQ_STAMPS): s_memtime per wave of workgroup 0
   int in_bf16;                // backward, adt_seqattn.cuh only: Q, K, V, O point at bf16 rows and ldq / ldk / ldv / ldo count bf16 elements
+  int out_bf16;               // backward, adt_seqattn.cuh only: dQ, dK, dV are written as bf16 rows in the saved-row order (adt_tt.cuh: tt_store_bf16), lddq /
+                              // lddk / lddv count bf16 elements -- for a consumer that only builds bf16 MFMA operands from them (k_seqtt_mid_bwd): the same
+                              // values it would have rounded itself, half the bytes
 };
 
 template <int HD>

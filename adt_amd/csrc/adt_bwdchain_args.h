@@ -16,6 +16,7 @@ struct BwdChainArgs {
   const float* o;             // attention core output feeding the out_proj of this chain (o / o2 / o1)
   const float* dqkv; int lddqkv;   // *_pre: packed (T x 192) gradient of q,k,v ; dec_mid: dq2 (ld 64)
   const float* dkv2;          // dec_mid: (T x 128) gradient of cross k,v
+  int grad_bf16;              // k_seqtt_mid_bwd: dqkv (ld 64) and dkv2 (ld 128) are bf16 rows in the saved-row order (AttnArgs::out_bf16)
   const float* dh;            // enc_pre: gradient wrt LN1 output from the residual path
   const float* f;             // dec_mid: log_feats
   // weights (64 x 64 blocks, row-major)

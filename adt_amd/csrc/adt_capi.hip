@@ -437,9 +437,10 @@ int adt_attn_bwd(int prec, const float* Q, int ldq, const float* K, int ldk, con
 
 int adt_attn_bwd_saved_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O, int ldo, const float* LSE,
                             const float* dO, int lddo, int B, int H, int L, int hd, float p, const uint32_t* seed, uint32_t site, uint32_t b_offset,
-                            float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, const uint32_t* mask, void* stream) {
+                            float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, const uint32_t* mask, int out_bf16, void* stream) {
   AttnArgs a{};
   a.mask = const_cast<uint32_t*>(mask);
+  a.out_bf16 = out_bf16;
   a.Q = reinterpret_cast<const float*>(Q); a.ldq = ldq; a.K = reinterpret_cast<const float*>(K); a.ldk = ldk;
   a.V = reinterpret_cast<const float*>(V); a.ldv = ldv; a.O = reinterpret_cast<float*>(const_cast<void*>(O)); a.ldo = ldo; a.in_bf16 = 1;
   a.LSE = const_cast<float*>(LSE); a.B = B; a.H = H; a.L = L; a.causal = 1; a.scale = 1.0f / sqrtf((float)hd);

@@ -38,7 +38,7 @@ int adt_launch_seq_attn_bwd(int hd, const adt::AttnArgs& a, void* stream);     /
 // cover is an error.  Defined in adt_capi.hip.
 int adt_attn_bwd_saved_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O, int ldo, const float* LSE,
                             const float* dO, int lddo, int B, int H, int L, int hd, float p, const uint32_t* seed, uint32_t site, uint32_t b_offset,
-                            float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, const uint32_t* mask, void* stream);
+                            float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, const uint32_t* mask, int out_bf16, void* stream);
 // per-sequence backward of the token-wise chains (adt_seqpost_tt.cuh); enc: 1 encoder post chain, 0 decoder post chain; 0 launched, 1 not covered
 int adt_launch_seq_post_bwd(int hd, int enc, const adt::BwdChainArgs& a, void* stream);
 int adt_launch_seq_mid_bwd(int hd, const adt::BwdChainArgs& a, void* stream);      // dec_mid + kv chains in one launch

@@ -673,8 +673,10 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       // cross attention core: dq2 -> s5, dkv2 -> s4
       if (lean) {
         const uint16_t* kvb = reinterpret_cast<const uint16_t*>(kv2);      // rows of 128 bf16: k2 | v2
+        // dq2 / dk2 / dv2 go to k_seqtt_mid_bwd only (with `parts` a "not covered" from it is an error), which builds bf16 MFMA operands from
+        // them: written as bf16 rows (the same rounding, half the bytes); s4 + d / 2 floats = 64 bf16 elements into the (k | v) row
         CK(adt_attn_bwd_saved_bf16(q2, d, kvb, 2 * d, kvb + d, 2 * d, o2, d, lse2, s1, d, B, H, L, hd, p, seed, dec_site(i, 1), b_offset,
-                                   s5, d, s4, 2 * d, s4 + d, 2 * d, reinterpret_cast<const uint32_t*>(base + w.d_mask2), st));
+                                   s5, d, s4, 2 * d, parts ? s4 + d / 2 : s4 + d, 2 * d, reinterpret_cast<const uint32_t*>(base + w.d_mask2), parts ? 1 : 0, st));
       } else {
         CK(adt_attn_bwd(prec, q2, d, kv2, 2 * d, kv2 + d, 2 * d, o2, d, lse2, s1, d, B, H, L, hd, 1, p, seed, dec_site(i, 1), b_offset,
                         s5, d, s4, 2 * d, s4 + d, 2 * d, reinterpret_cast<const uint32_t*>(base + w.d_mask2), st));
@@ -683,7 +685,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       int mid_rc = 1;
       if (use_seq) {   // both projections' reverse in one launch per sequence (adt_seqpost_tt.cuh)
         adt::BwdChainArgs a = BA(dec, 0.f, nullptr);
-        a.dqkv = s5; a.lddqkv = d; a.xin = a1; a.o = o1; a.saved_bf16 = lean; a.dkv2 = s4; a.f = f;
+        a.dqkv = s5; a.lddqkv = d; a.xin = a1; a.o = o1; a.saved_bf16 = lean; a.dkv2 = s4; a.f = f; a.grad_bf16 = (lean && parts) ? 1 : 0;
         a.W0 = einw; a.W1 = P + lo.dec(i, D_SOW); a.W2 = einw + dd; a.W3 = einw + 2 * dd;
         a.dW0 = geinw; a.dW1 = Gq + lo.dec(i, D_SOW); a.dW2 = geinw + dd; a.dW3 = geinw + 2 * dd;
         a.db0 = geinb; a.db1 = Gq + lo.dec(i, D_SOB); a.db2 = geinb + d; a.db3 = geinb + 2 * d;
@@ -972,11 +974,11 @@ int adt_seq_dec_layer_bwd(int B, int L, int H, const int32_t* ids, const float* 
   {  // cross attention core: dq2 -> s5, dk2 | dv2 -> s4
     const uint16_t* kvb = reinterpret_cast<const uint16_t*>(s.kv2);
     CK(adt_attn_bwd_saved_bf16(s.q2, d, kvb, 2 * d, kvb + d, 2 * d, s.o2, d, s.lse2, s1, d, B, H, L, hd, p, seed, site_enc, b_offset, s5, d, s4,
-                               2 * d, s4 + d, 2 * d, reinterpret_cast<const uint32_t*>(s.mask2), st));
+                               2 * d, s4 + d / 2, 2 * d, reinterpret_cast<const uint32_t*>(s.mask2), 1, st));      // bf16 rows for k_seqtt_mid_bwd below
   }
   {  // enc_attn q / k / v projections and slf_attn.out_proj reverse -> dO1 (s1), d feats +=
     adt::BwdChainArgs a = bwd_args(T, L, B, ids, 0.f, nullptr, ro);
-    a.dqkv = s5; a.lddqkv = d; a.xin = s.a1; a.o = s.o; a.saved_bf16 = 1; a.dkv2 = s4; a.f = feats;
+    a.dqkv = s5; a.lddqkv = d; a.xin = s.a1; a.o = s.o; a.saved_bf16 = 1; a.dkv2 = s4; a.f = feats; a.grad_bf16 = 1;
     a.W0 = P->ein_w; a.W1 = P->so_w; a.W2 = P->ein_w + d * d; a.W3 = P->ein_w + 2 * d * d;
     a.dW0 = G->ein_w; a.dW1 = G->so_w; a.dW2 = G->ein_w + d * d; a.dW3 = G->ein_w + 2 * d * d;
     a.db0 = G->ein_b; a.db1 = G->so_b; a.db2 = G->ein_b + d; a.db3 = G->ein_b + 2 * d;

@@ -324,7 +324,16 @@ __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
       const uint32_t bh_rng = (uint32_t)(b * H + h) + a.bh_offset;
       const uint32_t idx_q = (bh_rng * (uint32_t)L + (uint32_t)q) * (uint32_t)L;
       sab_pass_a<HD, MODE>(sK, sV, fq, fdo, lse_q, delta_q, sM + ((size_t)h * R + q) * 8, qt, h, a.drop, key_rng, idx_q, c, g, dq);
-      if (q < L) {
+      if (q < L && a.out_bf16) {          // saved-row order: feature 16 nt + 4 g + r of a 64-feature row at element 16 g + 4 nt + r
+        __bf16* dst = reinterpret_cast<__bf16*>(a.dQ) + (row_b + q) * a.lddq + 16 * g + 4 * h * NT;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          bf16x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (__bf16)(dq[nt][r] * a.scale);
+          *reinterpret_cast<bf16x4*>(dst + 4 * nt) = v;
+        }
+      } else if (q < L) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           *reinterpret_cast<float4*>(a.dQ + (row_b + q) * a.lddq + h * HD + nt * 16 + 4 * g) =
@@ -351,7 +360,18 @@ __global__ __launch_bounds__(SAB_NW * 64) void k_seq_attn_bwd(AttnArgs a) {
       const uint32_t bh_rng = (uint32_t)(b * H + h) + a.bh_offset;
       sab_pass_b<HD, MODE>(sQ, sdO, fk, fv, sLse + h * R, sDelta + h * R, sM + (size_t)h * R * 8, kt, nqt, h, a.drop, key_rng, bh_rng * (uint32_t)L, L, c,
                            g, dk, dv);
-      if (key < L) {
+      if (key < L && a.out_bf16) {
+        __bf16* dstk = reinterpret_cast<__bf16*>(a.dK) + (row_b + key) * a.lddk + 16 * g + 4 * h * NT;
+        __bf16* dstv = reinterpret_cast<__bf16*>(a.dV) + (row_b + key) * a.lddv + 16 * g + 4 * h * NT;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          bf16x4 vk, vv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { vk[r] = (__bf16)(dk[nt][r] * ln2); vv[r] = (__bf16)dv[nt][r]; }
+          *reinterpret_cast<bf16x4*>(dstk + 4 * nt) = vk;
+          *reinterpret_cast<bf16x4*>(dstv + 4 * nt) = vv;
+        }
+      } else if (key < L) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           // the Q image carries the factor log2(e) / sqrt(hd): dK = dS^T Q / sqrt(hd)

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(SP_MID_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a
     const int tile = tq_tile(s, w, ntiles, NW);
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = tile >= 0 && l < L;
-    dqa[s] = tt_load(a.dqkv + (size_t)row * a.lddqkv, valid, g);
+    dqa[s] = a.grad_bf16 ? tt_load_bf16(reinterpret_cast<const __bf16*>(a.dqkv) + (size_t)row * a.lddqkv, valid, g) : tt_load(a.dqkv + (size_t)row * a.lddqkv, valid, g);
     a1req[s] = tt_saved_request(a.xin, row, valid, g, a.saved_bf16);
     oreq[s] = tt_saved_request(a.o, row, valid, g, a.saved_bf16);
   }
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(SP_MID_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
-    dk[s] = tt_load(a.dkv2 + (size_t)row * 128, valid, g);
+    dk[s] = a.grad_bf16 ? tt_load_bf16(reinterpret_cast<const __bf16*>(a.dkv2) + (size_t)row * 128, valid, g) : tt_load(a.dkv2 + (size_t)row * 128, valid, g);
     fx[s] = tt_load(a.f + (size_t)row * 64, valid, g);
     tt_put_rows(img0, l, da1[s], valid, g);
     tt_put_rows(img1, l, tt_saved_value(oreq[s], a.saved_bf16), valid, g);
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(SP_MID_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
-    dv[s] = tt_load(a.dkv2 + (size_t)row * 128 + 64, valid, g);
+    dv[s] = a.grad_bf16 ? tt_load_bf16(reinterpret_cast<const __bf16*>(a.dkv2) + (size_t)row * 128 + 64, valid, g) : tt_load(a.dkv2 + (size_t)row * 128 + 64, valid, g);
     acc1v[s] = tt_load(a.out1 + (size_t)row * 64, valid && a.acc1, g);       // consumed in D (requested there it was an exposed round trip)
     tt_put_rows(img0, l, dk[s], valid, g);
     tt_put_rows(img1, l, fx[s], valid, g);
