@@ -4,6 +4,7 @@
 // enqueues kernels (via the per-stage C ABI) on the caller's stream.
 #include "adt_host.h"
 #include <string.h>
+#include <mutex>
 #include "adt_bwdchain_args.h"
 #include "adt_fwdchain_args.h"
 #include "adt_seq_args.h"
@@ -132,10 +133,12 @@ int side_sites() {
 }
 SideStream* side_stream(hipStream_t main) {
   static SideStream g[16];
+  static std::mutex mu;                          // first use from two host threads at once (one trainer per thread)
   if (!side_sites()) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   SideStream* sd = &g[dev];
+  std::lock_guard<std::mutex> lock(mu);
   if (sd->s) return sd;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(main, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
@@ -143,7 +146,11 @@ SideStream* side_stream(hipStream_t main) {
   if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   for (int i = 0; i < 3; ++i)
     if (hipEventCreateWithFlags(&sd->fork_ev[i], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&sd->join_ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        hipEventCreateWithFlags(&sd->join_ev[i], hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamDestroy(s);
+      return nullptr;
+    }
   sd->s = s;
   return sd;
 }
