@@ -564,6 +564,24 @@ int adt_clip_adam_pre(float* P, float* G, float* M, float* V, int64_t n, int64_t
   return check_launch("clip_adam_pre");
 }
 
+/* fold (d0 += replicas r0, d1 += replicas r1) + weight decay on job 0 + ||g||^2 partials, then Adam: adt_replica_reduce2 + adt_clip_adam_pre in two launches.
+ * d0 must be the item table's gradient (G + 0, n0 = nE floats); the padding between the two ranges holds zeros and is left alone. */
+int adt_fold_clip_adam(float* P, float* G, float* M, float* V, int64_t n, float* d0, const float* r0, int64_t n0, int nrep0, int64_t s0, float* d1,
+                       const float* r1, int64_t n1, int nrep1, int64_t s1, float wd, float clip, float lr, float b1, float b2, float eps, float* scal,
+                       void* stream) {
+  if (n0 <= 0 || n1 <= 0 || (n0 % 4) || (s0 % 4) || (n1 % 4) || (s1 % 4) || d0 != G) return adt_set_error("fold_clip_adam: ranges");
+  OptArgs a{};
+  a.P = P; a.G = G; a.M = M; a.Vv = V; a.n = (size_t)n; a.nE = (size_t)n0; a.wd = wd; a.clip = clip; a.lr = lr;
+  a.b1 = b1; a.b2 = b2; a.eps = eps; a.scal = scal; a.grad_scale = 1.0f;
+  RepReduce2Args r{{d0, d1}, {r0, r1}, {(size_t)n0, (size_t)n1}, {nrep0, nrep1}, {(size_t)s0, (size_t)s1}, 0};
+  const int g0 = grid_for((size_t)n0 / 4, 256, 1024), g1 = grid_for((size_t)n1 / 4, 256, 1024);
+  r.g0 = g0;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_fold_wd_gradnorm, dim3(g0 + g1), dim3(256), 0, s, r, a);
+  hipLaunchKernelGGL(k_adam, dim3(grid_for((size_t)n, 256, 1024)), dim3(256), 0, s, a);
+  return check_launch("fold_clip_adam");
+}
+
 static void step_begin_extras(StepBeginArgs& a, float* Z, int64_t nz, const float* pack_base, void* pack_img, const int* pack_offs, int npack) {
   a.Z = Z; a.nz = Z ? (size_t)nz : 0;
   a.pk.base = pack_base; a.pk.img = reinterpret_cast<__bf16*>(pack_img); a.pk.n = (pack_base && pack_img && pack_offs) ? npack : 0;

@@ -69,6 +69,9 @@ int adt_loss_seeds(const float* pos_logits, const float* neg_logits, const int32
                    float* loss_bce, int nmse, const float* const* A, const float* const* Bm, int64_t n, const float* lambdas, float* const* GA,
                    int accumulate_a, float* const* GB, float* const* loss_mse, int nnll, const float* const* rec, int n_rows, int H, float lambda2,
                    float* const* drec, float* const* loss_nll, void* stream);
+int adt_fold_clip_adam(float* P, float* G, float* M, float* V, int64_t n, float* d0, const float* r0, int64_t n0, int nrep0, int64_t s0, float* d1,
+                       const float* r1, int64_t n1, int nrep1, int64_t s1, float wd, float clip, float lr, float b1, float b2, float eps, float* scal,
+                       void* stream);
 int adt_replica_reduce2(float* d0, const float* r0, int64_t n0, int nrep0, int64_t s0, float* d1, const float* r1, int64_t n1, int nrep1, int64_t s1,
                         void* stream);
 }

@@ -689,6 +689,36 @@ __global__ __launch_bounds__(256) void k_adam(OptArgs a) {
   }
 }
 
+// The last fold of the backward (k_replica_reduce2) and k_wd_gradnorm in ONE pass, for a single-GPU step: every gradient element passes
+// through the fold anyway (job 0: item table = G + its replicas, job 1: every other parameter), so the scaling, the weight-decay term of the
+// item table and the partial sums of ||g||^2 are applied where the sum is formed.  Same per-element arithmetic as the two kernels in sequence.
+__global__ __launch_bounds__(256) void k_fold_wd_gradnorm(RepReduce2Args a, OptArgs o) {
+  __shared__ float sbuf[4];
+  const float nrm = sqrtf(sum64(o.scal + 64, sbuf));
+  const float coef = (o.wd != 0.f && nrm > 0.f) ? o.wd / nrm : 0.f;
+  const int j = (int)blockIdx.x >= a.g0 ? 1 : 0;
+  const int bid = j ? blockIdx.x - a.g0 : blockIdx.x, nblk = j ? gridDim.x - a.g0 : a.g0;
+  float* dst = a.dst[j];
+  const float* rep = a.rep[j];
+  const float* Pj = o.P + (dst - o.G);           // the parameters under this job's gradient range
+  const size_t n = a.n[j], stride = a.stride[j];
+  const int nrep = a.nrep[j];
+  float acc = 0.f;
+  for (size_t i = ((size_t)bid * 256 + threadIdx.x) * 4; i < n; i += (size_t)nblk * 1024) {
+    float4 g = replica_sum4(rep + i, stride, nrep, *reinterpret_cast<const float4*>(dst + i));
+    g.x *= o.grad_scale; g.y *= o.grad_scale; g.z *= o.grad_scale; g.w *= o.grad_scale;
+    if (j == 0) {                                // the item table is job 0 (flat offset 0, nE floats): + wd * E / ||E||_F
+      const float4 p = *reinterpret_cast<const float4*>(Pj + i);
+      g.x += coef * p.x; g.y += coef * p.y; g.z += coef * p.z; g.w += coef * p.w;
+    }
+    *reinterpret_cast<float4*>(dst + i) = g;
+    acc += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
+  }
+  const float s = block_sum(acc, sbuf);
+  if (threadIdx.x == 0) atomicAdd(o.scal + 128 + (blockIdx.x & 63), s);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { o.scal[0] = nrm * nrm; o.scal[3] = o.wd * nrm; o.scal[2] += 1.0f; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // SASRecADT.predict (sasrec/model.py:89-96) + the rank of evaluate_loader (sasrec/utils.py:410):
 // logits[b][c] = E[cand[b][c]] . f[b] ; rank[b] = #{c > 0 : logits[b][c] > logits[b][0]}.

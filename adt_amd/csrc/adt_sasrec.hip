@@ -618,6 +618,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   auto PART = [&](int layer, int slot) { return parts ? ws + w.part + (int64_t)(16 * layer + slot) * 4096 : nullptr; };
   const char* const no_fallback = "backward: shape L=%d hd=%d left the per-sequence kernels although the partial-gradient path was chosen";
   const bool prep_zeroed = (phase & 4) != 0;      // bit 2: adt_sasrec_step_begin* of this step zeroed the parameter-gradient replicas
+  const bool defer_fold = (phase & 8) != 0 && (phase & 3) == 0;      // bit 3 (one-phase only): adt_sasrec_fold_clip_adam does the last fold
   phase &= 3;
   // (one-phase backward by default: the two-phase form belongs to the data-parallel step, whose capture already carries the collectives'
   // stream; there the side stream measured 0.692 against 0.699 ms on a 1-rank RCCL group and is opt-in: ADT_SIDE_STREAM_DP=1)
@@ -861,10 +862,23 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       if (parts) CK(reduce_partials(c, lo, w, G, ws, true, phase == 0 && !dec_parts_done, s2));
       CK(side_join(sd2, 2, st));
     }
-    CK(adt_replica_reduce2(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, NREP, w.rep_stride, G + lo.posw(), Gq + lo.posw(),
-                           (phase == 0 ? lo.total : dec_begin) - lo.posw(), NREPP, w.prep_stride, st));
+    if (!defer_fold)
+      CK(adt_replica_reduce2(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, NREP, w.rep_stride, G + lo.posw(), Gq + lo.posw(),
+                             (phase == 0 ? lo.total : dec_begin) - lo.posw(), NREPP, w.prep_stride, st));
   }
   return 0;
+}
+
+int adt_sasrec_fold_clip_adam(const adt_sasrec_cfg* c, float* ws, int B, float* P, float* G, float* M, float* V, float wd, float clip, float lr,
+                              float b1, float b2, float eps, float* scal, void* st) {
+  CK(check_cfg(c));
+  Layout lo;
+  make_layout(c, &lo);
+  WS w;
+  make_ws(c, B, &w);
+  float* const Gq = ws + w.prep - lo.posw();
+  return adt_fold_clip_adam(P, G, M, V, lo.total, G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * c->hidden, NREP, w.rep_stride, G + lo.posw(),
+                            Gq + lo.posw(), lo.total - lo.posw(), NREPP, w.prep_stride, wd, clip, lr, b1, b2, eps, scal, st);
 }
 
 int adt_sasrec_predict(const adt_sasrec_cfg* c, const float* P, float* ws, const int32_t* seq, const int32_t* cand,

@@ -189,11 +189,19 @@ class SASRecADT(torch.nn.Module):
         fn = self.lib.adt_sasrec_loss_seed if zero_loss else self.lib.adt_sasrec_loss_seed_nz
         _lib.check(fn(ctypes.byref(self.cfg), _ptr(self.workspace(B)), _ptr(pos), B, l1, l2, self._stream()), "sasrec_loss_seed")
 
-    def run_backward(self, seq, dec, pos, neg, B, training, b_offset=0, phase=0, prezeroed=False):
-        """prezeroed: run_step_begin / run_step_begin_ring of THIS step already zeroed the parameter-gradient replicas (bit 2 of `phase`)."""
+    def run_backward(self, seq, dec, pos, neg, B, training, b_offset=0, phase=0, prezeroed=False, defer_fold=False):
+        """prezeroed: run_step_begin / run_step_begin_ring of THIS step already zeroed the parameter-gradient replicas (bit 2 of `phase`).
+        defer_fold (phase 0 only): the last replica fold is left to run_fold_clip_adam, which must follow (bit 3)."""
         _lib.check(self.lib.adt_sasrec_backward(ctypes.byref(self.cfg), _ptr(self.flat), _ptr(self.flat_grad), _ptr(self.workspace(B)),
                                                 _ptr(seq), _ptr(dec), _ptr(pos), _ptr(neg), B, int(training), _ptr(self._seed),
-                                                b_offset, phase | (4 if prezeroed else 0), self._stream()), "sasrec_backward")
+                                                b_offset, phase | (4 if prezeroed else 0) | (8 if defer_fold and phase == 0 else 0), self._stream()),
+                   "sasrec_backward")
+
+    def run_fold_clip_adam(self, B, m, v, wd, clip, lr, b1, b2, eps, scal):
+        """Optimizer step behind run_backward(..., defer_fold=True): replica fold + weight-decay term + ||g||^2 in one pass, then clip + Adam."""
+        _lib.check(self.lib.adt_sasrec_fold_clip_adam(ctypes.byref(self.cfg), _ptr(self.workspace(B)), B, _ptr(self.flat), _ptr(self.flat_grad),
+                                                      _ptr(m), _ptr(v), float(wd), float(clip), float(lr), float(b1), float(b2), float(eps),
+                                                      _ptr(scal), self._stream()), "sasrec_fold_clip_adam")
 
     # ------------------------------------------------------------------------------------------
     def forward(self, user_ids, log_seqs, dec_seqs, pos_seqs, neg_seqs):

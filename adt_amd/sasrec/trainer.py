@@ -96,7 +96,10 @@ class FusedTrainer:
         m.run_forward(seq, dec, pos, neg, B, True, b_offset, packed=True)      # run_step_begin* above packed the weight images ...
         m.run_loss_seed(pos, B, self.lambdas1, self.lambdas2, zero_loss=False)
         if not self._buckets.active:
-            m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=0, prezeroed=True)      # ... and zeroed the parameter-gradient replicas
+            # ... and zeroed the parameter-gradient replicas ; the last fold of the replicas happens inside the optimizer's first kernel
+            m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=0, prezeroed=True, defer_fold=True)
+            m.run_fold_clip_adam(B, self.m, self.v, self.wd, self.clip, self.lr, self.betas[0], self.betas[1], self.eps, self.scal)
+            return
         else:
             # two buckets: the decoder bucket's all-reduce (RCCL, its own stream) overlaps the encoder's backward.
             # NOTE: phase 1 also scatters the decoder-input embedding rows, which live in the encoder bucket

@@ -380,10 +380,17 @@ int adt_sasrec_loss_seed_nz(const adt_sasrec_cfg* cfg, float* ws, const int32_t*
  * phase: 0 = everything; 1 = logits + decoder stack only; 2 = last LN + encoder stack + embeddings (lets the
  * host overlap the gradient all-reduce of the decoder bucket with phase 2).  + 4: the parameter-gradient replicas were already zeroed by
  * adt_sasrec_step_begin / _ring of this step.  With phase 0 the scatter / fold kernels run on a side stream of the library under the
- * chain kernels (joined before the call returns its last launch; ADT_SIDE_STREAM=0 keeps everything on `stream`). */
+ * chain kernels (joined before the call returns its last launch; ADT_SIDE_STREAM=0 keeps everything on `stream`).  + 8 (with phase 0 only):
+ * the last fold of the gradient replicas into `grads` is left to adt_sasrec_fold_clip_adam, which must follow. */
 int adt_sasrec_backward(const adt_sasrec_cfg* cfg, const float* params, float* grads, float* ws,
                         const int32_t* seq, const int32_t* dec, const int32_t* pos, const int32_t* neg, int B,
                         int training, const uint32_t* seed, uint32_t b_offset, int phase, void* stream);
+/* The optimizer step of a single-GPU training step whose backward ran with phase 0 + 8 (and whose scal was prepared by
+ * adt_sasrec_step_begin): the last fold of the gradient replicas, grad += wd * E / ||E||_F on the item table and the partial sums of
+ * ||g||^2 in ONE pass over the gradient, then clip_grad_norm_(clip) + Adam (sasrec/main.py:170-173) -- adt_clip_adam_pre's result in two
+ * launches instead of three.  m, v: Adam moments laid out like params. */
+int adt_sasrec_fold_clip_adam(const adt_sasrec_cfg* cfg, float* ws, int B, float* params, float* grads, float* m, float* v, float wd,
+                              float clip, float lr, float b1, float b2, float eps, float* scal, void* stream);
 /* SASRecADT.predict (sasrec/model.py:83-97): encoder only, last position, candidate (cand != NULL, B x C) or
  * all-item (C = V+1) scores; optional rank of column 0. */
 int adt_sasrec_predict(const adt_sasrec_cfg* cfg, const float* params, float* ws, const int32_t* seq,
