@@ -594,7 +594,7 @@ int adt_step_begin_launch(uint32_t* seed, uint32_t inc, float* norms_dst, const 
   if (npack < 0 || npack > 256 || (nz & 3)) return adt_set_error("step_begin: %d weight blocks, %lld floats to zero", npack, (long long)nz);
   StepBeginArgs a{seed, inc, norms_dst, norms_src, loss, nloss, scal, G, (size_t)n, E, (size_t)nE, nullptr, 0, 0, nullptr, 0, nullptr, nullptr};
   step_begin_extras(a, Z, nz, pack_base, pack_img, pack_offs, npack);
-  hipLaunchKernelGGL(k_step_begin, dim3(256 + a.pk.n), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_step_begin, dim3(256 + 4 * a.pk.n), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("step_begin");
 }
 
@@ -607,7 +607,7 @@ int adt_step_begin_ring_launch(uint32_t* seed, uint32_t inc, float* norms_dst, f
   if (npack < 0 || npack > 256 || (nz & 3)) return adt_set_error("step_begin_ring: %d weight blocks, %lld floats to zero", npack, (long long)nz);
   StepBeginArgs a{seed, inc, norms_dst, nullptr, loss, nloss, scal, G, (size_t)n, E, (size_t)nE, ring, (size_t)slot_ints, nslots, ids_dst, (size_t)n_ints, state, consumed};
   step_begin_extras(a, Z, nz, pack_base, pack_img, pack_offs, npack);
-  hipLaunchKernelGGL(k_step_begin, dim3(256 + a.pk.n), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_step_begin, dim3(256 + 4 * a.pk.n), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("step_begin_ring");
 }
 

@@ -546,8 +546,8 @@ struct StepBeginArgs {
 __global__ __launch_bounds__(256) void k_step_begin(StepBeginArgs a) {
   __shared__ float sbuf[4];
   typedef int v4i __attribute__((ext_vector_type(4)));
-  const unsigned nblk = gridDim.x - (unsigned)a.pk.n;      // the workgroups of the step's own work ; the rest pack weight images
-  if (blockIdx.x >= nblk) { pack_wimg_block(a.pk, (int)(blockIdx.x - nblk)); return; }
+  const unsigned nblk = gridDim.x - 4u * (unsigned)a.pk.n;      // the workgroups of the step's own work ; the rest pack weight images, four per block
+  if (blockIdx.x >= nblk) { pack_wimg_block<4>(a.pk, (int)(blockIdx.x - nblk)); return; }
   const int32_t* slot = nullptr;
   v4i idv[2];
   size_t n16 = 0;

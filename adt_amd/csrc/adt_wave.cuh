@@ -96,14 +96,18 @@ struct PackArgs {
   int n;
   int off[256];           // float offsets (relative to base) of the 64 x 64 blocks
 };
-__device__ __forceinline__ void pack_wimg_block(const PackArgs& a, int blk) {
+// PARTS workgroups share one block (quarter q packs rows 16 q .. 16 q + 15 in one iteration per thread): as one workgroup per block the
+// four dependent iterations (a load, sixteen 2-byte stores each) made the packing the long pole of k_step_begin
+template <int PARTS = 1>
+__device__ __forceinline__ void pack_wimg_block(const PackArgs& a, int blk_part) {
+  const int blk = blk_part / PARTS, part = blk_part % PARTS;
   const int off = a.off[blk];
   const float* W = a.base + off;
   __bf16* plain = a.img + 6 * (size_t)off;
   __bf16* trans = plain + WPACK_IMG;
   __bf16* splain = plain + 2 * WPACK_IMG;       // slot-ordered forms for the transposed chains (adt_tt.cuh): column 32 kb + 4 g' + q + 16 s
   __bf16* strans = plain + 3 * WPACK_IMG;       // of a row sits at 32 kb + 8 g' + 4 s + q
-  for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+  for (int i = threadIdx.x + part * (64 * 16 / PARTS); i < (part + 1) * (64 * 16 / PARTS); i += 256) {
     const int n = i >> 4, k4 = (i & 15) * 4;
     const float4 v = *reinterpret_cast<const float4*>(W + n * 64 + k4);
     const float x[4] = {v.x, v.y, v.z, v.w};
