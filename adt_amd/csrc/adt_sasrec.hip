@@ -851,10 +851,13 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       }
     }
     if (phase == 2 && adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
-    if (dec_side == 2) { CK(side_join(sd, 1, st)); dec_side = 0; }
-    // the sum of the encoder blocks' partials runs beside the embedding gradient ; the fold (read-modify-write of the same range) behind both
+    // the sum of the encoder blocks' partials runs beside the embedding gradient ; the fold (read-modify-write of the same range) behind both.
+    // The side stream is in order: the join behind that sum also covers the decoder's work queued on it earlier -- a join of its own in front
+    // of the embedding gradient was one more cross-queue wait (5-9 us) on the caller's stream.
     {
       SideStream* const sd2 = (side_sites() & 4) ? sd : nullptr;
+      if (dec_side == 2 && !sd2) CK(side_join(sd, 1, st));
+      dec_side = 0;
       void* s2 = nullptr;
       CK(side_mark(sd2, 2, st));
       CK(adt_embed_bwd_rep(seq, ws + w.g_enc_x, T, L, d, p, seed, SITE_EMB_SEQ, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
