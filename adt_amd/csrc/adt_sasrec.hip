@@ -1,7 +1,8 @@
 // Model-level executor for SASRec-ADT: the sequence of stage launches that replaces SASRecADT.forward /
 // predict (sasrec/model.py:32-97), Encoder/EncoderLayer/Decoder/DecoderLayer (sasrec/modules.py:635-757) and
 // their autograd reverse pass, plus the loss seeds of sasrec/main.py:151-169.  Pure host code: it only
-// enqueues kernels (via the per-stage C ABI) on the caller's stream.
+// enqueues kernels (via the per-stage C ABI) on the caller's stream -- and, in the one-phase backward, a few scatter / fold
+// kernels on a side stream of its own that forks from and joins the caller's stream inside the call (side_stream below).
 #include "adt_host.h"
 #include <string.h>
 #include <mutex>
