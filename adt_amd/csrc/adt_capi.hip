@@ -282,6 +282,13 @@ int adt_logits_bwd_scatter(const float* F, int ldf, const float* E, const int32_
   return check_launch("logits_bwd_scatter");
 }
 
+int adt_logits_bce_scatter(const float* F, const float* E, const int32_t* pos, const int32_t* neg, const float* norms, int T, float* pos_logits,
+                           float* neg_logits, float* dpos, float* dneg, float* loss_bce, float* dF, float* rep, int nrep, int64_t rep_stride, void* stream) {
+  LogitsBceArgs a{F, E, pos, neg, norms, T, pos_logits, neg_logits, dpos, dneg, loss_bce, dF, rep, nrep, (size_t)rep_stride};
+  hipLaunchKernelGGL(k_logits_bce_scatter, dim3(grid_for(T, 4 * 16, 1024)), dim3(256), 0, (hipStream_t)stream, a);      // ~16 rows per wave
+  return check_launch("logits_bce_scatter");
+}
+
 int adt_embed_bwd_rep(const int32_t* ids, const float* dX, int T, int L, int d, float p, const uint32_t* seed, uint32_t site, uint32_t row_offset,
                       float* dP, float* rep, int nrep, int64_t rep_stride, void* stream) {
   if (d != 64 || T % L) {   // general widths: the two separate passes
@@ -532,7 +539,7 @@ int adt_loss_seeds(const float* pos_logits, const float* neg_logits, const int32
   for (int i = 0; i < nmse; ++i) a.mse[i] = MseArgs{A[i], Bm[i], (size_t)n, lambdas[i], norms, GA[i], accumulate_a, GB[i], loss_mse[i]};
   for (int i = 0; i < nnll; ++i) a.nll[i] = NllArgs{rec[i], n_rows, H, lambda2, norms, drec[i], loss_nll[i]};
   a.nmse = nmse; a.nnll = nnll;
-  a.gb = grid_for(T, 256, 256);
+  a.gb = pos_logits ? grid_for(T, 256, 256) : 0;      // no logits: the BCE seed is formed elsewhere (adt_logits_bce_scatter)
   a.gm = nmse ? grid_for((size_t)n / 4, 256, 512) : 1;
   a.gn = nnll ? grid_for((size_t)n_rows * H * H, 256, 512) : 1;
   hipLaunchKernelGGL(k_loss_seeds, dim3(a.gb + nmse * a.gm + nnll * a.gn), dim3(256), 0, (hipStream_t)stream, a);

@@ -165,6 +165,23 @@ __device__ __forceinline__ float wave_max(float v) {
 
 #define ADT_DEVICE_INLINE __device__ __forceinline__
 
+// wave sum that stays in the vector ALU: four DPP steps inside each row of 16 lanes, then v_permlane16_swap / v_permlane32_swap across the
+// rows (gfx950).  wave_sum above goes through ds_bpermute_b32 six times: a dependent chain of LDS-crossbar round trips.
+__device__ __forceinline__ float wave_sum_valu(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const u2v a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v += __builtin_bit_cast(float, (threadIdx.x & 16) ? a[0] : a[1]);
+  const unsigned w = __builtin_bit_cast(unsigned, v);
+  const u2v b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  v += __builtin_bit_cast(float, (threadIdx.x & 32) ? b[0] : b[1]);
+  return v;
+}
+
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop that is unrolled in the front end.  `#pragma unroll` runs late in
 // the optimizer: a register array indexed by the loop counter is still dynamically indexed when scalar replacement looks at it, stays an
 // alloca and ends up in scratch (the weight-image staging registers of the per-sequence kernels: 96-208 B of scratch per lane).

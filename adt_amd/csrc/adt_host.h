@@ -53,6 +53,9 @@ int adt_launch_seq_attn_pre_bwd(int hd, int dec, const adt::SeqBwdArgs& a, void*
 extern "C" {
 int adt_logits_bwd_scatter(const float* F, int ldf, const float* E, const int32_t* pos, const int32_t* neg, const float* dpos, const float* dneg,
                            int T, int d, float* dF, int lddf, float* rep, int nrep, int64_t rep_stride, void* stream);
+// d = 64: logits, BCE seed + loss terms, d log_feats and the item rows of the positive / negative items in one pass (adt_misc.cuh)
+int adt_logits_bce_scatter(const float* F, const float* E, const int32_t* pos, const int32_t* neg, const float* norms, int T, float* pos_logits,
+                           float* neg_logits, float* dpos, float* dneg, float* loss_bce, float* dF, float* rep, int nrep, int64_t rep_stride, void* stream);
 int adt_embed_bwd_rep(const int32_t* ids, const float* dX, int T, int L, int d, float p, const uint32_t* seed, uint32_t site, uint32_t row_offset,
                       float* dP, float* rep, int nrep, int64_t rep_stride, void* stream);
 int adt_layernorm_bwd_rep(const float* dY, int lddy, const float* X, int ldx, const float* gamma, float eps, int T, int d, float* dX, int lddx,

@@ -270,6 +270,28 @@ adt::SeqFwdArgs seq_args(int L, int B, int H, const int32_t* ids, float p, const
   return a;
 }
 
+// argument block of one encoder layer's fused forward (adt_seqfwd_tt.cuh / adt_seqfwd.cuh)
+adt::SeqFwdArgs enc_layer_seq_args(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const float* P, float* ws, const int32_t* seq, float p,
+                                   const uint32_t* seed, uint32_t b_offset, int i, bool training_outputs, bool lean) {
+  const int d = (int)w.d, H = (int)w.H, hd = d / H, L = (int)w.L, B = (int)w.B, prec = c->prec;
+  const int64_t Td = up64(w.T * w.d);
+  float* x = ws + w.enc_x + i * Td;
+  float* y = ws + w.enc_x + (i + 1) * Td;
+  float* base = ws + i * w.e_stride;
+  adt::SeqFwdArgs a = seq_args(L, B, H, seq, p, seed, b_offset, hd);
+  a.x = i == 0 ? nullptr : x; a.E = P + lo.item(); a.P = P + lo.posw(); a.emb_scale = sqrtf((float)d); a.site_emb = SITE_EMB_SEQ;
+  a.site_attn = enc_site(i, 0); a.site1 = enc_site(i, 1); a.site2 = enc_site(i, 2);
+  a.gamma = P + lo.enc(i, E_LN1W); a.beta = P + lo.enc(i, E_LN1B); a.Win = P + lo.enc(i, E_INW); a.bin = P + lo.enc(i, E_INB);
+  a.Wo = P + lo.enc(i, E_OW); a.bo = P + lo.enc(i, E_OB); a.gamma2 = P + lo.enc(i, E_LN2W); a.beta2 = P + lo.enc(i, E_LN2B);
+  a.W1 = P + lo.enc(i, E_C1W); a.b1 = P + lo.enc(i, E_C1B); a.W2 = P + lo.enc(i, E_C2W); a.b2 = P + lo.enc(i, E_C2B);
+  a.x_out = x; a.xn = base + w.e_qn; a.qkv = base + w.e_qkv; a.o = base + w.e_o; a.lse = base + w.e_lse;
+  a.mask = reinterpret_cast<uint32_t*>(base + w.e_mask); a.h = base + w.e_h; a.u = base + w.e_u; a.y = y;
+  if (training_outputs && H > 1) { a.rec = base + w.e_rec; a.Ws = P + lo.enc(i, E_SW); a.bs = P + lo.enc(i, E_SB); }
+  a.wp_base = P + lo.posw(); a.wp_img = prec == ADT_PREC_BF16 ? (const void*)(ws + w.wpack) : nullptr;
+  if (lean) { a.xn = nullptr; a.qkv = nullptr; a.saved_bf16 = 1; }
+  return a;
+}
+
 // encoder stack forward (gathers the input embedding inside the first chain) + last LayerNorm (+ logits and the
 // cross-attention k/v projections of every decoder layer when training_outputs)
 int encoder_forward(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const float* P, float* ws,
@@ -293,16 +315,7 @@ int encoder_forward(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, cons
     const float* inw = P + lo.enc(i, E_INW);
     const float* inb = P + lo.enc(i, E_INB);
     if (use_seq) {   // the whole layer in one launch, one workgroup per sequence (adt_seqfwd.cuh)
-      adt::SeqFwdArgs a = seq_args(L, B, H, seq, p, seed, b_offset, hd);
-      a.x = i == 0 ? nullptr : x; a.E = P + lo.item(); a.P = P + lo.posw(); a.emb_scale = sqrtf((float)d); a.site_emb = SITE_EMB_SEQ;
-      a.site_attn = enc_site(i, 0); a.site1 = enc_site(i, 1); a.site2 = enc_site(i, 2);
-      a.gamma = P + lo.enc(i, E_LN1W); a.beta = P + lo.enc(i, E_LN1B); a.Win = inw; a.bin = inb;
-      a.Wo = P + lo.enc(i, E_OW); a.bo = P + lo.enc(i, E_OB); a.gamma2 = P + lo.enc(i, E_LN2W); a.beta2 = P + lo.enc(i, E_LN2B);
-      a.W1 = P + lo.enc(i, E_C1W); a.b1 = P + lo.enc(i, E_C1B); a.W2 = P + lo.enc(i, E_C2W); a.b2 = P + lo.enc(i, E_C2B);
-      a.x_out = x; a.xn = qn; a.qkv = qkv; a.o = o; a.lse = lse; a.mask = reinterpret_cast<uint32_t*>(base + w.e_mask); a.h = h; a.u = u; a.y = y;
-      if (training_outputs && H > 1) { a.rec = rec; a.Ws = P + lo.enc(i, E_SW); a.bs = P + lo.enc(i, E_SB); }
-      a.wp_base = wp_base; a.wp_img = wp_img;
-      if (lean) { a.xn = nullptr; a.qkv = nullptr; a.saved_bf16 = 1; }
+      const adt::SeqFwdArgs a = enc_layer_seq_args(c, lo, w, P, ws, seq, p, seed, b_offset, i, training_outputs, lean);
       CK(adt_launch_seq_enc_fwd(hd, a, st));
       continue;
     }
@@ -354,8 +367,8 @@ int encoder_forward(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, cons
 }
 
 // one decoder layer, fused forward: one launch, one workgroup per sequence (adt_seqfwd_tt.cuh / adt_seqfwd.cuh)
-int dec_layer_seq_fwd(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const float* P, float* ws, const int32_t* dec, float p,
-                      const uint32_t* seed, uint32_t b_offset, int i, void* st) {
+adt::SeqFwdArgs dec_layer_seq_args(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const float* P, float* ws, const int32_t* dec, float p,
+                                   const uint32_t* seed, uint32_t b_offset, int i) {
   const int d = (int)w.d, H = (int)w.H, hd = d / H, L = (int)w.L, B_ = (int)w.B, prec = c->prec;
   const int64_t Td = up64(w.T * w.d);
   float* x = ws + w.dec_x + i * Td;
@@ -375,7 +388,45 @@ int dec_layer_seq_fwd(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, co
   a.h = a2; a.u = u; a.y = y;
   a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack;
   if (adt_seq_lean(prec, L, d, hd)) { a.xn = nullptr; a.qkv = nullptr; a.saved_bf16 = 1; }
-  return adt_launch_seq_dec_fwd(hd, a, st);
+  return a;
+}
+int dec_layer_seq_fwd(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const float* P, float* ws, const int32_t* dec, float p,
+                      const uint32_t* seed, uint32_t b_offset, int i, void* st) {
+  const adt::SeqFwdArgs a = dec_layer_seq_args(c, lo, w, P, ws, dec, p, seed, b_offset, i);
+  return adt_launch_seq_dec_fwd((int)(w.d / w.H), a, st);
+}
+
+// Training forward + loss assembly of the lean per-sequence path: log_feats is the tail of the last encoder layer's kernel (no k_final_fwd launch)
+// and the pos / neg logits + BCE seed are formed by the backward's first side kernel, which gathers E[pos], E[neg] and log_feats anyway
+// (adt_logits_bce_scatter; adt_sasrec_backward with phase bit 4).  Returns 1 when the shape is not covered (nothing launched).
+bool bce_deferred(const adt_sasrec_cfg* c) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("ADT_FWD_FUSED"); on = (e && atoi(e) == 0) ? 0 : 1; }
+  const int d = c->hidden, hd = d / c->num_heads;
+  return on && d == 64 && c->num_layers <= 4 && adt_seq_lean(c->prec, c->maxlen, d, hd) != 0;
+}
+int forward_loss_lean(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const float* P, float* ws, const int32_t* seq, const int32_t* dec,
+                      float p, const uint32_t* seed, uint32_t b_offset, const float* lambdas1, const float* lambdas2, void* st) {
+  const int d = (int)w.d, H = (int)w.H, hd = d / H, nl = c->num_layers, T = (int)w.T;
+  if (!bce_deferred(c)) return 1;
+  const int64_t Td = up64(w.T * w.d), rec = up64(w.T * w.H * w.H);
+  for (int i = 0; i < nl; ++i) {
+    adt::SeqFwdArgs a = enc_layer_seq_args(c, lo, w, P, ws, seq, p, seed, b_offset, i, true, true);
+    if (i == nl - 1) { a.lnl_gamma = P + lo.lnl_w(); a.lnl_beta = P + lo.lnl_b(); a.f_out = ws + w.f; }
+    CK(adt_launch_seq_enc_fwd(hd, a, st));
+  }
+  for (int j = 0; j < nl; ++j) CK(dec_layer_seq_fwd(c, lo, w, P, ws, dec, p, seed, b_offset, j, st));
+  // reconstruction + independence seeds in one launch (the BCE block is the backward's: no logits yet)
+  float* loss = ws + w.loss;
+  const float *A[4], *Bm[4], *rc[4];
+  float *GA[4], *GB[4], *lm[4], *dr[4], *ln[4];
+  for (int i = 0; i < nl; ++i) {
+    A[i] = ws + w.enc_x + i * Td; Bm[i] = ws + w.dec_x + (nl - i) * Td; GA[i] = ws + w.g_enc_x + i * Td; GB[i] = ws + w.g_dec_x + (nl - i) * Td;
+    lm[i] = loss + 64 * (2 + i);
+    rc[i] = ws + i * w.e_stride + w.e_rec; dr[i] = ws + w.g_rec + i * rec; ln[i] = loss + 64 * (2 + nl + i);
+  }
+  return adt_loss_seeds(nullptr, nullptr, nullptr, 0, ws + w.norms, nullptr, nullptr, loss, nl, A, Bm, w.T * w.d, lambdas1, GA, 0, GB, lm,
+                        H > 1 ? nl : 0, rc, T, H, lambdas2[nl - 1], dr, ln, st);
 }
 
 }  // namespace
@@ -481,6 +532,26 @@ int adt_sasrec_forward(const adt_sasrec_cfg* c, const float* P, float* ws, const
     }
   }
   return 0;
+}
+
+// adt_sasrec_forward (training) + adt_sasrec_loss_seed_nz in one call; on the lean per-sequence path (adt_sasrec_bce_deferred) without the
+// k_final_fwd launch and without the BCE block of the loss assembly: the caller must then run adt_sasrec_backward with phase bit 4 (+ 16).
+// The loss slots must have been zeroed (adt_sasrec_step_begin*).
+int adt_sasrec_bce_deferred(const adt_sasrec_cfg* c) { return check_cfg(c) == 0 && bce_deferred(c) ? 1 : 0; }
+int adt_sasrec_forward_loss(const adt_sasrec_cfg* c, const float* P, float* ws, const int32_t* seq, const int32_t* dec, const int32_t* pos,
+                            const int32_t* neg, int B, int training, const uint32_t* seed, uint32_t b_offset, const float* lambdas1,
+                            const float* lambdas2, void* st) {
+  CK(check_cfg(c));
+  if ((training & 1) && (training & 2)) {      // training forward on weight images packed by this step's adt_sasrec_step_begin*
+    Layout lo;
+    make_layout(c, &lo);
+    WS w;
+    make_ws(c, B, &w);
+    const int rc = forward_loss_lean(c, lo, w, P, ws, seq, dec, c->dropout, seed, b_offset, lambdas1, lambdas2, st);
+    if (rc <= 0) return rc;
+  }
+  CK(adt_sasrec_forward(c, P, ws, seq, dec, pos, neg, B, training, seed, b_offset, st));
+  return adt_sasrec_loss_seed_nz(c, ws, pos, B, lambdas1, lambdas2, st);
 }
 
 // Measurement hook (bench.py roofline): launches ONLY the fused forward of decoder layer `layer` on the workspace of a completed
@@ -620,7 +691,15 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   const char* const no_fallback = "backward: shape L=%d hd=%d left the per-sequence kernels although the partial-gradient path was chosen";
   const bool prep_zeroed = (phase & 4) != 0;      // bit 2: adt_sasrec_step_begin* of this step zeroed the parameter-gradient replicas
   const bool defer_fold = (phase & 8) != 0 && (phase & 3) == 0;      // bit 3 (one-phase only): adt_sasrec_fold_clip_adam does the last fold
+  const bool bce_here = (phase & 16) != 0;        // bit 4: the forward was adt_sasrec_forward_loss on the deferred path: logits + BCE seed are formed here
+  if (bce_here && !bce_deferred(c)) return adt_set_error("backward: phase bit 4 without the deferred-BCE forward (adt_sasrec_bce_deferred)");
   phase &= 3;
+  auto logits_scatter = [&](void* s) {      // d log_feats + item rows of pos / neg (+ logits and BCE seed on the deferred path)   (sasrec/model.py:72-76)
+    if (bce_here)
+      return adt_logits_bce_scatter(f, P + lo.item(), pos, neg, ws + w.norms, T, ws + w.posl, ws + w.negl, ws + w.g_pos, ws + w.g_neg, ws + w.loss,
+                                    gf, ws + w.rep, NREP, w.rep_stride, s);
+    return adt_logits_bwd_scatter(f, d, P + lo.item(), pos, neg, ws + w.g_pos, ws + w.g_neg, T, d, gf, d, ws + w.rep, NREP, w.rep_stride, s);
+  };
   // (one-phase backward by default: the two-phase form belongs to the data-parallel step, whose capture already carries the collectives'
   // stream; there the side stream measured 0.692 against 0.699 ms on a 1-rank RCCL group and is opt-in: ADT_SIDE_STREAM_DP=1)
   static int dp_on = -1;
@@ -641,7 +720,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       logits_side = 1;
     } else {
       if (adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride + (prep_zeroed ? 0 : (size_t)NREPP * w.prep_stride), (hipStream_t)st)) return adt_set_error("replica zero");
-      CK(adt_logits_bwd_scatter(f, d, P + lo.item(), pos, neg, ws + w.g_pos, ws + w.g_neg, T, d, gf, d, ws + w.rep, NREP, w.rep_stride, st));
+      CK(logits_scatter(st));
     }
     for (int i = nl - 1; i >= 0; --i) {
       float* gy = ws + w.g_dec_x + (i + 1) * Td;      // d loss / d (output of decoder layer i), complete
@@ -676,7 +755,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         void* s2 = nullptr;
         CK(side_enter(sd, 0, st, &s2));
         if (adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride, (hipStream_t)s2)) return adt_set_error("replica zero");
-        CK(adt_logits_bwd_scatter(f, d, P + lo.item(), pos, neg, ws + w.g_pos, ws + w.g_neg, T, d, gf, d, ws + w.rep, NREP, w.rep_stride, s2));
+        CK(logits_scatter(s2));
         logits_side = 2;
       }
       // cross attention core: dq2 -> s5, dkv2 -> s4

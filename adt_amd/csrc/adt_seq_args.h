@@ -40,6 +40,9 @@ struct SeqFwdArgs {
   const float* wp_base; const void* wp_img;        // pre-packed bf16 weight images (adt_wave.cuh: WPack); wp_img == nullptr: none
   unsigned long long* stamps;          // timing experiments only (ADT_SEQ_STAMPS): s_memtime per wave of workgroup 0 at phase ends
   int ablate;                          // timing experiments only (ADT_SEQ_ABLATE): 1 no saved-tensor stores, 2 no attention, 4 no ffn
+  // tail of the LAST encoder layer (optional): log_feats = last_layernorm(y) -> f_out, formed on the output tile while it is in registers
+  // (sasrec/model.py:48).  No loads: a global load this late in the kernel waits for every store the wave has issued before it (vmcnt is in order).
+  const float* lnl_gamma; const float* lnl_beta; float* f_out;
 };
 
 }  // namespace adt

@@ -18,7 +18,7 @@ constexpr int TQ_LP = TQ_MAXKT * 16;
 template <int NWT>
 struct SeqTtLds {
   static constexpr size_t wbytes = (size_t)NWT * TT_WIMG * 2, ibytes = (size_t)TQ_LP * TT_RS * 2;
-  static constexpr size_t vbytes = 1024 * sizeof(float);            // per-feature vectors (SeqVec offsets)
+  static constexpr size_t vbytes = 1152 * sizeof(float);            // per-feature vectors (SeqVec offsets)
   static constexpr size_t bytes = wbytes + 2 * ibytes + vbytes;
   __bf16* w[NWT]; __bf16* sK; __bf16* sV; float* vec;
   __device__ SeqTtLds(unsigned char* base) {
@@ -32,9 +32,10 @@ struct SeqTtLds {
 
 // offsets (floats) of the per-feature vectors in the LDS vector area
 enum SeqVec { SV_GAMMA = 0, SV_BETA = 64, SV_BIN = 128, SV_BO = 320, SV_GAMMA2 = 384, SV_BETA2 = 448, SV_B1 = 512, SV_B2 = 576, SV_BIN2 = 640,
-              SV_BO2 = 832, SV_WS = 896, SV_BS = 960 };
+              SV_BO2 = 832, SV_WS = 896, SV_BS = 960, SV_LNL_G = 1024, SV_LNL_B = 1088 };
+constexpr int SV_FLOATS = 1152;
 
-// all vectors in one pass: element i of the 1,024-float area comes from segment i >> 6.  Split into the global loads (issued together
+// all vectors in one pass: element i of the 1,152-float area comes from segment i >> 6.  Split into the global loads (issued together
 // with the weight-image loads at kernel entry) and the LDS stores (after the zero-fill), so the prologue pays ONE global round trip.
 struct TqVecRegs { float v[2]; };
 template <int NTHREADS>
@@ -58,8 +59,10 @@ ADT_DEVICE_INLINE TqVecRegs tq_vec_load(const SeqFwdArgs& a, int H, int HD) {
       case 13: src = a.bo2; break;
       case 14: src = (a.rec && j < H * HD) ? a.Ws : nullptr; break;
       case 15: src = (a.rec && j < H) ? a.bs : nullptr; break;
+      case 16: src = a.lnl_gamma; break;
+      case 17: src = a.lnl_gamma ? a.lnl_beta : nullptr; break;
     }
-    r.v[it] = (i < 1024 && src) ? src[j] : 0.f;
+    r.v[it] = (i < SV_FLOATS && src) ? src[j] : 0.f;
   }
   return r;
 }
@@ -68,7 +71,7 @@ ADT_DEVICE_INLINE void tq_vec_store(float* vec, const TqVecRegs& r) {
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int i = threadIdx.x + it * NTHREADS;
-    if (i < 1024) vec[i] = r.v[it];
+    if (i < SV_FLOATS) vec[i] = r.v[it];
   }
 }
 
@@ -383,6 +386,7 @@ __global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) 
     tt_add(y, h2);
     if (!valid || idm[s] == 0) y = tt_zero();
     tq_store_y(a, row, y, valid, g);
+    if (a.f_out) tt_store(a.f_out + (size_t)row * 64, tt_layernorm(y, lds.vec + SV_LNL_G, lds.vec + SV_LNL_B, a.ln_eps, g), valid, g);   // log_feats (model.py:48)
     TQ_STAMP(7 + 3 * s);
   }
 }

@@ -182,6 +182,21 @@ class SASRecADT(torch.nn.Module):
                                                        slot_ints, nslots, _ptr(ids_dst), _ptr(state), _ptr(consumed), _ptr(self.flat),
                                                        _ptr(self.flat_grad), self.flat_grad.numel(), _ptr(scal), self._stream()), "sasrec_step_begin_ring")
 
+    def bce_deferred(self):
+        """True when run_forward_loss leaves logits + BCE seed to run_backward(..., bce=True) (adt_sasrec_bce_deferred)."""
+        return bool(self.lib.adt_sasrec_bce_deferred(ctypes.byref(self.cfg)))
+
+    def run_forward_loss(self, seq, dec, pos, neg, B, lambdas1, lambdas2, b_offset=0, training=True, packed=True):
+        """run_forward(training) + run_loss_seed(zero_loss=False) of one step in one call (adt_sasrec_forward_loss).  Returns True when the
+        logits + BCE seed were deferred to the backward: pass bce=True to run_backward of the same step."""
+        nl = self.num_layers
+        l1 = (ctypes.c_float * nl)(*[float(x) for x in lambdas1])
+        l2 = (ctypes.c_float * nl)(*[float(x) for x in lambdas2])
+        _lib.check(self.lib.adt_sasrec_forward_loss(ctypes.byref(self.cfg), _ptr(self.flat), _ptr(self.workspace(B)), _ptr(seq), _ptr(dec),
+                                                    _ptr(pos), _ptr(neg), B, int(bool(training)) | (2 if packed else 0), _ptr(self._seed),
+                                                    b_offset, l1, l2, self._stream()), "sasrec_forward_loss")
+        return bool(training) and packed and self.bce_deferred()
+
     def run_loss_seed(self, pos, B, lambdas1, lambdas2, zero_loss=True):
         nl = self.num_layers
         l1 = (ctypes.c_float * nl)(*[float(x) for x in lambdas1])
@@ -189,12 +204,13 @@ class SASRecADT(torch.nn.Module):
         fn = self.lib.adt_sasrec_loss_seed if zero_loss else self.lib.adt_sasrec_loss_seed_nz
         _lib.check(fn(ctypes.byref(self.cfg), _ptr(self.workspace(B)), _ptr(pos), B, l1, l2, self._stream()), "sasrec_loss_seed")
 
-    def run_backward(self, seq, dec, pos, neg, B, training, b_offset=0, phase=0, prezeroed=False, defer_fold=False):
+    def run_backward(self, seq, dec, pos, neg, B, training, b_offset=0, phase=0, prezeroed=False, defer_fold=False, bce=False):
         """prezeroed: run_step_begin / run_step_begin_ring of THIS step already zeroed the parameter-gradient replicas (bit 2 of `phase`).
         defer_fold (phase 0 only): the last replica fold is left to run_fold_clip_adam, which must follow (bit 3)."""
         _lib.check(self.lib.adt_sasrec_backward(ctypes.byref(self.cfg), _ptr(self.flat), _ptr(self.flat_grad), _ptr(self.workspace(B)),
                                                 _ptr(seq), _ptr(dec), _ptr(pos), _ptr(neg), B, int(training), _ptr(self._seed),
-                                                b_offset, phase | (4 if prezeroed else 0) | (8 if defer_fold and phase == 0 else 0), self._stream()),
+                                                b_offset, phase | (4 if prezeroed else 0) | (8 if defer_fold and phase == 0 else 0) |
+                                                (16 if bce and phase in (0, 1) else 0), self._stream()),
                    "sasrec_backward")
 
     def run_fold_clip_adam(self, B, m, v, wd, clip, lr, b1, b2, eps, scal):

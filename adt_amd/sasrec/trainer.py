@@ -93,18 +93,18 @@ class FusedTrainer:
             m.run_step_begin(B, self._norms_dev, self.scal)
         else:
             m.run_step_begin_ring(B, src[0], self._st["n_int"], src[1], self._devbuf, src[2], src[3], self.scal)
-        m.run_forward(seq, dec, pos, neg, B, True, b_offset, packed=True)      # run_step_begin* above packed the weight images ...
-        m.run_loss_seed(pos, B, self.lambdas1, self.lambdas2, zero_loss=False)
+        # forward + loss assembly (run_step_begin* above packed the weight images and zeroed the loss slots ...)
+        bce = m.run_forward_loss(seq, dec, pos, neg, B, self.lambdas1, self.lambdas2, b_offset)      # bce: logits + BCE seed left to the backward
         if not self._buckets.active:
             # ... and zeroed the parameter-gradient replicas ; the last fold of the replicas happens inside the optimizer's first kernel
-            m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=0, prezeroed=True, defer_fold=True)
+            m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=0, prezeroed=True, defer_fold=True, bce=bce)
             m.run_fold_clip_adam(B, self.m, self.v, self.wd, self.clip, self.lr, self.betas[0], self.betas[1], self.eps, self.scal)
             return
         else:
             # two buckets: the decoder bucket's all-reduce (RCCL, its own stream) overlaps the encoder's backward.
             # NOTE: phase 1 also scatters the decoder-input embedding rows, which live in the encoder bucket
             # (item/pos tables at flat offset 0) -- that bucket is reduced after phase 2, so nothing is lost.
-            m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=1, prezeroed=True)
+            m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=1, prezeroed=True, bce=bce)
             self._buckets.tail_ready()
             m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=2)
             self._buckets.finish()

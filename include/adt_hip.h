@@ -376,12 +376,22 @@ int adt_sasrec_step_begin_ring(const adt_sasrec_cfg* cfg, float* ws, int B, uint
                                float* grads, int64_t n, float* scal, void* stream);
 int adt_sasrec_loss_seed_nz(const adt_sasrec_cfg* cfg, float* ws, const int32_t* pos, int B, const float* lambdas1,
                             const float* lambdas2, void* stream);
+/* adt_sasrec_forward + adt_sasrec_loss_seed_nz of one training step (sasrec/model.py:67-81 + sasrec/main.py:151-169) in one call.  When
+ * adt_sasrec_bce_deferred(cfg) is 1 (bf16, d = 64, the lean per-sequence kernels cover the shape, <= 4 blocks) and training == 3 (dropout on,
+ * weight images packed by adt_sasrec_step_begin* of this step), log_feats is written by the last encoder layer's own kernel and the pos / neg
+ * logits + BCE seed + BCE loss terms are NOT formed here: adt_sasrec_backward of the same step must be called with phase bit 4 (+ 16) and
+ * forms them in its first side kernel, which gathers the same rows.  Otherwise the two calls in sequence.  ADT_FWD_FUSED=0: never deferred. */
+int adt_sasrec_bce_deferred(const adt_sasrec_cfg* cfg);
+int adt_sasrec_forward_loss(const adt_sasrec_cfg* cfg, const float* params, float* ws, const int32_t* seq, const int32_t* dec,
+                            const int32_t* pos, const int32_t* neg, int B, int training, const uint32_t* seed, uint32_t b_offset,
+                            const float* lambdas1, const float* lambdas2, void* stream);
 /* reverse pass: consumes the G_* buffers (destroyed), accumulates into `grads` (same layout as params).
  * phase: 0 = everything; 1 = logits + decoder stack only; 2 = last LN + encoder stack + embeddings (lets the
  * host overlap the gradient all-reduce of the decoder bucket with phase 2).  + 4: the parameter-gradient replicas were already zeroed by
  * adt_sasrec_step_begin / _ring of this step.  With phase 0 the scatter / fold kernels run on a side stream of the library under the
  * chain kernels (joined before the call returns its last launch; ADT_SIDE_STREAM=0 keeps everything on `stream`).  + 8 (with phase 0 only):
- * the last fold of the gradient replicas into `grads` is left to adt_sasrec_fold_clip_adam, which must follow. */
+ * the last fold of the gradient replicas into `grads` is left to adt_sasrec_fold_clip_adam, which must follow.  + 16: the step's forward was
+ * adt_sasrec_forward_loss on the deferred path (adt_sasrec_bce_deferred): logits, BCE seed and BCE loss terms are formed here. */
 int adt_sasrec_backward(const adt_sasrec_cfg* cfg, const float* params, float* grads, float* ws,
                         const int32_t* seq, const int32_t* dec, const int32_t* pos, const int32_t* neg, int B,
                         int training, const uint32_t* seed, uint32_t b_offset, int phase, void* stream);
