@@ -101,6 +101,11 @@ SIGNATURES = {
     "adt_dense_workspace": (_I, [_P, _L]),
     "adt_dense_gradsrc": (_I, [_P, _I, _I, _I, _P, _F, _P, _U, _U, _I, _P, _I, _P, _I, _P, _P]),
     "adt_topk_masked": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "adt_item_sort_supported": (_I, [_I]),
+    "adt_item_sort_work_ints": (_L, [_I, _I, _I]),
+    "adt_item_sort": (_I, [_P, _I, _I, _I, _P, _P, _P, _U, _P, _P]),
+    "adt_item_segsum": (_I, [_P, _I, _I, _I, _U, _P, _F, _P, _F, _P, _I, _P]),
+    "adt_posemb_sum": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _U, _P, _P]),
     "adt_sasrec_param_layout": (_L, [_CP, _P]),
     "adt_sasrec_workspace_floats": (_L, [_CP, _I]),
     "adt_sasrec_ws_offset": (_L, [_CP, _I, _I, _I]),

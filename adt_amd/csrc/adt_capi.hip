@@ -8,6 +8,7 @@
 #include "adt_bwdchain.cuh"
 #include "adt_fwdchain.cuh"
 #include "adt_misc.cuh"
+#include "adt_itemgrad.cuh"
 #include "adt_rowops.cuh"
 
 using namespace adt;
@@ -546,6 +547,91 @@ int adt_loss_seeds(const float* pos_logits, const float* neg_logits, const int32
   return check_launch("loss_seeds");
 }
 
+// ---- deterministic item-table / positional-table gradient (adt_itemgrad.cuh) -----------------------------------------------------------
+namespace {
+struct ItemWork { int64_t hist, base, perm, pitem, pmeta, prow, pcoef, cflag, carry, total; int nblk; };
+ItemWork item_work(int nsrc, int T, int V1) {
+  ItemWork w;
+  const int64_t N = (int64_t)nsrc * T;
+  auto up = [](int64_t x) { return (x + 63) / 64 * 64; };
+  w.nblk = (int)((N + IG_PER_BLOCK - 1) / IG_PER_BLOCK);
+  int64_t o = 0;
+  w.hist = o; o += up((int64_t)IS_NCH * V1);
+  w.base = o; o += up(V1 + 1);
+  w.perm = o; o += up(N);
+  w.pitem = o; o += up(N);
+  w.pmeta = o; o += up(N);
+  w.prow = o; o += up(2 * N);          // 64-bit words
+  w.pcoef = o; o += up(2 * N);
+  w.cflag = o; o += up((int64_t)w.nblk * 4);
+  w.carry = o; o += up((int64_t)w.nblk * 2 * 64);
+  w.total = o;
+  return w;
+}
+}  // namespace
+
+int adt_item_sort_supported(int V1) { return V1 >= 2 && V1 <= IS_MAXV1 ? 1 : 0; }
+int64_t adt_item_sort_work_ints(int nsrc, int T, int V1) { return item_work(nsrc, T, V1).total; }
+
+/* kind[s] 0: rows[s] = gradient of an embedding layer's output (T x 64), summed as rows * emb_scale * keep / (1 - p) with the forward's dropout
+ * decisions (element index (t + row_offset) * 64 + f) ; 1: rows[s] * coef[s][t].  The pointers are only recorded here (the gather plan). */
+int adt_item_sort(const int32_t* const* ids, int nsrc, int T, int V1, const float* const* rows, const float* const* coef, const int* kind,
+                  uint32_t row_offset, int32_t* work, void* stream) {
+  if (nsrc < 1 || nsrc > 4 || T < 1 || !adt_item_sort_supported(V1)) return adt_set_error("item_sort: nsrc %d, T %d, %d items + 1", nsrc, T, V1);
+  if (((uintptr_t)work & 7) != 0) return adt_set_error("item_sort: work must be 8-byte aligned");
+  const ItemWork w = item_work(nsrc, T, V1);
+  ItemSortArgs a{};
+  for (int s = 0; s < 4; ++s) {
+    const int k = s < nsrc ? s : 0;
+    a.ids[s] = ids[k]; a.rows[s] = rows[k]; a.coef[s] = coef ? coef[k] : nullptr; a.kind[s] = kind[k];
+    if (s < nsrc && (!rows[s] || (kind[s] == 1 && (!coef || !coef[s])))) return adt_set_error("item_sort: source %d has no rows", s);
+  }
+  a.nsrc = nsrc; a.T = T; a.V1 = V1; a.hist = work + w.hist; a.base = work + w.base; a.perm = work + w.perm; a.pitem = work + w.pitem;
+  a.row_offset = row_offset; a.pmeta = reinterpret_cast<uint32_t*>(work + w.pmeta);
+  a.prow = reinterpret_cast<uint64_t*>(work + w.prow); a.pcoef = reinterpret_cast<uint64_t*>(work + w.pcoef);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)V1 * sizeof(int);
+  hipLaunchKernelGGL(k_isort_hist, dim3(IS_NCH), dim3(64), lds, s, a);
+  hipLaunchKernelGGL(k_isort_scan_chunks, dim3((V1 + 255) / 256), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_isort_scan_items, dim3(1), dim3(1024), 0, s, a);
+  hipLaunchKernelGGL(k_isort_place, dim3(IS_NCH), dim3(64), lds, s, a);
+  return check_launch("item_sort");
+}
+
+/* dE[item] (accumulate ? += : =) sum over the sorted entries of `item` that belong to the sources in src_mask (rows of items without entries are not touched). */
+int adt_item_segsum(const int32_t* work, int nsrc, int T, int V1, unsigned src_mask, const uint32_t* site, float p, const uint32_t* seed,
+                    float emb_scale, float* dE, int accumulate, void* stream) {
+  if (nsrc < 1 || nsrc > 4 || !adt_item_sort_supported(V1)) return adt_set_error("item_segsum: nsrc %d, %d items + 1", nsrc, V1);
+  const ItemWork w = item_work(nsrc, T, V1);
+  ItemSegArgs a{};
+  a.pitem = work + w.pitem; a.total = work + w.base + V1; a.nblk = w.nblk;
+  a.pmeta = reinterpret_cast<const uint32_t*>(work + w.pmeta);
+  a.prow = reinterpret_cast<const uint64_t*>(work + w.prow); a.pcoef = reinterpret_cast<const uint64_t*>(work + w.pcoef);
+  for (int s = 0; s < 4; ++s) a.site[s] = site ? site[s < nsrc ? s : 0] : 0u;
+  a.src_mask = src_mask & ((1u << nsrc) - 1u);
+  const DropCfg dc = adt_make_drop(p, seed, 0);
+  a.seed = seed; a.thr = dc.thr; a.dscale = dc.scale; a.emb_scale = emb_scale;
+  a.dE = dE; a.rmw = accumulate ? 1 : 0;
+  a.carry = reinterpret_cast<float*>(const_cast<int32_t*>(work) + w.carry); a.cflag = const_cast<int32_t*>(work) + w.cflag;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_item_segsum, dim3(w.nblk), dim3(IG_WAVES * 64), 0, s, a);
+  hipLaunchKernelGGL(k_item_carry, dim3(w.nblk), dim3(64), 0, s, a);
+  return check_launch("item_segsum");
+}
+
+/* dP[l] += sum_b [ids != 0] keep / (1 - p) dX[b, l] for nsrc (1 or 2) embedding layers, b ascending */
+int adt_posemb_sum(const int32_t* const* ids, const float* const* dX, const uint32_t* site, int nsrc, int B, int L, float p, const uint32_t* seed,
+                   uint32_t row_offset, float* dP, void* stream) {
+  if (nsrc < 1 || nsrc > 2) return adt_set_error("posemb_sum: nsrc %d", nsrc);
+  PosSumArgs a{};
+  for (int s = 0; s < 2; ++s) { const int k = s < nsrc ? s : 0; a.ids[s] = ids[k]; a.dX[s] = dX[k]; a.site[s] = site[k]; }
+  a.nsrc = nsrc; a.B = B; a.L = L;
+  const DropCfg dc = adt_make_drop(p, seed, 0);
+  a.seed = seed; a.thr = dc.thr; a.dscale = dc.scale; a.row_offset = row_offset; a.dP = dP;
+  hipLaunchKernelGGL(k_posemb_sum, dim3(L), dim3(PS_WAVES * 64), 0, (hipStream_t)stream, a);
+  return check_launch("posemb_sum");
+}
+
 int adt_clip_adam(float* P, float* G, float* M, float* V, int64_t n, int64_t nE, float wd, float clip, float lr,
                   float b1, float b2, float eps, float grad_scale, float* scal, void* stream) {
   OptArgs a{};
@@ -601,7 +687,7 @@ int adt_step_begin_launch(uint32_t* seed, uint32_t inc, float* norms_dst, const 
   if (npack < 0 || npack > 256 || (nz & 3)) return adt_set_error("step_begin: %d weight blocks, %lld floats to zero", npack, (long long)nz);
   StepBeginArgs a{seed, inc, norms_dst, norms_src, loss, nloss, scal, G, (size_t)n, E, (size_t)nE, nullptr, 0, 0, nullptr, 0, nullptr, nullptr};
   step_begin_extras(a, Z, nz, pack_base, pack_img, pack_offs, npack);
-  hipLaunchKernelGGL(k_step_begin, dim3(256 + 4 * a.pk.n), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_step_begin, dim3(256 + a.pk.n), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("step_begin");
 }
 
@@ -614,7 +700,7 @@ int adt_step_begin_ring_launch(uint32_t* seed, uint32_t inc, float* norms_dst, f
   if (npack < 0 || npack > 256 || (nz & 3)) return adt_set_error("step_begin_ring: %d weight blocks, %lld floats to zero", npack, (long long)nz);
   StepBeginArgs a{seed, inc, norms_dst, nullptr, loss, nloss, scal, G, (size_t)n, E, (size_t)nE, ring, (size_t)slot_ints, nslots, ids_dst, (size_t)n_ints, state, consumed};
   step_begin_extras(a, Z, nz, pack_base, pack_img, pack_offs, npack);
-  hipLaunchKernelGGL(k_step_begin, dim3(256 + 4 * a.pk.n), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_step_begin, dim3(256 + a.pk.n), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("step_begin_ring");
 }
 

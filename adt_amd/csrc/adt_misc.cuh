@@ -618,20 +618,26 @@ struct StepBeginArgs {
   float* Z; size_t nz;
   PackArgs pk;
 };
+constexpr int SB_RING_BLOCKS = 32;      // workgroups that fetch the id batch: enough bytes in flight for a PCIe read (25 x 16 B per thread at the
+                                        // flagship batch, eight at a time), few enough that their completion ticket is a short chain
 __global__ __launch_bounds__(256) void k_step_begin(StepBeginArgs a) {
   __shared__ float sbuf[4];
+  __shared__ __attribute__((aligned(16))) __bf16 spk[4 * WPACK_IMG];
   typedef int v4i __attribute__((ext_vector_type(4)));
-  const unsigned nblk = gridDim.x - 4u * (unsigned)a.pk.n;      // the workgroups of the step's own work ; the rest pack weight images, four per block
-  if (blockIdx.x >= nblk) { pack_wimg_block<4>(a.pk, (int)(blockIdx.x - nblk)); return; }
+  const unsigned nblk = gridDim.x - (unsigned)a.pk.n;      // the workgroups of the step's own work ; the rest pack weight images, one per block
+  if (blockIdx.x >= nblk) { pack_wimg_block_lds(a.pk, (int)(blockIdx.x - nblk), spk); return; }
+  const unsigned nring = a.ring ? (nblk < (unsigned)SB_RING_BLOCKS ? nblk : (unsigned)SB_RING_BLOCKS) : 0u;
+  const bool ring_blk = blockIdx.x < nring;
   const int32_t* slot = nullptr;
-  v4i idv[2];
+  constexpr int RU = 8;
+  v4i idv[RU];
   size_t n16 = 0;
-  if (a.ring) {      // requests first: the PCIe round trips run under the zero-fill and the ||E||^2 sums below
-    slot = a.ring + (size_t)(a.state[0] % (uint32_t)a.nslots) * a.slot_ints;
+  if (a.ring) slot = a.ring + (size_t)(a.state[0] % (uint32_t)a.nslots) * a.slot_ints;
+  if (ring_blk) {      // requests first: the PCIe round trips run under the zero-fill and the ||E||^2 sums below
     n16 = a.n_ints / 4;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x + (size_t)u * nblk * 256;
+    for (int u = 0; u < RU; ++u) {
+      const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x + (size_t)u * nring * 256;
       idv[u] = i < n16 ? __builtin_nontemporal_load(reinterpret_cast<const v4i*>(slot) + i) : v4i{0, 0, 0, 0};
     }
   }
@@ -641,11 +647,12 @@ __global__ __launch_bounds__(256) void k_step_begin(StepBeginArgs a) {
   if (blockIdx.x == 0 && threadIdx.x < (int)(a.n - n4 * 4)) a.G[n4 * 4 + threadIdx.x] = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.nz / 4; i += (size_t)nblk * 256)      // nz: a multiple of 4
     reinterpret_cast<float4*>(a.Z)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (blockIdx.x < 64) {
+  const unsigned eb = blockIdx.x - nring;       // the small jobs go to the workgroups behind the ring readers (nblk >= nring + 66)
+  if (blockIdx.x >= nring && eb < 64) {
     // 16-byte loads, four in flight (a scalar loop with a runtime trip count was 13 serial round trips at the ml-1m table: ~10 us)
     float acc = 0.f;
     const size_t nE4 = a.nE / 4, step = (size_t)64 * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t i = (size_t)eb * 256 + threadIdx.x;
     for (; i + 3 * step < nE4; i += 4 * step) {
       float4 v[4];
 #pragma unroll
@@ -657,33 +664,45 @@ __global__ __launch_bounds__(256) void k_step_begin(StepBeginArgs a) {
       const float4 v = reinterpret_cast<const float4*>(a.E)[i];
       acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
     }
-    if (blockIdx.x == 0 && threadIdx.x < (int)(a.nE - nE4 * 4)) { const float t = a.E[nE4 * 4 + threadIdx.x]; acc += t * t; }
+    if (eb == 0 && threadIdx.x < (int)(a.nE - nE4 * 4)) { const float t = a.E[nE4 * 4 + threadIdx.x]; acc += t * t; }
     const float s = block_sum(acc, sbuf);
-    if (threadIdx.x == 0) a.scal[64 + blockIdx.x] = s;
-  } else if (blockIdx.x == 64) {
+    if (threadIdx.x == 0) a.scal[64 + eb] = s;
+  } else if (eb == 64) {
     if (threadIdx.x < 64) a.scal[128 + threadIdx.x] = 0.f;
     for (int i = threadIdx.x; i < a.nloss; i += 256) a.loss[i] = 0.f;
-  } else if (blockIdx.x == 65) {
+  } else if (eb == 65) {
     const float* nsrc = slot ? reinterpret_cast<const float*>(slot + a.n_ints - 4) : a.norms_src;
     if (threadIdx.x < 4 && a.norms_dst) a.norms_dst[threadIdx.x] = nsrc[threadIdx.x];
     if (threadIdx.x == 4 && a.seed) *a.seed += a.inc;
   }
-  if (a.ring) {
+  if (ring_blk) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x + (size_t)u * nblk * 256;
+    for (int u = 0; u < RU; ++u) {
+      const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x + (size_t)u * nring * 256;
       if (i < n16) reinterpret_cast<v4i*>(a.ids_dst)[i] = idv[u];
     }
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x + (size_t)2 * nblk * 256; i < n16; i += (size_t)nblk * 256)      // larger batches
-      reinterpret_cast<v4i*>(a.ids_dst)[i] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(slot) + i);
-    __syncthreads();      // every thread of the block has its slot words in registers / stored: the block is done with the slot
+    for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x + (size_t)RU * nring * 256; i0 < n16; i0 += (size_t)RU * nring * 256) {      // larger batches
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const size_t i = i0 + (size_t)u * nring * 256;
+        idv[u] = i < n16 ? __builtin_nontemporal_load(reinterpret_cast<const v4i*>(slot) + i) : v4i{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const size_t i = i0 + (size_t)u * nring * 256;
+        if (i < n16) reinterpret_cast<v4i*>(a.ids_dst)[i] = idv[u];
+      }
+    }
+    // every word this block reads has arrived in registers (it was stored): the block is done with the slot.  The ticket only counts
+    // completed READS -- nothing another agent reads is published here, so no release fence (a __threadfence() here wrote back the L2 lines
+    // this block's zero-fill had dirtied, ~6 us) -- and it is taken by the nring reading blocks only (256 tickets on one word were a
+    // chain of 256 same-line atomics, ~5 us).
+    __syncthreads();
     if (threadIdx.x == 0) {
-      __threadfence();
-      if (atomicAdd(a.state + 1, 1u) == nblk - 1) {      // the last block: every block has read state[0] and its part of the slot
+      if (atomicAdd(a.state + 1, 1u) == nring - 1) {      // the last reader: every reader has read state[0] and its part of the slot
         a.state[1] = 0u;
         const uint32_t c = a.state[0] + 1u;
         a.state[0] = c;
-        __threadfence_system();
         if (a.consumed) __hip_atomic_store(a.consumed, c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }

@@ -123,6 +123,38 @@ __device__ __forceinline__ void pack_wimg_block(const PackArgs& a, int blk_part)
     }
   }
 }
+// The same four images of ONE block by one workgroup of 256 threads through LDS (sp: 4 * WPACK_IMG bf16): the fp32 block is read with 16-byte
+// loads, the images are assembled in LDS (2-byte LDS stores) and leave with 16-byte global stores.  pack_wimg_block writes the images with
+// 16k scattered 2-byte global stores per block, the slowest store form there is (MI355X_MICROARCH.md, "stores of each flavour").
+__device__ __forceinline__ void pack_wimg_block_lds(const PackArgs& a, int blk, __bf16* sp) {
+  const int off = a.off[blk];
+  const float* W = a.base + off;
+  float4 v[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) v[it] = *reinterpret_cast<const float4*>(W + (threadIdx.x + it * 256) * 4);
+  for (int i = threadIdx.x; i < 4 * WPACK_IMG / 8; i += 256) reinterpret_cast<uint4*>(sp)[i] = make_uint4(0u, 0u, 0u, 0u);      // the row padding
+  __syncthreads();
+  __bf16 *plain = sp, *trans = sp + WPACK_IMG, *splain = sp + 2 * WPACK_IMG, *strans = sp + 3 * WPACK_IMG;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int i = threadIdx.x + it * 256;
+    const int n = i >> 4, k4 = (i & 15) * 4;
+    const float x[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+    const int ns = (n & 32) + 8 * ((n >> 2) & 3) + 4 * ((n >> 4) & 1) + (n & 3);      // slot position of column n in a transposed row
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k4 + j;
+      const int ks = (k & 32) + 8 * ((k >> 2) & 3) + 4 * ((k >> 4) & 1) + (k & 3);
+      plain[n * 72 + k] = (__bf16)x[j];
+      trans[k * 72 + n] = (__bf16)x[j];
+      splain[n * 72 + ks] = (__bf16)x[j];
+      strans[k * 72 + ns] = (__bf16)x[j];
+    }
+  }
+  __syncthreads();
+  uint4* dst = reinterpret_cast<uint4*>(a.img + 6 * (size_t)off);
+  for (int i = threadIdx.x; i < 4 * WPACK_IMG / 8; i += 256) dst[i] = reinterpret_cast<const uint4*>(sp)[i];
+}
 struct WPack {
   const float* base;       // start of the packed parameter range (the positional table: everything after the item table)
   const __bf16* img;       // nullptr: not packed (fp32-exact mode, or a caller that did not pack)

@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["adt_capi.hip", "adt_sasrec.hip", "adt_wide.hip", "adt_seq.hip", "adt_lce.hip"]
-HEADERS = ["adt_common.cuh", "adt_rowops.cuh", "adt_attn.cuh", "adt_attn_bf16.cuh", "adt_misc.cuh", "adt_wave.cuh", "adt_bwdchain.cuh", "adt_bwdchain_args.h", "adt_fwdchain.cuh", "adt_fwdchain_args.h", "adt_seq_args.h", "adt_seqfwd.cuh", "adt_seqfwd_tt.cuh", "adt_tt.cuh", "adt_seqattn.cuh", "adt_seqbwd_tt.cuh", "adt_seqbwd_args.h", "adt_seqpost_tt.cuh", "adt_host.h", "adt_gemm.cuh", "adt_attn_gen.cuh", "adt_wide.cuh", "adt_stosa.cuh", "adt_wattn_mfma.cuh", "adt_lce.cuh", "../../include/adt_hip.h"]
+HEADERS = ["adt_common.cuh", "adt_itemgrad.cuh", "adt_rowops.cuh", "adt_attn.cuh", "adt_attn_bf16.cuh", "adt_misc.cuh", "adt_wave.cuh", "adt_bwdchain.cuh", "adt_bwdchain_args.h", "adt_fwdchain.cuh", "adt_fwdchain_args.h", "adt_seq_args.h", "adt_seqfwd.cuh", "adt_seqfwd_tt.cuh", "adt_tt.cuh", "adt_seqattn.cuh", "adt_seqbwd_tt.cuh", "adt_seqbwd_args.h", "adt_seqpost_tt.cuh", "adt_host.h", "adt_gemm.cuh", "adt_attn_gen.cuh", "adt_wide.cuh", "adt_stosa.cuh", "adt_wattn_mfma.cuh", "adt_lce.cuh", "../../include/adt_hip.h"]
 OUT = os.path.join(HERE, "libadt_hip.so")
 
 

@@ -461,3 +461,39 @@ def dense_rows_enable(on):
     """bf16 dense layers: True = row-streaming kernels where the shape allows (default), False = always the tiled kernels.
     Returns the previous setting."""
     return bool(_lib.load().adt_dense_rows_enable(int(bool(on))))
+
+
+# ---- deterministic item-table / positional-table gradient (include/adt_hip.h: adt_item_sort ...) -----------------------------------------
+def _ptr_array(tensors, n):
+    arr = (ctypes.c_void_p * n)()
+    for i in range(n):
+        t = tensors[i] if i < len(tensors) else None
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def item_sort(ids_list, V1, rows, coef, kind, row_offset=0):
+    """Sorts the entries (src, t) of the int32 id tensors in ids_list (same length T each) by item and records the gather plan (rows / coef /
+    kind per source: include/adt_hip.h); returns the work buffer for item_segsum."""
+    lib = _lib.load()
+    nsrc, T = len(ids_list), ids_list[0].numel()
+    work = torch.empty(lib.adt_item_sort_work_ints(nsrc, T, V1) + 2, device=ids_list[0].device, dtype=torch.int32)
+    kinds = (ctypes.c_int * 4)(*[int(kind[i]) if i < len(kind) else 0 for i in range(4)])
+    _lib.check(lib.adt_item_sort(_ptr_array([_i32(t) for t in ids_list], 4), nsrc, T, V1, _ptr_array(rows, 4), _ptr_array(coef, 4), kinds,
+                                 row_offset, _p(work), _stream()), "item_sort")
+    work._adt_keep = (rows, coef)          # the plan holds their addresses
+    return work
+
+
+def item_segsum(work, nsrc, T, V1, src_mask, site, p, seed, emb_scale, dE, accumulate=False):
+    """dE[item] (+)= the sorted entries of `item` from the sources in src_mask (adt_item_segsum)."""
+    sites = (ctypes.c_uint32 * 4)(*[int(site[i]) if i < len(site) else 0 for i in range(4)])
+    _lib.check(_lib.load().adt_item_segsum(_p(work), nsrc, T, V1, src_mask, sites, float(p), _p(seed), float(emb_scale), _p(_f32(dE)),
+                                           int(bool(accumulate)), _stream()), "item_segsum")
+
+
+def posemb_sum(ids_list, dX_list, sites, B, L, p, seed, row_offset, dP):
+    n = len(ids_list)
+    s = (ctypes.c_uint32 * 2)(*[int(sites[i]) if i < n else 0 for i in range(2)])
+    _lib.check(_lib.load().adt_posemb_sum(_ptr_array([_i32(t) for t in ids_list], 2), _ptr_array(dX_list, 2), s, n, B, L, float(p), _p(seed),
+                                          row_offset, _p(_f32(dP)), _stream()), "posemb_sum")

@@ -376,6 +376,26 @@ int adt_sasrec_step_begin_ring(const adt_sasrec_cfg* cfg, float* ws, int B, uint
                                float* grads, int64_t n, float* scal, void* stream);
 int adt_sasrec_loss_seed_nz(const adt_sasrec_cfg* cfg, float* ws, const int32_t* pos, int B, const float* lambdas1,
                             const float* lambdas2, void* stream);
+/* ---- Deterministic item-table / positional-table gradient (sasrec/model.py:34-41, :53-59, :72-76 reversed; d = 64) -----------------------
+ * The reference's autograd adds the rows that hit one item in a fixed order; float-atomic scatters add in arrival order.  Here the step's id
+ * arrays are sorted once (stable counting sort of the entries e = src * T + t by item: a pure function of the ids) and every item's rows are
+ * summed by one owner in sorted order -- no float atomics, two runs give the same bits.  item_num + 1 <= 16,000 (adt_item_sort_supported).
+ * work: adt_item_sort_work_ints(nsrc, T, item_num + 1) int32 of scratch, written by adt_item_sort, read by adt_item_segsum. */
+int adt_item_sort_supported(int V1);
+int64_t adt_item_sort_work_ints(int nsrc, int T, int V1);
+/* Sorts the entries and records the gather plan: rows[s] (T x 64 floats) are the rows source s contributes, kind[s] = 0: the gradient of
+ * an embedding layer's output, summed as rows * emb_scale * keep / (1 - p) with keep = the forward's dropout decision at site[s] (element
+ * index (t + row_offset) * 64 + f) ; kind[s] = 1: rows[s] * coef[s][t] (the logits' item rows: log_feats * dlogit).  Only the POINTERS are
+ * recorded: the values are read by adt_item_segsum.  work: 8-byte aligned. */
+int adt_item_sort(const int32_t* const* ids, int nsrc, int T, int V1, const float* const* rows, const float* const* coef, const int* kind,
+                  uint32_t row_offset, int32_t* work, void* stream);
+/* dE[item] = (accumulate ? dE[item] : 0) + sum of the sorted entries of `item` from the sources in src_mask (bit s = id array s of
+ * adt_item_sort); rows of items without entries are left alone (zero dE first).  accumulate = 0 is the fast form: plain stores. */
+int adt_item_segsum(const int32_t* work, int nsrc, int T, int V1, unsigned src_mask, const uint32_t* site, float p, const uint32_t* seed,
+                    float emb_scale, float* dE, int accumulate, void* stream);
+/* dP[l] += sum_b [ids[b, l] != 0] * keep / (1 - p) * dX[b, l] for nsrc (1 or 2) embedding layers, b ascending (one owner per position) */
+int adt_posemb_sum(const int32_t* const* ids, const float* const* dX, const uint32_t* site, int nsrc, int B, int L, float p, const uint32_t* seed,
+                   uint32_t row_offset, float* dP, void* stream);
 /* adt_sasrec_forward + adt_sasrec_loss_seed_nz of one training step (sasrec/model.py:67-81 + sasrec/main.py:151-169) in one call.  When
  * adt_sasrec_bce_deferred(cfg) is 1 (bf16, d = 64, the lean per-sequence kernels cover the shape, <= 4 blocks) and training == 3 (dropout on,
  * weight images packed by adt_sasrec_step_begin* of this step), log_feats is written by the last encoder layer's own kernel and the pos / neg
