@@ -344,7 +344,7 @@ struct LogitsBceArgs {
 __global__ __launch_bounds__(256) void k_logits_bce_scatter(LogitsBceArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-  float* dE = a.rep + (a.nrep > 1 ? (size_t)(wave % a.nrep) * a.rep_stride : 0);
+  float* dE = a.rep ? a.rep + (a.nrep > 1 ? (size_t)(wave % a.nrep) * a.rep_stride : 0) : nullptr;
   const float inv = 1.0f / a.norms[0];
   float lp = 0.f, ln = 0.f;
   // a wave owns R <= 64 CONSECUTIVE rows and keeps their four per-row scalars in lanes 0 .. R-1: one coalesced store per array at the end.
@@ -392,6 +392,7 @@ __global__ __launch_bounds__(256) void k_logits_bce_scatter(LogitsBceArgs a) {
         }
       }
       a.dF[(size_t)row * 64 + lane] = gp * p[u] + gn * q[u];
+      if (a.rep == nullptr) continue;           // the item rows are summed elsewhere (adt_itemgrad.cuh: sorted segments)
       if (ip[u] != 0 && gp != 0.f) atomicAdd(dE + (size_t)ip[u] * 64 + lane, f[u] * gp);
       if (in[u] != 0 && gn != 0.f) atomicAdd(dE + (size_t)in[u] * 64 + lane, f[u] * gn);
     }

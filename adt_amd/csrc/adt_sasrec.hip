@@ -68,6 +68,7 @@ struct WS {
   int64_t prep, prep_stride;                                            // replicas of every other parameter gradient
   int64_t wpack;                                                        // pre-packed bf16 weight images (3 floats per parameter float)
   int64_t part, part_stride;                                            // per-sequence partials of the 64 x 64 weight gradients (bf16 mode, d = 64)
+  int64_t isort, isort_n;                                               // scratch of the sorted item-table gradient (adt_item_sort), isort_n int32 (0: not used)
   int64_t total;
 };
 
@@ -110,6 +111,8 @@ void make_ws(const adt_sasrec_cfg* c, int B, WS* w) {
   }
   w->part_stride = (c->prec == ADT_PREC_BF16 && c->hidden == 64) ? (int64_t)w->nl * 16 * 4096 : 0;
   w->part = take((int64_t)B * w->part_stride);
+  w->isort_n = (c->hidden == 64 && adt_item_sort_supported(c->item_num + 1)) ? adt_item_sort_work_ints(4, (int)w->T, c->item_num + 1) : 0;
+  w->isort = take(up64(w->isort_n));
   w->total = o;
 }
 
@@ -123,7 +126,7 @@ void make_ws(const adt_sasrec_cfg* c, int B, WS* w) {
 // and with ADT_SIDE_STREAM=0, everything stays on the caller's stream.
 struct SideStream {
   hipStream_t s = nullptr;
-  hipEvent_t fork_ev[3] = {nullptr, nullptr, nullptr}, join_ev[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t fork_ev[4] = {nullptr, nullptr, nullptr, nullptr}, join_ev[4] = {nullptr, nullptr, nullptr, nullptr};      // [3]: the id sort
 };
 // ADT_SIDE_STREAM: bit 0 the logits' item rows, bit 1 the decoder's embedding gradient + partial sums, bit 2 the encoder's partial sums
 // (default 7, 0 = everything on the caller's stream)
@@ -145,7 +148,7 @@ SideStream* side_stream(hipStream_t main) {
   if (hipStreamIsCapturing(main, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
   hipStream_t s = nullptr;
   if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < 4; ++i)
     if (hipEventCreateWithFlags(&sd->fork_ev[i], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&sd->join_ev[i], hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError();
@@ -176,6 +179,14 @@ int side_join(SideStream* sd, int k, void* main) {
   if (hipEventRecord(sd->join_ev[k], sd->s) != hipSuccess || hipStreamWaitEvent((hipStream_t)main, sd->join_ev[k], 0) != hipSuccess)
     return adt_set_error("backward: side-stream join %d failed", k);
   return 0;
+}
+
+// The item-table and positional-table gradients as sorted segmented sums (adt_itemgrad.cuh) instead of float-atomic scatters into replicas:
+// deterministic, and no atomics-bound kernels beside the chain kernels.  ADT_ITEM_SORT=1 switches it on (default: the scatters).
+bool item_det(const WS& w) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("ADT_ITEM_SORT"); on = (e && atoi(e) != 0) ? 1 : 0; }      // opt-in: see DESIGN.md (costs ~55 us per step as it stands)
+  return on && w.isort_n > 0;
 }
 
 int check_cfg(const adt_sasrec_cfg* c) {
@@ -694,12 +705,16 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   const bool bce_here = (phase & 16) != 0;        // bit 4: the forward was adt_sasrec_forward_loss on the deferred path: logits + BCE seed are formed here
   if (bce_here && !bce_deferred(c)) return adt_set_error("backward: phase bit 4 without the deferred-BCE forward (adt_sasrec_bce_deferred)");
   phase &= 3;
+  const bool det = item_det(w);                   // item / positional table gradients by sorted segmented sums (no replicas, no float atomics)
   auto logits_scatter = [&](void* s) {      // d log_feats + item rows of pos / neg (+ logits and BCE seed on the deferred path)   (sasrec/model.py:72-76)
     if (bce_here)
       return adt_logits_bce_scatter(f, P + lo.item(), pos, neg, ws + w.norms, T, ws + w.posl, ws + w.negl, ws + w.g_pos, ws + w.g_neg, ws + w.loss,
-                                    gf, ws + w.rep, NREP, w.rep_stride, s);
+                                    gf, det ? nullptr : ws + w.rep, NREP, w.rep_stride, s);
+    if (det) return adt_logits_bwd_df(P + lo.item(), pos, neg, ws + w.g_pos, ws + w.g_neg, T, d, gf, d, s);
     return adt_logits_bwd_scatter(f, d, P + lo.item(), pos, neg, ws + w.g_pos, ws + w.g_neg, T, d, gf, d, ws + w.rep, NREP, w.rep_stride, s);
   };
+  int32_t* const iwork = reinterpret_cast<int32_t*>(ws + w.isort);
+  SideStream* const sd_sort = det ? side_stream((hipStream_t)st) : nullptr;      // the id sort runs beside the decoder's chain kernels, also in the two-phase form
   // (one-phase backward by default: the two-phase form belongs to the data-parallel step, whose capture already carries the collectives'
   // stream; there the side stream measured 0.692 against 0.699 ms on a 1-rank RCCL group and is opt-in: ADT_SIDE_STREAM_DP=1)
   static int dp_on = -1;
@@ -714,7 +729,21 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
     // The item-table rows of the logits (and d log_feats, first read by the reverse of the cross-attention projections) go to the side
     // stream: they run under the first two decoder kernels, which only need the parameter replicas zeroed.
     int logits_side = 0;      // 1: marked, to be enqueued behind the first chain kernel ; 2: enqueued, to be joined
-    if (sd && (side_sites() & 1)) {
+    if (det) {
+      // sort of the step's ids + gather plan (a function of the ids and of fixed workspace addresses only); joined in front of the sums
+      const int32_t* const ids4[4] = {seq, dec, pos, neg};
+      const float* const rows4[4] = {ws + w.g_enc_x, ws + w.g_dec_x, f, f};
+      const float* const coef4[4] = {nullptr, nullptr, ws + w.g_pos, ws + w.g_neg};
+      const int kind4[4] = {0, 0, 1, 1};
+      void* s2 = st;
+      if (sd_sort) { CK(side_mark(sd_sort, 3, st)); CK(side_enter(sd_sort, 3, st, &s2)); }
+      CK(adt_item_sort(ids4, 4, T, c->item_num + 1, rows4, coef4, kind4, ro, iwork, s2));
+      if (sd_sort && hipEventRecord(sd_sort->join_ev[3], sd_sort->s) != hipSuccess) return adt_set_error("backward: sort event");
+    }
+    if (det) {
+      if (!prep_zeroed && adt::zero_f32_async(ws + w.prep, (size_t)NREPP * w.prep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
+      CK(logits_scatter(st));      // no atomics left in it: a short streaming pass on the caller's stream
+    } else if (sd && (side_sites() & 1)) {
       CK(side_mark(sd, 0, st));
       if (!prep_zeroed && adt::zero_f32_async(ws + w.prep, (size_t)NREPP * w.prep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
       logits_side = 1;
@@ -841,7 +870,10 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       CK(side_mark(sd, 1, st));
       dec_side = 1;                      // enqueued behind the first kernel of the encoder phase
     } else if (phase == 0) {
-      CK(adt_embed_bwd_rep(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
+      if (!det) CK(adt_embed_bwd_rep(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
+    } else if (det) {      // two-phase form: the decoder blocks' partial sums and the fold of the decoder range (nothing of the tables yet)
+      if (parts) CK(reduce_partials(c, lo, w, G, ws, false, true, st));
+      CK(adt_replica_reduce(G + dec_begin, Gq + dec_begin, lo.total - dec_begin, NREPP, w.prep_stride, st));
     } else {
       void* s2 = nullptr;
       CK(side_mark(sd, 1, st));
@@ -860,7 +892,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
     if (dec_side == 1) {
       void* s2 = nullptr;
       CK(side_enter(sd, 1, st, &s2));
-      CK(adt_embed_bwd_rep(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, s2));
+      if (!det) CK(adt_embed_bwd_rep(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, s2));
       if (parts) { CK(reduce_partials(c, lo, w, G, ws, false, true, s2)); dec_parts_done = true; }
       dec_side = 2;
     }
@@ -930,7 +962,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         }
       }
     }
-    if (phase == 2 && adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
+    if (phase == 2 && !det && adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
     // the sum of the encoder blocks' partials runs beside the embedding gradient ; the fold (read-modify-write of the same range) behind both.
     // The side stream is in order: the join behind that sum also covers the decoder's work queued on it earlier -- a join of its own in front
     // of the embedding gradient was one more cross-queue wait (5-9 us) on the caller's stream.
@@ -940,13 +972,24 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       dec_side = 0;
       void* s2 = nullptr;
       CK(side_mark(sd2, 2, st));
-      CK(adt_embed_bwd_rep(seq, ws + w.g_enc_x, T, L, d, p, seed, SITE_EMB_SEQ, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
+      if (det) {
+        // item table: every item's rows (encoder ids, decoder ids, positive / negative items of the logits) summed by one owner in sorted
+        // order ; positional table: one owner per position.  (sasrec/model.py:34-41, :53-59, :72-76 reversed)
+        if (sd_sort && hipStreamWaitEvent((hipStream_t)st, sd_sort->join_ev[3], 0) != hipSuccess) return adt_set_error("backward: sort join");
+        const uint32_t site4[4] = {SITE_EMB_SEQ, SITE_EMB_DEC, 0u, 0u};
+        CK(adt_item_segsum(iwork, 4, T, c->item_num + 1, 0xFu, site4, p, seed, sqrtf((float)d), G + lo.item(), prep_zeroed ? 0 : 1, st));
+        const int32_t* const ids2[2] = {seq, dec};
+        const float* const dx2[2] = {ws + w.g_enc_x, ws + w.g_dec_x};
+        CK(adt_posemb_sum(ids2, dx2, site4, 2, (int)w.B, L, p, seed, ro, G + lo.posw(), st));
+      } else {
+        CK(adt_embed_bwd_rep(seq, ws + w.g_enc_x, T, L, d, p, seed, SITE_EMB_SEQ, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
+      }
       CK(side_enter(sd2, 2, st, &s2));
       if (parts) CK(reduce_partials(c, lo, w, G, ws, true, phase == 0 && !dec_parts_done, s2));
       CK(side_join(sd2, 2, st));
     }
     if (!defer_fold)
-      CK(adt_replica_reduce2(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, NREP, w.rep_stride, G + lo.posw(), Gq + lo.posw(),
+      CK(adt_replica_reduce2(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * d, det ? 0 : NREP, w.rep_stride, G + lo.posw(), Gq + lo.posw(),
                              (phase == 0 ? lo.total : dec_begin) - lo.posw(), NREPP, w.prep_stride, st));
   }
   return 0;
@@ -960,7 +1003,7 @@ int adt_sasrec_fold_clip_adam(const adt_sasrec_cfg* c, float* ws, int B, float* 
   WS w;
   make_ws(c, B, &w);
   float* const Gq = ws + w.prep - lo.posw();
-  return adt_fold_clip_adam(P, G, M, V, lo.total, G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * c->hidden, NREP, w.rep_stride, G + lo.posw(),
+  return adt_fold_clip_adam(P, G, M, V, lo.total, G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * c->hidden, item_det(w) ? 0 : NREP, w.rep_stride, G + lo.posw(),
                             Gq + lo.posw(), lo.total - lo.posw(), NREPP, w.prep_stride, wd, clip, lr, b1, b2, eps, scal, st);
 }
 
