@@ -16,6 +16,7 @@ SIGNATURES = {
     "adt_host_count_targets": (_L, [_P, _P, _I, _I]),
     "adt_host_pack_batch": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F]),
     "adt_host_wait_ge": (_I, [_P, _U, _L]),
+    "adt_host_store_release": (_I, [_P, _U]),
 }
 
 _lib = None
@@ -31,8 +32,8 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.adt_host_version() < 2:
-            raise RuntimeError("libadt_host.so is stale (version %d < 2): rebuild it" % lib.adt_host_version())
+        if lib.adt_host_version() < 3:
+            raise RuntimeError("libadt_host.so is stale (version %d < 3): rebuild it" % lib.adt_host_version())
         _lib = lib
     return _lib
 

@@ -534,8 +534,20 @@ int adt_loss_seeds(const float* pos_logits, const float* neg_logits, const int32
                    float* loss_bce, int nmse, const float* const* A, const float* const* Bm, int64_t n, const float* lambdas, float* const* GA,
                    int accumulate_a, float* const* GB, float* const* loss_mse, int nnll, const float* const* rec, int n_rows, int H, float lambda2,
                    float* const* drec, float* const* loss_nll, void* stream) {
+  return adt_loss_seeds_prefetch(pos_logits, neg_logits, pos, T, norms, dpos, dneg, loss_bce, nmse, A, Bm, n, lambdas, GA, accumulate_a, GB, loss_mse, nnll,
+                                 rec, n_rows, H, lambda2, drec, loss_nll, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, stream);
+}
+int adt_loss_seeds_prefetch(const float* pos_logits, const float* neg_logits, const int32_t* pos, int T, const float* norms, float* dpos, float* dneg,
+                            float* loss_bce, int nmse, const float* const* A, const float* const* Bm, int64_t n, const float* lambdas, float* const* GA,
+                            int accumulate_a, float* const* GB, float* const* loss_mse, int nnll, const float* const* rec, int n_rows, int H, float lambda2,
+                            float* const* drec, float* const* loss_nll, const int32_t* ring, int64_t slot_ints, int nslots, int64_t n_ints,
+                            uint32_t* state, uint32_t* consumed, int32_t* staging, void* stream) {
   if (nmse > 4 || nnll > 4 || n % 4) return adt_set_error("loss_seeds: at most 4 + 4 terms, n %% 4");
   LossSeedsArgs a{};
+  if (ring && staging && state) {
+    a.pf = RingPrefetchArgs{ring, (size_t)slot_ints, nslots, (size_t)n_ints, state, consumed, staging};
+    a.gp = 32;      // one round of 8 x 16-byte loads per thread covers the flagship batch (819 KB): a PCIe read wants everything in flight at once
+  }
   a.bce = BceArgs{pos_logits, neg_logits, pos, T, norms, dpos, dneg, loss_bce};
   for (int i = 0; i < nmse; ++i) a.mse[i] = MseArgs{A[i], Bm[i], (size_t)n, lambdas[i], norms, GA[i], accumulate_a, GB[i], loss_mse[i]};
   for (int i = 0; i < nnll; ++i) a.nll[i] = NllArgs{rec[i], n_rows, H, lambda2, norms, drec[i], loss_nll[i]};
@@ -543,7 +555,7 @@ int adt_loss_seeds(const float* pos_logits, const float* neg_logits, const int32
   a.gb = pos_logits ? grid_for(T, 256, 256) : 0;      // no logits: the BCE seed is formed elsewhere (adt_logits_bce_scatter)
   a.gm = nmse ? grid_for((size_t)n / 4, 256, 512) : 1;
   a.gn = nnll ? grid_for((size_t)n_rows * H * H, 256, 512) : 1;
-  hipLaunchKernelGGL(k_loss_seeds, dim3(a.gb + nmse * a.gm + nnll * a.gn), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_loss_seeds, dim3(a.gb + nmse * a.gm + nnll * a.gn + a.gp), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("loss_seeds");
 }
 
@@ -599,7 +611,7 @@ int adt_item_sort(const int32_t* const* ids, int nsrc, int T, int V1, const floa
 }
 
 /* dE[item] (accumulate ? += : =) sum over the sorted entries of `item` that belong to the sources in src_mask (rows of items without entries are not touched). */
-int adt_item_segsum(const int32_t* work, int nsrc, int T, int V1, unsigned src_mask, const uint32_t* site, float p, const uint32_t* seed,
+int adt_item_segsum(const int32_t* work, int nsrc, int T, int V1, uint32_t src_mask, const uint32_t* site, float p, const uint32_t* seed,
                     float emb_scale, float* dE, int accumulate, void* stream) {
   if (nsrc < 1 || nsrc > 4 || !adt_item_sort_supported(V1)) return adt_set_error("item_segsum: nsrc %d, %d items + 1", nsrc, V1);
   const ItemWork w = item_work(nsrc, T, V1);
@@ -693,12 +705,13 @@ int adt_step_begin_launch(uint32_t* seed, uint32_t inc, float* norms_dst, const 
 
 int adt_step_begin_ring_launch(uint32_t* seed, uint32_t inc, float* norms_dst, float* loss, int nloss, float* scal, float* G, int64_t n, const float* E,
                                int64_t nE, const int32_t* ring, int64_t slot_ints, int nslots, int32_t* ids_dst, int64_t n_ints, uint32_t* state,
-                               uint32_t* consumed, float* Z, int64_t nz, const float* pack_base, void* pack_img, const int* pack_offs, int npack,
-                               void* stream) {
+                               uint32_t* consumed, const int32_t* staging, const uint32_t* produced, float* Z, int64_t nz, const float* pack_base,
+                               void* pack_img, const int* pack_offs, int npack, void* stream) {
   if (!ring || !ids_dst || !state || nslots < 1 || n_ints < 4 || (n_ints & 3) || slot_ints < n_ints || (slot_ints & 3))
     return adt_set_error("step_begin_ring: ring %p, %d slots of %lld ints, %lld ints per step (multiples of 4)", (const void*)ring, nslots, (long long)slot_ints, (long long)n_ints);
   if (npack < 0 || npack > 256 || (nz & 3)) return adt_set_error("step_begin_ring: %d weight blocks, %lld floats to zero", npack, (long long)nz);
-  StepBeginArgs a{seed, inc, norms_dst, nullptr, loss, nloss, scal, G, (size_t)n, E, (size_t)nE, ring, (size_t)slot_ints, nslots, ids_dst, (size_t)n_ints, state, consumed};
+  StepBeginArgs a{seed, inc, norms_dst, nullptr, loss, nloss, scal, G, (size_t)n, E, (size_t)nE, ring, (size_t)slot_ints, nslots, ids_dst, (size_t)n_ints, state, consumed,
+                  staging, produced};
   step_begin_extras(a, Z, nz, pack_base, pack_img, pack_offs, npack);
   hipLaunchKernelGGL(k_step_begin, dim3(256 + a.pk.n), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("step_begin_ring");

@@ -66,8 +66,14 @@ int adt_step_begin_launch(uint32_t* seed, uint32_t inc, float* norms_dst, const 
                           int npack, void* stream);
 int adt_step_begin_ring_launch(uint32_t* seed, uint32_t inc, float* norms_dst, float* loss, int nloss, float* scal, float* G, int64_t n, const float* E,
                                int64_t nE, const int32_t* ring, int64_t slot_ints, int nslots, int32_t* ids_dst, int64_t n_ints, uint32_t* state,
-                               uint32_t* consumed, float* Z, int64_t nz, const float* pack_base, void* pack_img, const int* pack_offs, int npack,
-                               void* stream);
+                               uint32_t* consumed, const int32_t* staging, const uint32_t* produced, float* Z, int64_t nz, const float* pack_base,
+                               void* pack_img, const int* pack_offs, int npack, void* stream);
+// adt_loss_seeds + the prefetch of the next step's id batch into `staging` as extra workgroups of the same launch (adt_misc.cuh: ring_prefetch_body)
+int adt_loss_seeds_prefetch(const float* pos_logits, const float* neg_logits, const int32_t* pos, int T, const float* norms, float* dpos, float* dneg,
+                            float* loss_bce, int nmse, const float* const* A, const float* const* Bm, int64_t n, const float* lambdas, float* const* GA,
+                            int accumulate_a, float* const* GB, float* const* loss_mse, int nnll, const float* const* rec, int n_rows, int H, float lambda2,
+                            float* const* drec, float* const* loss_nll, const int32_t* ring, int64_t slot_ints, int nslots, int64_t n_ints,
+                            uint32_t* state, uint32_t* consumed, int32_t* staging, void* stream);
 int adt_loss_seeds(const float* pos_logits, const float* neg_logits, const int32_t* pos, int T, const float* norms, float* dpos, float* dneg,
                    float* loss_bce, int nmse, const float* const* A, const float* const* Bm, int64_t n, const float* lambdas, float* const* GA,
                    int accumulate_a, float* const* GB, float* const* loss_mse, int nnll, const float* const* rec, int n_rows, int H, float lambda2,

@@ -23,7 +23,7 @@ static inline uint64_t splitmix64(uint64_t& s) {
 
 extern "C" {
 
-int adt_host_version(void) { return 2; }
+int adt_host_version(void) { return 3; }
 
 // offsets: usernum + 2 entries (users are 1-based; history of user u = items[offsets[u] .. offsets[u+1]))
 // users: B user ids; outputs: B x L int32, row-major.  Returns 0, or -1 on bad arguments.
@@ -62,6 +62,10 @@ int adt_host_pack_batch(int32_t* dst, const int32_t* seq, const int32_t* dec, co
   dst[4 * T + 3] = 0;
   return 0;
 }
+
+// publish a 32-bit counter the GPU reads from pinned host memory: everything the caller wrote before (the batch's ids and normalisers) is
+// visible to a reader that sees the new value
+int adt_host_store_release(volatile uint32_t* p, uint32_t v) { __atomic_store_n(const_cast<uint32_t*>(p), v, __ATOMIC_RELEASE); return 0; }
 
 // wait until the 32-bit counter at p (written by the GPU into pinned host memory) has reached v, wrap-around safe; 0 ok, -1 timeout
 int adt_host_wait_ge(const volatile uint32_t* p, uint32_t v, int64_t timeout_us) {

@@ -565,9 +565,52 @@ __global__ __launch_bounds__(256) void k_nll_seed(NllArgs a) {
 // seeds are independent streaming passes; as five launches of 5-11 us each they cost 39 us at the flagship shape.  Blocks [0, gb) run the
 // BCE body, the next nmse * gm the MSE bodies, the last nnll * gn the NLL bodies (same arithmetic, same per-task block counts as the
 // stand-alone kernels).
+// Prefetch of the NEXT step's id batch (optional, the last `gp` workgroups of k_loss_seeds): the step's first kernel otherwise reads its batch
+// from the pinned host ring over PCIe (~16 us for the flagship's 819 KB) before anything else of the step can start.  If the producer has
+// already published the next batch (*produced > state[0], the count of batches fetched so far), these workgroups copy its slot into a
+// device staging buffer while the loss assembly streams, mark it staged (state[2] = batch index + 1) and release the slot (*consumed);
+// k_step_begin of the next step then copies the batch HBM -> HBM.  Not published yet: nothing happens, the next step reads the ring itself.
+// state: [0] batches fetched, [1] k_step_begin's ticket, [2] staged batch + 1, [3] the prefetch ticket, [4] *produced as k_step_begin saw it,
+// [5] statistics: batches k_step_begin took from the staging buffer.
+struct RingPrefetchArgs {
+  const int32_t* ring; size_t slot_ints; int nslots; size_t n_ints; uint32_t* state; uint32_t* consumed; int32_t* staging;
+};
+ADT_DEVICE_INLINE void ring_prefetch_body(const RingPrefetchArgs& a, int bid, int nblk) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const uint32_t k = a.state[0];                      // index of the next batch (this step's k_step_begin has counted its own)
+  if (a.state[4] <= k) return;                        // state[4]: the producer's count as k_step_begin of this step saw it -- the same answer in every workgroup
+  const int32_t* slot = a.ring + (size_t)(k % (uint32_t)a.nslots) * a.slot_ints;
+  const size_t n16 = a.n_ints / 4;
+  constexpr int RU = 8;
+  for (size_t i0 = (size_t)bid * 256 + threadIdx.x; i0 < n16; i0 += (size_t)RU * nblk * 256) {
+    v4i v[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const size_t i = i0 + (size_t)u * nblk * 256;
+      v[u] = i < n16 ? __builtin_nontemporal_load(reinterpret_cast<const v4i*>(slot) + i) : v4i{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const size_t i = i0 + (size_t)u * nblk * 256;
+      if (i < n16) reinterpret_cast<v4i*>(a.staging)[i] = v[u];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // no fences: the staging words and state[2] are read by the NEXT launch (a kernel boundary orders them), and the host only learns that
+    // the slot has been READ -- a system-scope release here would write back every dirty L2 line of the running step first
+    if (atomicAdd(a.state + 3, 1u) == (uint32_t)nblk - 1u) {
+      a.state[3] = 0u;
+      a.state[2] = k + 1u;
+      if (a.consumed) __hip_atomic_store(a.consumed, k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 struct LossSeedsArgs {
   BceArgs bce; MseArgs mse[4]; NllArgs nll[4];
-  int nmse, nnll, gb, gm, gn;
+  int nmse, nnll, gb, gm, gn, gp;
+  RingPrefetchArgs pf;
 };
 __global__ __launch_bounds__(256) void k_loss_seeds(LossSeedsArgs a) {
   __shared__ float sbuf[4];
@@ -576,8 +619,9 @@ __global__ __launch_bounds__(256) void k_loss_seeds(LossSeedsArgs a) {
   b -= a.gb;
   if (b < a.nmse * a.gm) { const int k = b / a.gm; mse_body(a.mse[k], b - k * a.gm, a.gm, sbuf); return; }
   b -= a.nmse * a.gm;
-  const int k = b / a.gn;
-  nll_body(a.nll[k], b - k * a.gn, a.gn, sbuf);
+  if (b < a.nnll * a.gn) { const int k = b / a.gn; nll_body(a.nll[k], b - k * a.gn, a.gn, sbuf); return; }
+  b -= a.nnll * a.gn;
+  if (b < a.gp) ring_prefetch_body(a.pf, b, a.gp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -613,6 +657,8 @@ struct StepBeginArgs {
   // ids_dst (n_ints int32, a multiple of 4; its last four words are the loss normalisers, which then replace norms_src).  The last block
   // to finish bumps state[0] and publishes the new count to *consumed (pinned host word the producer polls before it refills a slot).
   const int32_t* ring; size_t slot_ints; int nslots; int32_t* ids_dst; size_t n_ints; uint32_t* state; uint32_t* consumed;
+  const int32_t* staging;            // optional: device copy of a prefetched batch, valid when state[2] == state[0] + 1 (ring_prefetch_body)
+  const uint32_t* produced;          // optional: the producer's published batch count (pinned host word), sampled into state[4]
   // optional extras of the model-level step (adt_sasrec_step_begin*): a second range to zero (the parameter-gradient replicas the backward
   // chains flush into) and the bf16 weight images of the step (pk.n blocks, packed by the LAST pk.n workgroups of the grid: k_pack_wimg's
   // work without its launch)
@@ -633,7 +679,10 @@ __global__ __launch_bounds__(256) void k_step_begin(StepBeginArgs a) {
   constexpr int RU = 8;
   v4i idv[RU];
   size_t n16 = 0;
-  if (a.ring) slot = a.ring + (size_t)(a.state[0] % (uint32_t)a.nslots) * a.slot_ints;
+  if (a.ring) {
+    const uint32_t k = a.state[0];
+    slot = (a.staging && a.state[2] == k + 1u) ? a.staging : a.ring + (size_t)(k % (uint32_t)a.nslots) * a.slot_ints;      // prefetched by the previous step?
+  }
   if (ring_blk) {      // requests first: the PCIe round trips run under the zero-fill and the ||E||^2 sums below
     n16 = a.n_ints / 4;
 #pragma unroll
@@ -675,6 +724,7 @@ __global__ __launch_bounds__(256) void k_step_begin(StepBeginArgs a) {
     const float* nsrc = slot ? reinterpret_cast<const float*>(slot + a.n_ints - 4) : a.norms_src;
     if (threadIdx.x < 4 && a.norms_dst) a.norms_dst[threadIdx.x] = nsrc[threadIdx.x];
     if (threadIdx.x == 4 && a.seed) *a.seed += a.inc;
+    if (threadIdx.x == 5 && a.ring && a.produced) a.state[4] = __hip_atomic_load(a.produced, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (ring_blk) {
 #pragma unroll
@@ -703,8 +753,11 @@ __global__ __launch_bounds__(256) void k_step_begin(StepBeginArgs a) {
       if (atomicAdd(a.state + 1, 1u) == nring - 1) {      // the last reader: every reader has read state[0] and its part of the slot
         a.state[1] = 0u;
         const uint32_t c = a.state[0] + 1u;
+        if (slot == a.staging && a.staging) a.state[5] += 1u;      // statistics: batches taken from the staging buffer
         a.state[0] = c;
-        if (a.consumed) __hip_atomic_store(a.consumed, c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // relaxed: the host only learns that the slot has been read.  (As a system-scope RELEASE this one store wrote back the ~11 MB of
+        // zero-fill the kernel had just left dirty in L2: k_step_begin took 24-50 us on a host ring against 9.5 us on a device ring.)
+        if (a.consumed) __hip_atomic_store(a.consumed, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
   }

@@ -416,8 +416,9 @@ bool bce_deferred(const adt_sasrec_cfg* c) {
   const int d = c->hidden, hd = d / c->num_heads;
   return on && d == 64 && c->num_layers <= 4 && adt_seq_lean(c->prec, c->maxlen, d, hd) != 0;
 }
+struct RingRef { const int32_t* ring; int64_t slot_ints; int nslots; uint32_t* state; uint32_t* consumed; int32_t* staging; };
 int forward_loss_lean(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const float* P, float* ws, const int32_t* seq, const int32_t* dec,
-                      float p, const uint32_t* seed, uint32_t b_offset, const float* lambdas1, const float* lambdas2, void* st) {
+                      float p, const uint32_t* seed, uint32_t b_offset, const float* lambdas1, const float* lambdas2, const RingRef& rr, void* st) {
   const int d = (int)w.d, H = (int)w.H, hd = d / H, nl = c->num_layers, T = (int)w.T;
   if (!bce_deferred(c)) return 1;
   const int64_t Td = up64(w.T * w.d), rec = up64(w.T * w.H * w.H);
@@ -436,8 +437,10 @@ int forward_loss_lean(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, co
     lm[i] = loss + 64 * (2 + i);
     rc[i] = ws + i * w.e_stride + w.e_rec; dr[i] = ws + w.g_rec + i * rec; ln[i] = loss + 64 * (2 + nl + i);
   }
-  return adt_loss_seeds(nullptr, nullptr, nullptr, 0, ws + w.norms, nullptr, nullptr, loss, nl, A, Bm, w.T * w.d, lambdas1, GA, 0, GB, lm,
-                        H > 1 ? nl : 0, rc, T, H, lambdas2[nl - 1], dr, ln, st);
+  // (+ the next step's id batch, if its producer has published it: the PCIe read runs under this streaming pass)
+  return adt_loss_seeds_prefetch(nullptr, nullptr, nullptr, 0, ws + w.norms, nullptr, nullptr, loss, nl, A, Bm, w.T * w.d, lambdas1, GA, 0, GB, lm,
+                                 H > 1 ? nl : 0, rc, T, H, lambdas2[nl - 1], dr, ln, rr.ring, rr.slot_ints, rr.nslots, 4 * (int64_t)w.T + 4, rr.state,
+                                 rr.consumed, rr.staging, st);
 }
 
 }  // namespace
@@ -552,13 +555,22 @@ int adt_sasrec_bce_deferred(const adt_sasrec_cfg* c) { return check_cfg(c) == 0 
 int adt_sasrec_forward_loss(const adt_sasrec_cfg* c, const float* P, float* ws, const int32_t* seq, const int32_t* dec, const int32_t* pos,
                             const int32_t* neg, int B, int training, const uint32_t* seed, uint32_t b_offset, const float* lambdas1,
                             const float* lambdas2, void* st) {
+  return adt_sasrec_forward_loss_prefetch(c, P, ws, seq, dec, pos, neg, B, training, seed, b_offset, lambdas1, lambdas2, nullptr, 0, 0, nullptr, nullptr,
+                                          nullptr, st);
+}
+
+int adt_sasrec_forward_loss_prefetch(const adt_sasrec_cfg* c, const float* P, float* ws, const int32_t* seq, const int32_t* dec, const int32_t* pos,
+                                     const int32_t* neg, int B, int training, const uint32_t* seed, uint32_t b_offset, const float* lambdas1,
+                                     const float* lambdas2, const int32_t* ring, int64_t slot_ints, int nslots, uint32_t* state, uint32_t* consumed,
+                                     int32_t* staging, void* st) {
   CK(check_cfg(c));
   if ((training & 1) && (training & 2)) {      // training forward on weight images packed by this step's adt_sasrec_step_begin*
     Layout lo;
     make_layout(c, &lo);
     WS w;
     make_ws(c, B, &w);
-    const int rc = forward_loss_lean(c, lo, w, P, ws, seq, dec, c->dropout, seed, b_offset, lambdas1, lambdas2, st);
+    const RingRef rr{ring, slot_ints, nslots, state, consumed, staging};
+    const int rc = forward_loss_lean(c, lo, w, P, ws, seq, dec, c->dropout, seed, b_offset, lambdas1, lambdas2, rr, st);
     if (rc <= 0) return rc;
   }
   CK(adt_sasrec_forward(c, P, ws, seq, dec, pos, neg, B, training, seed, b_offset, st));
@@ -597,6 +609,12 @@ int adt_sasrec_step_begin(const adt_sasrec_cfg* c, float* ws, int B, uint32_t* s
 int adt_sasrec_step_begin_ring(const adt_sasrec_cfg* c, float* ws, int B, uint32_t* seed, uint32_t seed_inc, const int32_t* ring, int64_t slot_ints,
                                int nslots, int32_t* ids_dst, uint32_t* state, uint32_t* consumed, const float* P, float* G, int64_t n, float* scal,
                                void* st) {
+  return adt_sasrec_step_begin_ring_staged(c, ws, B, seed, seed_inc, ring, slot_ints, nslots, ids_dst, state, consumed, nullptr, nullptr, P, G, n, scal, st);
+}
+
+int adt_sasrec_step_begin_ring_staged(const adt_sasrec_cfg* c, float* ws, int B, uint32_t* seed, uint32_t seed_inc, const int32_t* ring,
+                                      int64_t slot_ints, int nslots, int32_t* ids_dst, uint32_t* state, uint32_t* consumed, const int32_t* staging,
+                                      const uint32_t* produced, const float* P, float* G, int64_t n, float* scal, void* st) {
   CK(check_cfg(c));
   Layout lo;
   make_layout(c, &lo);
@@ -606,7 +624,7 @@ int adt_sasrec_step_begin_ring(const adt_sasrec_cfg* c, float* ws, int B, uint32
   const int npack = pack_offsets(c, lo, offs);
   return adt_step_begin_ring_launch(seed, seed_inc, ws + w.norms, ws + w.loss, 64 * (2 + 2 * c->num_layers), scal, G, n, P + lo.item(),
                                     (int64_t)(c->item_num + 1) * c->hidden, ring, slot_ints, nslots, ids_dst, 4 * (int64_t)w.T + 4, state, consumed,
-                                    ws + w.prep, (int64_t)NREPP * w.prep_stride, P + lo.posw(), ws + w.wpack, offs, npack, st);
+                                    staging, produced, ws + w.prep, (int64_t)NREPP * w.prep_stride, P + lo.posw(), ws + w.wpack, offs, npack, st);
 }
 
 static int loss_seed_impl(const adt_sasrec_cfg* c, float* ws, const int32_t* pos, int B, const float* lambdas1, const float* lambdas2,

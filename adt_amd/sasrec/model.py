@@ -175,6 +175,14 @@ class SASRecADT(torch.nn.Module):
                                                   _ptr(self.flat), _ptr(self.flat_grad), self.flat_grad.numel(), _ptr(scal), self._stream()),
                    "sasrec_step_begin")
 
+    def run_step_begin_ring_staged(self, B, ring, slot_ints, nslots, ids_dst, state, consumed, staging, produced, scal, seed_inc=0x9E3779B1):
+        """run_step_begin_ring that takes the batch from `staging` when the previous step's run_forward_loss(..., prefetch=...) copied it there
+        (adt_sasrec_step_begin_ring_staged); `produced`: pinned host word with the producer's count of completely written batches."""
+        _lib.check(self.lib.adt_sasrec_step_begin_ring_staged(ctypes.byref(self.cfg), _ptr(self.workspace(B)), B, _ptr(self._seed), seed_inc, _ptr(ring),
+                                                              slot_ints, nslots, _ptr(ids_dst), _ptr(state), _ptr(consumed), _ptr(staging), _ptr(produced),
+                                                              _ptr(self.flat), _ptr(self.flat_grad), self.flat_grad.numel(), _ptr(scal), self._stream()),
+                   "sasrec_step_begin_ring_staged")
+
     def run_step_begin_ring(self, B, ring, slot_ints, nslots, ids_dst, state, consumed, scal, seed_inc=0x9E3779B1):
         """run_step_begin that first fetches the packed id batch of ring slot (state[0] % nslots) into ids_dst (adt_sasrec_step_begin_ring);
         `ring` / `consumed` are pinned host tensors (read / written by the kernel over PCIe) or device tensors."""
@@ -186,15 +194,17 @@ class SASRecADT(torch.nn.Module):
         """True when run_forward_loss leaves logits + BCE seed to run_backward(..., bce=True) (adt_sasrec_bce_deferred)."""
         return bool(self.lib.adt_sasrec_bce_deferred(ctypes.byref(self.cfg)))
 
-    def run_forward_loss(self, seq, dec, pos, neg, B, lambdas1, lambdas2, b_offset=0, training=True, packed=True):
+    def run_forward_loss(self, seq, dec, pos, neg, B, lambdas1, lambdas2, b_offset=0, training=True, packed=True, prefetch=None):
         """run_forward(training) + run_loss_seed(zero_loss=False) of one step in one call (adt_sasrec_forward_loss).  Returns True when the
         logits + BCE seed were deferred to the backward: pass bce=True to run_backward of the same step."""
         nl = self.num_layers
         l1 = (ctypes.c_float * nl)(*[float(x) for x in lambdas1])
         l2 = (ctypes.c_float * nl)(*[float(x) for x in lambdas2])
-        _lib.check(self.lib.adt_sasrec_forward_loss(ctypes.byref(self.cfg), _ptr(self.flat), _ptr(self.workspace(B)), _ptr(seq), _ptr(dec),
-                                                    _ptr(pos), _ptr(neg), B, int(bool(training)) | (2 if packed else 0), _ptr(self._seed),
-                                                    b_offset, l1, l2, self._stream()), "sasrec_forward_loss")
+        ring, slot_ints, nslots, state, consumed, staging = prefetch if prefetch is not None else (None, 0, 0, None, None, None)
+        _lib.check(self.lib.adt_sasrec_forward_loss_prefetch(ctypes.byref(self.cfg), _ptr(self.flat), _ptr(self.workspace(B)), _ptr(seq), _ptr(dec),
+                                                             _ptr(pos), _ptr(neg), B, int(bool(training)) | (2 if packed else 0), _ptr(self._seed),
+                                                             b_offset, l1, l2, _ptr(ring), slot_ints, nslots, _ptr(state), _ptr(consumed),
+                                                             _ptr(staging), self._stream()), "sasrec_forward_loss")
         return bool(training) and packed and self.bce_deferred()
 
     def run_loss_seed(self, pos, B, lambdas1, lambdas2, zero_loss=True):

@@ -59,8 +59,11 @@ class FusedTrainer:
             n_int = 4 * T + 4   # seq, dec, pos, neg, 3 normalisers (float bits), pad
             ring = torch.empty(self.NSLOTS * n_int, dtype=torch.int32).pin_memory()
             consumed = torch.zeros(16, dtype=torch.int32).pin_memory()
+            produced = torch.zeros(16, dtype=torch.int32).pin_memory()      # [0]: batches the producer has completely written (publish())
             st = {"T": T, "n_int": n_int, "ring": ring, "ring_np": ring.numpy(), "consumed": consumed, "consumed_np": consumed.numpy().view(np.uint32),
-                  "state": torch.zeros(2, device=m.dev, dtype=torch.int32), "nsub": 0,
+                  "produced": produced, "produced_np": produced.numpy().view(np.uint32),
+                  "state": torch.zeros(8, device=m.dev, dtype=torch.int32), "nsub": 0,
+                  "staging": torch.empty(n_int, device=m.dev, dtype=torch.int32),      # the next batch, prefetched beside this step's loss assembly
                   "devbuf": torch.empty(n_int, device=m.dev, dtype=torch.int32), "graphs": {}, "dev_rings": []}
             self._bstate[B] = st
             m.workspace(B)
@@ -89,12 +92,17 @@ class FusedTrainer:
         # one launch: [the id batch from the ring slot,] seed += 0x9E3779B1 (a fresh dropout stream every step, on the device), the normalisers into the
         # workspace (a kernel, not tensor.copy_: inside a captured step that would be a memcpy NODE, see DESIGN.md on captured memset nodes), zero_grad,
         # loss slots, ||E||^2 partials for the weight-decay term
+        prefetch = None
         if src is None:
             m.run_step_begin(B, self._norms_dev, self.scal)
+        elif len(src) > 4:      # pinned host ring: the next batch is prefetched beside this step's loss assembly when its producer is ahead
+            ring, nslots, state, consumed, staging, produced = src
+            m.run_step_begin_ring_staged(B, ring, self._st["n_int"], nslots, self._devbuf, state, consumed, staging, produced, self.scal)
+            prefetch = (ring, self._st["n_int"], nslots, state, consumed, staging)
         else:
             m.run_step_begin_ring(B, src[0], self._st["n_int"], src[1], self._devbuf, src[2], src[3], self.scal)
         # forward + loss assembly (run_step_begin* above packed the weight images and zeroed the loss slots ...)
-        bce = m.run_forward_loss(seq, dec, pos, neg, B, self.lambdas1, self.lambdas2, b_offset)      # bce: logits + BCE seed left to the backward
+        bce = m.run_forward_loss(seq, dec, pos, neg, B, self.lambdas1, self.lambdas2, b_offset, prefetch=prefetch)      # bce: logits + BCE seed left to the backward
         if not self._buckets.active:
             # ... and zeroed the parameter-gradient replicas ; the last fold of the replicas happens inside the optimizer's first kernel
             m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=0, prezeroed=True, defer_fold=True, bce=bce)
@@ -130,17 +138,26 @@ class FusedTrainer:
         flat = st["ring_np"][(k % self.NSLOTS) * n:(k % self.NSLOTS + 1) * n]
         return [flat[i * T:(i + 1) * T].reshape(B, L) for i in range(4)], flat
 
-    def commit(self, B, norms, b_offset=0):
-        """Submit the step whose batch the caller has written into slot() (ids in place); norms = (n_bce, n_mse, n_nll) of the GLOBAL batch."""
-        st = self._bind(B)
-        flat = st["ring_np"][(st["nsub"] % self.NSLOTS) * st["n_int"]:(st["nsub"] % self.NSLOTS + 1) * st["n_int"]]
+    def publish(self, B, k, norms):
+        """Producer side: ring step k of batch size B is completely written (ids in its slot()); stores its normalisers (n_bce, n_mse, n_nll of
+        the GLOBAL batch) and announces it to the GPU, which may then prefetch it beside the step in front of it.  Steps are published in order."""
+        st = self._alloc(B)
+        flat = st["ring_np"][(k % self.NSLOTS) * st["n_int"]:(k % self.NSLOTS + 1) * st["n_int"]]
         flat[4 * st["T"]:4 * st["T"] + 3] = np.asarray(norms, np.float32).view(np.int32)
         flat[4 * st["T"] + 3] = 0
+        _hostlib.load().adt_host_store_release(st["produced_np"].ctypes.data, (k + 1) & 0xFFFFFFFF)
+
+    def commit(self, B, norms=None, b_offset=0):
+        """Submit the step whose batch the caller has written into slot() (ids in place); norms = (n_bce, n_mse, n_nll) of the GLOBAL batch,
+        or None when the producer has already publish()ed this step."""
+        st = self._bind(B)
+        if norms is not None:
+            self.publish(B, st["nsub"], norms)
         self._submit(st, B, b_offset)
 
     def _submit(self, st, B, b_offset):
         st["nsub"] += 1
-        self._run(B, b_offset, ("host", (st["ring"], self.NSLOTS, st["state"], st["consumed"])))
+        self._run(B, b_offset, ("host", (st["ring"], self.NSLOTS, st["state"], st["consumed"], st["staging"], st["produced"])))
 
     def _norms(self, pos_flat, T):
         m = self.model
@@ -163,6 +180,7 @@ class FusedTrainer:
             norms = self._norms(arrs[2], st["T"])
         _hostlib.load().adt_host_pack_batch(flat.ctypes.data, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data,
                                             st["T"], norms[0], norms[1], norms[2])
+        _hostlib.load().adt_host_store_release(st["produced_np"].ctypes.data, (st["nsub"] + 1) & 0xFFFFFFFF)
         self._submit(st, B, b_offset)
 
     # ---- batches resident in HBM ------------------------------------------------------------------------------------------------
@@ -184,7 +202,7 @@ class FusedTrainer:
         bufs = [self.stage(b, None if norms is None else norms[i]) for i, b in enumerate(batches)]
         st = self._st
         ring = torch.cat(bufs)
-        h = ("dev%d" % len(st["dev_rings"]), (ring, len(bufs), torch.zeros(2, device=self.model.dev, dtype=torch.int32), None))
+        h = ("dev%d" % len(st["dev_rings"]), (ring, len(bufs), torch.zeros(8, device=self.model.dev, dtype=torch.int32), None))
         st["dev_rings"].append(h)
         torch.cuda.synchronize()
         return h
@@ -268,7 +286,8 @@ class RingFeeder:
                     warp.sample_rows_into(users[lo:hi], seed, views, b0=lo)
                     nxt[B] = k + 1
                     L = m.maxlen
-                    q.put((B, lo, n, (float(warp.count_targets(users)), float(n * L * m.hidden_units), float(n * L * m.num_heads))))
+                    tr.publish(B, k, (float(warp.count_targets(users)), float(n * L * m.hidden_units), float(n * L * m.num_heads)))
+                    q.put((B, lo, n, None))
             except BaseException as e:      # surfaces on the training thread
                 err.append(e)
             q.put(None)

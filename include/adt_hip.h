@@ -374,6 +374,15 @@ int adt_sasrec_step_begin(const adt_sasrec_cfg* cfg, float* ws, int B, uint32_t*
 int adt_sasrec_step_begin_ring(const adt_sasrec_cfg* cfg, float* ws, int B, uint32_t* seed, uint32_t seed_inc, const int32_t* ring,
                                int64_t slot_ints, int nslots, int32_t* ids_dst, uint32_t* state, uint32_t* consumed, const float* params,
                                float* grads, int64_t n, float* scal, void* stream);
+/* The same with a PREFETCH of the next batch: `state` = eight zero-initialised device uint32 (batches fetched, ticket, staged batch + 1, prefetch
+ * ticket, producer count as seen, statistics: batches taken from `staging`), `staging` = device buffer of 4 B L + 4 int32, `produced` = pinned host word holding the number of batches
+ * the producer has completely written (slot k is published by storing k + 1 AFTER its ids and normalisers).  This call samples *produced;
+ * adt_sasrec_forward_loss_prefetch of the same step then copies the NEXT batch's slot into `staging` beside its loss-assembly pass if it
+ * was published (and releases the slot through *consumed), and this call of the next step takes the batch from `staging` (HBM) instead of
+ * the ring (PCIe: ~16 us at the flagship batch, in front of everything else of the step). */
+int adt_sasrec_step_begin_ring_staged(const adt_sasrec_cfg* cfg, float* ws, int B, uint32_t* seed, uint32_t seed_inc, const int32_t* ring,
+                                      int64_t slot_ints, int nslots, int32_t* ids_dst, uint32_t* state, uint32_t* consumed, const int32_t* staging,
+                                      const uint32_t* produced, const float* params, float* grads, int64_t n, float* scal, void* stream);
 int adt_sasrec_loss_seed_nz(const adt_sasrec_cfg* cfg, float* ws, const int32_t* pos, int B, const float* lambdas1,
                             const float* lambdas2, void* stream);
 /* ---- Deterministic item-table / positional-table gradient (sasrec/model.py:34-41, :53-59, :72-76 reversed; d = 64) -----------------------
@@ -391,7 +400,7 @@ int adt_item_sort(const int32_t* const* ids, int nsrc, int T, int V1, const floa
                   uint32_t row_offset, int32_t* work, void* stream);
 /* dE[item] = (accumulate ? dE[item] : 0) + sum of the sorted entries of `item` from the sources in src_mask (bit s = id array s of
  * adt_item_sort); rows of items without entries are left alone (zero dE first).  accumulate = 0 is the fast form: plain stores. */
-int adt_item_segsum(const int32_t* work, int nsrc, int T, int V1, unsigned src_mask, const uint32_t* site, float p, const uint32_t* seed,
+int adt_item_segsum(const int32_t* work, int nsrc, int T, int V1, uint32_t src_mask, const uint32_t* site, float p, const uint32_t* seed,
                     float emb_scale, float* dE, int accumulate, void* stream);
 /* dP[l] += sum_b [ids[b, l] != 0] * keep / (1 - p) * dX[b, l] for nsrc (1 or 2) embedding layers, b ascending (one owner per position) */
 int adt_posemb_sum(const int32_t* const* ids, const float* const* dX, const uint32_t* site, int nsrc, int B, int L, float p, const uint32_t* seed,
@@ -405,6 +414,11 @@ int adt_sasrec_bce_deferred(const adt_sasrec_cfg* cfg);
 int adt_sasrec_forward_loss(const adt_sasrec_cfg* cfg, const float* params, float* ws, const int32_t* seq, const int32_t* dec,
                             const int32_t* pos, const int32_t* neg, int B, int training, const uint32_t* seed, uint32_t b_offset,
                             const float* lambdas1, const float* lambdas2, void* stream);
+/* adt_sasrec_forward_loss + the prefetch half of adt_sasrec_step_begin_ring_staged (ring == NULL: plain adt_sasrec_forward_loss) */
+int adt_sasrec_forward_loss_prefetch(const adt_sasrec_cfg* cfg, const float* params, float* ws, const int32_t* seq, const int32_t* dec,
+                                     const int32_t* pos, const int32_t* neg, int B, int training, const uint32_t* seed, uint32_t b_offset,
+                                     const float* lambdas1, const float* lambdas2, const int32_t* ring, int64_t slot_ints, int nslots,
+                                     uint32_t* state, uint32_t* consumed, int32_t* staging, void* stream);
 /* reverse pass: consumes the G_* buffers (destroyed), accumulates into `grads` (same layout as params).
  * phase: 0 = everything; 1 = logits + decoder stack only; 2 = last LN + encoder stack + embeddings (lets the
  * host overlap the gradient all-reduce of the decoder bucket with phase 2).  + 4: the parameter-gradient replicas were already zeroed by

@@ -32,6 +32,8 @@ int adt_host_pack_batch(int32_t* dst, const int32_t* seq, const int32_t* dec, co
                         float n_mse, float n_nll);
 /* spin until the uint32 counter at p (stored by the GPU into pinned host memory) has reached v (wrap-around safe); -1 after timeout_us */
 int adt_host_wait_ge(const volatile uint32_t* p, uint32_t v, int64_t timeout_us);
+/* release-store of a counter the GPU polls in pinned host memory (the producer's "batches written" word of the id ring) */
+int adt_host_store_release(volatile uint32_t* p, uint32_t v);
 
 #ifdef __cplusplus
 }
