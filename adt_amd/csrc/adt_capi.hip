@@ -687,6 +687,33 @@ int adt_fold_clip_adam(float* P, float* G, float* M, float* V, int64_t n, float*
   return check_launch("fold_clip_adam");
 }
 
+/* adt_fold_clip_adam that also sums the per-sequence partials of the 64 x 64 weight gradients (nslots blocks: slot index inside a workgroup's
+ * partial area, float offset in G) in workgroup order; mask_base = offset in G of the range the row mask describes (the positional table). */
+int adt_fold_parts_clip_adam(float* P, float* G, float* M, float* V, int64_t n, float* d0, const float* r0, int64_t n0, int nrep0, int64_t s0, float* d1,
+                             const float* r1, int64_t n1, int nrep1, int64_t s1, const float* part, int64_t part_stride, int nwg, const int* slots,
+                             const int* offs, int nslots, float wd, float clip, float lr, float b1, float b2, float eps, float* scal, void* stream) {
+  if (n0 <= 0 || n1 <= 0 || (n0 % 4) || (s0 % 4) || (n1 % 4) || (s1 % 4) || d0 != G) return adt_set_error("fold_parts_clip_adam: ranges");
+  if (nslots < 1 || nslots > FP_MAXSLOTS || (d1 - G) % 64 || n1 > (int64_t)FP_MASKWORDS * 32 * 64) return adt_set_error("fold_parts_clip_adam: %d blocks, %lld floats", nslots, (long long)n1);
+  OptArgs a{};
+  a.P = P; a.G = G; a.M = M; a.Vv = V; a.n = (size_t)n; a.nE = (size_t)n0; a.wd = wd; a.clip = clip; a.lr = lr;
+  a.b1 = b1; a.b2 = b2; a.eps = eps; a.scal = scal; a.grad_scale = 1.0f;
+  RepReduce2Args r{{d0, d1}, {r0, r1}, {(size_t)n0, (size_t)n1}, {nrep0, nrep1}, {(size_t)s0, (size_t)s1}, 0};
+  const int g0 = grid_for((size_t)n0 / 4, 256, 1024), g1 = grid_for((size_t)n1 / 4, 256, 1024);
+  r.g0 = g0;
+  PartFoldArgs pf{};
+  pf.part = part; pf.stride = (size_t)part_stride; pf.nwg = nwg; pf.nslots = nslots; pf.mask_base = d1 - G;
+  for (int i = 0; i < nslots; ++i) {
+    pf.slot[i] = slots[i]; pf.off[i] = offs[i];
+    const int64_t r0w = (offs[i] - pf.mask_base) / 64;
+    if (offs[i] < pf.mask_base || (offs[i] - pf.mask_base) % 64 || r0w + 64 > (int64_t)FP_MASKWORDS * 32) return adt_set_error("fold_parts_clip_adam: block %d outside the masked range", i);
+    for (int64_t rr = r0w; rr < r0w + 64; ++rr) pf.rowmask[rr >> 5] |= 1u << (rr & 31);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_fold_parts_gradnorm, dim3(g0 + g1 + 16 * nslots), dim3(256), 0, s, r, a, pf, g1);
+  hipLaunchKernelGGL(k_adam, dim3(grid_for((size_t)n, 256, 1024)), dim3(256), 0, s, a);
+  return check_launch("fold_parts_clip_adam");
+}
+
 static void step_begin_extras(StepBeginArgs& a, float* Z, int64_t nz, const float* pack_base, void* pack_img, const int* pack_offs, int npack) {
   a.Z = Z; a.nz = Z ? (size_t)nz : 0;
   a.pk.base = pack_base; a.pk.img = reinterpret_cast<__bf16*>(pack_img); a.pk.n = (pack_base && pack_img && pack_offs) ? npack : 0;

@@ -83,4 +83,7 @@ int adt_fold_clip_adam(float* P, float* G, float* M, float* V, int64_t n, float*
                        void* stream);
 int adt_replica_reduce2(float* d0, const float* r0, int64_t n0, int nrep0, int64_t s0, float* d1, const float* r1, int64_t n1, int nrep1, int64_t s1,
                         void* stream);
+int adt_fold_parts_clip_adam(float* P, float* G, float* M, float* V, int64_t n, float* d0, const float* r0, int64_t n0, int nrep0, int64_t s0, float* d1,
+                             const float* r1, int64_t n1, int nrep1, int64_t s1, const float* part, int64_t part_stride, int nwg, const int* slots,
+                             const int* offs, int nslots, float wd, float clip, float lr, float b1, float b2, float eps, float* scal, void* stream);
 }

@@ -867,6 +867,85 @@ __global__ __launch_bounds__(256) void k_fold_wd_gradnorm(RepReduce2Args a, OptA
   if (blockIdx.x == 0 && threadIdx.x == 0) { o.scal[0] = nrm * nrm; o.scal[3] = o.wd * nrm; o.scal[2] += 1.0f; }
 }
 
+// The same pass that ALSO sums the per-sequence partials of the 64 x 64 weight gradients (adt_seqbwd_tt.cuh: sb_dw_tiles), in workgroup
+// order, into G -- the two k_dwpart_reduce launches of a step (one beside the encoder's chain kernels, which it slowed, one at the tail in
+// front of a cross-queue join) and their atomics are gone, and every weight gradient is one ordered sum.  Job 1 (the non-item parameters)
+// leaves the rows of the weight blocks alone (rowmask: one bit per 64 floats from `mask_base`); job 2 owns them:
+// G[block] = G[block] + sum_wg part[wg][slot] (the replicas hold nothing there: the chain kernels wrote partials instead).
+// Job 2: 16 workgroups per block, 64 float4 outputs each, FOUR threads per output (64 workgroups' partials each, ascending), joined in order.
+constexpr int FP_MAXSLOTS = 64, FP_MASKWORDS = 160;      // 64 x 64 blocks per step ; 160 x 32 rows of 64 floats = 327,680 non-item floats
+struct PartFoldArgs {
+  const float* part; size_t stride; int nwg, nslots;
+  int slot[FP_MAXSLOTS]; int off[FP_MAXSLOTS];      // slot inside a workgroup's partial area ; float offset of the block in G
+  uint32_t rowmask[FP_MASKWORDS]; int64_t mask_base;       // bit r: row r (64 floats, from G + mask_base) belongs to a weight block
+};
+__global__ __launch_bounds__(256) void k_fold_parts_gradnorm(RepReduce2Args a, OptArgs o, PartFoldArgs pf, int g1) {
+  __shared__ float sbuf[4];
+  __shared__ float4 sq[256];
+  const float nrm = sqrtf(sum64(o.scal + 64, sbuf));
+  const float coef = (o.wd != 0.f && nrm > 0.f) ? o.wd / nrm : 0.f;
+  float acc = 0.f;
+  if ((int)blockIdx.x < a.g0 + g1) {
+    const int j = (int)blockIdx.x >= a.g0 ? 1 : 0;
+    const int bid = j ? blockIdx.x - a.g0 : blockIdx.x, nblk = j ? g1 : a.g0;
+    float* dst = a.dst[j];
+    const float* rep = a.rep[j];
+    const float* Pj = o.P + (dst - o.G);           // the parameters under this job's gradient range
+    const size_t n = a.n[j], stride = a.stride[j];
+    const int nrep = a.nrep[j];
+    const int64_t row0 = j ? ((dst - o.G) - pf.mask_base) / 64 : 0;
+    for (size_t i = ((size_t)bid * 256 + threadIdx.x) * 4; i < n; i += (size_t)nblk * 1024) {
+      if (j == 1) {
+        const int64_t r = row0 + (int64_t)(i >> 6);
+        if ((pf.rowmask[r >> 5] >> (r & 31)) & 1u) continue;      // a weight block's row: job 2
+      }
+      float4 g = replica_sum4(rep + i, stride, nrep, *reinterpret_cast<const float4*>(dst + i));
+      g.x *= o.grad_scale; g.y *= o.grad_scale; g.z *= o.grad_scale; g.w *= o.grad_scale;
+      if (j == 0) {                                // the item table is job 0 (flat offset 0, nE floats): + wd * E / ||E||_F
+        const float4 p = *reinterpret_cast<const float4*>(Pj + i);
+        g.x += coef * p.x; g.y += coef * p.y; g.z += coef * p.z; g.w += coef * p.w;
+      }
+      *reinterpret_cast<float4*>(dst + i) = g;
+      acc += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
+    }
+  } else {
+    const int bid = blockIdx.x - a.g0 - g1;
+    const int js = bid >> 4, o4 = (bid & 15) * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;      // float4 o4 of the partial layout, quarter q of the workgroups
+    const int e4 = o4 * 4;
+    const int per = (pf.nwg + 3) / 4, w0 = q * per, w1 = min(pf.nwg, w0 + per);
+    const float* p = pf.part + (size_t)pf.slot[js] * 4096 + e4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int wg = w0;
+    for (; wg + 8 <= w1; wg += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(wg + u) * pf.stride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; wg < w1; ++wg) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (size_t)wg * pf.stride);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    sq[threadIdx.x] = s;
+    __syncthreads();
+    if (q == 0) {
+      const float4 s1 = sq[threadIdx.x + 1], s2 = sq[threadIdx.x + 2], s3 = sq[threadIdx.x + 3];
+      const int tile = e4 >> 8, r = (e4 >> 6) & 3, lane = e4 & 63;
+      float* dst = o.G + pf.off[js] + (16 * (tile >> 2) + 4 * (lane >> 4) + r) * 64 + 16 * (tile & 3) + (lane & 15);
+      float4 g = *reinterpret_cast<const float4*>(dst);
+      g.x += ((s.x + s1.x) + s2.x) + s3.x; g.y += ((s.y + s1.y) + s2.y) + s3.y;
+      g.z += ((s.z + s1.z) + s2.z) + s3.z; g.w += ((s.w + s1.w) + s2.w) + s3.w;
+      g.x *= o.grad_scale; g.y *= o.grad_scale; g.z *= o.grad_scale; g.w *= o.grad_scale;
+      *reinterpret_cast<float4*>(dst) = g;
+      acc += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
+    }
+  }
+  const float s = block_sum(acc, sbuf);
+  if (threadIdx.x == 0) atomicAdd(o.scal + 128 + (blockIdx.x & 63), s);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { o.scal[0] = nrm * nrm; o.scal[3] = o.wd * nrm; o.scal[2] += 1.0f; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // SASRecADT.predict (sasrec/model.py:89-96) + the rank of evaluate_loader (sasrec/utils.py:410):
 // logits[b][c] = E[cand[b][c]] . f[b] ; rank[b] = #{c > 0 : logits[b][c] > logits[b][0]}.

@@ -241,9 +241,15 @@ int pack_weights(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const f
 // slot of a 64 x 64 block in a workgroup's partial area: the order of pack_weights
 enum { PS_E_IN = 0, PS_E_O = 3, PS_E_C1 = 4, PS_E_C2 = 5, PS_D_SIN = 6, PS_D_EIN = 9, PS_D_SO = 12, PS_D_EO = 13, PS_D_C1 = 14, PS_D_C2 = 15 };
 
+// the partial slots of the encoder (enc = true) and / or decoder (dec = true) blocks of every layer and their offsets in G
+int partial_slots(const adt_sasrec_cfg* c, const Layout& lo, bool enc, bool dec, int* slots, int* offs);
 // sums the partials of the encoder (enc = true) and / or decoder (dec = true) blocks of every layer into G
 int reduce_partials(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, float* G, float* ws, bool enc, bool dec, void* st) {
   int slots[256], offs[256];
+  const int n = partial_slots(c, lo, enc, dec, slots, offs);
+  return adt_dwpart_reduce(G, ws + w.part, (size_t)w.part_stride, (int)w.B, slots, offs, n, st);
+}
+int partial_slots(const adt_sasrec_cfg* c, const Layout& lo, bool enc, bool dec, int* slots, int* offs) {
   int n = 0;
   const int dd = c->hidden * c->hidden;
   for (int i = 0; i < c->num_layers; ++i) {
@@ -262,7 +268,13 @@ int reduce_partials(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, floa
       slots[n] = 16 * i + PS_D_C2; offs[n++] = (int)lo.dec(i, D_C2W);
     }
   }
-  return adt_dwpart_reduce(G, ws + w.part, (size_t)w.part_stride, (int)w.B, slots, offs, n, st);
+  return n;
+}
+// single-GPU step: the partials are summed by the optimizer's first kernel (adt_fold_parts_clip_adam), not by k_dwpart_reduce launches
+bool fold_sums_partials(const adt_sasrec_cfg* c, const WS& w) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("ADT_FOLD_PARTS"); on = (e && atoi(e) == 0) ? 0 : 1; }
+  return on && w.part_stride > 0 && c->num_layers <= 2 && adt_seq_partials(c->prec, c->maxlen, c->hidden, c->hidden / c->num_heads) != 0;
 }
 
 adt::SeqBwdArgs seq_bwd_args(int L, int B, int H, const int32_t* ids, float p, const uint32_t* seed, uint32_t site, uint32_t b_offset, int hd) {
@@ -720,6 +732,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   const char* const no_fallback = "backward: shape L=%d hd=%d left the per-sequence kernels although the partial-gradient path was chosen";
   const bool prep_zeroed = (phase & 4) != 0;      // bit 2: adt_sasrec_step_begin* of this step zeroed the parameter-gradient replicas
   const bool defer_fold = (phase & 8) != 0 && (phase & 3) == 0;      // bit 3 (one-phase only): adt_sasrec_fold_clip_adam does the last fold
+  const bool late_parts = defer_fold && fold_sums_partials(c, w);      // adt_sasrec_fold_clip_adam sums the weight-gradient partials too
   const bool bce_here = (phase & 16) != 0;        // bit 4: the forward was adt_sasrec_forward_loss on the deferred path: logits + BCE seed are formed here
   if (bce_here && !bce_deferred(c)) return adt_set_error("backward: phase bit 4 without the deferred-BCE forward (adt_sasrec_bce_deferred)");
   phase &= 3;
@@ -911,7 +924,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       void* s2 = nullptr;
       CK(side_enter(sd, 1, st, &s2));
       if (!det) CK(adt_embed_bwd_rep(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, s2));
-      if (parts) { CK(reduce_partials(c, lo, w, G, ws, false, true, s2)); dec_parts_done = true; }
+      if (parts && !late_parts) { CK(reduce_partials(c, lo, w, G, ws, false, true, s2)); dec_parts_done = true; }
       dec_side = 2;
     }
     for (int i = nl - 1; i >= 0; --i) {
@@ -1003,7 +1016,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         CK(adt_embed_bwd_rep(seq, ws + w.g_enc_x, T, L, d, p, seed, SITE_EMB_SEQ, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
       }
       CK(side_enter(sd2, 2, st, &s2));
-      if (parts) CK(reduce_partials(c, lo, w, G, ws, true, phase == 0 && !dec_parts_done, s2));
+      if (parts && !late_parts) CK(reduce_partials(c, lo, w, G, ws, true, phase == 0 && !dec_parts_done, s2));
       CK(side_join(sd2, 2, st));
     }
     if (!defer_fold)
@@ -1021,6 +1034,13 @@ int adt_sasrec_fold_clip_adam(const adt_sasrec_cfg* c, float* ws, int B, float* 
   WS w;
   make_ws(c, B, &w);
   float* const Gq = ws + w.prep - lo.posw();
+  if (fold_sums_partials(c, w)) {
+    int slots[256], offs[256];
+    const int ns = partial_slots(c, lo, true, true, slots, offs);
+    return adt_fold_parts_clip_adam(P, G, M, V, lo.total, G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * c->hidden, item_det(w) ? 0 : NREP,
+                                    w.rep_stride, G + lo.posw(), Gq + lo.posw(), lo.total - lo.posw(), NREPP, w.prep_stride, ws + w.part,
+                                    w.part_stride, (int)w.B, slots, offs, ns, wd, clip, lr, b1, b2, eps, scal, st);
+  }
   return adt_fold_clip_adam(P, G, M, V, lo.total, G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * c->hidden, item_det(w) ? 0 : NREP, w.rep_stride, G + lo.posw(),
                             Gq + lo.posw(), lo.total - lo.posw(), NREPP, w.prep_stride, wd, clip, lr, b1, b2, eps, scal, st);
 }
