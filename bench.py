@@ -113,7 +113,7 @@ def cpu_baseline():
         m.train_step(batch, CFG["lambdas1"], CFG["lambdas2"], CFG["weight_decay"], seed=2 + nst)
         nst += 1
     dt = time.time() - t0
-    return {"value": round(B * nst / dt, 2), "unit": "sequences/s", "cores": int(cr.load().adt_cpu_threads()), "host_cpus": os.cpu_count(), "kind": "port",
+    return {"value": round(B * nst / dt, 2), "unit": "sequences/s", "cores": int(cr.load().adt_cpu_threads()), "host_cpus": os.cpu_count(), "kind": "port", "kind_detail": "restatement",
             "sample": "libadt_cpu.so (C++/OpenMP fp32 restatement of the reference step), %d full train steps at batch %d (same L=200, d=64, 2 blocks, "
                       "dropout 0.5) after 1 warm-up, %.1f s" % (nst, B, dt)}
 
@@ -342,6 +342,26 @@ def lce_probe(dev):
         return None
 
 
+def visible_gpus():
+    """Number of GPUs this process may use, WITHOUT initialising any GPU runtime: the device-visibility variables if set, else the KFD
+    topology in sysfs (nodes with a non-zero simd_count are GPUs).  None when neither is readable."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            return len([x for x in v.split(",") if x.strip() != ""])
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            props = open(os.path.join(root, node, "properties")).read()
+            for line in props.splitlines():
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+        return n
+    except Exception:
+        return None
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) with torch.distributed.run on 127.0.0.1 and
     pass their output through.  Runs BEFORE anything in this process touches the GPU; the parent only waits."""
@@ -367,11 +387,11 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: 256 sequences per GPU (global batch 256 N); strong: global batch 256 split over the ranks")
     ap.add_argument("--no-ndcg", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        import torch
-        have = torch.cuda.device_count()      # counting devices does not initialise the GPU
-        if have < args.gpus:
+        have = visible_gpus()                 # from sysfs / the environment: this parent process never touches the HIP runtime
+        if have is not None and have < args.gpus and os.environ.get("ADT_DIST_BACKEND", "nccl") == "nccl":
             sys.exit("bench.py: --gpus %d but this node shows %d GPU(s)" % (args.gpus, have))
         sys.exit(self_launch(args.gpus))
     if args.force_dp:
@@ -385,31 +405,17 @@ def main():
     import torch
     import torch.distributed as dist
     from adt_amd.dp import init_from_env, shard_bounds
-    pg, rank, world, local = init_from_env("nccl")
+    backend = os.environ.get("ADT_DIST_BACKEND", "nccl")      # "gloo": the multi-rank branch on one GPU / on CPU-side collectives (tests/test_bench_dp_gpu.py)
+    pg, rank, world, local = init_from_env(backend)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     device = "cuda:%d" % local
     torch.cuda.set_device(local)
     from adt_amd.sasrec.trainer import FusedTrainer
-    GB = CFG["batch"] * (world if args.scaling == "weak" else 1)      # global batch
-    lo, hi = shard_bounds(GB, rank, world)
-    B = hi - lo                                                         # this rank's rows of every global batch
-    model = build_model(device, args.precision)
-    if world > 1:
-        dist.broadcast(model.flat, 0)
-    tr = FusedTrainer(model, CFG["lambdas1"], CFG["lambdas2"], lr=CFG["lr"], weight_decay=CFG["weight_decay"], clip=CFG["clip"],
-                      process_group=pg, use_graph=not args.no_graph, seed=23)
-    # every rank draws the same global batches (same seed) and keeps rows [lo, hi); loss normalisers are those of the GLOBAL batch,
-    # dropout indices are global (b_offset = lo): N ranks compute the step one process would compute on the global batch
-    nb = 4
     L, d, H = CFG["maxlen"], CFG["hidden_units"], CFG["num_heads"]
-    gbatches = synth_batches(nb, GB, L, CFG["item_num"], seed=100)
-    norms = [(float(np.count_nonzero(b[2])), float(GB * L * d), float(GB * L * H)) for b in gbatches]
-    batches = [tuple(a[lo:hi] for a in b) for b in gbatches]
-    ring = tr.stage_ring(batches, norms)
-    torch.cuda.synchronize()
 
     def timed(fn, k):
+        """EXACTLY k steps between barrier + synchronize on both sides; MAX over the ranks."""
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -423,39 +429,94 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t)
         return dt
 
-    for i in range(args.warmup):
-        tr.step_staged(ring, b_offset=lo)
-    dt = timed(lambda i: tr.step_staged(ring, b_offset=lo), args.steps)
-    loss = float(tr.loss())
-    # the same steps from HOST int arrays: packed into a slot of the pinned ring, fetched by the step's first kernel over PCIe
-    for i in range(max(3, min(args.warmup, 10))):
-        tr.step(*batches[i % nb], norms=norms[i % nb], b_offset=lo)
-    dt_h2d = timed(lambda i: tr.step(*batches[i % nb], norms=norms[i % nb], b_offset=lo), args.steps)
+    def blocks(fn, k, min_blocks=5, min_seconds=0.5, max_blocks=200):
+        """Blocks of exactly k steps each (every block bracketed like `timed`), at least min_blocks of them and until min_seconds of timed
+        steps have run: returns the per-block seconds.  The figure of the line is the MEDIAN block."""
+        fixed = int(os.environ.get("ADT_BENCH_BLOCKS", "0"))      # a fixed block count (tests: the step count must not depend on the clock)
+        out = []
+        while (len(out) < fixed) if fixed > 0 else (len(out) < min_blocks or (sum(out) < min_seconds and len(out) < max_blocks)):
+            out.append(timed(fn, k))
+        return out
+
+    def run(scaling):
+        """One complete measurement at `scaling`: every rank draws the same global batches (same seed) and keeps rows [lo, hi); loss
+        normalisers are those of the GLOBAL batch, dropout indices are global (b_offset = lo): N ranks compute the step one process would
+        compute on the global batch."""
+        GB = CFG["batch"] * (world if scaling == "weak" else 1)      # global batch
+        lo, hi = shard_bounds(GB, rank, world)
+        B = hi - lo                                                   # this rank's rows of every global batch
+        model = build_model(device, args.precision)
+        if world > 1:
+            if backend == "nccl":
+                dist.broadcast(model.flat, 0)
+            else:
+                t = model.flat.detach().cpu()
+                dist.broadcast(t, 0)
+                model.flat.copy_(t.to(device))
+        tr = FusedTrainer(model, CFG["lambdas1"], CFG["lambdas2"], lr=CFG["lr"], weight_decay=CFG["weight_decay"], clip=CFG["clip"],
+                          process_group=pg, use_graph=not args.no_graph and (backend == "nccl" or world == 1), seed=23)
+        nb = 4
+        gbatches = synth_batches(nb, GB, L, CFG["item_num"], seed=100)
+        norms = [(float(np.count_nonzero(b[2])), float(GB * L * d), float(GB * L * H)) for b in gbatches]
+        batches = [tuple(a[lo:hi] for a in b) for b in gbatches]
+        ring = tr.stage_ring(batches, norms)
+        torch.cuda.synchronize()
+        for i in range(args.warmup):
+            tr.step_staged(ring, b_offset=lo)
+        bl = blocks(lambda i: tr.step_staged(ring, b_offset=lo), args.steps)
+        loss = float(tr.loss())
+        # the same steps from HOST int arrays: packed into a slot of the pinned ring, fetched by the step's first kernel / prefetched
+        for i in range(max(3, min(args.warmup, 10))):
+            tr.step(*batches[i % nb], norms=norms[i % nb], b_offset=lo)
+        bl_h = blocks(lambda i: tr.step(*batches[i % nb], norms=norms[i % nb], b_offset=lo), args.steps)
+        return dict(GB=GB, B=B, lo=lo, model=model, tr=tr, batches=batches, bl=bl, bl_h=bl_h, loss=loss)
+
+    def stats(bl, GB):
+        med = sorted(bl)[len(bl) // 2]
+        return {"ms_per_step": round(med / args.steps * 1e3, 4), "ms_per_step_min": round(min(bl) / args.steps * 1e3, 4),
+                "ms_per_step_max": round(max(bl) / args.steps * 1e3, 4), "blocks": len(bl), "timed_s": round(sum(bl), 3),
+                "sequences_per_s": round(GB * args.steps / med, 1)}
+
+    main_scaling = args.scaling
+    r = run(main_scaling)
+    other = None
+    if world > 1:      # both scalings in one line: weak (256 sequences per GPU) and strong (the reference's global batch of 256 split over the ranks)
+        del r["tr"], r["model"]
+        torch.cuda.empty_cache()
+        other = run("strong" if main_scaling == "weak" else "weak")
     if rank == 0:
-        sps, sps_h2d = GB * args.steps / dt, GB * args.steps / dt_h2d
-        res = {"metric": "train sequences/sec, SASRec-ADT ml-1m (seq_len=200, d=64, 2 blocks)", "value": round(sps, 1),
+        st, st_h = stats(r["bl"], r["GB"]), stats(r["bl_h"], r["GB"])
+        res = {"metric": "train sequences/sec, SASRec-ADT ml-1m (seq_len=200, d=64, 2 blocks)", "value": st["sequences_per_s"],
                "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+               "ms_per_step": st["ms_per_step"], "higher_is_better": True, "scaling": main_scaling, "vs_baseline": None,
                "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
                "config": {"workload": "SASRec-ADT ml-1m shape, 2 blocks d=64 H=2 seq_len=200, global batch %d (%d sequences on this GPU), dropout 0.5, "
-                                      "full train step (fwd+loss+bwd+clip+Adam), ids resident in HBM" % (GB, B),
-                          "global_batch": GB, "seq_len": CFG["maxlen"],
-                          "parallelism": "dp%d%s" % (world, "-rccl" if pg is not None else ""), "hip_graph": not args.no_graph,
+                                      "full train step (fwd+loss+bwd+clip+Adam), ids resident in HBM" % (r["GB"], r["B"]),
+                          "global_batch": r["GB"], "seq_len": CFG["maxlen"],
+                          "parallelism": "dp%d%s" % (world, ("-rccl" if backend == "nccl" else "-" + backend) if pg is not None else ""),
+                          "hip_graph": not args.no_graph and (backend == "nccl" or world == 1),
                           "world_size": dist.get_world_size() if pg is not None else 1,
                           "backend": dist.get_backend() if pg is not None else None},
-               "loss_last_step": round(loss, 5),
-               "value_incl_h2d": round(sps_h2d, 1), "ms_per_step_incl_h2d": round(dt_h2d / args.steps * 1e3, 4)}
+               "value_definition": "median of `blocks` blocks of exactly `steps` steps each (barrier + synchronize around every block, MAX over ranks), "
+                                   "id batches resident in HBM; value_incl_h2d = the same from host int arrays through the pinned ring (SURVEY 8d's step)",
+               "timing": st, "loss_last_step": round(r["loss"], 5),
+               "value_incl_h2d": st_h["sequences_per_s"], "ms_per_step_incl_h2d": st_h["ms_per_step"], "timing_incl_h2d": st_h}
+        if other is not None:
+            so, so_h = stats(other["bl"], other["GB"]), stats(other["bl_h"], other["GB"])
+            res["strong" if main_scaling == "weak" else "weak"] = {
+                "global_batch": other["GB"], "sequences_per_gpu": other["B"], "value": so["sequences_per_s"], "ms_per_step": so["ms_per_step"],
+                "timing": so, "value_incl_h2d": so_h["sequences_per_s"], "ms_per_step_incl_h2d": so_h["ms_per_step"], "loss_last_step": round(other["loss"], 5)}
         if world == 1 and not args.no_ndcg:
             res["ndcg"] = ndcg_check(device)
-        if B == CFG["batch"]:
-            res["roofline"] = roofline_probe(model, tr, B, B * args.steps / dt, batches[0])
-            res["roofline"]["step"]["incl_h2d"] = {"achieved_GBps": round(B * args.steps / dt_h2d * 2.4e6 / 1e9, 1),
-                                                   "frac": round(B * args.steps / dt_h2d * 2.4e6 / 1e9 / HBM_PEAK_GBS, 4)}
+        if r["B"] == CFG["batch"] and world == 1 and not args.no_roofline:
+            res["roofline"] = roofline_probe(r["model"], r["tr"], r["B"], st["sequences_per_s"], r["batches"][0])
+            res["roofline"]["step"]["incl_h2d"] = {"achieved_GBps": round(st_h["sequences_per_s"] * 2.4e6 / 1e9, 1),
+                                                   "frac": round(st_h["sequences_per_s"] * 2.4e6 / 1e9 / HBM_PEAK_GBS, 4)}
         if world == 1 and not args.no_cpu_baseline and not args.force_dp:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), file=json_out, flush=True)
