@@ -285,9 +285,21 @@ adt::SeqBwdArgs seq_bwd_args(int L, int B, int H, const int32_t* ids, float p, c
   return a;
 }
 
+// workgroups per sequence of the per-sequence kernels: the largest power of two that keeps B * S within the CUs (ADT_SEQ_SPLIT overrides;
+// 1 at B >= 129).  Small batches -- a data-parallel rank's share of a global batch -- otherwise leave most CUs without a workgroup.
+int seq_split(int B) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("ADT_SEQ_SPLIT"); forced = e ? atoi(e) : 0; }
+  if (forced > 0) return forced;
+  int s = 1;
+  while (s < 8 && B * s * 2 <= 256) s *= 2;
+  return s;
+}
+
 adt::SeqFwdArgs seq_args(int L, int B, int H, const int32_t* ids, float p, const uint32_t* seed, uint32_t b_offset, int hd) {
   adt::SeqFwdArgs a;
   memset(&a, 0, sizeof(a));
+  a.nsplit = seq_split(B);
   a.L = L; a.B = B; a.H = H; a.ids = ids; a.drop = adt_make_drop(p, seed, 0); a.b_offset = b_offset; a.ln_eps = LN_EPS;
   a.scale = 1.0f / sqrtf((float)hd);
   return a;

@@ -95,11 +95,13 @@ int adt_launch_seq_enc_fwd(int hd, const SeqFwdArgs& a, void* stream) {
   seq_ablate(args);
   hipStream_t s = (hipStream_t)stream;
   if (seq_use_tt(args)) {
+    const int nsp = args.nsplit > 1 ? args.nsplit : 1;
     const size_t smem_tt = SeqTtLds<6>::bytes;
-    if (hd == 64) return seq_launch((const void*)k_seqtt_enc_fwd<64>, smem_tt, done_tt[0], a.B, &args, s, "seqtt_enc_fwd<64>", TQ_FWD_NW);
-    if (hd == 32) return seq_launch((const void*)k_seqtt_enc_fwd<32>, smem_tt, done_tt[1], a.B, &args, s, "seqtt_enc_fwd<32>", TQ_FWD_NW);
-    if (hd == 16) return seq_launch((const void*)k_seqtt_enc_fwd<16>, smem_tt, done_tt[2], a.B, &args, s, "seqtt_enc_fwd<16>", TQ_FWD_NW);
+    if (hd == 64) return seq_launch((const void*)k_seqtt_enc_fwd<64>, smem_tt, done_tt[0], a.B * nsp, &args, s, "seqtt_enc_fwd<64>", TQ_FWD_NW);
+    if (hd == 32) return seq_launch((const void*)k_seqtt_enc_fwd<32>, smem_tt, done_tt[1], a.B * nsp, &args, s, "seqtt_enc_fwd<32>", TQ_FWD_NW);
+    if (hd == 16) return seq_launch((const void*)k_seqtt_enc_fwd<16>, smem_tt, done_tt[2], a.B * nsp, &args, s, "seqtt_enc_fwd<16>", TQ_FWD_NW);
   }
+  args.nsplit = 0;
   const size_t smem = SeqFwdLds<6>::bytes;
   if (hd == 64) return seq_launch((const void*)k_seq_enc_fwd<64, 2>, smem, done[0], a.B, &args, s, "seq_enc_fwd<64>");
   if (hd == 32) return seq_launch((const void*)k_seq_enc_fwd<32, 2>, smem, done[1], a.B, &args, s, "seq_enc_fwd<32>");
@@ -114,11 +116,13 @@ int adt_launch_seq_dec_fwd(int hd, const SeqFwdArgs& a, void* stream) {
   seq_ablate(args);
   hipStream_t s = (hipStream_t)stream;
   if (seq_use_tt(args)) {
+    const int nsp = args.nsplit > 1 ? args.nsplit : 1;
     const size_t smem_tt = SeqTtLds<5>::bytes;
-    if (hd == 64) return seq_launch((const void*)k_seqtt_dec_fwd<64>, smem_tt, done_tt[0], a.B, &args, s, "seqtt_dec_fwd<64>", TQ_FWD_NW);
-    if (hd == 32) return seq_launch((const void*)k_seqtt_dec_fwd<32>, smem_tt, done_tt[1], a.B, &args, s, "seqtt_dec_fwd<32>", TQ_FWD_NW);
-    if (hd == 16) return seq_launch((const void*)k_seqtt_dec_fwd<16>, smem_tt, done_tt[2], a.B, &args, s, "seqtt_dec_fwd<16>", TQ_FWD_NW);
+    if (hd == 64) return seq_launch((const void*)k_seqtt_dec_fwd<64>, smem_tt, done_tt[0], a.B * nsp, &args, s, "seqtt_dec_fwd<64>", TQ_FWD_NW);
+    if (hd == 32) return seq_launch((const void*)k_seqtt_dec_fwd<32>, smem_tt, done_tt[1], a.B * nsp, &args, s, "seqtt_dec_fwd<32>", TQ_FWD_NW);
+    if (hd == 16) return seq_launch((const void*)k_seqtt_dec_fwd<16>, smem_tt, done_tt[2], a.B * nsp, &args, s, "seqtt_dec_fwd<16>", TQ_FWD_NW);
   }
+  args.nsplit = 0;
   const size_t smem = SeqFwdLds<5>::bytes;
   if (hd == 64) return seq_launch((const void*)k_seq_dec_fwd<64>, smem, done[0], a.B, &args, s, "seq_dec_fwd<64>");
   if (hd == 32) return seq_launch((const void*)k_seq_dec_fwd<32>, smem, done[1], a.B, &args, s, "seq_dec_fwd<32>");

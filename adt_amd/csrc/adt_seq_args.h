@@ -43,6 +43,10 @@ struct SeqFwdArgs {
   // tail of the LAST encoder layer (optional): log_feats = last_layernorm(y) -> f_out, formed on the output tile while it is in registers
   // (sasrec/model.py:48).  No loads: a global load this late in the kernel waits for every store the wave has issued before it (vmcnt is in order).
   const float* lnl_gamma; const float* lnl_beta; float* f_out;
+  // Several workgroups per sequence (small batches: fewer sequences than CUs).  nsplit = S > 1: the grid is B * S workgroups, workgroup
+  // (b, part) = (blockIdx / S, blockIdx % S) computes the key / value rows of EVERY tile (each workgroup needs them all: recomputed, not
+  // exchanged) but queries, attention, out_proj, feed-forward and every store only for the tiles t with t % S == part.  0 / 1: one workgroup.
+  int nsplit;
 };
 
 }  // namespace adt

@@ -265,7 +265,9 @@ __global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   SeqTtLds<6> lds(smem_raw);
-  const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16;
+  const int nsp = a.nsplit > 1 ? a.nsplit : 1, b = blockIdx.x / nsp, part = blockIdx.x % nsp;      // adt_seq_args.h: several workgroups per sequence
+  const int L = a.L, ntiles = (L + 15) / 16;
+  const bool own[2] = {tq_tile12(0, w, ntiles) >= 0 && tq_tile12(0, w, ntiles) % nsp == part, tq_tile12(1, w, ntiles) >= 0 && tq_tile12(1, w, ntiles) % nsp == part};
   TQ_STAMP(0);
   uint32_t seedv = 0u;
   TqX xr[2];
@@ -321,11 +323,13 @@ __global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) 
   TT xn[2];
   {
     const int tile = tq_tile12(0, w, ntiles);
-    if (tile >= 0) tq_pre_tile<HD, true>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[0], xn[0], xr[0]);
+    if (tile >= 0 && own[0]) tq_pre_tile<HD, true>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[0], xn[0], xr[0]);
+    else if (tile >= 0) tq_pre_tile<HD, true, 1>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[0], xn[0], xr[0]);      // another workgroup's tile: k / v rows only
     TQ_STAMP(2);
     const int tile1 = tq_tile12(1, w, ntiles);
     if (htile >= 0) tq_pre_tile<HD, true, 1>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, htile, b, key0, qmul, c, g, fq[1], xn[1], xr[1]);
-    else if (tile1 >= 0 && !split2) tq_pre_tile<HD, true>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile1, b, key0, qmul, c, g, fq[1], xn[1], xr[1]);
+    else if (tile1 >= 0 && !split2 && own[1]) tq_pre_tile<HD, true>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile1, b, key0, qmul, c, g, fq[1], xn[1], xr[1]);
+    else if (tile1 >= 0 && !split2) tq_pre_tile<HD, true, 1>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile1, b, key0, qmul, c, g, fq[1], xn[1], xr[1]);
     TQ_STAMP(3);
   }
   adt_wait_vm0();            // the three images requested behind the first barrier have landed: published by this one
@@ -333,12 +337,12 @@ __global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_enc_fwd(SeqFwdArgs a) 
   TQ_STAMP(4);
   {      // the owner's part of a split second tile, first (its layer-input registers die here, as they did in front of the barrier)
     const int tile1 = tq_tile12(1, w, ntiles);
-    if (split2 && tile1 >= 0) tq_pre_tile<HD, true, 2>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile1, b, key0, qmul, c, g, fq[1], xn[1], xr[1]);
+    if (split2 && tile1 >= 0 && own[1]) tq_pre_tile<HD, true, 2>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile1, b, key0, qmul, c, g, fq[1], xn[1], xr[1]);
   }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile12(s, w, ntiles);
-    if (tile < 0) continue;
+    if (tile < 0 || !own[s]) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
     const TT o = tt_attn_heads<HD, TQ_MAXKT>(lds.sK, lds.sV, fq[s], tile, L, b, a.b_offset, a.drop, a.site_attn, seedv, a.lse, a.mask, lane, c, g);
@@ -401,7 +405,9 @@ __global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   SeqTtLds<5> lds(smem_raw);
-  const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16;
+  const int nsp = a.nsplit > 1 ? a.nsplit : 1, b = blockIdx.x / nsp, part = blockIdx.x % nsp;      // adt_seq_args.h: several workgroups per sequence
+  const int L = a.L, ntiles = (L + 15) / 16;
+  const bool own[2] = {tq_tile12(0, w, ntiles) >= 0 && tq_tile12(0, w, ntiles) % nsp == part, tq_tile12(1, w, ntiles) >= 0 && tq_tile12(1, w, ntiles) % nsp == part};
   uint32_t seedv = 0u;
   const bool tq_body = TQW * 64 <= TQ_CH || threadIdx.x < TQ_CH;
   const bool tq_tail = (int)threadIdx.x < TQ_CH - TQW * 64;        // chunks beyond the first TQW * 64 (wave-uniform: whole waves)
@@ -449,21 +455,23 @@ __global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) 
   // self attention: D = LN(x); q, k, v = D Win^T + b                                                    (sasrec/modules.py:668-670)
   {
     const int tile = tq_tile12(0, w, ntiles), tile1 = tq_tile12(1, w, ntiles);
-    if (tile >= 0) tq_pre_tile<HD, false>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[0], dn[0], xr[0]);
+    if (tile >= 0 && own[0]) tq_pre_tile<HD, false>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[0], dn[0], xr[0]);
+    else if (tile >= 0) tq_pre_tile<HD, false, 1>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile, b, key0, qmul, c, g, fq[0], dn[0], xr[0]);      // another workgroup's tile: k / v rows only
     if (htile >= 0) tq_pre_tile<HD, false, 1>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, htile, b, key0, qmul, c, g, fq[1], dn[1], xr[1]);
-    else if (tile1 >= 0 && !split2) tq_pre_tile<HD, false>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile1, b, key0, qmul, c, g, fq[1], dn[1], xr[1]);
+    else if (tile1 >= 0 && !split2 && own[1]) tq_pre_tile<HD, false>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile1, b, key0, qmul, c, g, fq[1], dn[1], xr[1]);
+    else if (tile1 >= 0 && !split2) tq_pre_tile<HD, false, 1>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile1, b, key0, qmul, c, g, fq[1], dn[1], xr[1]);
   }
   adt_wait_vm0();
   __syncthreads();
   {
     const int tile1 = tq_tile12(1, w, ntiles);
-    if (split2 && tile1 >= 0) tq_pre_tile<HD, false, 2>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile1, b, key0, qmul, c, g, fq[1], dn[1], xr[1]);
+    if (split2 && tile1 >= 0 && own[1]) tq_pre_tile<HD, false, 2>(a, lds.vec, lds.w[0], lds.w[1], lds.w[2], lds.sK, lds.sV, tile1, b, key0, qmul, c, g, fq[1], dn[1], xr[1]);
   }
   // a1 = out_proj(o1) ; q2 = a1 Wq2^T + b : the cross attention's queries replace the self attention's in the registers
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile12(s, w, ntiles);
-    if (tile < 0) continue;
+    if (tile < 0 || !own[s]) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
     const TT o1 = tt_attn_heads<HD, TQ_MAXKT>(lds.sK, lds.sV, fq[s], tile, L, b, a.b_offset, a.drop, a.site_attn, seedv, a.lse, a.mask, lane, c, g);
@@ -499,7 +507,9 @@ __global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) 
     tt_add_vec(k2, lds.vec + SV_BIN2 + 64, g);
     TT v2 = tt_gemm(bf, lds.w[1], c, g);
     tt_add_vec(v2, lds.vec + SV_BIN2 + 128, g);
-    if (a.kv2 && a.saved_bf16) {          // rows of 128 bf16: k2 | v2
+    const bool mine = tile % nsp == part;      // every workgroup of a split sequence computes these rows; one of them stores them
+    if (!mine) {
+    } else if (a.kv2 && a.saved_bf16) {          // rows of 128 bf16: k2 | v2
       __bf16* kvrow = reinterpret_cast<__bf16*>(a.kv2) + (size_t)row * 128;
       tt_store_bf16(kvrow, k2, valid, g);
       tt_store_bf16(kvrow + 64, v2, valid, g);
@@ -518,7 +528,7 @@ __global__ __launch_bounds__(TQ_FWD_NW * 64) void k_seqtt_dec_fwd(SeqFwdArgs a) 
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int tile = tq_tile12(s, w, ntiles);
-    if (tile < 0) continue;
+    if (tile < 0 || !own[s]) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
     const TT o2 = tt_attn_heads<HD, TQ_MAXKT>(lds.sK, lds.sV, fq[s], tile, L, b, a.b_offset, a.drop, a.site_attn2, seedv, a.lse2, a.mask2, lane, c, g);
