@@ -690,7 +690,7 @@ int adt_fold_clip_adam(float* P, float* G, float* M, float* V, int64_t n, float*
 /* adt_fold_clip_adam that also sums the per-sequence partials of the 64 x 64 weight gradients (nslots blocks: slot index inside a workgroup's
  * partial area, float offset in G) in workgroup order; mask_base = offset in G of the range the row mask describes (the positional table). */
 int adt_fold_parts_clip_adam(float* P, float* G, float* M, float* V, int64_t n, float* d0, const float* r0, int64_t n0, int nrep0, int64_t s0, float* d1,
-                             const float* r1, int64_t n1, int nrep1, int64_t s1, const float* part, int64_t part_stride, int nwg, const int* slots,
+                             const float* r1, int64_t n1, int nrep1, int64_t s1, const float* part, int64_t part_stride, const int* nwg_slot, const int* slots,
                              const int* offs, int nslots, float wd, float clip, float lr, float b1, float b2, float eps, float* scal, void* stream) {
   if (n0 <= 0 || n1 <= 0 || (n0 % 4) || (s0 % 4) || (n1 % 4) || (s1 % 4) || d0 != G) return adt_set_error("fold_parts_clip_adam: ranges");
   if (nslots < 1 || nslots > FP_MAXSLOTS || (d1 - G) % 64 || n1 > (int64_t)FP_MASKWORDS * 32 * 64) return adt_set_error("fold_parts_clip_adam: %d blocks, %lld floats", nslots, (long long)n1);
@@ -701,9 +701,9 @@ int adt_fold_parts_clip_adam(float* P, float* G, float* M, float* V, int64_t n, 
   const int g0 = grid_for((size_t)n0 / 4, 256, 1024), g1 = grid_for((size_t)n1 / 4, 256, 1024);
   r.g0 = g0;
   PartFoldArgs pf{};
-  pf.part = part; pf.stride = (size_t)part_stride; pf.nwg = nwg; pf.nslots = nslots; pf.mask_base = d1 - G;
+  pf.part = part; pf.stride = (size_t)part_stride; pf.nslots = nslots; pf.mask_base = d1 - G;
   for (int i = 0; i < nslots; ++i) {
-    pf.slot[i] = slots[i]; pf.off[i] = offs[i];
+    pf.slot[i] = slots[i]; pf.off[i] = offs[i]; pf.nwg[i] = nwg_slot[i];
     const int64_t r0w = (offs[i] - pf.mask_base) / 64;
     if (offs[i] < pf.mask_base || (offs[i] - pf.mask_base) % 64 || r0w + 64 > (int64_t)FP_MASKWORDS * 32) return adt_set_error("fold_parts_clip_adam: block %d outside the masked range", i);
     for (int64_t rr = r0w; rr < r0w + 64; ++rr) pf.rowmask[rr >> 5] |= 1u << (rr & 31);

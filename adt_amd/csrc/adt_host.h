@@ -45,6 +45,8 @@ int adt_launch_seq_mid_bwd(int hd, const adt::BwdChainArgs& a, void* stream);   
 // private per-workgroup partials of the 64 x 64 weight gradients instead of atomics (adt_seqbwd_tt.cuh: sb_dw_tiles) and their sum
 int adt_seq_partials(int prec, int L, int d, int hd);
 int adt_dwpart_reduce(float* G, const float* part, size_t stride, int nwg, const int* slots, const int* offs, int nslots, void* stream);
+// the same with a workgroup count per slot (nwg_slot[i] workgroups wrote slot i ; null: nwg everywhere)
+int adt_dwpart_reduce_n(float* G, const float* part, size_t stride, int nwg, const int* nwg_slot, const int* slots, const int* offs, int nslots, void* stream);
 namespace adt { struct SeqBwdArgs; }
 int adt_launch_seq_attn_pre_bwd(int hd, int dec, const adt::SeqBwdArgs& a, void* stream);     // 0 launched, 1 not covered, < 0 error
 
@@ -84,6 +86,6 @@ int adt_fold_clip_adam(float* P, float* G, float* M, float* V, int64_t n, float*
 int adt_replica_reduce2(float* d0, const float* r0, int64_t n0, int nrep0, int64_t s0, float* d1, const float* r1, int64_t n1, int nrep1, int64_t s1,
                         void* stream);
 int adt_fold_parts_clip_adam(float* P, float* G, float* M, float* V, int64_t n, float* d0, const float* r0, int64_t n0, int nrep0, int64_t s0, float* d1,
-                             const float* r1, int64_t n1, int nrep1, int64_t s1, const float* part, int64_t part_stride, int nwg, const int* slots,
+                             const float* r1, int64_t n1, int nrep1, int64_t s1, const float* part, int64_t part_stride, const int* nwg_slot, const int* slots,
                              const int* offs, int nslots, float wd, float clip, float lr, float b1, float b2, float eps, float* scal, void* stream);
 }

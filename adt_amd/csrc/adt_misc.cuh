@@ -875,8 +875,9 @@ __global__ __launch_bounds__(256) void k_fold_wd_gradnorm(RepReduce2Args a, OptA
 // Job 2: 16 workgroups per block, 64 float4 outputs each, FOUR threads per output (64 workgroups' partials each, ascending), joined in order.
 constexpr int FP_MAXSLOTS = 64, FP_MASKWORDS = 160;      // 64 x 64 blocks per step ; 160 x 32 rows of 64 floats = 327,680 non-item floats
 struct PartFoldArgs {
-  const float* part; size_t stride; int nwg, nslots;
+  const float* part; size_t stride; int nslots;
   int slot[FP_MAXSLOTS]; int off[FP_MAXSLOTS];      // slot inside a workgroup's partial area ; float offset of the block in G
+  int nwg[FP_MAXSLOTS];                             // workgroups that wrote the slot (B, or B * S for kernels with S workgroups per sequence)
   uint32_t rowmask[FP_MASKWORDS]; int64_t mask_base;       // bit r: row r (64 floats, from G + mask_base) belongs to a weight block
 };
 __global__ __launch_bounds__(256) void k_fold_parts_gradnorm(RepReduce2Args a, OptArgs o, PartFoldArgs pf, int g1) {
@@ -912,7 +913,7 @@ __global__ __launch_bounds__(256) void k_fold_parts_gradnorm(RepReduce2Args a, O
     const int bid = blockIdx.x - a.g0 - g1;
     const int js = bid >> 4, o4 = (bid & 15) * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;      // float4 o4 of the partial layout, quarter q of the workgroups
     const int e4 = o4 * 4;
-    const int per = (pf.nwg + 3) / 4, w0 = q * per, w1 = min(pf.nwg, w0 + per);
+    const int per = (pf.nwg[js] + 3) / 4, w0 = q * per, w1 = min(pf.nwg[js], w0 + per);
     const float* p = pf.part + (size_t)pf.slot[js] * 4096 + e4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     int wg = w0;

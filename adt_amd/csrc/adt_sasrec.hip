@@ -33,6 +33,18 @@ enum { D_LNW, D_LNB, D_SINW, D_SINB, D_SOW, D_SOB, D_EINW, D_EINB, D_EOW, D_EOB,
 
 int64_t up64(int64_t x) { return (x + 63) / 64 * 64; }
 
+// workgroups per sequence of the per-sequence kernels: the largest power of two that keeps B * S within the CUs (ADT_SEQ_SPLIT overrides;
+// 1 at B >= 129).  Small batches -- a data-parallel rank's share of a global batch -- otherwise leave most CUs without a workgroup.
+int seq_split(int B) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("ADT_SEQ_SPLIT"); forced = e ? atoi(e) : 0; }
+  if (forced > 0) return forced;
+  int s = 1;
+  while (s < 8 && B * s * 2 <= 256) s *= 2;
+  return s;
+}
+
+
 bool make_layout(const adt_sasrec_cfg* c, Layout* lo) {
   if (c->num_layers < 1 || c->num_layers > 16) return false;
   const int64_t d = c->hidden, H = c->num_heads, hd = d / H, L = c->maxlen, V = c->item_num;
@@ -110,7 +122,7 @@ void make_ws(const adt_sasrec_cfg* c, int B, WS* w) {
     w->wpack = take(3 * w->prep_stride);
   }
   w->part_stride = (c->prec == ADT_PREC_BF16 && c->hidden == 64) ? (int64_t)w->nl * 16 * 4096 : 0;
-  w->part = take((int64_t)B * w->part_stride);
+  w->part = take((int64_t)B * seq_split(B) * w->part_stride);      // one partial area per WORKGROUP (several per sequence at small batches)
   w->isort_n = (c->hidden == 64 && adt_item_sort_supported(c->item_num + 1)) ? adt_item_sort_work_ints(4, (int)w->T, c->item_num + 1) : 0;
   w->isort = take(up64(w->isort_n));
   w->total = o;
@@ -243,11 +255,19 @@ enum { PS_E_IN = 0, PS_E_O = 3, PS_E_C1 = 4, PS_E_C2 = 5, PS_D_SIN = 6, PS_D_EIN
 
 // the partial slots of the encoder (enc = true) and / or decoder (dec = true) blocks of every layer and their offsets in G
 int partial_slots(const adt_sasrec_cfg* c, const Layout& lo, bool enc, bool dec, int* slots, int* offs);
+// workgroups that write partial slot `slot` of a step with B sequences: the token-chain kernels run S workgroups per sequence
+int partial_nwg(int slot, int B) {
+  const int k = slot % 16;
+  const bool attn_block = (k >= PS_E_IN && k < PS_E_IN + 3) || (k >= PS_D_SIN && k < PS_D_SIN + 3);      // k_seqtt_attn_pre_bwd: one workgroup per sequence
+  return attn_block ? B : B * seq_split(B);
+}
 // sums the partials of the encoder (enc = true) and / or decoder (dec = true) blocks of every layer into G
 int reduce_partials(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, float* G, float* ws, bool enc, bool dec, void* st) {
   int slots[256], offs[256];
   const int n = partial_slots(c, lo, enc, dec, slots, offs);
-  return adt_dwpart_reduce(G, ws + w.part, (size_t)w.part_stride, (int)w.B, slots, offs, n, st);
+  int nwg[256];
+  for (int i = 0; i < n; ++i) nwg[i] = partial_nwg(slots[i], (int)w.B);
+  return adt_dwpart_reduce_n(G, ws + w.part, (size_t)w.part_stride, (int)w.B, nwg, slots, offs, n, st);
 }
 int partial_slots(const adt_sasrec_cfg* c, const Layout& lo, bool enc, bool dec, int* slots, int* offs) {
   int n = 0;
@@ -283,17 +303,6 @@ adt::SeqBwdArgs seq_bwd_args(int L, int B, int H, const int32_t* ids, float p, c
   a.L = L; a.B = B; a.H = H; a.ids = ids; a.drop = adt_make_drop(p, seed, site); a.b_offset = b_offset; a.ln_eps = LN_EPS;
   a.scale = 1.0f / sqrtf((float)hd);
   return a;
-}
-
-// workgroups per sequence of the per-sequence kernels: the largest power of two that keeps B * S within the CUs (ADT_SEQ_SPLIT overrides;
-// 1 at B >= 129).  Small batches -- a data-parallel rank's share of a global batch -- otherwise leave most CUs without a workgroup.
-int seq_split(int B) {
-  static int forced = -1;
-  if (forced < 0) { const char* e = getenv("ADT_SEQ_SPLIT"); forced = e ? atoi(e) : 0; }
-  if (forced > 0) return forced;
-  int s = 1;
-  while (s < 8 && B * s * 2 <= 256) s *= 2;
-  return s;
 }
 
 adt::SeqFwdArgs seq_args(int L, int B, int H, const int32_t* ids, float p, const uint32_t* seed, uint32_t b_offset, int hd) {
@@ -732,6 +741,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
     adt::BwdChainArgs a = bwd_args(T, L, (int)w.B, ids, pp, sd, ro);
     a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride;
     a.wp_base = P + lo.posw(); a.wp_img = prec == ADT_PREC_BF16 ? (const void*)(ws + w.wpack) : nullptr;   // packed by the forward of this step
+    a.nsplit = seq_split((int)w.B);
     return a;
   };
   const int64_t dec_begin = lo.dec(0, 0);
@@ -1049,9 +1059,11 @@ int adt_sasrec_fold_clip_adam(const adt_sasrec_cfg* c, float* ws, int B, float* 
   if (fold_sums_partials(c, w)) {
     int slots[256], offs[256];
     const int ns = partial_slots(c, lo, true, true, slots, offs);
+    int nwg[256];
+    for (int i = 0; i < ns; ++i) nwg[i] = partial_nwg(slots[i], B);
     return adt_fold_parts_clip_adam(P, G, M, V, lo.total, G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * c->hidden, item_det(w) ? 0 : NREP,
                                     w.rep_stride, G + lo.posw(), Gq + lo.posw(), lo.total - lo.posw(), NREPP, w.prep_stride, ws + w.part,
-                                    w.part_stride, (int)w.B, slots, offs, ns, wd, clip, lr, b1, b2, eps, scal, st);
+                                    w.part_stride, nwg, slots, offs, ns, wd, clip, lr, b1, b2, eps, scal, st);
   }
   return adt_fold_clip_adam(P, G, M, V, lo.total, G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * c->hidden, item_det(w) ? 0 : NREP, w.rep_stride, G + lo.posw(),
                             Gq + lo.posw(), lo.total - lo.posw(), NREPP, w.prep_stride, wd, clip, lr, b1, b2, eps, scal, st);

@@ -200,13 +200,13 @@ int adt_launch_seq_post_bwd(int hd, int enc, const BwdChainArgs& a, void* stream
   const int slot = (hd == 64 ? 0 : hd == 32 ? 2 : 4) + (enc ? 1 : 0);
   BwdChainArgs args = a;
   args.stamps = enc ? seq_stamp_buffer_post() : nullptr;
-  return seq_launch(fns[slot], SeqPostLds<3>::bytes, done[slot], a.B, &args, (hipStream_t)stream, "seqtt_post_bwd", SP_NW);
+  return seq_launch(fns[slot], SeqPostLds<3>::bytes, done[slot], a.B * (a.nsplit > 1 ? a.nsplit : 1), &args, (hipStream_t)stream, "seqtt_post_bwd", SP_NW);
 }
 
 int adt_launch_seq_mid_bwd(int hd, const BwdChainArgs& a, void* stream) {
   if (!seq_post_ok(a, hd)) return 1;
   static bool done = false;
-  return seq_launch((const void*)k_seqtt_mid_bwd, SeqPostLds<4>::bytes, done, a.B, &a, (hipStream_t)stream, "seqtt_mid_bwd", SP_MID_NW);
+  return seq_launch((const void*)k_seqtt_mid_bwd, SeqPostLds<4>::bytes, done, a.B * (a.nsplit > 1 ? a.nsplit : 1), &a, (hipStream_t)stream, "seqtt_mid_bwd", SP_MID_NW);
 }
 
 // ---- sum of the per-workgroup weight-gradient partials (adt_seqbwd_tt.cuh: sb_dw_tiles) --------------------------------------------
@@ -216,11 +216,13 @@ int adt_launch_seq_mid_bwd(int hd, const BwdChainArgs& a, void* stream) {
 struct PartReduceArgs {
   float* G; const float* part; size_t stride; int nwg; int nslots;
   int slot[256]; int off[256];      // slot index inside a workgroup's partial ; float offset of the 64 x 64 block in G
+  int nwg_slot[256];                // workgroups that wrote this slot (kernels with several workgroups per sequence write B * S partials)
 };
 constexpr int PR_SPLIT = 4;
 __global__ __launch_bounds__(256) void k_dwpart_reduce(PartReduceArgs a) {
   const int j = blockIdx.x >> 2, e4 = ((blockIdx.x & 3) * 256 + threadIdx.x) * 4;
-  const int per = (a.nwg + PR_SPLIT - 1) / PR_SPLIT, w0 = blockIdx.y * per, w1 = min(a.nwg, w0 + per);
+  const int nwg = a.nwg_slot[j];
+  const int per = (nwg + PR_SPLIT - 1) / PR_SPLIT, w0 = blockIdx.y * per, w1 = min(nwg, w0 + per);
   const float* p = a.part + (size_t)a.slot[j] * 4096 + e4;
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
   int wg = w0;
@@ -244,10 +246,13 @@ __global__ __launch_bounds__(256) void k_dwpart_reduce(PartReduceArgs a) {
 }
 
 int adt_dwpart_reduce(float* G, const float* part, size_t stride, int nwg, const int* slots, const int* offs, int nslots, void* stream) {
+  return adt_dwpart_reduce_n(G, part, stride, nwg, nullptr, slots, offs, nslots, stream);
+}
+int adt_dwpart_reduce_n(float* G, const float* part, size_t stride, int nwg, const int* nwg_slot, const int* slots, const int* offs, int nslots, void* stream) {
   if (nslots < 1 || nslots > 256) return adt_set_error("dwpart_reduce: %d slots", nslots);
   PartReduceArgs a;
   a.G = G; a.part = part; a.stride = stride; a.nwg = nwg; a.nslots = nslots;
-  for (int i = 0; i < nslots; ++i) { a.slot[i] = slots[i]; a.off[i] = offs[i]; }
+  for (int i = 0; i < nslots; ++i) { a.slot[i] = slots[i]; a.off[i] = offs[i]; a.nwg_slot[i] = nwg_slot ? nwg_slot[i] : nwg; }
   hipLaunchKernelGGL(k_dwpart_reduce, dim3(nslots * 4, PR_SPLIT), dim3(256), 0, (hipStream_t)stream, a);
   return seq_check("dwpart_reduce");
 }

@@ -63,7 +63,9 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   float* sVec = sRed + 448;                                                  // gamma, beta, Ws
   const float *vgamma = sVec, *vbeta = sVec + 64, *vws = sVec + 128;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16, npair = (L + 31) / 32;
+  const int nsp = a.nsplit > 1 ? a.nsplit : 1, b = blockIdx.x / nsp, part = blockIdx.x % nsp;
+  const int L = a.L, ntiles = (L + 15) / 16, npair = (L + 31) / 32;
+  auto tileof = [&](int s) { const int t = tq_tile(s, w, ntiles, NW); return (t >= 0 && t % nsp == part) ? t : -1; };      // this workgroup's tiles only
   const bool cls = ENC && H > 1 && a.drec != nullptr;
   sp_replica(a);
   SB_STAMP(0);
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   int idv[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const int tile = tq_tile(s, w, ntiles, NW);
+    const int tile = tileof(s);
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = tile >= 0 && l < L;
     dy[s] = tt_load(a.gy + (size_t)row * 64, valid, g);
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   TT dt[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const int tile = tq_tile(s, w, ntiles, NW);
+    const int tile = tileof(s);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   TT dgm = tt_zero(), dbt = tt_zero();
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const int tile = tq_tile(s, w, ntiles, NW);
+    const int tile = tileof(s);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   }
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const int tile = tq_tile(s, w, ntiles, NW);
+    const int tile = tileof(s);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
@@ -282,7 +284,9 @@ __global__ __launch_bounds__(SP_MID_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a
   __bf16* img1 = reinterpret_cast<__bf16*>(smem_raw + Lds::wbytes + Lds::ibytes);
   float* sRed = reinterpret_cast<float*>(smem_raw + Lds::wbytes + 2 * Lds::ibytes + 64);   // the four bias gradients
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16, npair = (L + 31) / 32;
+  const int nsp = a.nsplit > 1 ? a.nsplit : 1, b = blockIdx.x / nsp, part = blockIdx.x % nsp;
+  const int L = a.L, ntiles = (L + 15) / 16, npair = (L + 31) / 32;
+  auto tileof = [&](int s) { const int t = tq_tile(s, w, ntiles, NW); return (t >= 0 && t % nsp == part) ? t : -1; };      // this workgroup's tiles only
   sp_replica(a);
   const float* const ws4[4] = {a.W0, a.W1, a.W2, a.W3};
   sp_wdma<4, NW>(a, ws4, wimg);
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(SP_MID_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a
   TTSaved a1req[NS], oreq[NS];             // phase A's activations are requested right behind the weight images (see k_seqtt_post_bwd)
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const int tile = tq_tile(s, w, ntiles, NW);
+    const int tile = tileof(s);
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = tile >= 0 && l < L;
     dqa[s] = a.grad_bf16 ? tt_load_bf16(reinterpret_cast<const __bf16*>(a.dqkv) + (size_t)row * a.lddqkv, valid, g) : tt_load(a.dqkv + (size_t)row * a.lddqkv, valid, g);
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(SP_MID_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a
   TT da1[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const int tile = tq_tile(s, w, ntiles, NW);
+    const int tile = tileof(s);
     if (tile < 0) continue;
     const int l = tile * 16 + c;
     const bool valid = l < L;
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(SP_MID_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a
   TT dk[NS], fx[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const int tile = tq_tile(s, w, ntiles, NW);
+    const int tile = tileof(s);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(SP_MID_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a
   TT df[NS], dv[NS], acc1v[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const int tile = tq_tile(s, w, ntiles, NW);
+    const int tile = tileof(s);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(SP_MID_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a
   // ---- D: cross-attention values (the X image still holds f) --------------------------------------------------------------------------
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const int tile = tq_tile(s, w, ntiles, NW);
+    const int tile = tileof(s);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;
