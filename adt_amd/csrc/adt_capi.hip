@@ -709,7 +709,7 @@ int adt_fold_parts_clip_adam(float* P, float* G, float* M, float* V, int64_t n, 
     for (int64_t rr = r0w; rr < r0w + 64; ++rr) pf.rowmask[rr >> 5] |= 1u << (rr & 31);
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_fold_parts_gradnorm, dim3(g0 + g1 + 16 * nslots), dim3(256), 0, s, r, a, pf, g1);
+  hipLaunchKernelGGL(k_fold_parts_gradnorm, dim3(g0 + g1 + 8 * nslots), dim3(256), 0, s, r, a, pf, g1);
   hipLaunchKernelGGL(k_adam, dim3(grid_for((size_t)n, 256, 1024)), dim3(256), 0, s, a);
   return check_launch("fold_parts_clip_adam");
 }

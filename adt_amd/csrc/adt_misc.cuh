@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void k_fold_wd_gradnorm(RepReduce2Args a, OptA
 // front of a cross-queue join) and their atomics are gone, and every weight gradient is one ordered sum.  Job 1 (the non-item parameters)
 // leaves the rows of the weight blocks alone (rowmask: one bit per 64 floats from `mask_base`); job 2 owns them:
 // G[block] = G[block] + sum_wg part[wg][slot] (the replicas hold nothing there: the chain kernels wrote partials instead).
-// Job 2: 16 workgroups per block, 64 float4 outputs each, FOUR threads per output (64 workgroups' partials each, ascending), joined in order.
+// Job 2: see its body.
 constexpr int FP_MAXSLOTS = 64, FP_MASKWORDS = 160;      // 64 x 64 blocks per step ; 160 x 32 rows of 64 floats = 327,680 non-item floats
 struct PartFoldArgs {
   const float* part; size_t stride; int nslots;
@@ -910,36 +910,57 @@ __global__ __launch_bounds__(256) void k_fold_parts_gradnorm(RepReduce2Args a, O
       acc += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
     }
   } else {
+    // bf16 partials: element (tile, lane, r) of a slot at (tile * 64 + lane) * 4 + r.  A work item = 16 consecutive elements (32 bytes):
+    // lanes l .. l + 3 of one tile, r = 0 .. 3 -> rows n = 16 nt + 4 g + r (four of them), columns k .. k + 3: four float4 of G.
+    // 8 workgroups of this job per slot, 32 work items each, EIGHT threads per work item (an eighth of the workgroups' partials each,
+    // ascending), joined in order.
     const int bid = blockIdx.x - a.g0 - g1;
-    const int js = bid >> 4, o4 = (bid & 15) * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;      // float4 o4 of the partial layout, quarter q of the workgroups
-    const int e4 = o4 * 4;
-    const int per = (pf.nwg[js] + 3) / 4, w0 = q * per, w1 = min(pf.nwg[js], w0 + per);
-    const float* p = pf.part + (size_t)pf.slot[js] * 4096 + e4;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int js = bid >> 3, item = (bid & 7) * 32 + (threadIdx.x >> 3), q = threadIdx.x & 7;
+    const int nwg = pf.nwg[js];
+    const int per = (nwg + 7) / 8, w0 = q * per, w1 = min(nwg, w0 + per);
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const __bf16* p = reinterpret_cast<const __bf16*>(pf.part + (size_t)pf.slot[js] * 4096) + item * 16;
+    const size_t strideb = pf.stride * 2;                  // bf16 elements between two workgroups' areas
+    float sum[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum[i] = 0.f;
+    auto add = [&](const u4v& lo, const u4v& hi) {
+      const unsigned wds[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { sum[2 * i] += __uint_as_float(wds[i] << 16); sum[2 * i + 1] += __uint_as_float(wds[i] & 0xFFFF0000u); }
+    };
     int wg = w0;
-    for (; wg + 8 <= w1; wg += 8) {
-      float4 v[8];
+    for (; wg + 4 <= w1; wg += 4) {
+      u4v lo[4], hi[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(wg + u) * pf.stride);
+      for (int u = 0; u < 4; ++u) {
+        const u4v* src = reinterpret_cast<const u4v*>(p + (size_t)(wg + u) * strideb);
+        lo[u] = src[0]; hi[u] = src[1];
+      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+      for (int u = 0; u < 4; ++u) add(lo[u], hi[u]);
     }
     for (; wg < w1; ++wg) {
-      const float4 v = *reinterpret_cast<const float4*>(p + (size_t)wg * pf.stride);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      const u4v* src = reinterpret_cast<const u4v*>(p + (size_t)wg * strideb);
+      add(src[0], src[1]);
     }
-    sq[threadIdx.x] = s;
-    __syncthreads();
-    if (q == 0) {
-      const float4 s1 = sq[threadIdx.x + 1], s2 = sq[threadIdx.x + 2], s3 = sq[threadIdx.x + 3];
-      const int tile = e4 >> 8, r = (e4 >> 6) & 3, lane = e4 & 63;
-      float* dst = o.G + pf.off[js] + (16 * (tile >> 2) + 4 * (lane >> 4) + r) * 64 + 16 * (tile & 3) + (lane & 15);
-      float4 g = *reinterpret_cast<const float4*>(dst);
-      g.x += ((s.x + s1.x) + s2.x) + s3.x; g.y += ((s.y + s1.y) + s2.y) + s3.y;
-      g.z += ((s.z + s1.z) + s2.z) + s3.z; g.w += ((s.w + s1.w) + s2.w) + s3.w;
-      g.x *= o.grad_scale; g.y *= o.grad_scale; g.z *= o.grad_scale; g.w *= o.grad_scale;
-      *reinterpret_cast<float4*>(dst) = g;
-      acc += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
+    // join the eight range sums in order through LDS (sq: 256 float4 = 4 KB ; 16 floats per thread = 4 float4: four rounds)
+    const int tile = item >> 4, lane0 = (item & 15) * 4;      // element e = (tile * 64 + lane0 + j) * 4 + r  <->  sum[4 j + r]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      __syncthreads();
+      sq[threadIdx.x] = make_float4(sum[r], sum[4 + r], sum[8 + r], sum[12 + r]);      // row r: lanes lane0 .. lane0 + 3 = columns k .. k + 3
+      __syncthreads();
+      if (q == 0) {
+        float4 t = sq[threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { const float4 v = sq[threadIdx.x + k]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        float* dst = o.G + pf.off[js] + (16 * (tile >> 2) + 4 * (lane0 >> 4) + r) * 64 + 16 * (tile & 3) + (lane0 & 15);
+        float4 g = *reinterpret_cast<const float4*>(dst);
+        g.x = (g.x + t.x) * o.grad_scale; g.y = (g.y + t.y) * o.grad_scale; g.z = (g.z + t.z) * o.grad_scale; g.w = (g.w + t.w) * o.grad_scale;
+        *reinterpret_cast<float4*>(dst) = g;
+        acc += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
+      }
     }
   }
   const float s = block_sum(acc, sbuf);

@@ -219,30 +219,48 @@ struct PartReduceArgs {
   int nwg_slot[256];                // workgroups that wrote this slot (kernels with several workgroups per sequence write B * S partials)
 };
 constexpr int PR_SPLIT = 4;
+// bf16 partials (adt_seqbwd_tt.cuh: sb_dw_tiles): element (tile, lane, r) of a slot at (tile * 64 + lane) * 4 + r.  A thread owns 16
+// consecutive elements (32 bytes: lanes l .. l + 3 of one tile, r = 0 .. 3 -> four rows n, four columns k) and a contiguous range of
+// workgroups, summed in ascending order in fp32; the PR_SPLIT range sums meet in G by atomics.  grid (slots, PR_SPLIT), 256 threads.
 __global__ __launch_bounds__(256) void k_dwpart_reduce(PartReduceArgs a) {
-  const int j = blockIdx.x >> 2, e4 = ((blockIdx.x & 3) * 256 + threadIdx.x) * 4;
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  const int j = blockIdx.x, item = threadIdx.x;
   const int nwg = a.nwg_slot[j];
   const int per = (nwg + PR_SPLIT - 1) / PR_SPLIT, w0 = blockIdx.y * per, w1 = min(nwg, w0 + per);
-  const float* p = a.part + (size_t)a.slot[j] * 4096 + e4;
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  const __bf16* p = reinterpret_cast<const __bf16*>(a.part + (size_t)a.slot[j] * 4096) + item * 16;
+  const size_t strideb = a.stride * 2;
+  float sum[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sum[i] = 0.f;
   int wg = w0;
-  for (; wg + 8 <= w1; wg += 8) {
-    float4 v[8];
+  for (; wg + 4 <= w1; wg += 4) {
+    u4v lo[4], hi[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(wg + u) * a.stride);
+    for (int u = 0; u < 4; ++u) {
+      const u4v* src = reinterpret_cast<const u4v*>(p + (size_t)(wg + u) * strideb);
+      lo[u] = src[0]; hi[u] = src[1];
+    }
 #pragma unroll
-    for (int u = 0; u < 8; u += 2) {
-      s0.x += v[u].x; s0.y += v[u].y; s0.z += v[u].z; s0.w += v[u].w;
-      s1.x += v[u + 1].x; s1.y += v[u + 1].y; s1.z += v[u + 1].z; s1.w += v[u + 1].w;
+    for (int u = 0; u < 4; ++u) {
+      const unsigned wds[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { sum[2 * i] += __uint_as_float(wds[i] << 16); sum[2 * i + 1] += __uint_as_float(wds[i] & 0xFFFF0000u); }
     }
   }
   for (; wg < w1; ++wg) {
-    const float4 v = *reinterpret_cast<const float4*>(p + (size_t)wg * a.stride);
-    s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+    const u4v* src = reinterpret_cast<const u4v*>(p + (size_t)wg * strideb);
+    const u4v lo = src[0], hi = src[1];
+    const unsigned wds[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sum[2 * i] += __uint_as_float(wds[i] << 16); sum[2 * i + 1] += __uint_as_float(wds[i] & 0xFFFF0000u); }
   }
-  const int tile = e4 >> 8, r = (e4 >> 6) & 3, lane = e4 & 63;
-  float* dst = a.G + a.off[j] + (16 * (tile >> 2) + 4 * (lane >> 4) + r) * 64 + 16 * (tile & 3) + (lane & 15);
-  atomicAdd(dst, s0.x + s1.x); atomicAdd(dst + 1, s0.y + s1.y); atomicAdd(dst + 2, s0.z + s1.z); atomicAdd(dst + 3, s0.w + s1.w);
+  const int tile = item >> 4, lane0 = (item & 15) * 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float* dst = a.G + a.off[j] + (16 * (tile >> 2) + 4 * (lane0 >> 4) + r) * 64 + 16 * (tile & 3) + (lane0 & 15);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicAdd(dst + k, sum[4 * k + r]);
+  }
 }
 
 int adt_dwpart_reduce(float* G, const float* part, size_t stride, int nwg, const int* slots, const int* offs, int nslots, void* stream) {
@@ -253,7 +271,7 @@ int adt_dwpart_reduce_n(float* G, const float* part, size_t stride, int nwg, con
   PartReduceArgs a;
   a.G = G; a.part = part; a.stride = stride; a.nwg = nwg; a.nslots = nslots;
   for (int i = 0; i < nslots; ++i) { a.slot[i] = slots[i]; a.off[i] = offs[i]; a.nwg_slot[i] = nwg_slot ? nwg_slot[i] : nwg; }
-  hipLaunchKernelGGL(k_dwpart_reduce, dim3(nslots * 4, PR_SPLIT), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_dwpart_reduce, dim3(nslots, PR_SPLIT), dim3(256), 0, (hipStream_t)stream, a);
   return seq_check("dwpart_reduce");
 }
 

@@ -167,12 +167,17 @@ ADT_DEVICE_INLINE void sb_dw_tiles(const __bf16* sG, const __bf16* sX, float* dW
     sb_dw_accumulate<NP, STEP, false>(sG, sX, kt, nt0, two, c, g, acc0, acc1, b0, b1);
   }
   if (part) {
+    // private partial of this workgroup, bf16: element (tile, lane, r) at (tile * 64 + lane) * 4 + r of the slot -- a lane's four accumulator
+    // registers are one 8-byte store.  The sum over the workgroups runs in fp32 (k_fold_parts_gradnorm / k_dwpart_reduce); rounding a
+    // per-sequence partial to bf16 (2^-9 relative) is far below what the bf16 operands of the product already cost, and halves the
+    // 268 MB per step the partials used to move.
     const int lane = 16 * g + c;
+    __bf16* pb = reinterpret_cast<__bf16*>(part);
+    bf16x4 v0, v1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      part[(w * 4 + r) * 64 + lane] = acc0[r];              // tile 4 nt0 + kt == w
-      if (two) part[((w + NW) * 4 + r) * 64 + lane] = acc1[r];
-    }
+    for (int r = 0; r < 4; ++r) { v0[r] = (__bf16)acc0[r]; v1[r] = (__bf16)acc1[r]; }
+    *reinterpret_cast<bf16x4*>(pb + ((size_t)w * 64 + lane) * 4) = v0;              // tile 4 nt0 + kt == w
+    if (two) *reinterpret_cast<bf16x4*>(pb + ((size_t)(w + NW) * 64 + lane) * 4) = v1;
     return;
   }
 #pragma unroll
