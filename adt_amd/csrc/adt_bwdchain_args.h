@@ -42,6 +42,9 @@ struct BwdChainArgs {
   int saved_bf16;             // u / xin / o were saved as bf16 rows by the transposed-chain forward (post and mid chains)
   unsigned long long* stamps;  // timing experiments only (ADT_SEQ_STAMPS=3): s_memtime per wave of workgroup 0 (adt_seqpost_tt.cuh)
   const float* wp_base; const void* wp_img;      // pre-packed bf16 weight images (adt_wave.cuh: WPack); wp_img == nullptr: none
+  float* vpart;               // adt_seqpost_tt.cuh: non-null: this workgroup's bias / LayerNorm / classifier gradient sums are STORED at
+                              // vpart + blockIdx * 512 (the kernel's sRed layout) instead of added to the replicas with float atomics; they
+                              // are summed over the workgroups in order by the optimizer's fold (k_fold_parts_gradnorm, job 3)
   int nsplit;                 // adt_seqpost_tt.cuh: S > 1 workgroups per sequence (adt_seq_args.h): workgroup (blockIdx / S, blockIdx % S) runs the token
                               // chains of the tiles t with t % S == part; its weight-gradient partial (slot blockIdx) covers those tokens only
 };

@@ -373,6 +373,22 @@ int adt_layernorm_bwd_rep(const float* dY, int lddy, const float* X, int ldx, co
   return check_launch("layernorm_bwd");
 }
 
+/* adt_layernorm_bwd_rep with PRIVATE per-block sums: block b stores dgamma / dbeta sums at part + b * 2 * d (dgamma | dbeta); returns the number of
+ * blocks (<= max_blocks) or < 0.  The caller adds them up in block order (k_fold_parts_gradnorm, job 3). */
+int adt_layernorm_bwd_parts(const float* dY, int lddy, const float* X, int ldx, const float* gamma, float eps, int T, int d, float* dX, int lddx,
+                            int accumulate, float* part, int max_blocks, void* stream) {
+  LnArgs a{};
+  a.X = X; a.ldx = ldx; a.gamma = gamma; a.eps = eps; a.T = T; a.dY = dY; a.lddy = lddy; a.dX = dX; a.lddx = lddx;
+  a.acc = accumulate; a.dgamma = part; a.dbeta = part + d; a.nrep = 1; a.rep_stride = (size_t)(2 * d); a.plain = 1;
+  const int grid = grid_for(T, 16, max_blocks);
+  if (d == 64) hipLaunchKernelGGL(k_ln_bwd<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else if (d == 128) hipLaunchKernelGGL(k_ln_bwd<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else if (d == 256) hipLaunchKernelGGL(k_ln_bwd<256>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else return adt_set_error("layernorm_bwd_parts: d=%d unsupported (64/128/256)", d);
+  const int rc = check_launch("layernorm_bwd_parts");
+  return rc < 0 ? rc : grid;
+}
+
 int adt_linear_fwd(int prec, const float* X, int ldx, const float* W, const float* b, int T, int K, int N,
                    float* Y, int ldy, float p, const uint32_t* seed, uint32_t site, uint32_t row_offset,
                    int relu, const float* R1, int ldr1, const float* R2, int ldr2, const int32_t* mask_ids,
@@ -691,7 +707,8 @@ int adt_fold_clip_adam(float* P, float* G, float* M, float* V, int64_t n, float*
  * partial area, float offset in G) in workgroup order; mask_base = offset in G of the range the row mask describes (the positional table). */
 int adt_fold_parts_clip_adam(float* P, float* G, float* M, float* V, int64_t n, float* d0, const float* r0, int64_t n0, int nrep0, int64_t s0, float* d1,
                              const float* r1, int64_t n1, int nrep1, int64_t s1, const float* part, int64_t part_stride, const int* nwg_slot, const int* slots,
-                             const int* offs, int nslots, float wd, float clip, float lr, float b1, float b2, float eps, float* scal, void* stream) {
+                             const int* offs, int nslots, const float* vpart, const int* vsrc, const int* vnwg, const int* vstride, const int* voff, int nvec,
+                             float* gn_part, float wd, float clip, float lr, float b1, float b2, float eps, float* scal, void* stream) {
   if (n0 <= 0 || n1 <= 0 || (n0 % 4) || (s0 % 4) || (n1 % 4) || (s1 % 4) || d0 != G) return adt_set_error("fold_parts_clip_adam: ranges");
   if (nslots < 1 || nslots > FP_MAXSLOTS || (d1 - G) % 64 || n1 > (int64_t)FP_MASKWORDS * 32 * 64) return adt_set_error("fold_parts_clip_adam: %d blocks, %lld floats", nslots, (long long)n1);
   OptArgs a{};
@@ -708,8 +725,19 @@ int adt_fold_parts_clip_adam(float* P, float* G, float* M, float* V, int64_t n, 
     if (offs[i] < pf.mask_base || (offs[i] - pf.mask_base) % 64 || r0w + 64 > (int64_t)FP_MASKWORDS * 32) return adt_set_error("fold_parts_clip_adam: block %d outside the masked range", i);
     for (int64_t rr = r0w; rr < r0w + 64; ++rr) pf.rowmask[rr >> 5] |= 1u << (rr & 31);
   }
+  if (nvec < 0 || nvec > FV_MAXCHUNKS) return adt_set_error("fold_parts_clip_adam: %d vector chunks", nvec);
+  VecFoldArgs vf{};
+  vf.vpart = vpart; vf.n = vpart ? nvec : 0;
+  for (int i = 0; i < vf.n; ++i) {      // the vector chunks' rows belong to job 3: job 1 leaves them alone
+    vf.src[i] = vsrc[i]; vf.nwg[i] = vnwg[i]; vf.stride[i] = vstride[i]; vf.off[i] = voff[i];
+    const int64_t rr = (voff[i] - pf.mask_base) / 64;
+    if (voff[i] < pf.mask_base || (voff[i] - pf.mask_base) % 64 || rr >= (int64_t)FP_MASKWORDS * 32) return adt_set_error("fold_parts_clip_adam: vector chunk %d outside the masked range", i);
+    pf.rowmask[rr >> 5] |= 1u << (rr & 31);
+  }
+  const int g2 = 8 * nslots, g3 = vf.n;
+  if (gn_part) { a.gn_part = gn_part; a.gn_n = g0 + g1 + g2 + g3; }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_fold_parts_gradnorm, dim3(g0 + g1 + 8 * nslots), dim3(256), 0, s, r, a, pf, g1);
+  hipLaunchKernelGGL(k_fold_parts_gradnorm, dim3(g0 + g1 + g2 + g3), dim3(256), 0, s, r, a, pf, vf, g1, g2);
   hipLaunchKernelGGL(k_adam, dim3(grid_for((size_t)n, 256, 1024)), dim3(256), 0, s, a);
   return check_launch("fold_parts_clip_adam");
 }

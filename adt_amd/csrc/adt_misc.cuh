@@ -635,6 +635,8 @@ struct OptArgs {
                      // sums of ||E||^2, [128..192) partial sums of ||g||^2 (64 sub-slots each: no same-address contention)
   float grad_scale;  // multiply grads first (1/world for averaged all-reduce; normally 1)
   float l2;          // Adam's coupled weight_decay (bert4rec/trainer.py:41): g += l2 * p AFTER clipping; 0 = off
+  float* gn_part; int gn_n;      // optional: ||g||^2 as gn_n per-block partials (stored by k_fold_parts_gradnorm, summed in order by k_adam) instead of
+                                 // the 64 atomically added sub-slots scal[128..192): the norm, and with it the clip factor, has the same bits in every run
 };
 
 __global__ __launch_bounds__(256) void k_sumsq(const float* x, size_t n, float* out) {
@@ -812,7 +814,18 @@ __global__ __launch_bounds__(256) void k_adam(OptArgs a) {
   float g0 = 0.f, p0 = 0.f, m0 = 0.f, v0 = 0.f;
   if (first) { g0 = a.G[i]; p0 = a.P[i]; m0 = a.M[i]; v0 = a.Vv[i]; }
   const float t = a.scal[2];
-  const float gn2 = sum64(a.scal + 128, sbuf);
+  float gn2;
+  if (a.gn_part) {      // ordered: thread t sums partials t, t + 256, ... ; then the block's fixed reduction tree
+    float part = 0.f;
+    for (int i = threadIdx.x; i < a.gn_n; i += 256) part += a.gn_part[i];
+    const float bs = block_sum(part, sbuf);
+    if (threadIdx.x == 0) sbuf[0] = bs;
+    __syncthreads();
+    gn2 = sbuf[0];
+    __syncthreads();
+  } else {
+    gn2 = sum64(a.scal + 128, sbuf);
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) a.scal[1] = gn2;
   const float tn = sqrtf(gn2);
   const float coef = fminf(1.0f, a.clip / (tn + 1e-6f));
@@ -874,13 +887,19 @@ __global__ __launch_bounds__(256) void k_fold_wd_gradnorm(RepReduce2Args a, OptA
 // G[block] = G[block] + sum_wg part[wg][slot] (the replicas hold nothing there: the chain kernels wrote partials instead).
 // Job 2: see its body.
 constexpr int FP_MAXSLOTS = 64, FP_MASKWORDS = 160;      // 64 x 64 blocks per step ; 160 x 32 rows of 64 floats = 327,680 non-item floats
+// Job 3: the bias / LayerNorm / head-classifier gradient sums the chain kernels STORED per workgroup (BwdChainArgs::vpart, SeqBwdArgs::vpart, the
+// last LayerNorm's per-block sums) instead of adding them to replicas with float atomics: chunk i is 64 consecutive floats of G at off[i],
+// = the sum over nwg[i] workgroups of 64 floats at vpart + src[i] + wg * stride[i], ascending.  One workgroup per chunk: wave q sums a quarter
+// of the workgroups (lane = element, 256-byte rows), the four range sums are joined in order.
+constexpr int FV_MAXCHUNKS = 80;
+struct VecFoldArgs { const float* vpart; int n; int src[FV_MAXCHUNKS]; int nwg[FV_MAXCHUNKS]; int stride[FV_MAXCHUNKS]; int off[FV_MAXCHUNKS]; };
 struct PartFoldArgs {
   const float* part; size_t stride; int nslots;
   int slot[FP_MAXSLOTS]; int off[FP_MAXSLOTS];      // slot inside a workgroup's partial area ; float offset of the block in G
   int nwg[FP_MAXSLOTS];                             // workgroups that wrote the slot (B, or B * S for kernels with S workgroups per sequence)
   uint32_t rowmask[FP_MASKWORDS]; int64_t mask_base;       // bit r: row r (64 floats, from G + mask_base) belongs to a weight block
 };
-__global__ __launch_bounds__(256) void k_fold_parts_gradnorm(RepReduce2Args a, OptArgs o, PartFoldArgs pf, int g1) {
+__global__ __launch_bounds__(256) void k_fold_parts_gradnorm(RepReduce2Args a, OptArgs o, PartFoldArgs pf, VecFoldArgs vf, int g1, int g2) {
   __shared__ float sbuf[4];
   __shared__ float4 sq[256];
   const float nrm = sqrtf(sum64(o.scal + 64, sbuf));
@@ -909,12 +928,36 @@ __global__ __launch_bounds__(256) void k_fold_parts_gradnorm(RepReduce2Args a, O
       *reinterpret_cast<float4*>(dst + i) = g;
       acc += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
     }
+  } else if ((int)blockIdx.x >= a.g0 + g1 + g2) {      // job 3
+    const int ci = blockIdx.x - a.g0 - g1 - g2, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int nwg = vf.nwg[ci], per = (nwg + 3) / 4, w0 = q * per, w1 = min(nwg, w0 + per);
+    const float* p = vf.vpart + vf.src[ci] + lane;
+    const size_t st = (size_t)vf.stride[ci];
+    float sum = 0.f;
+    int wg = w0;
+    for (; wg + 8 <= w1; wg += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(wg + u) * st];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    for (; wg < w1; ++wg) sum += p[(size_t)wg * st];
+    float* sf = reinterpret_cast<float*>(sq);
+    sf[threadIdx.x] = sum;
+    __syncthreads();
+    if (q == 0) {
+      float* dst = o.G + vf.off[ci] + lane;
+      const float g = (*dst + (((sf[lane] + sf[64 + lane]) + sf[128 + lane]) + sf[192 + lane])) * o.grad_scale;
+      *dst = g;
+      acc += g * g;
+    }
   } else {
     // bf16 partials: element (tile, lane, r) of a slot at (tile * 64 + lane) * 4 + r.  A work item = 16 consecutive elements (32 bytes):
     // lanes l .. l + 3 of one tile, r = 0 .. 3 -> rows n = 16 nt + 4 g + r (four of them), columns k .. k + 3: four float4 of G.
     // 8 workgroups of this job per slot, 32 work items each, EIGHT threads per work item (an eighth of the workgroups' partials each,
     // ascending), joined in order.
-    const int bid = blockIdx.x - a.g0 - g1;
+    const int bid = blockIdx.x - a.g0 - g1;      // job 2
     const int js = bid >> 3, item = (bid & 7) * 32 + (threadIdx.x >> 3), q = threadIdx.x & 7;
     const int nwg = pf.nwg[js];
     const int per = (nwg + 7) / 8, w0 = q * per, w1 = min(nwg, w0 + per);
@@ -964,7 +1007,10 @@ __global__ __launch_bounds__(256) void k_fold_parts_gradnorm(RepReduce2Args a, O
     }
   }
   const float s = block_sum(acc, sbuf);
-  if (threadIdx.x == 0) atomicAdd(o.scal + 128 + (blockIdx.x & 63), s);
+  if (threadIdx.x == 0) {
+    if (o.gn_part) o.gn_part[blockIdx.x] = s;      // summed in block order by k_adam
+    else atomicAdd(o.scal + 128 + (blockIdx.x & 63), s);
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) { o.scal[0] = nrm * nrm; o.scal[3] = o.wd * nrm; o.scal[2] += 1.0f; }
 }
 

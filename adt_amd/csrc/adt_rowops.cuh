@@ -292,6 +292,7 @@ struct LnArgs {
   float* dX; int lddx; int acc;   // acc: dX += result
   float* dgamma; float* dbeta;    // atomically accumulated
   int nrep; size_t rep_stride;    // nrep > 1: block b adds into replica b % nrep (rep_stride floats apart): shorter same-address chains
+  int plain;                      // backward: block b STORES its sums at dgamma / dbeta + b * rep_stride (private slots, summed in order elsewhere)
 };
 
 template <int K>
@@ -419,6 +420,11 @@ __global__ __launch_bounds__(NTHREADS) void k_ln_bwd(LnArgs a) {
   for (int col = threadIdx.x; col < K; col += NTHREADS) {
     float s0 = 0.f, s1 = 0.f;
     for (int r = 0; r < NTHREADS / 16; ++r) { s0 += sred[0][r][col]; s1 += sred[1][r][col]; }
+    if (a.plain) {
+      a.dgamma[(size_t)blockIdx.x * a.rep_stride + col] = s0;
+      a.dbeta[(size_t)blockIdx.x * a.rep_stride + col] = s1;
+      continue;
+    }
     const size_t ro = a.nrep > 1 ? (size_t)(blockIdx.x % a.nrep) * a.rep_stride : 0;
     atomicAdd(a.dgamma + ro + col, s0);
     atomicAdd(a.dbeta + ro + col, s1);

@@ -15,6 +15,7 @@ namespace {
 
 constexpr float LN_EPS = 1e-8f;
 constexpr int NREPP = 16;          // replicas of the layer-parameter gradients the backward chains flush into (one per XCD)
+constexpr int LN_PART_BLOCKS = 256;      // blocks of the last LayerNorm's backward when it stores per-block sums (adt_layernorm_bwd_parts)
 constexpr int NREP = 16;          // replicas of the item-table gradient (contention relief for popular items)   // sasrec/modules.py:638,640,660 ; sasrec/model.py:28
 
 struct Layout {
@@ -81,6 +82,8 @@ struct WS {
   int64_t wpack;                                                        // pre-packed bf16 weight images (3 floats per parameter float)
   int64_t part, part_stride;                                            // per-sequence partials of the 64 x 64 weight gradients (bf16 mode, d = 64)
   int64_t isort, isort_n;                                               // scratch of the sorted item-table gradient (adt_item_sort), isort_n int32 (0: not used)
+  int64_t vpart, vcall, lnpart, gnpart;                                 // per-workgroup bias / LayerNorm / classifier gradient sums: 5 * nl calls x vcall floats ;
+                                                                        // the last LayerNorm's per-block sums ; per-block partials of ||g||^2
   int64_t total;
 };
 
@@ -125,6 +128,10 @@ void make_ws(const adt_sasrec_cfg* c, int B, WS* w) {
   w->part = take((int64_t)B * seq_split(B) * w->part_stride);      // one partial area per WORKGROUP (several per sequence at small batches)
   w->isort_n = (c->hidden == 64 && adt_item_sort_supported(c->item_num + 1)) ? adt_item_sort_work_ints(4, (int)w->T, c->item_num + 1) : 0;
   w->isort = take(up64(w->isort_n));
+  w->vcall = (int64_t)B * seq_split(B) * 512;
+  w->vpart = take(w->part_stride > 0 ? 5 * w->nl * w->vcall : 0);
+  w->lnpart = take(LN_PART_BLOCKS * 128);
+  w->gnpart = take(4096);
   w->total = o;
 }
 
@@ -755,6 +762,8 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   const bool prep_zeroed = (phase & 4) != 0;      // bit 2: adt_sasrec_step_begin* of this step zeroed the parameter-gradient replicas
   const bool defer_fold = (phase & 8) != 0 && (phase & 3) == 0;      // bit 3 (one-phase only): adt_sasrec_fold_clip_adam does the last fold
   const bool late_parts = defer_fold && fold_sums_partials(c, w);      // adt_sasrec_fold_clip_adam sums the weight-gradient partials too
+  // ... and the bias / LayerNorm / classifier gradient sums, which the chain kernels then STORE per workgroup (no float atomics, no replicas)
+  auto VPART = [&](int layer, int k) { return late_parts ? ws + w.vpart + (int64_t)(5 * layer + k) * w.vcall : nullptr; };
   const bool bce_here = (phase & 16) != 0;        // bit 4: the forward was adt_sasrec_forward_loss on the deferred path: logits + BCE seed are formed here
   if (bce_here && !bce_deferred(c)) return adt_set_error("backward: phase bit 4 without the deferred-BCE forward (adt_sasrec_bce_deferred)");
   phase &= 3;
@@ -828,6 +837,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.db0 = Gq + lo.dec(i, D_C2B); a.db1 = Gq + lo.dec(i, D_C1B); a.db2 = Gq + lo.dec(i, D_EOB);
         a.out0 = s1;
         a.part[0] = PART(i, PS_D_C2); a.part[1] = PART(i, PS_D_C1); a.part[2] = PART(i, PS_D_EO); a.part_stride = (size_t)w.part_stride;
+        a.vpart = VPART(i, 0);
         const int rc = use_seq ? adt_launch_seq_post_bwd(hd, 0, a, st) : 1;
         if (rc < 0) return rc;
         if (rc && parts) return adt_set_error(no_fallback, L, hd);
@@ -862,6 +872,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.out0 = s1; a.out1 = gf; a.acc1 = 1;
         a.part[0] = PART(i, PS_D_EIN); a.part[1] = PART(i, PS_D_SO); a.part[2] = PART(i, PS_D_EIN + 1); a.part[3] = PART(i, PS_D_EIN + 2);
         a.part_stride = (size_t)w.part_stride;
+        a.vpart = VPART(i, 1);
         mid_rc = adt_launch_seq_mid_bwd(hd, a, st);
         if (mid_rc < 0) return mid_rc;
         if (mid_rc && parts) return adt_set_error(no_fallback, L, hd);
@@ -892,6 +903,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.gx = gx; a.acc = i > 0 ? 1 : 0; a.dWin = gsinw; a.dbin = gsinb; a.dgamma = Gq + lo.dec(i, D_LNW); a.dbeta = Gq + lo.dec(i, D_LNB);
         a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride; a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack; a.saved_bf16 = lean;
         a.part = PART(i, PS_D_SIN); a.part_stride = (size_t)w.part_stride;
+        a.vpart = VPART(i, 2);
         time_mark(2, i, true, st);
         const int rc = adt_launch_seq_attn_pre_bwd(hd, 1, a, st);
         time_mark(2, i, false, st);
@@ -940,6 +952,11 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   }
   if (phase == 0 || phase == 2) {
     // last_layernorm: g_enc_x[nl] = LN'(g_f)
+    if (late_parts) {
+      const int nb = adt_layernorm_bwd_parts(gf, d, ws + w.enc_x + nl * Td, d, P + lo.lnl_w(), LN_EPS, T, d, ws + w.g_enc_x + nl * Td, d, 0,
+                                             ws + w.lnpart, LN_PART_BLOCKS, st);
+      if (nb < 0) return nb;
+    } else
     CK(adt_layernorm_bwd_rep(gf, d, ws + w.enc_x + nl * Td, d, P + lo.lnl_w(), LN_EPS, T, d, ws + w.g_enc_x + nl * Td, d, 0,
                              Gq + lo.lnl_w(), Gq + lo.lnl_b(), NREPP, w.prep_stride, st));
     if (dec_side == 1) {
@@ -977,6 +994,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
           a.dbs = Gq + lo.enc(i, E_SB); a.H = H;
         }
         a.part[0] = PART(i, PS_E_C2); a.part[1] = PART(i, PS_E_C1); a.part[2] = PART(i, PS_E_O); a.part_stride = (size_t)w.part_stride;
+        a.vpart = VPART(i, 3);
         const int rc = use_seq ? adt_launch_seq_post_bwd(hd, 1, a, st) : 1;
         if (rc < 0) return rc;
         if (rc && parts) return adt_set_error(no_fallback, L, hd);
@@ -993,6 +1011,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.gx = gx; a.acc = 1; a.dWin = ginw; a.dbin = ginb; a.dgamma = Gq + lo.enc(i, E_LN1W); a.dbeta = Gq + lo.enc(i, E_LN1B);
         a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride; a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack; a.saved_bf16 = lean;
         a.part = PART(i, PS_E_IN); a.part_stride = (size_t)w.part_stride;
+        a.vpart = VPART(i, 4);
         time_mark(1, i, true, st);
         const int rc = adt_launch_seq_attn_pre_bwd(hd, 0, a, st);
         time_mark(1, i, false, st);
@@ -1061,9 +1080,35 @@ int adt_sasrec_fold_clip_adam(const adt_sasrec_cfg* c, float* ws, int B, float* 
     const int ns = partial_slots(c, lo, true, true, slots, offs);
     int nwg[256];
     for (int i = 0; i < ns; ++i) nwg[i] = partial_nwg(slots[i], B);
+    // the stored bias / LayerNorm / classifier sums (BwdChainArgs::vpart: the kernels' sRed layouts) -> 64-float chunks of G
+    int vsrc[128], vnwg[128], vstr[128], voff[128];
+    int nv = 0;
+    const int nsplit_wg = B * seq_split(B), d = c->hidden;
+    auto chunk = [&](int layer, int k, int t0, int nw, int64_t goff) {
+      vsrc[nv] = (int)((int64_t)(5 * layer + k) * w.vcall + t0); vnwg[nv] = nw; vstr[nv] = 512; voff[nv] = (int)goff; ++nv;
+    };
+    for (int i = 0; i < c->num_layers; ++i) {
+      chunk(i, 0, 256, nsplit_wg, lo.dec(i, D_C2B)); chunk(i, 0, 320, nsplit_wg, lo.dec(i, D_C1B)); chunk(i, 0, 384, nsplit_wg, lo.dec(i, D_EOB));
+      chunk(i, 1, 0, nsplit_wg, lo.dec(i, D_EINB)); chunk(i, 1, 64, nsplit_wg, lo.dec(i, D_SOB));
+      chunk(i, 1, 128, nsplit_wg, lo.dec(i, D_EINB) + d); chunk(i, 1, 192, nsplit_wg, lo.dec(i, D_EINB) + 2 * d);
+      chunk(i, 2, 0, B, lo.dec(i, D_LNW)); chunk(i, 2, 64, B, lo.dec(i, D_LNB));
+      for (int j = 0; j < 3; ++j) chunk(i, 2, 128 + 64 * j, B, lo.dec(i, D_SINB) + j * d);
+      chunk(i, 3, 0, nsplit_wg, lo.enc(i, E_LN2W)); chunk(i, 3, 64, nsplit_wg, lo.enc(i, E_LN2B));
+      if (c->num_heads > 1) { chunk(i, 3, 128, nsplit_wg, lo.enc(i, E_SW)); chunk(i, 3, 192, nsplit_wg, lo.enc(i, E_SB)); }
+      chunk(i, 3, 256, nsplit_wg, lo.enc(i, E_C2B)); chunk(i, 3, 320, nsplit_wg, lo.enc(i, E_C1B)); chunk(i, 3, 384, nsplit_wg, lo.enc(i, E_OB));
+      chunk(i, 4, 0, B, lo.enc(i, E_LN1W)); chunk(i, 4, 64, B, lo.enc(i, E_LN1B));
+      for (int j = 0; j < 3; ++j) chunk(i, 4, 128 + 64 * j, B, lo.enc(i, E_INB) + j * d);
+    }
+    {      // the last LayerNorm: per-block sums (dgamma | dbeta, 128 floats per block)
+      const int T = B * c->maxlen, nb = (T + 15) / 16 < LN_PART_BLOCKS ? (T + 15) / 16 : LN_PART_BLOCKS;
+      const int base = (int)(w.lnpart - w.vpart);
+      vsrc[nv] = base; vnwg[nv] = nb; vstr[nv] = 128; voff[nv] = (int)lo.lnl_w(); ++nv;
+      vsrc[nv] = base + 64; vnwg[nv] = nb; vstr[nv] = 128; voff[nv] = (int)lo.lnl_b(); ++nv;
+    }
     return adt_fold_parts_clip_adam(P, G, M, V, lo.total, G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * c->hidden, item_det(w) ? 0 : NREP,
-                                    w.rep_stride, G + lo.posw(), Gq + lo.posw(), lo.total - lo.posw(), NREPP, w.prep_stride, ws + w.part,
-                                    w.part_stride, nwg, slots, offs, ns, wd, clip, lr, b1, b2, eps, scal, st);
+                                    w.rep_stride, G + lo.posw(), Gq + lo.posw(), lo.total - lo.posw(), 0 /* no replicas: partials */, w.prep_stride,
+                                    ws + w.part, w.part_stride, nwg, slots, offs, ns, ws + w.vpart, vsrc, vnwg, vstr, voff, nv, ws + w.gnpart,
+                                    wd, clip, lr, b1, b2, eps, scal, st);
   }
   return adt_fold_clip_adam(P, G, M, V, lo.total, G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * c->hidden, item_det(w) ? 0 : NREP, w.rep_stride, G + lo.posw(),
                             Gq + lo.posw(), lo.total - lo.posw(), NREPP, w.prep_stride, wd, clip, lr, b1, b2, eps, scal, st);

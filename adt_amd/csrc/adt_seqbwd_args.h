@@ -22,6 +22,7 @@ struct SeqBwdArgs {
   int nrep; size_t rep_stride;        // parameter-gradient replicas (adt_bwdchain_args.h): workgroup b adds into replica b % nrep
   const float* wp_base; const void* wp_img;        // pre-packed weight images (slot-ordered: + 2 plain, + 3 transposed)
   int saved_bf16;                     // `o` holds bf16 rows (written by the transposed-chain forward in its lean mode)
+  float* vpart;                       // non-null: dgamma[64] | dbeta[64] | dbin[192] of this workgroup stored at vpart + blockIdx * 512 (no atomics)
   unsigned long long* stamps;
 };
 

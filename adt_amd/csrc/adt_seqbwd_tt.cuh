@@ -581,21 +581,31 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     }
     if (s == 0) SB_STAMP(15);
   }
-  // LayerNorm gamma / beta gradients: per-lane partials over this wave's tokens -> workgroup sums in LDS -> one atomic per feature
+  // LayerNorm gamma / beta gradients: per-lane partials over this wave's tokens -> this wave's sums in its own LDS row (the keep-bit area is
+  // dead behind the attention passes) -> joined in wave order behind the barrier: no LDS float atomics, whose order is the waves' arrival order
+  float* sWave = reinterpret_cast<float*>(sM) + w * 128;
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float sg = tt_rowsum16(dgm.v[nt][r]), sb = tt_rowsum16(dbt.v[nt][r]);      // over the 16 tokens on this row of lanes
-      if (c == 0) {
-        atomicAdd(sRed + 16 * nt + 4 * g + r, sg);
-        atomicAdd(sRed + 64 + 16 * nt + 4 * g + r, sb);
-      }
+      if (c == 0) { sWave[16 * nt + 4 * g + r] = sg; sWave[64 + 16 * nt + 4 * g + r] = sb; }
     }
   __syncthreads();
-  if (threadIdx.x < 64) atomicAdd(a.dgamma + threadIdx.x, sRed[threadIdx.x]);
-  else if (threadIdx.x < 128) atomicAdd(a.dbeta + threadIdx.x - 64, sRed[threadIdx.x]);
-  else if (threadIdx.x < 320) atomicAdd(a.dbin + threadIdx.x - 128, sRed[threadIdx.x]);
+  {
+    const int t = threadIdx.x;
+    if (t < 128) {
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) sum += reinterpret_cast<const float*>(sM)[k * 128 + t];
+      sRed[t] = sum;
+    }
+    if (a.vpart) {
+      if (t < 320) a.vpart[(size_t)blockIdx.x * 512 + t] = sRed[t];
+    } else if (t < 64) atomicAdd(a.dgamma + t, sRed[t]);
+    else if (t < 128) atomicAdd(a.dbeta + t - 64, sRed[t]);
+    else if (t < 320) atomicAdd(a.dbin + t - 128, sRed[t]);
+  }
   SB_STAMP(6);
 }
 

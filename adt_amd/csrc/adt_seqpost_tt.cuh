@@ -18,7 +18,8 @@ template <int NWT>
 struct SeqPostLds {
   static constexpr size_t wbytes = (size_t)NWT * TT_WIMG * 2, ibytes = (size_t)SB_R * TT_RS * 2;
   static constexpr size_t rbytes = (448 + 192) * 4;             // sRed: dgamma, dbeta, dWs, dbs, 3-4 bias vectors ; sVec: gamma, beta, Ws
-  static constexpr size_t bytes = wbytes + 2 * ibytes + 64 + rbytes;
+  static constexpr size_t wvbytes = 8 * 256 * 4;                // per-wave sums of dgamma, dbeta, dWs, dbs (joined in wave order: no LDS atomics)
+  static constexpr size_t bytes = wbytes + 2 * ibytes + 64 + rbytes + wvbytes;
 };
 
 ADT_DEVICE_INLINE void sp_replica(BwdChainArgs& a) {
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   __bf16* img1 = reinterpret_cast<__bf16*>(smem_raw + Lds::wbytes + Lds::ibytes);
   float* sRed = reinterpret_cast<float*>(smem_raw + Lds::wbytes + 2 * Lds::ibytes + 64);   // [0,64) dgamma [64,128) dbeta [128,192) dWs [192,196) dbs [256,448) db0, db1, db2
   float* sVec = sRed + 448;                                                  // gamma, beta, Ws
+  float* sWave = sVec + 192;                                                 // [8 waves][256]: dgamma, dbeta, dWs, dbs of each wave
   const float *vgamma = sVec, *vbeta = sVec + 64, *vws = sVec + 128;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int nsp = a.nsplit > 1 ? a.nsplit : 1, b = blockIdx.x / nsp, part = blockIdx.x % nsp;
@@ -239,9 +241,16 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   sb_dw_product16<NW>(img0, img1, npair, a.dW2, a.part[2] ? a.part[2] + (size_t)blockIdx.x * a.part_stride : nullptr, sRed + 384, w, c, g);
   SB_STAMP(13);
   if (ENC) {
-    // per-lane partials over this wave's tokens -> workgroup sums in LDS -> one atomic per element
-    sb_colsum_flush(sRed, dgm, c, g);
-    sb_colsum_flush(sRed + 64, dbt, c, g);
+    // per-lane partials over this wave's tokens -> this wave's sums in its own LDS row (16-lane DPP sums, plain stores) -> joined below in
+    // wave order: the workgroup's sums do not depend on which wave arrives first (LDS float atomics added in arrival order)
+    float* mine = sWave + w * 256;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sg = tt_rowsum16(dgm.v[nt][r]), sb = tt_rowsum16(dbt.v[nt][r]);
+        if (c == 0) { mine[16 * nt + 4 * g + r] = sg; mine[64 + 16 * nt + 4 * g + r] = sb; }
+      }
     if (cls) {
 #pragma unroll
       for (int cc = 0; cc < H; ++cc) {
@@ -250,23 +259,31 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float sw = tt_rowsum16(dws[cc][nt][r]);
-            if (c == 0) atomicAdd(sRed + 128 + cc * HD + 16 * nt + 4 * g + r, sw);
+            if (c == 0) mine[128 + cc * HD + 16 * nt + 4 * g + r] = sw;
           }
         const float sb = tt_rowsum16(dbs_acc[cc]);
-        if (c == 0 && g == 0) atomicAdd(sRed + 192 + cc, sb);
+        if (c == 0 && g == 0) mine[192 + cc] = sb;
       }
     }
   }
   __syncthreads();
   {
     const int t = threadIdx.x;
-    if (t < 64) { if (ENC) atomicAdd(a.dgamma + t, sRed[t]); }
-    else if (t < 128) { if (ENC) atomicAdd(a.dbeta + t - 64, sRed[t]); }
-    else if (t < 192) { if (cls) atomicAdd(a.dWs + t - 128, sRed[t]); }
-    else if (t < 192 + H) { if (cls) atomicAdd(a.dbs + t - 192, sRed[t]); }
-    else if (t >= 256 && t < 320) atomicAdd(a.db0 + t - 256, sRed[t]);
-    else if (t >= 320 && t < 384) atomicAdd(a.db1 + t - 320, sRed[t]);
-    else if (t >= 384 && t < 448) atomicAdd(a.db2 + t - 384, sRed[t]);
+    if (ENC && t < 196) {
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) sum += sWave[k * 256 + t];
+      sRed[t] = sum;
+    }
+    // (each thread flushes the element it has just formed, or a bias sum of the weight-gradient sweep that the last barrier published)
+    const bool live = t < 128 ? ENC : (t < 192 + H ? cls : (t >= 256 && t < 448));
+    if (a.vpart) {
+      if (t < 448) a.vpart[(size_t)blockIdx.x * 512 + t] = live ? sRed[t] : 0.f;
+    } else if (live) {
+      float* dst = t < 64 ? a.dgamma + t : t < 128 ? a.dbeta + t - 64 : t < 192 ? a.dWs + t - 128 : t < 256 ? a.dbs + t - 192
+                 : t < 320 ? a.db0 + t - 256 : t < 384 ? a.db1 + t - 320 : a.db2 + t - 384;
+      atomicAdd(dst, sRed[t]);
+    }
   }
   SB_STAMP(14);
 }
@@ -373,7 +390,10 @@ __global__ __launch_bounds__(SP_MID_NW * 64) void k_seqtt_mid_bwd(BwdChainArgs a
   {
     const int t = threadIdx.x;
     float* const dst[4] = {a.db0, a.db1, a.db2, a.db3};
-    if (t < 256) atomicAdd(dst[t >> 6] + (t & 63), sRed[t]);
+    if (t < 256) {
+      if (a.vpart) a.vpart[(size_t)blockIdx.x * 512 + t] = sRed[t];
+      else atomicAdd(dst[t >> 6] + (t & 63), sRed[t]);
+    }
   }
 }
 

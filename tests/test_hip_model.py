@@ -421,6 +421,51 @@ def test_lean_step_is_deterministic_and_ignores_workspace_garbage(L):
         assert abs(loss - runs[0][2]) <= 1e-6 * abs(loss)
         assert torch.isfinite(grad).all()
         assert float((grad - runs[0][1]).abs().max()) <= 2e-6 * float(runs[0][1].abs().max())
+        # every parameter gradient EXCEPT the two embedding tables is one ordered sum (weight-gradient and vector partials per workgroup,
+        # summed in workgroup order; LDS sums in wave order): bit-equal.  The tables are float-atomic scatters unless ADT_ITEM_SORT=1
+        # (test_step_is_bit_deterministic_with_sorted_item_gradient).
+        n_tab = m.offsets[2]      # item table + positional table
+        assert torch.equal(grad[n_tab:], runs[0][1][n_tab:]), "a non-table gradient differs between two runs: %g" % float((grad[n_tab:] - runs[0][1][n_tab:]).abs().max())
+
+
+def test_step_is_bit_deterministic_with_sorted_item_gradient(tmp_path):
+    """ADT_ITEM_SORT=1: the item / positional table gradients are sorted segmented sums (adt_itemgrad.cuh) instead of float-atomic scatters, so
+    with the ordered partial sums of everything else the WHOLE step is a pure function of its inputs: two processes-worth of fresh models give
+    bit-equal gradients, gradient norm and updated weights after three steps (the reference's CPU step is run-to-run deterministic too:
+    sasrec/model.py:34-41,72-76 via autograd's index_add).  Own process: the switch is read once per process."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from oracle import sasrec_oracle as so
+from tests.test_hip_model import build, make_batch
+from adt_amd.sasrec.trainer import FusedTrainer
+L, B = 52, 6
+cfg = so.Cfg(300, L, 64, 2, 2, dropout=0.5)
+P = so.init_params(cfg, seed=3)
+batches = [make_batch(np.random.RandomState(4 + i), B, L, cfg.item_num) for i in range(3)]
+outs = []
+for rep in range(3):
+    m = build(cfg, P, "bf16", dropout=0.5)
+    m.train()
+    m.workspace(B).fill_(float("nan"))
+    tr = FusedTrainer(m, [0.104292, 0.065892], [0.100833, 0.000607], lr=1e-3, weight_decay=1e-3, clip=5.0, seed=5, use_graph=(rep == 2))
+    g = []
+    for b in batches:
+        tr.step(*b)
+        torch.cuda.synchronize()
+        g.append(m.flat_grad.clone())
+    outs.append((g, m.flat.clone(), float(tr.grad_norm())))
+for g, w, gn in outs[1:]:
+    for a, b in zip(outs[0][0], g):
+        assert torch.isfinite(a).all() and torch.equal(a, b), float((a - b).abs().max())
+    assert torch.equal(outs[0][1], w), float((outs[0][1] - w).abs().max())
+    assert gn == outs[0][2]
+print("bit-equal")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ADT_ITEM_SORT="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0 and "bit-equal" in p.stdout, p.stderr[-3000:]
 
 
 def test_side_stream_matches_single_stream(tmp_path):
