@@ -106,6 +106,7 @@ SIGNATURES = {
     "adt_item_sort": (_I, [_P, _I, _I, _I, _P, _P, _P, _U, _P, _P]),
     "adt_item_segsum": (_I, [_P, _I, _I, _I, _U, _P, _F, _P, _F, _P, _I, _P]),
     "adt_posemb_sum": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _U, _P, _P]),
+    "adt_item_segsum_posemb": (_I, [_P, _I, _I, _I, _U, _P, _F, _P, _F, _P, _I, _P, _P, _P, _I, _I, _I, _U, _P, _P]),
     "adt_sasrec_param_layout": (_L, [_CP, _P]),
     "adt_sasrec_workspace_floats": (_L, [_CP, _I]),
     "adt_sasrec_ws_offset": (_L, [_CP, _I, _I, _I]),

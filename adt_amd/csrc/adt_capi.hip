@@ -585,7 +585,7 @@ ItemWork item_work(int nsrc, int T, int V1) {
   w.nblk = (int)((N + IG_PER_BLOCK - 1) / IG_PER_BLOCK);
   int64_t o = 0;
   w.hist = o; o += up((int64_t)IS_NCH * V1);
-  w.base = o; o += up(V1 + 1);
+  w.base = o; o += up(V1 + 1 + 256);      // + the totals of the 64-item groups
   w.perm = o; o += up(N);
   w.pitem = o; o += up(N);
   w.pmeta = o; o += up(N);
@@ -598,7 +598,7 @@ ItemWork item_work(int nsrc, int T, int V1) {
 }
 }  // namespace
 
-int adt_item_sort_supported(int V1) { return V1 >= 2 && V1 <= IS_MAXV1 ? 1 : 0; }
+int adt_item_sort_supported(int V1) { return V1 >= 2 && V1 <= IS_MAXV1 ? 1 : 0; }      // (and at most 262,144 entries: adt_item_sort checks)
 int64_t adt_item_sort_work_ints(int nsrc, int T, int V1) { return item_work(nsrc, T, V1).total; }
 
 /* kind[s] 0: rows[s] = gradient of an embedding layer's output (T x 64), summed as rows * emb_scale * keep / (1 - p) with the forward's dropout
@@ -614,24 +614,23 @@ int adt_item_sort(const int32_t* const* ids, int nsrc, int T, int V1, const floa
     a.ids[s] = ids[k]; a.rows[s] = rows[k]; a.coef[s] = coef ? coef[k] : nullptr; a.kind[s] = kind[k];
     if (s < nsrc && (!rows[s] || (kind[s] == 1 && (!coef || !coef[s])))) return adt_set_error("item_sort: source %d has no rows", s);
   }
-  a.nsrc = nsrc; a.T = T; a.V1 = V1; a.hist = work + w.hist; a.base = work + w.base; a.perm = work + w.perm; a.pitem = work + w.pitem;
+  a.nsrc = nsrc; a.T = T; a.V1 = V1; a.hist = work + w.hist; a.base = work + w.base; a.bsum = a.base + V1 + 1; a.perm = work + w.perm; a.pitem = work + w.pitem;
   a.row_offset = row_offset; a.pmeta = reinterpret_cast<uint32_t*>(work + w.pmeta);
   a.prow = reinterpret_cast<uint64_t*>(work + w.prow); a.pcoef = reinterpret_cast<uint64_t*>(work + w.pcoef);
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)V1 * sizeof(int);
+  if ((int64_t)nsrc * T > (int64_t)IS_NCH * 64 * IS_MAXR) return adt_set_error("item_sort: %lld entries > %d", (long long)nsrc * T, IS_NCH * 64 * IS_MAXR);
   hipLaunchKernelGGL(k_isort_hist, dim3(IS_NCH), dim3(64), lds, s, a);
-  hipLaunchKernelGGL(k_isort_scan_chunks, dim3((V1 + 255) / 256), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_isort_scan_items, dim3(1), dim3(1024), 0, s, a);
-  hipLaunchKernelGGL(k_isort_place, dim3(IS_NCH), dim3(64), lds, s, a);
+  hipLaunchKernelGGL(k_isort_scan_chunks, dim3((V1 + 63) / 64), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_isort_place, dim3(IS_NCH), dim3(64), lds + 256 * sizeof(int), s, a);
   return check_launch("item_sort");
 }
 
 /* dE[item] (accumulate ? += : =) sum over the sorted entries of `item` that belong to the sources in src_mask (rows of items without entries are not touched). */
-int adt_item_segsum(const int32_t* work, int nsrc, int T, int V1, uint32_t src_mask, const uint32_t* site, float p, const uint32_t* seed,
-                    float emb_scale, float* dE, int accumulate, void* stream) {
+static int item_seg_args(ItemSegArgs& a, const int32_t* work, int nsrc, int T, int V1, uint32_t src_mask, const uint32_t* site, float p,
+                         const uint32_t* seed, float emb_scale, float* dE, int accumulate) {
   if (nsrc < 1 || nsrc > 4 || !adt_item_sort_supported(V1)) return adt_set_error("item_segsum: nsrc %d, %d items + 1", nsrc, V1);
   const ItemWork w = item_work(nsrc, T, V1);
-  ItemSegArgs a{};
   a.pitem = work + w.pitem; a.total = work + w.base + V1; a.nblk = w.nblk;
   a.pmeta = reinterpret_cast<const uint32_t*>(work + w.pmeta);
   a.prow = reinterpret_cast<const uint64_t*>(work + w.prow); a.pcoef = reinterpret_cast<const uint64_t*>(work + w.pcoef);
@@ -641,23 +640,49 @@ int adt_item_segsum(const int32_t* work, int nsrc, int T, int V1, uint32_t src_m
   a.seed = seed; a.thr = dc.thr; a.dscale = dc.scale; a.emb_scale = emb_scale;
   a.dE = dE; a.rmw = accumulate ? 1 : 0;
   a.carry = reinterpret_cast<float*>(const_cast<int32_t*>(work) + w.carry); a.cflag = const_cast<int32_t*>(work) + w.cflag;
+  return 0;
+}
+static int pos_sum_args(PosSumArgs& a, const int32_t* const* ids, const float* const* dX, const uint32_t* site, int nsrc, int B, int L, float p,
+                        const uint32_t* seed, uint32_t row_offset, float* dP) {
+  if (nsrc < 1 || nsrc > 2) return adt_set_error("posemb_sum: nsrc %d", nsrc);
+  for (int s = 0; s < 2; ++s) { const int k = s < nsrc ? s : 0; a.ids[s] = ids[k]; a.dX[s] = dX[k]; a.site[s] = site[k]; }
+  a.nsrc = nsrc; a.B = B; a.L = L;
+  const DropCfg dc = adt_make_drop(p, seed, 0);
+  a.seed = seed; a.thr = dc.thr; a.dscale = dc.scale; a.row_offset = row_offset; a.dP = dP;
+  return 0;
+}
+
+int adt_item_segsum(const int32_t* work, int nsrc, int T, int V1, uint32_t src_mask, const uint32_t* site, float p, const uint32_t* seed,
+                    float emb_scale, float* dE, int accumulate, void* stream) {
+  ItemSegArgs a{};
+  if (item_seg_args(a, work, nsrc, T, V1, src_mask, site, p, seed, emb_scale, dE, accumulate)) return 1;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_item_segsum, dim3(w.nblk), dim3(IG_WAVES * 64), 0, s, a);
-  hipLaunchKernelGGL(k_item_carry, dim3(w.nblk), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_item_segsum, dim3(a.nblk), dim3(IG_WAVES * 64), 0, s, a);
+  hipLaunchKernelGGL(k_item_carry, dim3(a.nblk), dim3(64), 0, s, a);
   return check_launch("item_segsum");
 }
 
 /* dP[l] += sum_b [ids != 0] keep / (1 - p) dX[b, l] for nsrc (1 or 2) embedding layers, b ascending */
 int adt_posemb_sum(const int32_t* const* ids, const float* const* dX, const uint32_t* site, int nsrc, int B, int L, float p, const uint32_t* seed,
                    uint32_t row_offset, float* dP, void* stream) {
-  if (nsrc < 1 || nsrc > 2) return adt_set_error("posemb_sum: nsrc %d", nsrc);
   PosSumArgs a{};
-  for (int s = 0; s < 2; ++s) { const int k = s < nsrc ? s : 0; a.ids[s] = ids[k]; a.dX[s] = dX[k]; a.site[s] = site[k]; }
-  a.nsrc = nsrc; a.B = B; a.L = L;
-  const DropCfg dc = adt_make_drop(p, seed, 0);
-  a.seed = seed; a.thr = dc.thr; a.dscale = dc.scale; a.row_offset = row_offset; a.dP = dP;
+  if (pos_sum_args(a, ids, dX, site, nsrc, B, L, p, seed, row_offset, dP)) return 1;
   hipLaunchKernelGGL(k_posemb_sum, dim3(L), dim3(PS_WAVES * 64), 0, (hipStream_t)stream, a);
   return check_launch("posemb_sum");
+}
+
+/* adt_item_segsum + adt_posemb_sum (same p / seed) in one launch + the carry launch */
+int adt_item_segsum_posemb(const int32_t* work, int nsrc, int T, int V1, uint32_t src_mask, const uint32_t* site, float p, const uint32_t* seed,
+                           float emb_scale, float* dE, int accumulate, const int32_t* const* pos_ids, const float* const* pos_dX,
+                           const uint32_t* pos_site, int pos_nsrc, int B, int L, uint32_t row_offset, float* dP, void* stream) {
+  ItemSegArgs a{};
+  PosSumArgs ps{};
+  if (item_seg_args(a, work, nsrc, T, V1, src_mask, site, p, seed, emb_scale, dE, accumulate)) return 1;
+  if (pos_sum_args(ps, pos_ids, pos_dX, pos_site, pos_nsrc, B, L, p, seed, row_offset, dP)) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_item_segsum_posemb, dim3(a.nblk + L), dim3(IG_WAVES * 64), 0, s, a, ps);
+  hipLaunchKernelGGL(k_item_carry, dim3(a.nblk), dim3(64), 0, s, a);
+  return check_launch("item_segsum_posemb");
 }
 
 int adt_clip_adam(float* P, float* G, float* M, float* V, int64_t n, int64_t nE, float wd, float clip, float lr,

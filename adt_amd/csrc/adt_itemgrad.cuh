@@ -5,7 +5,7 @@
 // popular item's row is thousands of requests deep even with 16 replicas) and add in arrival order, so two runs differ in the last bits.
 // Here the step's ids are SORTED once (they are known when the step begins: the sort runs beside the forward) and every item's rows are
 // summed by one owner in sorted order:
-//   k_isort_hist / k_isort_scan_chunks / k_isort_scan_items / k_isort_place : stable counting sort of the entries e = src * T + t
+//   k_isort_hist / k_isort_scan_chunks / k_isort_place : stable counting sort of the entries e = src * T + t
 //       (src: which id array, t: token) by item -- 256 chunks of consecutive entries, one wave each, an LDS histogram per chunk, ranks of
 //       equal keys inside a wave from ballots (lane order), so the order inside an item is the entry order: a pure function of the ids.
 //   k_item_segsum : segmented sums over the sorted list, 1,024 entries per workgroup: 64 sub-ranges of 16 entries, one 16-lane group each
@@ -31,7 +31,8 @@ struct ItemSortArgs {
   const int* ids[4];                 // the id arrays (T entries each); entry e = src * T + t
   int nsrc, T, V1;                   // V1 = item_num + 1 (id 0 = padding: not an entry)
   int* hist;                         // [IS_NCH][V1]: counts per chunk, rewritten to the exclusive prefix over the chunks
-  int* base;                         // [V1 + 1]: exclusive scan of the item totals ; base[V1] = number of entries
+  int* base;                         // [V1 + 1]: per item the prefix of the totals inside its 64-item group ; base[V1] = number of entries
+  int* bsum;                         // [ceil(V1 / 64)]: totals of the 64-item groups
   int* perm;                         // [nsrc * T]: the entries sorted by item (stable)
   int* pitem;                        // [nsrc * T]: item of each sorted entry
   // the gather plan of k_item_segsum, written with the sorted list (everything about an entry that does not depend on gradient VALUES):
@@ -43,90 +44,136 @@ struct ItemSortArgs {
 static __device__ __attribute__((aligned(256))) const float ig_zero_row[64] = {};
 
 ADT_DEVICE_INLINE int is_key(const ItemSortArgs& a, int e) {
+  typedef const int __attribute__((address_space(1))) * gi;
   const int T = a.T;
   const int src = (e >= T) + (e >= 2 * T) + (e >= 3 * T);
-  return a.ids[src][e - src * T];
+  const int* p = src == 0 ? a.ids[0] : (src == 1 ? a.ids[1] : (src == 2 ? a.ids[2] : a.ids[3]));
+  return *(gi)(p + (e - src * T));
+}
+constexpr int IS_MAXR = 16;          // rounds of 64 entries a chunk's wave keeps in registers (16 x 64 x 256 chunks = 262,144 entries)
+
+// the keys of a chunk, every load issued before the first use (a round per loop iteration was a dependent round trip per 64 entries:
+// 13 of them per wave at the flagship step)
+ADT_DEVICE_INLINE void is_load_keys(const ItemSortArgs& a, int e0, int e1, int lane, int (&key)[IS_MAXR]) {
+#pragma unroll
+  for (int r = 0; r < IS_MAXR; ++r) {
+    const int e = e0 + r * 64 + lane;
+    int k = e < e1 ? is_key(a, e < e1 ? e : e0) : 0;
+    key[r] = (k > 0 && k < a.V1) ? k : 0;
+  }
 }
 
 __global__ __launch_bounds__(64) void k_isort_hist(ItemSortArgs a) {
   extern __shared__ int sh[];
   const int lane = threadIdx.x, c = blockIdx.x, N = a.nsrc * a.T;
   const int CH = (N + IS_NCH - 1) / IS_NCH, e0 = c * CH, e1 = min(N, e0 + CH);
+  int key[IS_MAXR];
+  is_load_keys(a, e0, e1, lane, key);
   for (int i = lane; i < a.V1; i += 64) sh[i] = 0;
   __syncthreads();
-  for (int e = e0 + lane; e < e1; e += 64) {
-    const int key = is_key(a, e);
-    if (key > 0 && key < a.V1) atomicAdd(&sh[key], 1);
-  }
+#pragma unroll
+  for (int r = 0; r < IS_MAXR; ++r)
+    if (key[r] > 0) atomicAdd(&sh[key[r]], 1);
   __syncthreads();
   for (int i = lane; i < a.V1; i += 64) a.hist[(size_t)c * a.V1 + i] = sh[i];
 }
 
-// per item: exclusive prefix of its counts over the chunks (in place) and its total -> base[item]
+// per item: exclusive prefix of its counts over the chunks (in place) and its total -> base[item].  A workgroup takes 64 items: the
+// [256 chunks][64 items] tile goes through LDS (256-byte rows in, 256-byte rows out), a wave scans an item's 256 counts in one go
+// (four per lane + a 64-lane scan).  (One thread per item walking the 256 chunks was 32 dependent round trips: 13.7 us.)
 __global__ __launch_bounds__(256) void k_isort_scan_chunks(ItemSortArgs a) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= a.V1) return;
-  int run = 0;
-  for (int c0 = 0; c0 < IS_NCH; c0 += 8) {
-    int h[8];
+  __shared__ int tile[IS_NCH][65];
+  __shared__ int stot[64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, k0 = blockIdx.x * 64;
+  const int k = k0 + lane;
+  for (int c0 = w; c0 < IS_NCH; c0 += 64) {            // sixteen rows in flight per wave
+    int h[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) h[u] = a.hist[(size_t)(c0 + u) * a.V1 + k];
+    for (int u = 0; u < 16; ++u) h[u] = k < a.V1 ? a.hist[(size_t)(c0 + 4 * u) * a.V1 + k] : 0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { a.hist[(size_t)(c0 + u) * a.V1 + k] = run; run += h[u]; }
+    for (int u = 0; u < 16; ++u) tile[c0 + 4 * u][lane] = h[u];
   }
-  a.base[k] = run;
-}
-
-// exclusive scan of base[0 .. V1) in place ; base[V1] = total.  One workgroup of 1,024 threads, tiles of 1,024 items.
-__global__ __launch_bounds__(1024) void k_isort_scan_items(ItemSortArgs a) {
-  __shared__ int swave[16];
-  __shared__ int scarry;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (threadIdx.x == 0) scarry = 0;
   __syncthreads();
-  for (int k0 = 0; k0 < a.V1; k0 += 1024) {
-    const int k = k0 + threadIdx.x;
-    const int v = k < a.V1 ? a.base[k] : 0;
-    int s = v;                                   // inclusive scan inside the wave
+  for (int it = w * 16; it < w * 16 + 16; ++it) {      // item k0 + it: lane l owns chunks 4 l .. 4 l + 3
+    int h[4], s = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(s, o, 64); if (lane >= o) s += t; }
-    if (lane == 63) swave[w] = s;
-    __syncthreads();
-    int woff = 0;
-    for (int i = 0; i < w; ++i) woff += swave[i];
-    const int carry = scarry;
-    if (k < a.V1) a.base[k] = carry + woff + s - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) scarry = carry + woff + s;
-    __syncthreads();
+    for (int j = 0; j < 4; ++j) { h[j] = tile[4 * lane + j][it]; s += h[j]; }
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    int run = inc - s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { tile[4 * lane + j][it] = run; run += h[j]; }
+    if (lane == 63) stot[it] = k0 + it < a.V1 ? inc : 0;
   }
-  if (threadIdx.x == 0) a.base[a.V1] = scarry;
+  __syncthreads();
+  if (w == 0) {      // the 64 totals: exclusive prefix inside the workgroup -> base[item], their sum -> bsum[workgroup] (k_isort_place adds the
+                     // prefix over the workgroups: no scan kernel in between)
+    const int t = stot[lane];
+    int inc = t;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+    if (k < a.V1) a.base[k] = inc - t;
+    if (lane == 63) a.bsum[blockIdx.x] = inc;
+  }
+  for (int c = w; c < IS_NCH; c += 4)
+    if (k < a.V1) a.hist[(size_t)c * a.V1 + k] = tile[c][lane];
 }
 
 __global__ __launch_bounds__(64) void k_isort_place(ItemSortArgs a) {
   extern __shared__ int sh[];
   const int lane = threadIdx.x, c = blockIdx.x, N = a.nsrc * a.T;
   const int CH = (N + IS_NCH - 1) / IS_NCH, e0 = c * CH, e1 = min(N, e0 + CH);
-  for (int i = lane; i < a.V1; i += 64) sh[i] = a.base[i] + a.hist[(size_t)c * a.V1 + i];      // this chunk's cursor of every item
+  int key[IS_MAXR];
+  is_load_keys(a, e0, e1, lane, key);
+  // the cursor of every item for this chunk = base[item] (prefix inside its 64-item group) + the prefix of bsum over the groups + this
+  // chunk's prefix over the chunks.  Every wave scans the <= 250 group sums itself (four per lane + a 64-lane scan).
+  static_assert(IS_MAXV1 <= 64 * 64 * 4, "four groups per lane");
+  const int ngrp = (a.V1 + 63) / 64;
+  int gs[4], gsum = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { gs[j] = 4 * lane + j < ngrp ? a.bsum[4 * lane + j] : 0; gsum += gs[j]; }
+  int ginc = gsum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(ginc, o, 64); if (lane >= o) ginc += t; }
+  int* const goff = sh + a.V1;                          // [256] exclusive prefix of the groups
+  {
+    int run = ginc - gsum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { goff[4 * lane + j] = run; run += gs[j]; }
+  }
+  if (c == 0 && lane == 63) a.base[a.V1] = ginc;        // number of entries (k_item_segsum's bound)
   __syncthreads();
-  for (int eb = e0; eb < e1; eb += 64) {
-    const int e = eb + lane;
-    int key = e < e1 ? is_key(a, e) : 0;
-    if (key < 0 || key >= a.V1) key = 0;
-    // rank of this lane among the lanes with the same key, in lane (= entry) order
-    unsigned long long mine = 0ull;
-    for (int j = 0; j < 64; ++j) {
-      const int kj = __builtin_amdgcn_readlane(key, j);
-      const unsigned long long m = __ballot(key == kj);
-      if (lane == j) mine = m;
+  for (int i0 = lane; i0 < a.V1; i0 += 64 * 8) {
+    int bs[8], hs[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 64 * u, ii = i < a.V1 ? i : 0;
+      bs[u] = a.base[ii]; hs[u] = a.hist[(size_t)c * a.V1 + ii];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + 64 * u < a.V1) sh[i0 + 64 * u] = bs[u] + hs[u] + goff[(i0 + 64 * u) >> 6];
+  }
+  __syncthreads();
+  const int nbits = 32 - __builtin_clz((unsigned)(a.V1 > 1 ? a.V1 - 1 : 1));
+  const int T = a.T;
+#pragma unroll
+  for (int r = 0; r < IS_MAXR; ++r) {
+    if (e0 + r * 64 >= e1) break;                  // wave-uniform
+    const int k = key[r], e = e0 + r * 64 + lane;
+    // the lanes with the same key, from one ballot per key BIT (lanes that agree with this lane on every bit); rank = those below this lane
+    unsigned long long mine = ~0ull;
+    for (int b = 0; b < nbits; ++b) {
+      const unsigned long long m = __ballot((k >> b) & 1);
+      mine &= ((k >> b) & 1) ? m : ~m;
     }
     const int rank = __popcll(mine & ((1ull << lane) - 1ull)), cnt = __popcll(mine);
-    if (key > 0) {
-      const int pos = sh[key] + rank;
+    if (k > 0) {
+      const int pos = sh[k] + rank;
       a.perm[pos] = e;
-      a.pitem[pos] = key;
+      a.pitem[pos] = k;
       if (a.prow) {
-        const int T = a.T;
         const int src = (e >= T) + (e >= 2 * T) + (e >= 3 * T), t = e - src * T;
         const int kind = src == 0 ? a.kind[0] : (src == 1 ? a.kind[1] : (src == 2 ? a.kind[2] : a.kind[3]));
         const float* rows = src == 0 ? a.rows[0] : (src == 1 ? a.rows[1] : (src == 2 ? a.rows[2] : a.rows[3]));
@@ -137,7 +184,7 @@ __global__ __launch_bounds__(64) void k_isort_place(ItemSortArgs a) {
       }
     }
     __syncthreads();                              // one wave: orders the cursor reads above before the updates below
-    if (key > 0 && rank == 0) sh[key] += cnt;
+    if (k > 0 && rank == 0) sh[k] += cnt;
     __syncthreads();
   }
 }
@@ -172,12 +219,12 @@ ADT_DEVICE_INLINE void ig_emit(const ItemSegArgs& a, int item, int q, const floa
 // per entry, 55 us for the 205k entries of the flagship step; with per-lane descriptors + v_readlane 26 us; this form: see DESIGN.md.
 // A sub-range is IG_PER_GROUP consecutive sorted entries; a segment inside a sub-range is written by its group, pieces that cross
 // sub-ranges are joined by wave 0 in sub-range order, pieces that cross workgroups go to the carry area (k_item_carry).
-__global__ __launch_bounds__(IG_WAVES * 64) void k_item_segsum(ItemSegArgs a) {
+ADT_DEVICE_INLINE void item_segsum_body(const ItemSegArgs& a, const int b) {
   __shared__ __attribute__((aligned(16))) float sp[IG_SUBS][2][64];          // per sub-range: left-open piece, right-open piece
   __shared__ int sflag[IG_SUBS][4];                                          // left item (-1), right item (-1), through (1: one piece, in slot 0)
   typedef const f32x4 __attribute__((address_space(1))) * gf4;
   typedef const float __attribute__((address_space(1))) * gf;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.x, g = lane >> 4, q = lane & 15;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, q = lane & 15;
   const int N = *a.total;
   uint32_t key[4] = {0u, 0u, 0u, 0u};
   if (a.thr) {
@@ -320,9 +367,9 @@ struct PosSumArgs {
   float* dP;                         // [L][64], += (one owner per position)
 };
 constexpr int PS_WAVES = 16;         // waves per position: (source, eighth of the batch) each -- the sums are chains of dependent round trips
-__global__ __launch_bounds__(PS_WAVES * 64) void k_posemb_sum(PosSumArgs a) {
+ADT_DEVICE_INLINE void posemb_sum_body(const PosSumArgs& a, const int l) {
   __shared__ float sw[PS_WAVES][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t sd = a.thr ? *a.seed : 0u;
   float acc = 0.f;
   const int s = w >> 3, part = w & 7;
@@ -359,6 +406,16 @@ __global__ __launch_bounds__(PS_WAVES * 64) void k_posemb_sum(PosSumArgs a) {
     for (int k = 0; k < PS_WAVES; ++k) t += sw[k][lane];      // fixed order: source 0's eighths, then source 1's
     a.dP[(size_t)l * 64 + lane] += t;
   }
+}
+
+static_assert(PS_WAVES == IG_WAVES, "one launch runs both bodies");
+__global__ __launch_bounds__(IG_WAVES * 64) void k_item_segsum(ItemSegArgs a) { item_segsum_body(a, blockIdx.x); }
+__global__ __launch_bounds__(PS_WAVES * 64) void k_posemb_sum(PosSumArgs a) { posemb_sum_body(a, blockIdx.x); }
+// the two in one launch (they are independent, and each alone leaves most of the chip idle): workgroups [0, nblk) the item segments, then one
+// per position
+__global__ __launch_bounds__(IG_WAVES * 64) void k_item_segsum_posemb(ItemSegArgs a, PosSumArgs p) {
+  if ((int)blockIdx.x < a.nblk) item_segsum_body(a, blockIdx.x);
+  else posemb_sum_body(p, (int)blockIdx.x - a.nblk);
 }
 
 }  // namespace adt

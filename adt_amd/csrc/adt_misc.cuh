@@ -935,12 +935,12 @@ __global__ __launch_bounds__(256) void k_fold_parts_gradnorm(RepReduce2Args a, O
     const size_t st = (size_t)vf.stride[ci];
     float sum = 0.f;
     int wg = w0;
-    for (; wg + 8 <= w1; wg += 8) {
-      float v[8];
+    for (; wg + 16 <= w1; wg += 16) {      // sixteen rows in flight (the last LayerNorm has 1,024 of them)
+      float v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(wg + u) * st];
+      for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(wg + u) * st];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) sum += v[u];
+      for (int u = 0; u < 16; ++u) sum += v[u];
     }
     for (; wg < w1; ++wg) sum += p[(size_t)wg * st];
     float* sf = reinterpret_cast<float*>(sq);

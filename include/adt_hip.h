@@ -405,6 +405,11 @@ int adt_item_segsum(const int32_t* work, int nsrc, int T, int V1, uint32_t src_m
 /* dP[l] += sum_b [ids[b, l] != 0] * keep / (1 - p) * dX[b, l] for nsrc (1 or 2) embedding layers, b ascending (one owner per position) */
 int adt_posemb_sum(const int32_t* const* ids, const float* const* dX, const uint32_t* site, int nsrc, int B, int L, float p, const uint32_t* seed,
                    uint32_t row_offset, float* dP, void* stream);
+/* adt_item_segsum + adt_posemb_sum (same p / seed) as one launch (+ the carry launch): the two are independent and each alone leaves most
+ * of the chip idle */
+int adt_item_segsum_posemb(const int32_t* work, int nsrc, int T, int V1, uint32_t src_mask, const uint32_t* site, float p, const uint32_t* seed,
+                           float emb_scale, float* dE, int accumulate, const int32_t* const* pos_ids, const float* const* pos_dX,
+                           const uint32_t* pos_site, int pos_nsrc, int B, int L, uint32_t row_offset, float* dP, void* stream);
 /* adt_sasrec_forward + adt_sasrec_loss_seed_nz of one training step (sasrec/model.py:67-81 + sasrec/main.py:151-169) in one call.  When
  * adt_sasrec_bce_deferred(cfg) is 1 (bf16, d = 64, the lean per-sequence kernels cover the shape, <= 4 blocks) and training == 3 (dropout on,
  * weight images packed by adt_sasrec_step_begin* of this step), log_feats is written by the last encoder layer's own kernel and the pos / neg

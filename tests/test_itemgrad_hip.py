@@ -92,7 +92,7 @@ def test_item_segsum_vs_numpy_and_deterministic(B, L, V, mode, p):
     base = work[ops._lib.load().adt_item_sort_work_ints(4, T, V1) * 0:].cpu().numpy()      # whole buffer
     up = lambda x: (x + 63) // 64 * 64
     o_base = up(256 * V1)
-    o_perm = o_base + up(V1 + 1)
+    o_perm = o_base + up(V1 + 1 + 256)
     o_item = o_perm + up(N)
     n_ent = int(base[o_base + V1])
     allids = np.concatenate([a.reshape(-1) for a in ids])
