@@ -204,7 +204,7 @@ int side_join(SideStream* sd, int k, void* main) {
 // deterministic, and no atomics-bound kernels beside the chain kernels.  ADT_ITEM_SORT=1 switches it on (default: the scatters).
 bool item_det(const WS& w) {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("ADT_ITEM_SORT"); on = (e && atoi(e) != 0) ? 1 : 0; }      // opt-in: see DESIGN.md (costs ~55 us per step as it stands)
+  if (on < 0) { const char* e = getenv("ADT_ITEM_SORT"); on = (e && atoi(e) != 0) ? 1 : 0; }      // opt-in: +12 us per flagship step (0.637 against 0.625 ms: DESIGN.md "item-table gradient")
   return on && w.isort_n > 0;
 }
 

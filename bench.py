@@ -163,16 +163,16 @@ def _time_in_step(model, trainer, batch, which, layer, reps=12):
 
 def roofline_probe(model, trainer, B, seq_per_s, batch):
     """`roofline` of the bench line.  The object itself describes the kernel with the LARGEST share of the step -- the fused attention-block
-    backward k_seqtt_attn_pre_bwd (one workgroup per sequence; four launches per step, 26 % of it in profiles/r03_kernel_stats.csv).
+    backward k_seqtt_attn_pre_bwd (one workgroup per sequence; four launches per step, 24 % of it in profiles/r04_kernel_stats.csv).
     Algorithmic bytes per launch = tokens x (x 256 + dO 256 + residual-path gradient 256 + gx read 256 + gx write 256 fp32; O 128 bf16;
-    H log-sum-exp floats; H x 32 B of dropout keep bits) + 3 x 16 KB of private weight-gradient partials per sequence, divided by its launch
+    H log-sum-exp floats; H x 32 B of dropout keep bits) + 3 x 8 KB of private bf16 weight-gradient partials per sequence, divided by its launch
     duration measured live with HIP events recorded by the library right around that launch inside complete training steps
     (adt_debug_time_launch), net of what the event pair itself adds (the same two events recorded with nothing between them, at the same
     place in the same steps: `event_pair_us`); the committed rocprofv3 average is used instead when it is the larger, i.e. the conservative,
     figure.
     `kernels` adds the fused decoder-layer forward (the round-2 dominant kernel), and what north_star asks for by name: achieved HBM GB/s of
     the embedding gather and MFMA utilisation of the attention kernels (causal-aware FLOPs, SURVEY 8d: 4*L(L+1)/2*hd per (b,h) forward,
-    2.5x that backward; counter-based matrix-pipe busy fractions: profiles/r03_mfma.json) on the standalone C-ABI kernels; `step` is
+    2.5x that backward; counter-based matrix-pipe busy fractions: profiles/r04_mfma.json) on the standalone C-ABI kernels; `step` is
     SURVEY 8d's step-level figure, sequences/s x 2.4 MB of ideal fused-step traffic against the HBM peak."""
     import torch
     from adt_amd import ops
@@ -188,7 +188,7 @@ def roofline_probe(model, trainer, B, seq_per_s, batch):
     us_bwd_blk = us_bwd_raw - us_pair
     us_prof = _profile_avg_us("k_seqtt_attn_pre_bwd<32, 1, false>")
     us_used = max(us_bwd_blk, us_prof or 0.0)
-    blk_bytes = T * (5 * 256 + 128 + H * 4 + H * 32) + B * 3 * 16384
+    blk_bytes = T * (5 * 256 + 128 + H * 4 + H * 32) + B * 3 * 8192       # (the weight-gradient partials are bf16 since round 4)
     blk_flops = T * 9 * 2 * d * d + B * H * 10 * (L * (L + 1) // 2) * hd      # 3 recomputed + 3 weight-gradient + 3 input-gradient 64x64 products per token; five causal score-sized products per head
     achieved = blk_bytes / (us_used * 1e-6) / 1e9
     # the fused decoder-layer forward: back-to-back relaunches, and in context (a whole forward before every timed launch)
@@ -221,7 +221,7 @@ def roofline_probe(model, trainer, B, seq_per_s, batch):
     # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes of this same command,
     # corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py): a profiler measurement, committed under profiles/
     traffic = dec_traffic = None
-    for name, key in (("r03_attn_pre_bwd_pmc.json", "blk"), ("r03_dec_fwd_pmc.json", "dec"), ("r02_dec_fwd_pmc.json", "dec")):
+    for name, key in (("r04_attn_pre_bwd_pmc.json", "blk"), ("r04_dec_fwd_pmc.json", "dec"), ("r03_attn_pre_bwd_pmc.json", "blk"), ("r03_dec_fwd_pmc.json", "dec")):
         pmc = os.path.join(REPO, "profiles", name)
         if os.path.exists(pmc):
             if key == "blk" and traffic is None:
@@ -231,8 +231,16 @@ def roofline_probe(model, trainer, B, seq_per_s, batch):
     step_bytes = 2.4e6
     logits_entry = lce_probe(dev)
     mfma_pmc = {}
+    for name in ("r04_mfma.json", "r03_mfma.json"):
+        try:
+            mfma_pmc = json.load(open(os.path.join(REPO, "profiles", name)))["runs"]["flagship"]
+            break
+        except Exception:
+            pass
+    # whole-step HBM traffic (every kernel between two k_step_begin launches; tools/pmc_step_traffic.py on the same two PMC passes)
+    step_traffic = None
     try:
-        mfma_pmc = json.load(open(os.path.join(REPO, "profiles", "r03_mfma.json")))["runs"]["flagship"]
+        step_traffic = round(json.load(open(os.path.join(REPO, "profiles", "r04_step_traffic.json")))["traffic_bytes"])
     except Exception:
         pass
 
@@ -267,6 +275,9 @@ def roofline_probe(model, trainer, B, seq_per_s, batch):
                  "mfma_util": round(2.5 * fl_fwd / (us_bwd * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4), "mfma_busy_frac_pmc": busy("k_seq_attn_bwd")}] + ([logits_entry] if logits_entry else []),
             "step": {"bytes_per_sequence_ideal": step_bytes, "achieved_GBps": round(seq_per_s * step_bytes / 1e9, 1),
                      "frac": round(seq_per_s * step_bytes / 1e9 / HBM_PEAK_GBS, 4),
+                     "traffic": step_traffic, "ideal_bytes_per_step": round(step_bytes * B),
+                     "traffic_over_ideal": round(step_traffic / (step_bytes * B), 3) if step_traffic else None,
+                     "traffic_source": "profiles/r04_step_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE of every kernel of one graph-replayed step, separate --pmc passes)",
                      "mfma_util": round(seq_per_s * 250e6 / 1e12 / MFMA_PEAK_TFLOPS, 4)}}
 
 
@@ -340,6 +351,22 @@ def lce_probe(dev):
     except Exception as e:       # a measurement extra: never fails the bench line
         print("bench.py: lce probe skipped (%s)" % e, file=sys.stderr)
         return None
+
+
+def deterministic_leg(args):
+    """The same step with ADT_ITEM_SORT=1 (item / positional table gradients as sorted segmented sums: no float atomics anywhere, two runs of
+    a step give the same bits -- tests/test_hip_model.py::test_step_is_bit_deterministic_with_sorted_item_gradient), in a child process (the
+    library reads the switch once).  Reported beside `value`, never as it."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--precision", args.precision,
+           "--no-cpu-baseline", "--no-ndcg", "--no-roofline"] + (["--no-graph"] if args.no_graph else [])
+    try:
+        p = subprocess.run(cmd, env=dict(os.environ, ADT_ITEM_SORT="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        d = json.loads(p.stdout.strip().splitlines()[-1])
+        return {"env": "ADT_ITEM_SORT=1", "value": d["value"], "ms_per_step": d["ms_per_step"], "value_incl_h2d": d["value_incl_h2d"],
+                "ms_per_step_incl_h2d": d["ms_per_step_incl_h2d"], "blocks": d["timing"]["blocks"]}
+    except Exception as e:      # a reported extra: never fails the bench line
+        return {"env": "ADT_ITEM_SORT=1", "error": repr(e)[:200]}
 
 
 def visible_gpus():
@@ -517,6 +544,8 @@ def main():
             res["roofline"] = roofline_probe(r["model"], r["tr"], r["B"], st["sequences_per_s"], r["batches"][0])
             res["roofline"]["step"]["incl_h2d"] = {"achieved_GBps": round(st_h["sequences_per_s"] * 2.4e6 / 1e9, 1),
                                                    "frac": round(st_h["sequences_per_s"] * 2.4e6 / 1e9 / HBM_PEAK_GBS, 4)}
+        if world == 1 and not args.no_roofline and not args.force_dp and os.environ.get("ADT_ITEM_SORT", "0") == "0":
+            res["deterministic_mode"] = deterministic_leg(args)
         if world == 1 and not args.no_cpu_baseline and not args.force_dp:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), file=json_out, flush=True)
