@@ -38,7 +38,8 @@ def parse_args(argv=None):
     p.add_argument("--attention_dropout", type=float, default=0.5)
     p.add_argument("--dropout", type=float, default=0.5)
     p.add_argument("--initializer_range", type=float, default=0.02)
-    p.add_argument("--distance_metric", default="wasserstein")
+    p.add_argument("--distance_metric", default="wasserstein", choices=["wasserstein"],
+                   help="the reference's default (stosa/main.py); its 'kl' variant (stosa/modules.py:52-70) is not built")
     p.add_argument("--kernel_param", type=float, default=1.0)
     p.add_argument("--warmup_epochs", default=200, type=int)
     p.add_argument("--search_epochs", default=50, type=int)

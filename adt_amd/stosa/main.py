@@ -33,7 +33,8 @@ def parse_args(argv=None):
     p.add_argument("--dropout", type=float, default=0.5)
     p.add_argument("--initializer_range", type=float, default=0.02)
     p.add_argument("--maxlen", type=int, default=50)
-    p.add_argument("--distance_metric", default="wasserstein")
+    p.add_argument("--distance_metric", default="wasserstein", choices=["wasserstein"],
+                   help="the reference's default (stosa/main.py); its 'kl' variant (stosa/modules.py:52-70) is not built")
     p.add_argument("--pvn_weight", type=float, default=0.1)
     p.add_argument("--lr", type=float, default=0.001)
     p.add_argument("--batch_size", type=int, default=256)
