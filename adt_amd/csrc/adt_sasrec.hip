@@ -129,7 +129,7 @@ void make_ws(const adt_sasrec_cfg* c, int B, WS* w) {
   w->isort_n = (c->hidden == 64 && adt_item_sort_supported(c->item_num + 1)) ? adt_item_sort_work_ints(4, (int)w->T, c->item_num + 1) : 0;
   w->isort = take(up64(w->isort_n));
   w->vcall = (int64_t)B * seq_split(B) * 512;
-  w->vpart = take(w->part_stride > 0 ? 5 * w->nl * w->vcall : 0);
+  w->vpart = take(w->part_stride > 0 ? (5 * w->nl + 1) * w->vcall : 0);      // (+ 1: the last LayerNorm's sums from the first encoder kernel of the backward)
   w->lnpart = take(LN_PART_BLOCKS * 128);
   w->gnpart = take(4096);
   w->total = o;
@@ -206,6 +206,13 @@ bool item_det(const WS& w) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("ADT_ITEM_SORT"); on = (e && atoi(e) != 0) ? 1 : 0; }      // opt-in: +12 us per flagship step (0.637 against 0.625 ms: DESIGN.md "item-table gradient")
   return on && w.isort_n > 0;
+}
+
+// ADT_LNL_FUSED=0: the model's last LayerNorm is reversed by its own kernel (k_ln_bwd) instead of inside k_seqtt_post_bwd<ENC>
+bool lnl_fuse_on() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("ADT_LNL_FUSED"); on = (e && atoi(e) == 0) ? 0 : 1; }
+  return on != 0;
 }
 
 int check_cfg(const adt_sasrec_cfg* c) {
@@ -951,21 +958,28 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
     }
   }
   if (phase == 0 || phase == 2) {
-    // last_layernorm: g_enc_x[nl] = LN'(g_f)
-    if (late_parts) {
+    // last_layernorm: g_enc_x[nl] = LN'(g_f) -- inside the last encoder block's first backward kernel when that is the per-sequence kernel
+    // with stored vector sums (k_seqtt_post_bwd<ENC>: BwdChainArgs::lnl_x)
+    const bool lnl_fused = late_parts && use_seq && lnl_fuse_on();
+    if (lnl_fused) {
+      // (nothing to launch: BwdChainArgs::lnl_x of the first encoder kernel below)
+    } else if (late_parts) {
       const int nb = adt_layernorm_bwd_parts(gf, d, ws + w.enc_x + nl * Td, d, P + lo.lnl_w(), LN_EPS, T, d, ws + w.g_enc_x + nl * Td, d, 0,
                                              ws + w.lnpart, LN_PART_BLOCKS, st);
       if (nb < 0) return nb;
     } else
     CK(adt_layernorm_bwd_rep(gf, d, ws + w.enc_x + nl * Td, d, P + lo.lnl_w(), LN_EPS, T, d, ws + w.g_enc_x + nl * Td, d, 0,
                              Gq + lo.lnl_w(), Gq + lo.lnl_b(), NREPP, w.prep_stride, st));
-    if (dec_side == 1) {
+    auto dec_side_enter = [&]() -> int {      // behind the first kernel of the encoder phase (which keeps the caller's queue)
+      if (dec_side != 1) return 0;
       void* s2 = nullptr;
       CK(side_enter(sd, 1, st, &s2));
       if (!det) CK(adt_embed_bwd_rep(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, s2));
       if (parts && !late_parts) { CK(reduce_partials(c, lo, w, G, ws, false, true, s2)); dec_parts_done = true; }
       dec_side = 2;
-    }
+      return 0;
+    };
+    if (!lnl_fused) CK(dec_side_enter());
     for (int i = nl - 1; i >= 0; --i) {
       float* gy = ws + w.g_enc_x + (i + 1) * Td;
       float* gx = ws + w.g_enc_x + i * Td;     // already holds the reconstruction seed for enc_in[i]
@@ -995,9 +1009,14 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         }
         a.part[0] = PART(i, PS_E_C2); a.part[1] = PART(i, PS_E_C1); a.part[2] = PART(i, PS_E_O); a.part_stride = (size_t)w.part_stride;
         a.vpart = VPART(i, 3);
+        if (lnl_fused && i == nl - 1) {
+          a.gy = gf; a.lnl_x = ws + w.enc_x + nl * Td; a.lnl_gamma = P + lo.lnl_w(); a.lnl_eps = LN_EPS;
+          a.vpart2 = ws + w.vpart + (int64_t)(5 * nl) * w.vcall;
+        }
         const int rc = use_seq ? adt_launch_seq_post_bwd(hd, 1, a, st) : 1;
         if (rc < 0) return rc;
         if (rc && parts) return adt_set_error(no_fallback, L, hd);
+        if (lnl_fused && i == nl - 1) CK(dec_side_enter());
         if (rc) CK(adt_launch_bwdchain(prec, which, a, st));
       }
       if (H > 4)   // wider classifiers: separate kernel
@@ -1099,7 +1118,9 @@ int adt_sasrec_fold_clip_adam(const adt_sasrec_cfg* c, float* ws, int B, float* 
       chunk(i, 4, 0, B, lo.enc(i, E_LN1W)); chunk(i, 4, 64, B, lo.enc(i, E_LN1B));
       for (int j = 0; j < 3; ++j) chunk(i, 4, 128 + 64 * j, B, lo.enc(i, E_INB) + j * d);
     }
-    {      // the last LayerNorm: per-block sums (dgamma | dbeta, 128 floats per block)
+    if (lnl_fuse_on()) {      // the last LayerNorm: per-workgroup sums of the first encoder kernel of the backward (BwdChainArgs::vpart2)
+      chunk(c->num_layers, 0, 0, nsplit_wg, lo.lnl_w()); chunk(c->num_layers, 0, 64, nsplit_wg, lo.lnl_b());
+    } else {      // per-block sums of k_ln_bwd (dgamma | dbeta, 128 floats per block)
       const int T = B * c->maxlen, nb = (T + 15) / 16 < LN_PART_BLOCKS ? (T + 15) / 16 : LN_PART_BLOCKS;
       const int base = (int)(w.lnpart - w.vpart);
       vsrc[nv] = base; vnwg[nv] = nb; vstr[nv] = 128; voff[nv] = (int)lo.lnl_w(); ++nv;

@@ -17,8 +17,9 @@ namespace adt {
 template <int NWT>
 struct SeqPostLds {
   static constexpr size_t wbytes = (size_t)NWT * TT_WIMG * 2, ibytes = (size_t)SB_R * TT_RS * 2;
-  static constexpr size_t rbytes = (448 + 192) * 4;             // sRed: dgamma, dbeta, dWs, dbs, 3-4 bias vectors ; sVec: gamma, beta, Ws
-  static constexpr size_t wvbytes = 8 * 256 * 4;                // per-wave sums of dgamma, dbeta, dWs, dbs (joined in wave order: no LDS atomics)
+  static constexpr size_t rbytes = (448 + 256) * 4;             // sRed: dgamma, dbeta, dWs, dbs, 3-4 bias vectors ; sVec: gamma, beta, Ws, last-LN gamma
+  static constexpr int wvrow = 384;                             // per wave: dgamma, dbeta, dWs, dbs [0, 196) ; last LayerNorm's dgamma, dbeta [256, 384)
+  static constexpr size_t wvbytes = 8 * wvrow * 4;              // per-wave sums (joined in wave order: no LDS atomics)
   static constexpr size_t bytes = wbytes + 2 * ibytes + 64 + rbytes + wvbytes;
 };
 
@@ -62,8 +63,12 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   __bf16* img1 = reinterpret_cast<__bf16*>(smem_raw + Lds::wbytes + Lds::ibytes);
   float* sRed = reinterpret_cast<float*>(smem_raw + Lds::wbytes + 2 * Lds::ibytes + 64);   // [0,64) dgamma [64,128) dbeta [128,192) dWs [192,196) dbs [256,448) db0, db1, db2
   float* sVec = sRed + 448;                                                  // gamma, beta, Ws
-  float* sWave = sVec + 192;                                                 // [8 waves][256]: dgamma, dbeta, dWs, dbs of each wave
-  const float *vgamma = sVec, *vbeta = sVec + 64, *vws = sVec + 128;
+  float* sWave = sVec + 256;                                                 // [8 waves][wvrow]: the sums of each wave
+  constexpr int WVR = Lds::wvrow;
+  const float *vgamma = sVec, *vbeta = sVec + 64, *vws = sVec + 128, *vgl = sVec + 192;
+  // encoder, last block only: the upstream gradient is d log_feats and the model's last LayerNorm (sasrec/model.py:44, reversed) is undone
+  // HERE, per tile, in front of everything else -- its own kernel was a 13.5 us streaming pass + a 6 us queue hop in the middle of the backward
+  const bool lnl = ENC && a.lnl_x != nullptr;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int nsp = a.nsplit > 1 ? a.nsplit : 1, b = blockIdx.x / nsp, part = blockIdx.x % nsp;
   const int L = a.L, ntiles = (L + 15) / 16, npair = (L + 31) / 32;
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   // weight images, so that HBM streams them while the prologue runs (requested at the top of phase A they arrived ~8k cycles after it)
   const float* const ws3[3] = {a.W0, a.W1, a.W2};
   sp_wdma<3, NW>(a, ws3, wimg);
-  TT dy[NS];
+  TT dy[NS], xl[NS];
   TTSaved uraw[NS], hreq[NS];                            // requested here, converted where they are first needed (tt_saved_value)
   int idv[NS];
 #pragma unroll
@@ -84,6 +89,7 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = tile >= 0 && l < L;
     dy[s] = tt_load(a.gy + (size_t)row * 64, valid, g);
+    if (ENC) xl[s] = tt_load(a.lnl_x + (size_t)row * 64, valid && lnl, g);
     uraw[s] = tt_saved_request(a.u, row, valid, g, a.saved_bf16);
     hreq[s] = tt_saved_request(a.xin, row, valid, g, a.saved_bf16);
     idv[s] = tt_load_id(a.ids, row, valid);
@@ -99,6 +105,7 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
     if (threadIdx.x < 448) sRed[threadIdx.x] = 0.f;
     if (ENC) { tt_stage_vec<NW * 64>(sVec, a.gamma, 64); tt_stage_vec<NW * 64>(sVec + 64, a.beta, 64); }
     if (cls) tt_stage_vec<NW * 64>(sVec + 128, a.Ws, 64);
+    if (lnl) tt_stage_vec<NW * 64>(sVec + 192, a.lnl_gamma, 64);
     adt_wait_vm0();
   }
   const uint32_t seedv = a.drop.thr ? *a.drop.seed : 0u;
@@ -108,6 +115,24 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   SB_STAMP(2);
   // ---- A: masked upstream gradient through dropout2 and conv2 ; dW(conv2) = df^T u ----------------------------------------------------
   TT dt[NS];
+  if (ENC) {
+    if (lnl) {      // (workgroup-uniform) every row of the tile, padded positions too: the mask below is the layer's, not the LayerNorm's
+      TT dgl = tt_zero(), dbl = tt_zero();
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (tileof(s) < 0) continue;
+        dy[s] = tt_ln_bwd(dy[s], tt_ln_stats(xl[s], a.lnl_eps), vgl, dgl, dbl, g);
+      }
+      float* mine = sWave + w * WVR + 256;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sg = tt_rowsum16(dgl.v[nt][r]), sb = tt_rowsum16(dbl.v[nt][r]);
+          if (c == 0) { mine[16 * nt + 4 * g + r] = sg; mine[64 + 16 * nt + 4 * g + r] = sb; }
+        }
+    }
+  }
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int tile = tileof(s);
@@ -243,7 +268,7 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
   if (ENC) {
     // per-lane partials over this wave's tokens -> this wave's sums in its own LDS row (16-lane DPP sums, plain stores) -> joined below in
     // wave order: the workgroup's sums do not depend on which wave arrives first (LDS float atomics added in arrival order)
-    float* mine = sWave + w * 256;
+    float* mine = sWave + w * WVR;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -272,8 +297,16 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
     if (ENC && t < 196) {
       float sum = 0.f;
 #pragma unroll
-      for (int k = 0; k < NW; ++k) sum += sWave[k * 256 + t];
+      for (int k = 0; k < NW; ++k) sum += sWave[k * WVR + t];
       sRed[t] = sum;
+    }
+    if (ENC) {
+      if (lnl && t >= 256 && t < 384) {      // the last LayerNorm's dgamma | dbeta of this workgroup, waves in order
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) sum += sWave[k * WVR + t];
+        a.vpart2[(size_t)blockIdx.x * 512 + (t - 256)] = sum;
+      }
     }
     // (each thread flushes the element it has just formed, or a bias sum of the weight-gradient sweep that the last barrier published)
     const bool live = t < 128 ? ENC : (t < 192 + H ? cls : (t >= 256 && t < 448));
