@@ -270,10 +270,17 @@ enum { PS_E_IN = 0, PS_E_O = 3, PS_E_C1 = 4, PS_E_C2 = 5, PS_D_SIN = 6, PS_D_EIN
 // the partial slots of the encoder (enc = true) and / or decoder (dec = true) blocks of every layer and their offsets in G
 int partial_slots(const adt_sasrec_cfg* c, const Layout& lo, bool enc, bool dec, int* slots, int* offs);
 // workgroups that write partial slot `slot` of a step with B sequences: the token-chain kernels run S workgroups per sequence
+// k_seqtt_attn_pre_bwd: one workgroup per sequence, two at small batches (ADT_ATTN_SPLIT=0: always one)
+int attn_split(int B) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("ADT_ATTN_SPLIT"); on = (e && atoi(e) == 0) ? 0 : 1; }
+  return on && seq_split(B) >= 2 ? 2 : 1;
+}
+// workgroups that wrote partial `slot`
 int partial_nwg(int slot, int B) {
   const int k = slot % 16;
-  const bool attn_block = (k >= PS_E_IN && k < PS_E_IN + 3) || (k >= PS_D_SIN && k < PS_D_SIN + 3);      // k_seqtt_attn_pre_bwd: one workgroup per sequence
-  return attn_block ? B : B * seq_split(B);
+  const bool attn_block = (k >= PS_E_IN && k < PS_E_IN + 3) || (k >= PS_D_SIN && k < PS_D_SIN + 3);
+  return attn_block ? B * attn_split(B) : B * seq_split(B);
 }
 // sums the partials of the encoder (enc = true) and / or decoder (dec = true) blocks of every layer into G
 int reduce_partials(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, float* G, float* ws, bool enc, bool dec, void* st) {
@@ -911,6 +918,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride; a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack; a.saved_bf16 = lean;
         a.part = PART(i, PS_D_SIN); a.part_stride = (size_t)w.part_stride;
         a.vpart = VPART(i, 2);
+        a.nsplit = a.part ? attn_split((int)w.B) : 1;
         time_mark(2, i, true, st);
         const int rc = adt_launch_seq_attn_pre_bwd(hd, 1, a, st);
         time_mark(2, i, false, st);
@@ -1031,6 +1039,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride; a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack; a.saved_bf16 = lean;
         a.part = PART(i, PS_E_IN); a.part_stride = (size_t)w.part_stride;
         a.vpart = VPART(i, 4);
+        a.nsplit = a.part ? attn_split((int)w.B) : 1;
         time_mark(1, i, true, st);
         const int rc = adt_launch_seq_attn_pre_bwd(hd, 0, a, st);
         time_mark(1, i, false, st);
@@ -1102,7 +1111,7 @@ int adt_sasrec_fold_clip_adam(const adt_sasrec_cfg* c, float* ws, int B, float* 
     // the stored bias / LayerNorm / classifier sums (BwdChainArgs::vpart: the kernels' sRed layouts) -> 64-float chunks of G
     int vsrc[128], vnwg[128], vstr[128], voff[128];
     int nv = 0;
-    const int nsplit_wg = B * seq_split(B), d = c->hidden;
+    const int nsplit_wg = B * seq_split(B), nattn_wg = B * attn_split(B), d = c->hidden;
     auto chunk = [&](int layer, int k, int t0, int nw, int64_t goff) {
       vsrc[nv] = (int)((int64_t)(5 * layer + k) * w.vcall + t0); vnwg[nv] = nw; vstr[nv] = 512; voff[nv] = (int)goff; ++nv;
     };
@@ -1110,13 +1119,13 @@ int adt_sasrec_fold_clip_adam(const adt_sasrec_cfg* c, float* ws, int B, float* 
       chunk(i, 0, 256, nsplit_wg, lo.dec(i, D_C2B)); chunk(i, 0, 320, nsplit_wg, lo.dec(i, D_C1B)); chunk(i, 0, 384, nsplit_wg, lo.dec(i, D_EOB));
       chunk(i, 1, 0, nsplit_wg, lo.dec(i, D_EINB)); chunk(i, 1, 64, nsplit_wg, lo.dec(i, D_SOB));
       chunk(i, 1, 128, nsplit_wg, lo.dec(i, D_EINB) + d); chunk(i, 1, 192, nsplit_wg, lo.dec(i, D_EINB) + 2 * d);
-      chunk(i, 2, 0, B, lo.dec(i, D_LNW)); chunk(i, 2, 64, B, lo.dec(i, D_LNB));
-      for (int j = 0; j < 3; ++j) chunk(i, 2, 128 + 64 * j, B, lo.dec(i, D_SINB) + j * d);
+      chunk(i, 2, 0, nattn_wg, lo.dec(i, D_LNW)); chunk(i, 2, 64, nattn_wg, lo.dec(i, D_LNB));
+      for (int j = 0; j < 3; ++j) chunk(i, 2, 128 + 64 * j, nattn_wg, lo.dec(i, D_SINB) + j * d);
       chunk(i, 3, 0, nsplit_wg, lo.enc(i, E_LN2W)); chunk(i, 3, 64, nsplit_wg, lo.enc(i, E_LN2B));
       if (c->num_heads > 1) { chunk(i, 3, 128, nsplit_wg, lo.enc(i, E_SW)); chunk(i, 3, 192, nsplit_wg, lo.enc(i, E_SB)); }
       chunk(i, 3, 256, nsplit_wg, lo.enc(i, E_C2B)); chunk(i, 3, 320, nsplit_wg, lo.enc(i, E_C1B)); chunk(i, 3, 384, nsplit_wg, lo.enc(i, E_OB));
-      chunk(i, 4, 0, B, lo.enc(i, E_LN1W)); chunk(i, 4, 64, B, lo.enc(i, E_LN1B));
-      for (int j = 0; j < 3; ++j) chunk(i, 4, 128 + 64 * j, B, lo.enc(i, E_INB) + j * d);
+      chunk(i, 4, 0, nattn_wg, lo.enc(i, E_LN1W)); chunk(i, 4, 64, nattn_wg, lo.enc(i, E_LN1B));
+      for (int j = 0; j < 3; ++j) chunk(i, 4, 128 + 64 * j, nattn_wg, lo.enc(i, E_INB) + j * d);
     }
     if (lnl_fuse_on()) {      // the last LayerNorm: per-workgroup sums of the first encoder kernel of the backward (BwdChainArgs::vpart2)
       chunk(c->num_layers, 0, 0, nsplit_wg, lo.lnl_w()); chunk(c->num_layers, 0, 64, nsplit_wg, lo.lnl_b());

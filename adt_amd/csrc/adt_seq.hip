@@ -169,7 +169,9 @@ static int seq_attn_pre_bwd_t(int mode, const SeqBwdArgs& a, hipStream_t s) {
                         (const void*)k_seqtt_attn_pre_bwd<HD, 2, DEC>};
   SeqBwdArgs args = a;
   args.stamps = seq_stamp_buffer(true);
-  return seq_launch(fns[mode], smem, done[mode], a.B, &args, s, "seqtt_attn_pre_bwd");
+  if (a.nsplit == 2 && !a.part) return adt_set_error("seqtt_attn_pre_bwd: two workgroups per sequence need the weight-gradient partials");
+  if (a.nsplit != 2) args.nsplit = 1;
+  return seq_launch(fns[mode], smem, done[mode], a.B * args.nsplit, &args, s, "seqtt_attn_pre_bwd");
 }
 
 int adt_launch_seq_attn_pre_bwd(int hd, int dec, const SeqBwdArgs& a, void* stream) {

@@ -23,6 +23,7 @@ struct SeqBwdArgs {
   const float* wp_base; const void* wp_img;        // pre-packed weight images (slot-ordered: + 2 plain, + 3 transposed)
   int saved_bf16;                     // `o` holds bf16 rows (written by the transposed-chain forward in its lean mode)
   float* vpart;                       // non-null: dgamma[64] | dbeta[64] | dbin[192] of this workgroup stored at vpart + blockIdx * 512 (no atomics)
+  int nsplit;                         // 2: two workgroups per sequence (grid 2 B; workgroup 2 b + part owns the tiles t % 2 == part; needs `part`)
   unsigned long long* stamps;
 };
 

@@ -267,7 +267,21 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   float* sVec = sRed + 320;                                                  // gamma, beta, packed in-projection bias (LDS copies)
   const float *vgamma = sVec, *vbeta = sVec + 64, *vbin = sVec + 128;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x, L = a.L, ntiles = (L + 15) / 16, npair = (L + 31) / 32;
+  const int L = a.L, ntiles = (L + 15) / 16, npair = (L + 31) / 32;
+  // Two workgroups per sequence (a.nsplit == 2: small batches, adt_seq_args.h): workgroup `part` OWNS the tiles t % 2 == part -- pass A for
+  // them as query tiles, pass B for them as key tiles (a tile costs t + 1 there and 13 - t here: every wave carries the same sum), their
+  // rows of the weight-gradient products and of the input gradient -- and recomputes q / k / v / delta of ALL tiles, which both passes
+  // read (slot 0 of wave w: own tile wpart + 2 w ; slot 1: the other workgroup's tile 1 - wpart + 2 w, operands only).  The G images of
+  // the weight-gradient products hold zeros in the rows of the other workgroup's tiles.
+  const bool split = a.nsplit == 2;
+  const int b = split ? blockIdx.x >> 1 : blockIdx.x, wpart = split ? (blockIdx.x & 1) : 0;
+  auto TM = [&](int s) {      // tile whose operands slot s of this wave prepares (P1 / P3 / the X images)
+    if (!split) return tq_tile(s, w, ntiles);
+    const int t = (s == 0 ? wpart : 1 - wpart) + 2 * w;
+    return t < ntiles ? t : -1;
+  };
+  auto TA = [&](int s) { return (split && s == 1) ? -1 : TM(s); };                                     // ... it runs pass A / P5 for
+  auto TB = [&](int s) { return split ? TA(s) : sb_tile_b(s, w, ntiles); };                            // ... it runs pass B for
   if (a.nrep > 1) {
     const size_t off = (size_t)(blockIdx.x % a.nrep) * a.rep_stride;
     a.dWin += off; a.dbin += off; a.dgamma += off; a.dbeta += off;
@@ -322,7 +336,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   int idv[2] = {1, 1};                           // decoder block: the pad mask of the residual-path gradient in P5 (read there it was an exposed round trip)
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+    const int tile = TM(s);
     const int l = tile * 16 + c, row = b * L + l;
     xa[s] = tt_load(a.x + (size_t)row * 64, tile >= 0 && l < L, g);               // unconditional (address-select) loads: all in flight together
     if (DEC) idv[s] = tt_load_id(a.ids, row, tile >= 0 && l < L);
@@ -353,7 +367,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   SB_STAMP(1);
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+    const int tile = TM(s);
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = tile >= 0 && l < L;
     doa[s] = tt_load(a.dO + (size_t)row * 64, valid, g);
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   float delta[2][H];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+    const int tile = TM(s);
     if (tile < 0) continue;
     const int l = tile * 16 + c;
     const bool valid = l < L;
@@ -408,9 +422,10 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   }
   // ---- P2: pass A (dQ): keys / values from the images, own query and dO rows from registers ----------------------------------------
   TT dq[2], dk[2], dv[2];
+  dq[1] = tt_zero();                             // (two workgroups per sequence: slot 1 is not this workgroup's tile -- zero rows in the dq image of P4)
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+    const int tile = TA(s);
     if (tile < 0) continue;
     const int q = tile * 16 + c;
 #pragma unroll
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   bf16x8 fk[2][NF], fv[2][NF];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int tile = sb_tile_b(s, w, ntiles);
+    const int tile = TB(s);
     const int row = (tile >= 0 ? tile : 0) * 16 + c;
 #pragma unroll
     for (int h = 0; h < H; ++h)
@@ -443,7 +458,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   // ---- P3: Q / dO images, then pass B (dK, dV) with own key and value rows from registers ----------------------------------------------
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+    const int tile = TM(s);
     if (tile < 0) continue;
     const int l = tile * 16 + c;
     sb_put_frags<HD>(img0, l, fq[s], l < L, g);
@@ -458,12 +473,12 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
       // (whose operand registers are free by now), the rows arrive while slot 1 is swept instead of stalling P4 (3.4-6.2k cycles)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const int tile2 = tq_tile(s2, w, ntiles);
+        const int tile2 = TM(s2);
         const int l2 = tile2 * 16 + c;
         xk[s2] = tt_load(a.x + (size_t)(b * L + l2) * 64, tile2 >= 0 && l2 < L, g);
       }
     }
-    const int tile = sb_tile_b(s, w, ntiles);
+    const int tile = TB(s);
     if (tile < 0) continue;
     {
       f32x4 tk[4], tv[4];
@@ -485,7 +500,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int tile = tq_tile(s, w, ntiles);
+      const int tile = TM(s);
       if (tile < 0) continue;
       const int l = tile * 16 + c;
       const bool valid = l < L;
@@ -494,7 +509,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {                // dk of pass B's tiles
-      const int tile = sb_tile_b(s, w, ntiles);
+      const int tile = TB(s);
       if (tile < 0) continue;
       const int l = tile * 16 + c;
       tt_put_rows(img2, l, dk[s], l < L, g);
@@ -508,7 +523,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   TT resa[2], gxo[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+    const int tile = TA(s);
     const int l = tile * 16 + c;
     resa[s] = tt_load(a.dres + (size_t)(b * L + l) * 64, tile >= 0 && l < L, g);
   }
@@ -518,7 +533,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+    const int tile = TM(s);
     if (tile < 0) continue;
     const int l = tile * 16 + c;
     const bool valid = l < L;
@@ -526,7 +541,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {                  // dv of pass B's tiles
-    const int tile = sb_tile_b(s, w, ntiles);
+    const int tile = TB(s);
     if (tile < 0) continue;
     const int l = tile * 16 + c;
     tt_put_rows(img0, l, dv[s], l < L, g);
@@ -538,14 +553,14 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   // ---- P5: gradient of the block input ----------------------------------------------------------------------------------------
   TT dgm = tt_zero(), dbt = tt_zero();
   auto gx_request = [&](int s) {
-    const int tile = tq_tile(s, w, ntiles);
+    const int tile = TA(s);
     const int l = tile * 16 + c;
     gxo[s] = tt_load(a.gx + (size_t)(b * L + l) * 64, a.acc && tile >= 0 && l < L, g);
   };
   gx_request(0);
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int tile = tq_tile(s, w, ntiles);
+    const int tile = TA(s);
     if (tile < 0) continue;
     const int l = tile * 16 + c, row = b * L + l;
     const bool valid = l < L;

@@ -468,6 +468,22 @@ print("bit-equal")
     assert p.returncode == 0 and "bit-equal" in p.stdout, p.stderr[-3000:]
 
 
+def test_lean_parity_with_one_workgroup_per_sequence():
+    """Below 129 sequences per GPU the per-sequence kernels map several workgroups to a sequence (adt_sasrec.hip: seq_split / attn_split), so
+    the small batches of this suite exercise the SPLIT mapping; the benchmarked batch of 256 runs one workgroup per sequence.  This runs the
+    oracle-parity, bf16-operand-parity, determinism and cfg-A golden cases again in a child process with ADT_SEQ_SPLIT=1 (the switch is read
+    once per process): the mapping bench.py times."""
+    import subprocess
+    import sys
+    here = os.path.abspath(__file__)
+    cases = ["test_lean_step_with_dropout_vs_oracle", "test_lean_step_vs_bf16_operand_oracle_cfga_shape",
+             "test_lean_step_is_deterministic_and_ignores_workspace_garbage", "test_cfga_slice_vs_reference_golden", "test_graph_replay_matches_eager"]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"] + ["%s::%s" % (here, c) for c in cases],
+                       cwd=os.path.dirname(os.path.dirname(here)), env=dict(os.environ, ADT_SEQ_SPLIT="1"), capture_output=True, text=True, timeout=850)
+    tail = r.stdout[-3000:] + "\n" + r.stderr[-2000:]
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, tail
+
+
 def test_side_stream_matches_single_stream(tmp_path):
     """The backward puts its scatter / fold kernels on a side stream under the chain kernels (adt_sasrec.hip: side_stream; in the captured
     step they are parallel branches of the HIP graph).  Two processes run the same three steps at the flagship shape's L = 200 (eager
