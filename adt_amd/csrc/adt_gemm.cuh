@@ -465,7 +465,11 @@ ADT_DEVICE_INLINE bf16x8 dw64_trfrag(const __bf16* img, int row0, int col0, int 
   u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dw64_s4 __attribute__((address_space(3)))*)(p + 16 * DW64_RS));
   return u.v;
 }
-__global__ __launch_bounds__(DW64_NTH) void k_dense_dw64(DenseBwdArgs a) {
+// part != nullptr: the workgroup's 64 x 64 product (+ its 64 bias sums) is STORED at part + (blockIdx.y * gridDim.x + blockIdx.x) * 4160 in
+// register order and k_dense_dw64_reduce adds the partials up: with ~200 workgroups flushing 4,096 float atomics each onto the same 4,096
+// addresses the flush was most of the kernel's 27.5 us at 25,600 tokens (STOSA-ADT runs it twenty times per step).
+constexpr int DW64_PART = 4096 + 64;
+__global__ __launch_bounds__(DW64_NTH) void k_dense_dw64(DenseBwdArgs a, float* part) {
   __shared__ __attribute__((aligned(16))) __bf16 sG[DW64_ROWS * DW64_RS];
   __shared__ __attribute__((aligned(16))) __bf16 sX[DW64_ROWS * DW64_RS];
   __shared__ float sB[16][64];
@@ -509,10 +513,16 @@ __global__ __launch_bounds__(DW64_NTH) void k_dense_dw64(DenseBwdArgs a) {
     }
     __syncthreads();
   }
+  float* const mine = part ? part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * DW64_PART : nullptr;
+  if (mine) {
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < 4; ++kt) *reinterpret_cast<f32x4*>(mine + ((w * 4 + kt) * 64 + lane) * 4) = acc[kt];      // element ((w, kt, lane), r)
+  } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(a.dW + (size_t)(n0 + 16 * w + 4 * g + r) * a.lddw + k0 + 16 * kt + c, acc[kt][r]);
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(a.dW + (size_t)(n0 + 16 * w + 4 * g + r) * a.lddw + k0 + 16 * kt + c, acc[kt][r]);
+  }
   if (a.db && k0 == 0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) sB[rsub][col4 + j] = bs[j];
@@ -521,9 +531,52 @@ __global__ __launch_bounds__(DW64_NTH) void k_dense_dw64(DenseBwdArgs a) {
       float t = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) t += sB[i][threadIdx.x];
-      atomicAdd(a.db + n0 + threadIdx.x, t);
+      if (mine) mine[4096 + threadIdx.x] = t;
+      else atomicAdd(a.db + n0 + threadIdx.x, t);
     }
   }
+}
+// dW (+ db) += the partials of k_dense_dw64, workgroups in order: block (x, y) takes 64 float4 slots (x < 16) or the bias sums (x == 16) of
+// 64 x 64 block y; sixteen waves split the workgroups (wave j: j, j + 16, ..), joined through LDS in wave order.  Workgroups whose token
+// chunk was empty (t_dev) left their partial unwritten: nwg_dev = number of chunks that ran.
+__global__ __launch_bounds__(1024) void k_dense_dw64_reduce(const float* part, int nwg, const int* t_dev, int T, int t_chunk, float* dW, int lddw,
+                                                            int kblocks, float* db) {
+  __shared__ float4 sp[16][64];
+  int tt = T;
+  if (t_dev && tt > *t_dev) tt = *t_dev;
+  const int nrun = (tt + t_chunk - 1) / t_chunk < nwg ? (tt + t_chunk - 1) / t_chunk : nwg;
+  const int lane = threadIdx.x & 63, j = threadIdx.x >> 6, y = blockIdx.y;
+  const float* base = part + (size_t)y * nwg * DW64_PART;
+  const bool bias = blockIdx.x == 16;
+  if (bias && (!db || (y % kblocks) != 0)) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!bias) {
+    const int slot = blockIdx.x * 64 + lane;
+    for (int z0 = j; z0 < nrun; z0 += 16 * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int z = z0 + 16 * u;
+        v[u] = z < nrun ? reinterpret_cast<const float4*>(base + (size_t)z * DW64_PART)[slot] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+  } else {
+    for (int z = j; z < nrun; z += 16) s.x += base[(size_t)z * DW64_PART + 4096 + lane];
+  }
+  sp[j][lane] = s;
+  __syncthreads();
+  if (j != 0) return;
+  float4 t = sp[0][lane];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) { t.x += sp[k][lane].x; t.y += sp[k][lane].y; t.z += sp[k][lane].z; t.w += sp[k][lane].w; }
+  const int n0 = 64 * (y / kblocks), k0 = 64 * (y % kblocks);
+  if (bias) { db[n0 + lane] += t.x; return; }
+  const int slot = blockIdx.x * 64 + lane;              // (w, kt, lane'): slot = (w * 4 + kt) * 64 + lane'
+  const int lp = slot & 63, kt = (slot >> 6) & 3, w = slot >> 8, c = lp & 15, g = lp >> 4;
+  float* dst = dW + (size_t)(n0 + 16 * w + 4 * g) * lddw + k0 + 16 * kt + c;
+  dst[0] += t.x; dst[(size_t)lddw] += t.y; dst[2 * (size_t)lddw] += t.z; dst[3 * (size_t)lddw] += t.w;
 }
 
 // ---- weight gradient of a 256 x 256 layer through private partials (bf16 operands) -------------------------------------------------------

@@ -1067,7 +1067,8 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
     // The side stream is in order: the join behind that sum also covers the decoder's work queued on it earlier -- a join of its own in front
     // of the embedding gradient was one more cross-queue wait (5-9 us) on the caller's stream.
     {
-      SideStream* const sd2 = (side_sites() & 4) ? sd : nullptr;
+      // (nothing to put beside the embedding gradient when the optimizer's fold sums the partials: no empty fork / join pair then)
+      SideStream* const sd2 = ((side_sites() & 4) && parts && !late_parts) ? sd : nullptr;
       if (dec_side == 2 && !sd2) CK(side_join(sd, 1, st));
       dec_side = 0;
       void* s2 = nullptr;

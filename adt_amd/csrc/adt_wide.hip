@@ -339,7 +339,12 @@ static int launch_dense_bwd(const DenseBwdArgs& a0, hipStream_t s) {
     int chunk = ((T + 255) / 256 + DW64_ROWS - 1) / DW64_ROWS * DW64_ROWS;
     if (chunk < DW64_ROWS) chunk = DW64_ROWS;
     a.t_chunk = chunk;
-    hipLaunchKernelGGL(k_dense_dw64, dim3((T + chunk - 1) / chunk, (N / 64) * (K / 64)), dim3(DW64_NTH), 0, s, a);
+    const int nwg = (T + chunk - 1) / chunk, blocks = (N / 64) * (K / 64);
+    // private partials in the registered workspace + an ordered sum (no float atomics) when there is one
+    float* const part = (g_dense_ws && (int64_t)nwg * blocks * DW64_PART * 4 <= g_dense_ws_bytes) ? g_dense_ws : nullptr;
+    hipLaunchKernelGGL(k_dense_dw64, dim3(nwg, blocks), dim3(DW64_NTH), 0, s, a, part);
+    if (part)
+      hipLaunchKernelGGL(k_dense_dw64_reduce, dim3(17, blocks), dim3(1024), 0, s, (const float*)part, nwg, a.t_dev, T, chunk, a.dW, a.lddw, K / 64, a.db);
     a.dW = nullptr;
   }
   if (a.dW) {

@@ -243,8 +243,8 @@ def dense_bwd(prec, dY, X, W, dW=None, db=None, dX=None, beta=False, act=ACT_NON
     """G = dY * mask * dropmask * act'(U); dX (+)= G W; dW += G^T X; db += colsum(G)."""
     T, N = dY.shape
     K = W.shape[1]
-    if dW is not None and N % 256 == 0 and K % 256 == 0 and prec == PREC_BF16:
-        _ensure_dense_ws(dY.device)
+    if dW is not None and prec == PREC_BF16 and ((N % 256 == 0 and K % 256 == 0) or (N % 64 == 0 and K % 64 == 0 and (N // 64) * (K // 64) <= 4)):
+        _ensure_dense_ws(dY.device)      # 256-wide layers and 64 x 64 blocks: private partials + an ordered sum instead of an atomic flush
     _lib.check(_lib.load().adt_dense_bwd(prec, _p(_f32(dY)), _ld(dY), T, K, N, _p(mask_ids), float(p), _p(seed), site, row_offset, act, _p(U),
                                          _ld(U), _p(X), _ld(X), _p(_f32(W)), _ld(W), _p(dX), _ld(dX), int(beta), _p(dW), _ld(dW) if dW is not None else 0,
                                          _p(db), _p(t_dev), _stream()), "dense_bwd")
