@@ -45,10 +45,11 @@ struct BwdChainArgs {
   float* vpart;               // adt_seqpost_tt.cuh: non-null: this workgroup's bias / LayerNorm / classifier gradient sums are STORED at
                               // vpart + blockIdx * 512 (the kernel's sRed layout) instead of added to the replicas with float atomics; they
                               // are summed over the workgroups in order by the optimizer's fold (k_fold_parts_gradnorm, job 3)
-  const float* lnl_x; const float* lnl_gamma; float lnl_eps; float* vpart2;
+  const float* lnl_x; const float* lnl_gamma; float lnl_eps; float* vpart2; float* lnl_dgamma; float* lnl_dbeta;
                               // k_seqtt_post_bwd<ENC>: lnl_x != nullptr: gy is the gradient of the model's LAST LayerNorm's output; its input
                               // rows lnl_x and weight lnl_gamma: the LayerNorm is reversed per tile in front of the chain, its dgamma | dbeta
-                              // sums of this workgroup are stored at vpart2 + blockIdx * 512 (128 floats)
+                              // sums of this workgroup are stored at vpart2 + blockIdx * 512 (128 floats), or (vpart2 == nullptr) added to
+                              // lnl_dgamma / lnl_dbeta (replicas like dgamma / dbeta) with float atomics
   int nsplit;                 // adt_seqpost_tt.cuh: S > 1 workgroups per sequence (adt_seq_args.h): workgroup (blockIdx / S, blockIdx % S) runs the token
                               // chains of the tiles t with t % S == part; its weight-gradient partial (slot blockIdx) covers those tokens only
 };

@@ -968,7 +968,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   if (phase == 0 || phase == 2) {
     // last_layernorm: g_enc_x[nl] = LN'(g_f) -- inside the last encoder block's first backward kernel when that is the per-sequence kernel
     // with stored vector sums (k_seqtt_post_bwd<ENC>: BwdChainArgs::lnl_x)
-    const bool lnl_fused = late_parts && use_seq && lnl_fuse_on();
+    const bool lnl_fused = parts && use_seq && lnl_fuse_on();      // (without the stored sums: float atomics into the replicas, like its other vectors)
     if (lnl_fused) {
       // (nothing to launch: BwdChainArgs::lnl_x of the first encoder kernel below)
     } else if (late_parts) {
@@ -1019,7 +1019,8 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.vpart = VPART(i, 3);
         if (lnl_fused && i == nl - 1) {
           a.gy = gf; a.lnl_x = ws + w.enc_x + nl * Td; a.lnl_gamma = P + lo.lnl_w(); a.lnl_eps = LN_EPS;
-          a.vpart2 = ws + w.vpart + (int64_t)(5 * nl) * w.vcall;
+          a.vpart2 = late_parts ? ws + w.vpart + (int64_t)(5 * nl) * w.vcall : nullptr;
+          a.lnl_dgamma = Gq + lo.lnl_w(); a.lnl_dbeta = Gq + lo.lnl_b();
         }
         const int rc = use_seq ? adt_launch_seq_post_bwd(hd, 1, a, st) : 1;
         if (rc < 0) return rc;

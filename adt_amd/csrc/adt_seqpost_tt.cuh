@@ -26,9 +26,9 @@ struct SeqPostLds {
 ADT_DEVICE_INLINE void sp_replica(BwdChainArgs& a) {
   if (a.nrep <= 1) return;
   const size_t off = (size_t)(blockIdx.x % a.nrep) * a.rep_stride;
-  float** const ptrs[] = {&a.dW0, &a.dW1, &a.dW2, &a.dW3, &a.db0, &a.db1, &a.db2, &a.db3, &a.dgamma, &a.dbeta, &a.dWs, &a.dbs};
+  float** const ptrs[] = {&a.dW0, &a.dW1, &a.dW2, &a.dW3, &a.db0, &a.db1, &a.db2, &a.db3, &a.dgamma, &a.dbeta, &a.dWs, &a.dbs, &a.lnl_dgamma, &a.lnl_dbeta};
 #pragma unroll
-  for (int i = 0; i < 12; ++i)
+  for (int i = 0; i < 14; ++i)
     if (*ptrs[i]) *ptrs[i] += off;
 }
 
@@ -305,7 +305,8 @@ __global__ __launch_bounds__(SP_NW * 64) void k_seqtt_post_bwd(BwdChainArgs a) {
         float sum = 0.f;
 #pragma unroll
         for (int k = 0; k < NW; ++k) sum += sWave[k * WVR + t];
-        a.vpart2[(size_t)blockIdx.x * 512 + (t - 256)] = sum;
+        if (a.vpart2) a.vpart2[(size_t)blockIdx.x * 512 + (t - 256)] = sum;
+        else atomicAdd((t < 320 ? a.lnl_dgamma : a.lnl_dbeta - 64) + (t - 256), sum);
       }
     }
     // (each thread flushes the element it has just formed, or a bias sum of the weight-gradient sweep that the last barrier published)
