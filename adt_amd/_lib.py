@@ -126,6 +126,7 @@ SIGNATURES = {
     "adt_sasrec_forward_loss_prefetch": (_I, [_CP, _P, _P, _P, _P, _P, _P, _I, _I, _P, _U, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
     "adt_sasrec_step_begin_ring_staged": (_I, [_CP, _P, _I, _P, _U, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P]),
     "adt_sasrec_fold_clip_adam": (_I, [_CP, _P, _I, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _P, _P]),
+    "adt_sasrec_fold_grads": (_I, [_CP, _P, _I, _P, _P, _P, _P]),
     "adt_sasrec_step_begin": (_I, [_CP, _P, _I, _P, _U, _P, _P, _P, _L, _P, _P]),
     "adt_sasrec_step_begin_ring": (_I, [_CP, _P, _I, _P, _U, _P, _L, _I, _P, _P, _P, _P, _P, _L, _P, _P]),
     "adt_sasrec_backward": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _U, _I, _P]),

@@ -730,15 +730,15 @@ int adt_fold_clip_adam(float* P, float* G, float* M, float* V, int64_t n, float*
 
 /* adt_fold_clip_adam that also sums the per-sequence partials of the 64 x 64 weight gradients (nslots blocks: slot index inside a workgroup's
  * partial area, float offset in G) in workgroup order; mask_base = offset in G of the range the row mask describes (the positional table). */
-int adt_fold_parts_clip_adam(float* P, float* G, float* M, float* V, int64_t n, float* d0, const float* r0, int64_t n0, int nrep0, int64_t s0, float* d1,
-                             const float* r1, int64_t n1, int nrep1, int64_t s1, const float* part, int64_t part_stride, const int* nwg_slot, const int* slots,
-                             const int* offs, int nslots, const float* vpart, const int* vsrc, const int* vnwg, const int* vstride, const int* voff, int nvec,
-                             float* gn_part, float wd, float clip, float lr, float b1, float b2, float eps, float* scal, void* stream) {
+static int fold_parts_impl(bool adam, float* P, float* G, float* M, float* V, int64_t n, float* d0, const float* r0, int64_t n0, int nrep0, int64_t s0, float* d1,
+                           const float* r1, int64_t n1, int nrep1, int64_t s1, const float* part, int64_t part_stride, const int* nwg_slot, const int* slots,
+                           const int* offs, int nslots, const float* vpart, const int* vsrc, const int* vnwg, const int* vstride, const int* voff, int nvec,
+                           float* gn_part, float wd, float clip, float lr, float b1, float b2, float eps, float* scal, void* stream) {
   if (n0 <= 0 || n1 <= 0 || (n0 % 4) || (s0 % 4) || (n1 % 4) || (s1 % 4) || d0 != G) return adt_set_error("fold_parts_clip_adam: ranges");
   if (nslots < 1 || nslots > FP_MAXSLOTS || (d1 - G) % 64 || n1 > (int64_t)FP_MASKWORDS * 32 * 64) return adt_set_error("fold_parts_clip_adam: %d blocks, %lld floats", nslots, (long long)n1);
   OptArgs a{};
   a.P = P; a.G = G; a.M = M; a.Vv = V; a.n = (size_t)n; a.nE = (size_t)n0; a.wd = wd; a.clip = clip; a.lr = lr;
-  a.b1 = b1; a.b2 = b2; a.eps = eps; a.scal = scal; a.grad_scale = 1.0f;
+  a.b1 = b1; a.b2 = b2; a.eps = eps; a.scal = scal; a.grad_scale = 1.0f; a.fold_only = adam ? 0 : 1;
   RepReduce2Args r{{d0, d1}, {r0, r1}, {(size_t)n0, (size_t)n1}, {nrep0, nrep1}, {(size_t)s0, (size_t)s1}, 0};
   const int g0 = grid_for((size_t)n0 / 4, 256, 1024), g1 = grid_for((size_t)n1 / 4, 256, 1024);
   r.g0 = g0;
@@ -763,8 +763,25 @@ int adt_fold_parts_clip_adam(float* P, float* G, float* M, float* V, int64_t n, 
   if (gn_part) { a.gn_part = gn_part; a.gn_n = g0 + g1 + g2 + g3; }
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_fold_parts_gradnorm, dim3(g0 + g1 + g2 + g3), dim3(256), 0, s, r, a, pf, vf, g1, g2);
-  hipLaunchKernelGGL(k_adam, dim3(grid_for((size_t)n, 256, 1024)), dim3(256), 0, s, a);
+  if (adam) hipLaunchKernelGGL(k_adam, dim3(grid_for((size_t)n, 256, 1024)), dim3(256), 0, s, a);
   return check_launch("fold_parts_clip_adam");
+}
+
+int adt_fold_parts_clip_adam(float* P, float* G, float* M, float* V, int64_t n, float* d0, const float* r0, int64_t n0, int nrep0, int64_t s0, float* d1,
+                             const float* r1, int64_t n1, int nrep1, int64_t s1, const float* part, int64_t part_stride, const int* nwg_slot, const int* slots,
+                             const int* offs, int nslots, const float* vpart, const int* vsrc, const int* vnwg, const int* vstride, const int* voff, int nvec,
+                             float* gn_part, float wd, float clip, float lr, float b1, float b2, float eps, float* scal, void* stream) {
+  return fold_parts_impl(true, P, G, M, V, n, d0, r0, n0, nrep0, s0, d1, r1, n1, nrep1, s1, part, part_stride, nwg_slot, slots, offs, nslots, vpart, vsrc, vnwg,
+                         vstride, voff, nvec, gn_part, wd, clip, lr, b1, b2, eps, scal, stream);
+}
+
+/* the fold half alone: the gradient sums into G (no weight-decay term, no optimizer step) -- in front of a gradient all-reduce */
+int adt_fold_parts(float* P, float* G, int64_t n, float* d0, const float* r0, int64_t n0, int nrep0, int64_t s0, float* d1, const float* r1, int64_t n1,
+                   int nrep1, int64_t s1, const float* part, int64_t part_stride, const int* nwg_slot, const int* slots, const int* offs, int nslots,
+                   const float* vpart, const int* vsrc, const int* vnwg, const int* vstride, const int* voff, int nvec, float* gn_part, float* scal,
+                   void* stream) {
+  return fold_parts_impl(false, P, G, nullptr, nullptr, n, d0, r0, n0, nrep0, s0, d1, r1, n1, nrep1, s1, part, part_stride, nwg_slot, slots, offs, nslots, vpart,
+                         vsrc, vnwg, vstride, voff, nvec, gn_part, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, scal, stream);
 }
 
 static void step_begin_extras(StepBeginArgs& a, float* Z, int64_t nz, const float* pack_base, void* pack_img, const int* pack_offs, int npack) {

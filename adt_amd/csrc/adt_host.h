@@ -89,6 +89,11 @@ int adt_fold_parts_clip_adam(float* P, float* G, float* M, float* V, int64_t n, 
                              const float* r1, int64_t n1, int nrep1, int64_t s1, const float* part, int64_t part_stride, const int* nwg_slot, const int* slots,
                              const int* offs, int nslots, const float* vpart, const int* vsrc, const int* vnwg, const int* vstride, const int* voff, int nvec,
                              float* gn_part, float wd, float clip, float lr, float b1, float b2, float eps, float* scal, void* stream);
+// its fold half alone (no weight-decay term, no optimizer step)
+int adt_fold_parts(float* P, float* G, int64_t n, float* d0, const float* r0, int64_t n0, int nrep0, int64_t s0, float* d1, const float* r1, int64_t n1,
+                   int nrep1, int64_t s1, const float* part, int64_t part_stride, const int* nwg_slot, const int* slots, const int* offs, int nslots,
+                   const float* vpart, const int* vsrc, const int* vnwg, const int* vstride, const int* voff, int nvec, float* gn_part, float* scal,
+                   void* stream);
 int adt_layernorm_bwd_parts(const float* dY, int lddy, const float* X, int ldx, const float* gamma, float eps, int T, int d, float* dX, int lddx,
                             int accumulate, float* part, int max_blocks, void* stream);
 }

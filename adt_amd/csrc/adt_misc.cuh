@@ -635,6 +635,7 @@ struct OptArgs {
                      // sums of ||E||^2, [128..192) partial sums of ||g||^2 (64 sub-slots each: no same-address contention)
   float grad_scale;  // multiply grads first (1/world for averaged all-reduce; normally 1)
   float l2;          // Adam's coupled weight_decay (bert4rec/trainer.py:41): g += l2 * p AFTER clipping; 0 = off
+  int fold_only;                 // k_fold_parts_gradnorm in front of a gradient all-reduce: the step count and the optimizer scalars are left to the kernels behind it
   float* gn_part; int gn_n;      // optional: ||g||^2 as gn_n per-block partials (stored by k_fold_parts_gradnorm, summed in order by k_adam) instead of
                                  // the 64 atomically added sub-slots scal[128..192): the norm, and with it the clip factor, has the same bits in every run
 };
@@ -1011,7 +1012,7 @@ __global__ __launch_bounds__(256) void k_fold_parts_gradnorm(RepReduce2Args a, O
     if (o.gn_part) o.gn_part[blockIdx.x] = s;      // summed in block order by k_adam
     else atomicAdd(o.scal + 128 + (blockIdx.x & 63), s);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { o.scal[0] = nrm * nrm; o.scal[3] = o.wd * nrm; o.scal[2] += 1.0f; }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && !o.fold_only) { o.scal[0] = nrm * nrm; o.scal[3] = o.wd * nrm; o.scal[2] += 1.0f; }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1097,8 +1097,8 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   return 0;
 }
 
-int adt_sasrec_fold_clip_adam(const adt_sasrec_cfg* c, float* ws, int B, float* P, float* G, float* M, float* V, float wd, float clip, float lr,
-                              float b1, float b2, float eps, float* scal, void* st) {
+static int fold_impl(bool adam, const adt_sasrec_cfg* c, float* ws, int B, float* P, float* G, float* M, float* V, float wd, float clip, float lr,
+                     float b1, float b2, float eps, float* scal, void* st) {
   CK(check_cfg(c));
   Layout lo;
   make_layout(c, &lo);
@@ -1137,13 +1137,29 @@ int adt_sasrec_fold_clip_adam(const adt_sasrec_cfg* c, float* ws, int B, float* 
       vsrc[nv] = base; vnwg[nv] = nb; vstr[nv] = 128; voff[nv] = (int)lo.lnl_w(); ++nv;
       vsrc[nv] = base + 64; vnwg[nv] = nb; vstr[nv] = 128; voff[nv] = (int)lo.lnl_b(); ++nv;
     }
+    if (!adam)
+      return adt_fold_parts(P, G, lo.total, G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * c->hidden, item_det(w) ? 0 : NREP, w.rep_stride,
+                            G + lo.posw(), Gq + lo.posw(), lo.total - lo.posw(), 0, w.prep_stride, ws + w.part, w.part_stride, nwg, slots, offs, ns,
+                            ws + w.vpart, vsrc, vnwg, vstr, voff, nv, ws + w.gnpart, scal, st);
     return adt_fold_parts_clip_adam(P, G, M, V, lo.total, G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * c->hidden, item_det(w) ? 0 : NREP,
                                     w.rep_stride, G + lo.posw(), Gq + lo.posw(), lo.total - lo.posw(), 0 /* no replicas: partials */, w.prep_stride,
                                     ws + w.part, w.part_stride, nwg, slots, offs, ns, ws + w.vpart, vsrc, vnwg, vstr, voff, nv, ws + w.gnpart,
                                     wd, clip, lr, b1, b2, eps, scal, st);
   }
+  if (!adam)      // the replica fold the backward left out (phase bit 8)
+    return adt_replica_reduce2(G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * c->hidden, item_det(w) ? 0 : NREP, w.rep_stride, G + lo.posw(),
+                               Gq + lo.posw(), lo.total - lo.posw(), NREPP, w.prep_stride, st);
   return adt_fold_clip_adam(P, G, M, V, lo.total, G + lo.item(), ws + w.rep, (int64_t)(c->item_num + 1) * c->hidden, item_det(w) ? 0 : NREP, w.rep_stride, G + lo.posw(),
                             Gq + lo.posw(), lo.total - lo.posw(), NREPP, w.prep_stride, wd, clip, lr, b1, b2, eps, scal, st);
+}
+
+int adt_sasrec_fold_clip_adam(const adt_sasrec_cfg* c, float* ws, int B, float* P, float* G, float* M, float* V, float wd, float clip, float lr,
+                              float b1, float b2, float eps, float* scal, void* st) {
+  return fold_impl(true, c, ws, B, P, G, M, V, wd, clip, lr, b1, b2, eps, scal, st);
+}
+
+int adt_sasrec_fold_grads(const adt_sasrec_cfg* c, float* ws, int B, float* P, float* G, float* scal, void* st) {
+  return fold_impl(false, c, ws, B, P, G, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, scal, st);
 }
 
 int adt_sasrec_predict(const adt_sasrec_cfg* c, const float* P, float* ws, const int32_t* seq, const int32_t* cand,

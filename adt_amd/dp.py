@@ -91,6 +91,16 @@ class GradBuckets:
         import torch.distributed as dist
         self._h.append(dist.all_reduce(self.tail, group=self.group, async_op=True))
 
+    def whole(self, flat_grad):
+        """One sum of the whole flat gradient (the one-phase data-parallel step: nothing to overlap it with, but the backward in front of
+        it is the single-GPU one -- side stream, stored partial sums)."""
+        if self.group is None:
+            return
+        import torch.distributed as dist
+        h = dist.all_reduce(flat_grad, group=self.group, async_op=True)
+        if h is not None:
+            h.wait()
+
     def finish(self):
         if self.group is None:
             return

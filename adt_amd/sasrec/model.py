@@ -229,6 +229,12 @@ class SASRecADT(torch.nn.Module):
                                                       _ptr(m), _ptr(v), float(wd), float(clip), float(lr), float(b1), float(b2), float(eps),
                                                       _ptr(scal), self._stream()), "sasrec_fold_clip_adam")
 
+    def run_fold_grads(self, B, scal):
+        """The gradient sums behind run_backward(..., defer_fold=True) without the optimizer step: flat_grad is complete afterwards (the
+        data-parallel step all-reduces it, then clip_adam_pre)."""
+        _lib.check(self.lib.adt_sasrec_fold_grads(ctypes.byref(self.cfg), _ptr(self.workspace(B)), B, _ptr(self.flat), _ptr(self.flat_grad), _ptr(scal),
+                                                  self._stream()), "sasrec_fold_grads")
+
     # ------------------------------------------------------------------------------------------
     def forward(self, user_ids, log_seqs, dec_seqs, pos_seqs, neg_seqs):
         """sasrec/model.py:67-81.  Returns (pos_logits, neg_logits, encoder_layer_input, decoder_layer_output

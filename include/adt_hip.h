@@ -440,6 +440,10 @@ int adt_sasrec_backward(const adt_sasrec_cfg* cfg, const float* params, float* g
  * launches instead of three.  m, v: Adam moments laid out like params. */
 int adt_sasrec_fold_clip_adam(const adt_sasrec_cfg* cfg, float* ws, int B, float* params, float* grads, float* m, float* v, float wd,
                               float clip, float lr, float b1, float b2, float eps, float* scal, void* stream);
+/* The fold half of adt_sasrec_fold_clip_adam alone: completes `grads` behind adt_sasrec_backward(phase | 8) -- no weight-decay term, no
+ * norm, no optimizer step.  The data-parallel step runs it in front of the gradient all-reduce (sasrec/main.py:170 on every rank, then one
+ * sum over the ranks) and adt_clip_adam_pre behind it. */
+int adt_sasrec_fold_grads(const adt_sasrec_cfg* cfg, float* ws, int B, float* params, float* grads, float* scal, void* stream);
 /* SASRecADT.predict (sasrec/model.py:83-97): encoder only, last position, candidate (cand != NULL, B x C) or
  * all-item (C = V+1) scores; optional rank of column 0. */
 int adt_sasrec_predict(const adt_sasrec_cfg* cfg, const float* params, float* ws, const int32_t* seq,

@@ -34,6 +34,9 @@ def _nsteps(prec):
 
 def _worker(rank, world, port, q, prec="f32"):
     import torch.distributed as dist
+    if prec.endswith("-2phase"):      # the two-bucket exchange (decoder bucket overlapped with the encoder backward) instead of the one-phase default
+        os.environ["ADT_DP_PHASES"] = "2"
+        prec = prec[:-7]
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from adt_amd.dp import shard_bounds, global_norms
@@ -51,10 +54,11 @@ def _worker(rank, world, port, q, prec="f32"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16", "bf16-2phase"])
 def test_two_rank_trainer_matches_single_process(prec):
     import torch.multiprocessing as mp
     from adt_amd.sasrec.trainer import FusedTrainer
+    wprec, prec = prec, prec.split("-")[0]
     cfg, m, batch = _build(prec)
     if prec == "bf16":
         assert m.lib.adt_seq_layer_supported(1, cfg.maxlen, 64, 32) == 1
@@ -67,7 +71,7 @@ def test_two_rank_trainer_matches_single_process(prec):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29600 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, prec)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, wprec)) for r in range(2)]
     for p in procs:
         p.start()
     w2, g2, n2 = q.get(timeout=300)
