@@ -656,8 +656,8 @@ int adt_sasrec_step_begin(const adt_sasrec_cfg* c, float* ws, int B, uint32_t* s
   int offs[256];
   const int npack = pack_offsets(c, lo, offs);
   return adt_step_begin_launch(seed, seed_inc, ws + w.norms, norms_src, ws + w.loss, 64 * (2 + 2 * c->num_layers), scal, G, n, P + lo.item(),
-                               (int64_t)(c->item_num + 1) * c->hidden, ws + w.prep, (int64_t)NREPP * w.prep_stride, P + lo.posw(), ws + w.wpack, offs,
-                               npack, st);
+                               (int64_t)(c->item_num + 1) * c->hidden, ws + w.rep, (int64_t)NREP * w.rep_stride + (int64_t)NREPP * w.prep_stride,
+                               P + lo.posw(), ws + w.wpack, offs, npack, st);      // item-table replicas + parameter replicas (adjacent): one fill
 }
 
 int adt_sasrec_step_begin_ring(const adt_sasrec_cfg* c, float* ws, int B, uint32_t* seed, uint32_t seed_inc, const int32_t* ring, int64_t slot_ints,
@@ -678,7 +678,8 @@ int adt_sasrec_step_begin_ring_staged(const adt_sasrec_cfg* c, float* ws, int B,
   const int npack = pack_offsets(c, lo, offs);
   return adt_step_begin_ring_launch(seed, seed_inc, ws + w.norms, ws + w.loss, 64 * (2 + 2 * c->num_layers), scal, G, n, P + lo.item(),
                                     (int64_t)(c->item_num + 1) * c->hidden, ring, slot_ints, nslots, ids_dst, 4 * (int64_t)w.T + 4, state, consumed,
-                                    staging, produced, ws + w.prep, (int64_t)NREPP * w.prep_stride, P + lo.posw(), ws + w.wpack, offs, npack, st);
+                                    staging, produced, ws + w.rep, (int64_t)NREP * w.rep_stride + (int64_t)NREPP * w.prep_stride, P + lo.posw(),
+                                    ws + w.wpack, offs, npack, st);
 }
 
 static int loss_seed_impl(const adt_sasrec_cfg* c, float* ws, const int32_t* pos, int B, const float* lambdas1, const float* lambdas2,
@@ -773,7 +774,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   const bool parts = w.part_stride > 0 && adt_seq_partials(prec, L, d, hd) != 0;
   auto PART = [&](int layer, int slot) { return parts ? ws + w.part + (int64_t)(16 * layer + slot) * 4096 : nullptr; };
   const char* const no_fallback = "backward: shape L=%d hd=%d left the per-sequence kernels although the partial-gradient path was chosen";
-  const bool prep_zeroed = (phase & 4) != 0;      // bit 2: adt_sasrec_step_begin* of this step zeroed the parameter-gradient replicas
+  const bool prep_zeroed = (phase & 4) != 0;      // bit 2: adt_sasrec_step_begin* of this step zeroed the item-table and parameter-gradient replicas
   const bool defer_fold = (phase & 8) != 0 && (phase & 3) == 0;      // bit 3 (one-phase only): adt_sasrec_fold_clip_adam does the last fold
   const bool late_parts = defer_fold && fold_sums_partials(c, w);      // adt_sasrec_fold_clip_adam sums the weight-gradient partials too
   // ... and the bias / LayerNorm / classifier gradient sums, which the chain kernels then STORE per workgroup (no float atomics, no replicas)
@@ -824,7 +825,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       if (!prep_zeroed && adt::zero_f32_async(ws + w.prep, (size_t)NREPP * w.prep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
       logits_side = 1;
     } else {
-      if (adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride + (prep_zeroed ? 0 : (size_t)NREPP * w.prep_stride), (hipStream_t)st)) return adt_set_error("replica zero");
+      if (!prep_zeroed && adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride + (size_t)NREPP * w.prep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
       CK(logits_scatter(st));
     }
     for (int i = nl - 1; i >= 0; --i) {
@@ -860,7 +861,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       if (logits_side == 1) {
         void* s2 = nullptr;
         CK(side_enter(sd, 0, st, &s2));
-        if (adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride, (hipStream_t)s2)) return adt_set_error("replica zero");
+        if (!prep_zeroed && adt::zero_f32_async(ws + w.rep, (size_t)NREP * w.rep_stride, (hipStream_t)s2)) return adt_set_error("replica zero");
         CK(logits_scatter(s2));
         logits_side = 2;
       }

@@ -426,8 +426,8 @@ int adt_sasrec_forward_loss_prefetch(const adt_sasrec_cfg* cfg, const float* par
                                      uint32_t* state, uint32_t* consumed, int32_t* staging, void* stream);
 /* reverse pass: consumes the G_* buffers (destroyed), accumulates into `grads` (same layout as params).
  * phase: 0 = everything; 1 = logits + decoder stack only; 2 = last LN + encoder stack + embeddings (lets the
- * host overlap the gradient all-reduce of the decoder bucket with phase 2).  + 4: the parameter-gradient replicas were already zeroed by
- * adt_sasrec_step_begin / _ring of this step.  With phase 0 the scatter / fold kernels run on a side stream of the library under the
+ * host overlap the gradient all-reduce of the decoder bucket with phase 2).  + 4: the item-table and parameter-gradient replicas were already
+ * zeroed by adt_sasrec_step_begin / _ring of this step (phase 2 zeroes the item-table replicas again for its own scatter).  With phase 0 the scatter / fold kernels run on a side stream of the library under the
  * chain kernels (joined before the call returns its last launch; ADT_SIDE_STREAM=0 keeps everything on `stream`).  + 8 (with phase 0 only):
  * the last fold of the gradient replicas into `grads` is left to adt_sasrec_fold_clip_adam, which must follow.  + 16: the step's forward was
  * adt_sasrec_forward_loss on the deferred path (adt_sasrec_bce_deferred): logits, BCE seed and BCE loss terms are formed here. */
