@@ -471,8 +471,13 @@ bool bce_deferred(const adt_sasrec_cfg* c) {
   return on && d == 64 && c->num_layers <= 4 && adt_seq_lean(c->prec, c->maxlen, d, hd) != 0;
 }
 struct RingRef { const int32_t* ring; int64_t slot_ints; int nslots; uint32_t* state; uint32_t* consumed; int32_t* staging; };
+// bce_side (training bit 2 of adt_sasrec_forward_loss*): the logits + BCE + item-row scatter kernel of the deferred path is launched HERE, on
+// the library's side stream beside the streaming loss pass (both are memory passes; under the backward's first chain kernels it stretched the
+// latency-bound cross-attention backward by about its own duration), and joined by adt_sasrec_backward(phase bit 5) in front of the first
+// kernel that reads d log_feats.  The item-table replicas are zero: adt_sasrec_step_begin* of this step.
 int forward_loss_lean(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, const float* P, float* ws, const int32_t* seq, const int32_t* dec,
-                      float p, const uint32_t* seed, uint32_t b_offset, const float* lambdas1, const float* lambdas2, const RingRef& rr, void* st) {
+                      const int32_t* pos, const int32_t* neg, bool bce_side, float p, const uint32_t* seed, uint32_t b_offset, const float* lambdas1,
+                      const float* lambdas2, const RingRef& rr, void* st) {
   const int d = (int)w.d, H = (int)w.H, hd = d / H, nl = c->num_layers, T = (int)w.T;
   if (!bce_deferred(c)) return 1;
   const int64_t Td = up64(w.T * w.d), rec = up64(w.T * w.H * w.H);
@@ -491,10 +496,20 @@ int forward_loss_lean(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, co
     lm[i] = loss + 64 * (2 + i);
     rc[i] = ws + i * w.e_stride + w.e_rec; dr[i] = ws + w.g_rec + i * rec; ln[i] = loss + 64 * (2 + nl + i);
   }
+  SideStream* const sd = (bce_side && (side_sites() & 1)) ? side_stream((hipStream_t)st) : nullptr;
+  if (bce_side) CK(side_mark(sd, 0, st));
   // (+ the next step's id batch, if its producer has published it: the PCIe read runs under this streaming pass)
-  return adt_loss_seeds_prefetch(nullptr, nullptr, nullptr, 0, ws + w.norms, nullptr, nullptr, loss, nl, A, Bm, w.T * w.d, lambdas1, GA, 0, GB, lm,
-                                 H > 1 ? nl : 0, rc, T, H, lambdas2[nl - 1], dr, ln, rr.ring, rr.slot_ints, rr.nslots, 4 * (int64_t)w.T + 4, rr.state,
-                                 rr.consumed, rr.staging, st);
+  CK(adt_loss_seeds_prefetch(nullptr, nullptr, nullptr, 0, ws + w.norms, nullptr, nullptr, loss, nl, A, Bm, w.T * w.d, lambdas1, GA, 0, GB, lm,
+                             H > 1 ? nl : 0, rc, T, H, lambdas2[nl - 1], dr, ln, rr.ring, rr.slot_ints, rr.nslots, 4 * (int64_t)w.T + 4, rr.state,
+                             rr.consumed, rr.staging, st));
+  if (bce_side) {
+    void* s2 = nullptr;
+    CK(side_enter(sd, 0, st, &s2));
+    CK(adt_logits_bce_scatter(ws + w.f, P + lo.item(), pos, neg, ws + w.norms, T, ws + w.posl, ws + w.negl, ws + w.g_pos, ws + w.g_neg, ws + w.loss,
+                              ws + w.g_f, item_det(w) ? nullptr : ws + w.rep, NREP, w.rep_stride, s2));
+    if (sd && hipEventRecord(sd->join_ev[0], sd->s) != hipSuccess) return adt_set_error("forward_loss: logits event");
+  }
+  return 0;
 }
 
 }  // namespace
@@ -624,7 +639,7 @@ int adt_sasrec_forward_loss_prefetch(const adt_sasrec_cfg* c, const float* P, fl
     WS w;
     make_ws(c, B, &w);
     const RingRef rr{ring, slot_ints, nslots, state, consumed, staging};
-    const int rc = forward_loss_lean(c, lo, w, P, ws, seq, dec, c->dropout, seed, b_offset, lambdas1, lambdas2, rr, st);
+    const int rc = forward_loss_lean(c, lo, w, P, ws, seq, dec, pos, neg, (training & 4) != 0, c->dropout, seed, b_offset, lambdas1, lambdas2, rr, st);
     if (rc <= 0) return rc;
   }
   CK(adt_sasrec_forward(c, P, ws, seq, dec, pos, neg, B, training, seed, b_offset, st));
@@ -780,7 +795,9 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   // ... and the bias / LayerNorm / classifier gradient sums, which the chain kernels then STORE per workgroup (no float atomics, no replicas)
   auto VPART = [&](int layer, int k) { return late_parts ? ws + w.vpart + (int64_t)(5 * layer + k) * w.vcall : nullptr; };
   const bool bce_here = (phase & 16) != 0;        // bit 4: the forward was adt_sasrec_forward_loss on the deferred path: logits + BCE seed are formed here
-  if (bce_here && !bce_deferred(c)) return adt_set_error("backward: phase bit 4 without the deferred-BCE forward (adt_sasrec_bce_deferred)");
+  const bool bce_fwd = (phase & 32) != 0;         // bit 5: ... and launched that kernel itself (training bit 2): only its join is left
+  if ((bce_here || bce_fwd) && !bce_deferred(c)) return adt_set_error("backward: phase bit 4 / 5 without the deferred-BCE forward (adt_sasrec_bce_deferred)");
+  if (bce_fwd && (bce_here || (phase & 4) == 0 || (phase & 3) == 2)) return adt_set_error("backward: phase bit 5 goes with bit 2, without bit 4, in phase 0 or 1");
   phase &= 3;
   const bool det = item_det(w);                   // item / positional table gradients by sorted segmented sums (no replicas, no float atomics)
   auto logits_scatter = [&](void* s) {      // d log_feats + item rows of pos / neg (+ logits and BCE seed on the deferred path)   (sasrec/model.py:72-76)
@@ -805,7 +822,8 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
     if (w.prep != w.rep + NREP * w.rep_stride) return adt_set_error("workspace layout: replica areas not adjacent");
     // The item-table rows of the logits (and d log_feats, first read by the reverse of the cross-attention projections) go to the side
     // stream: they run under the first two decoder kernels, which only need the parameter replicas zeroed.
-    int logits_side = 0;      // 1: marked, to be enqueued behind the first chain kernel ; 2: enqueued, to be joined
+    int logits_side = 0;      // 1: marked, to be enqueued behind the first chain kernel ; 2: enqueued, to be joined ; 3: enqueued by the forward
+    if (bce_fwd) logits_side = 3;
     if (det) {
       // sort of the step's ids + gather plan (a function of the ids and of fixed workspace addresses only); joined in front of the sums
       const int32_t* const ids4[4] = {seq, dec, pos, neg};
@@ -817,7 +835,9 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       CK(adt_item_sort(ids4, 4, T, c->item_num + 1, rows4, coef4, kind4, ro, iwork, s2));
       if (sd_sort && hipEventRecord(sd_sort->join_ev[3], sd_sort->s) != hipSuccess) return adt_set_error("backward: sort event");
     }
-    if (det) {
+    if (bce_fwd) {
+      // nothing to launch: the forward put the kernel on the side stream (or, without one, on this stream); joined below
+    } else if (det) {
       if (!prep_zeroed && adt::zero_f32_async(ws + w.prep, (size_t)NREPP * w.prep_stride, (hipStream_t)st)) return adt_set_error("replica zero");
       CK(logits_scatter(st));      // no atomics left in it: a short streaming pass on the caller's stream
     } else if (sd && (side_sites() & 1)) {
@@ -877,6 +897,11 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
                         s5, d, s4, 2 * d, s4 + d, 2 * d, reinterpret_cast<const uint32_t*>(base + w.d_mask2), st));
       }
       if (logits_side == 2) { CK(side_join(sd, 0, st)); logits_side = 0; }      // d log_feats is complete from here on
+      if (logits_side == 3) {
+        SideStream* const sl = (side_sites() & 1) ? side_stream((hipStream_t)st) : nullptr;
+        if (sl && hipStreamWaitEvent((hipStream_t)st, sl->join_ev[0], 0) != hipSuccess) return adt_set_error("backward: logits join");
+        logits_side = 0;
+      }
       int mid_rc = 1;
       if (use_seq) {   // both projections' reverse in one launch per sequence (adt_seqpost_tt.cuh)
         adt::BwdChainArgs a = BA(dec, 0.f, nullptr);

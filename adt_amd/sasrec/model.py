@@ -194,18 +194,22 @@ class SASRecADT(torch.nn.Module):
         """True when run_forward_loss leaves logits + BCE seed to run_backward(..., bce=True) (adt_sasrec_bce_deferred)."""
         return bool(self.lib.adt_sasrec_bce_deferred(ctypes.byref(self.cfg)))
 
-    def run_forward_loss(self, seq, dec, pos, neg, B, lambdas1, lambdas2, b_offset=0, training=True, packed=True, prefetch=None):
+    def run_forward_loss(self, seq, dec, pos, neg, B, lambdas1, lambdas2, b_offset=0, training=True, packed=True, prefetch=None, bce_side=False):
         """run_forward(training) + run_loss_seed(zero_loss=False) of one step in one call (adt_sasrec_forward_loss).  Returns True when the
-        logits + BCE seed were deferred to the backward: pass bce=True to run_backward of the same step."""
+        logits + BCE seed were deferred to the backward: pass bce=True to run_backward of the same step -- or "fwd" when bce_side was set (the
+        kernel is then launched here, on the side stream beside the loss pass, and the backward only joins it; needs run_step_begin* of this
+        step, which zeroes the item-table replicas)."""
         nl = self.num_layers
         l1 = (ctypes.c_float * nl)(*[float(x) for x in lambdas1])
         l2 = (ctypes.c_float * nl)(*[float(x) for x in lambdas2])
         ring, slot_ints, nslots, state, consumed, staging = prefetch if prefetch is not None else (None, 0, 0, None, None, None)
+        deferred = bool(training) and packed and self.bce_deferred()
+        side = bool(bce_side) and deferred
         _lib.check(self.lib.adt_sasrec_forward_loss_prefetch(ctypes.byref(self.cfg), _ptr(self.flat), _ptr(self.workspace(B)), _ptr(seq), _ptr(dec),
-                                                             _ptr(pos), _ptr(neg), B, int(bool(training)) | (2 if packed else 0), _ptr(self._seed),
+                                                             _ptr(pos), _ptr(neg), B, int(bool(training)) | (2 if packed else 0) | (4 if side else 0), _ptr(self._seed),
                                                              b_offset, l1, l2, _ptr(ring), slot_ints, nslots, _ptr(state), _ptr(consumed),
                                                              _ptr(staging), self._stream()), "sasrec_forward_loss")
-        return bool(training) and packed and self.bce_deferred()
+        return "fwd" if side else deferred
 
     def run_loss_seed(self, pos, B, lambdas1, lambdas2, zero_loss=True):
         nl = self.num_layers
@@ -220,7 +224,7 @@ class SASRecADT(torch.nn.Module):
         _lib.check(self.lib.adt_sasrec_backward(ctypes.byref(self.cfg), _ptr(self.flat), _ptr(self.flat_grad), _ptr(self.workspace(B)),
                                                 _ptr(seq), _ptr(dec), _ptr(pos), _ptr(neg), B, int(training), _ptr(self._seed),
                                                 b_offset, phase | (4 if prezeroed else 0) | (8 if defer_fold and phase == 0 else 0) |
-                                                (16 if bce and phase in (0, 1) else 0), self._stream()),
+                                                ((32 if bce == "fwd" else 16) if bce and phase in (0, 1) else 0), self._stream()),
                    "sasrec_backward")
 
     def run_fold_clip_adam(self, B, m, v, wd, clip, lr, b1, b2, eps, scal):

@@ -46,6 +46,7 @@ class FusedTrainer:
         self._dec_off = model.offsets[4 + 14 * nl]
         self._buckets = GradBuckets(model.flat_grad, self._dec_off, process_group)
         self._dp_phases = 2 if os.environ.get("ADT_DP_PHASES", "1") == "2" else 1
+        self._bce_side = os.environ.get("ADT_BCE_SIDE", "1") != "0"
 
     # ------------------------------------------------------------------------------------------
     NSLOTS = 4          # pinned id ring: the producer may run up to three batches ahead of the step the GPU is executing
@@ -104,7 +105,8 @@ class FusedTrainer:
         else:
             m.run_step_begin_ring(B, src[0], self._st["n_int"], src[1], self._devbuf, src[2], src[3], self.scal)
         # forward + loss assembly (run_step_begin* above packed the weight images and zeroed the loss slots ...)
-        bce = m.run_forward_loss(seq, dec, pos, neg, B, self.lambdas1, self.lambdas2, b_offset, prefetch=prefetch)      # bce: logits + BCE seed left to the backward
+        # bce: logits + BCE seed left to the backward (True), or launched beside the loss pass on the side stream and joined by the backward ("fwd")
+        bce = m.run_forward_loss(seq, dec, pos, neg, B, self.lambdas1, self.lambdas2, b_offset, prefetch=prefetch, bce_side=self._bce_side)
         if not self._buckets.active:
             # ... and zeroed the parameter-gradient replicas ; the last fold of the replicas happens inside the optimizer's first kernel
             m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=0, prezeroed=True, defer_fold=True, bce=bce)

@@ -415,6 +415,9 @@ int adt_item_segsum_posemb(const int32_t* work, int nsrc, int T, int V1, uint32_
  * weight images packed by adt_sasrec_step_begin* of this step), log_feats is written by the last encoder layer's own kernel and the pos / neg
  * logits + BCE seed + BCE loss terms are NOT formed here: adt_sasrec_backward of the same step must be called with phase bit 4 (+ 16) and
  * forms them in its first side kernel, which gathers the same rows.  Otherwise the two calls in sequence.  ADT_FWD_FUSED=0: never deferred. */
+/* training bit 2 (value 4, with bits 0 and 1, deferred path only): the logits / BCE / item-row kernel is launched by THIS call on the library's
+ * side stream beside the loss pass (adt_sasrec_step_begin* of the step zeroed the item-table replicas); adt_sasrec_backward of the step takes
+ * phase bit 5 (+ 32) instead of bit 4 and joins it. */
 int adt_sasrec_bce_deferred(const adt_sasrec_cfg* cfg);
 int adt_sasrec_forward_loss(const adt_sasrec_cfg* cfg, const float* params, float* ws, const int32_t* seq, const int32_t* dec,
                             const int32_t* pos, const int32_t* neg, int B, int training, const uint32_t* seed, uint32_t b_offset,
@@ -430,7 +433,8 @@ int adt_sasrec_forward_loss_prefetch(const adt_sasrec_cfg* cfg, const float* par
  * zeroed by adt_sasrec_step_begin / _ring of this step (phase 2 zeroes the item-table replicas again for its own scatter).  With phase 0 the scatter / fold kernels run on a side stream of the library under the
  * chain kernels (joined before the call returns its last launch; ADT_SIDE_STREAM=0 keeps everything on `stream`).  + 8 (with phase 0 only):
  * the last fold of the gradient replicas into `grads` is left to adt_sasrec_fold_clip_adam, which must follow.  + 16: the step's forward was
- * adt_sasrec_forward_loss on the deferred path (adt_sasrec_bce_deferred): logits, BCE seed and BCE loss terms are formed here. */
+ * adt_sasrec_forward_loss on the deferred path (adt_sasrec_bce_deferred): logits, BCE seed and BCE loss terms are formed here.  + 32 (instead
+ * of + 16, with + 4, phase 0 or 1): that forward was called with training bit 2 and launched the kernel itself: only its join is left. */
 int adt_sasrec_backward(const adt_sasrec_cfg* cfg, const float* params, float* grads, float* ws,
                         const int32_t* seq, const int32_t* dec, const int32_t* pos, const int32_t* neg, int B,
                         int training, const uint32_t* seed, uint32_t b_offset, int phase, void* stream);
