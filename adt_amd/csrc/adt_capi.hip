@@ -565,7 +565,9 @@ int adt_loss_seeds_prefetch(const float* pos_logits, const float* neg_logits, co
     a.gp = 32;      // one round of 8 x 16-byte loads per thread covers the flagship batch (819 KB): a PCIe read wants everything in flight at once
   }
   a.bce = BceArgs{pos_logits, neg_logits, pos, T, norms, dpos, dneg, loss_bce};
-  for (int i = 0; i < nmse; ++i) a.mse[i] = MseArgs{A[i], Bm[i], (size_t)n, lambdas[i], norms, GA[i], accumulate_a, GB[i], loss_mse[i]};
+  // (a seed that is not materialised -- GA[i] or GB[i] == nullptr -- leaves its coefficient at norms[8 + i] for its consumer)
+  for (int i = 0; i < nmse; ++i)
+    a.mse[i] = MseArgs{A[i], Bm[i], (size_t)n, lambdas[i], norms, GA[i], accumulate_a, GB[i], loss_mse[i], (!GA[i] || !GB[i]) ? const_cast<float*>(norms) + 8 + i : nullptr};
   for (int i = 0; i < nnll; ++i) a.nll[i] = NllArgs{rec[i], n_rows, H, lambda2, norms, drec[i], loss_nll[i]};
   a.nmse = nmse; a.nnll = nnll;
   a.gb = pos_logits ? grid_for(T, 256, 256) : 0;      // no logits: the BCE seed is formed elsewhere (adt_logits_bce_scatter)

@@ -506,11 +506,13 @@ struct MseArgs {
   float* GA; int accA;       // accA: GA += g
   float* GB;
   float* loss;               // one slot
+  float* coef_out;           // optional: 2 lambda / n_mse for the consumers that form the seed themselves (GA / GB == nullptr)
 };
 
 ADT_DEVICE_INLINE void mse_body(const MseArgs& a, int bid, int nblk, float* sbuf) {
   const float inv = 1.0f / a.norms[1];
   const float coef = 2.0f * a.lambda * inv;
+  if (a.coef_out && bid == 0 && threadIdx.x == 0) *a.coef_out = coef;
   float acc = 0.f;
   for (size_t i = ((size_t)bid * 256 + threadIdx.x) * 4; i < a.n; i += (size_t)nblk * 1024) {
     const float4 x = *reinterpret_cast<const float4*>(a.A + i);
@@ -518,12 +520,15 @@ ADT_DEVICE_INLINE void mse_body(const MseArgs& a, int bid, int nblk, float* sbuf
     float4 dlt = make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
     acc += dlt.x * dlt.x + dlt.y * dlt.y + dlt.z * dlt.z + dlt.w * dlt.w;
     float4 g = make_float4(coef * dlt.x, coef * dlt.y, coef * dlt.z, coef * dlt.w);
-    *reinterpret_cast<float4*>(a.GB + i) = make_float4(-g.x, -g.y, -g.z, -g.w);
-    if (a.accA) {
-      const float4 o = *reinterpret_cast<const float4*>(a.GA + i);
-      g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w;
+    // GA / GB == nullptr: that seed is not materialised -- its consumer (k_seqtt_attn_pre_bwd: SeqBwdArgs::seed_other) forms it from the two rows
+    if (a.GB) *reinterpret_cast<float4*>(a.GB + i) = make_float4(-g.x, -g.y, -g.z, -g.w);
+    if (a.GA) {
+      if (a.accA) {
+        const float4 o = *reinterpret_cast<const float4*>(a.GA + i);
+        g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w;
+      }
+      *reinterpret_cast<float4*>(a.GA + i) = g;
     }
-    *reinterpret_cast<float4*>(a.GA + i) = g;
   }
   const float s = block_sum(acc, sbuf);
   if (threadIdx.x == 0) atomicAdd(a.loss + (bid & 63), s * inv);

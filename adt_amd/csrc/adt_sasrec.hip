@@ -491,8 +491,12 @@ int forward_loss_lean(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, co
   float* loss = ws + w.loss;
   const float *A[4], *Bm[4], *rc[4];
   float *GA[4], *GB[4], *lm[4], *dr[4], *ln[4];
+  // Reconstruction seeds: only the one the backward's FIRST kernels read as a plain input (d / d decoder output) is written here.  The others
+  // were written to be added to the input gradient of a block that re-reads that very input: k_seqtt_attn_pre_bwd forms them from its own x
+  // rows and the other stack's rows (SeqBwdArgs::seed_other) -- 39 MB of stores here and as many loads there less per step.
   for (int i = 0; i < nl; ++i) {
-    A[i] = ws + w.enc_x + i * Td; Bm[i] = ws + w.dec_x + (nl - i) * Td; GA[i] = ws + w.g_enc_x + i * Td; GB[i] = ws + w.g_dec_x + (nl - i) * Td;
+    A[i] = ws + w.enc_x + i * Td; Bm[i] = ws + w.dec_x + (nl - i) * Td;
+    GA[i] = nullptr; GB[i] = i == 0 ? ws + w.g_dec_x + (nl - i) * Td : nullptr;
     lm[i] = loss + 64 * (2 + i);
     rc[i] = ws + i * w.e_stride + w.e_rec; dr[i] = ws + w.g_rec + i * rec; ln[i] = loss + 64 * (2 + nl + i);
   }
@@ -798,6 +802,8 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   const bool bce_fwd = (phase & 32) != 0;         // bit 5: ... and launched that kernel itself (training bit 2): only its join is left
   if ((bce_here || bce_fwd) && !bce_deferred(c)) return adt_set_error("backward: phase bit 4 / 5 without the deferred-BCE forward (adt_sasrec_bce_deferred)");
   if (bce_fwd && (bce_here || (phase & 4) == 0 || (phase & 3) == 2)) return adt_set_error("backward: phase bit 5 goes with bit 2, without bit 4, in phase 0 or 1");
+  // the forward of the deferred path (forward_loss_lean) does not materialise the reconstruction seeds that k_seqtt_attn_pre_bwd can form itself
+  const bool seeds_virtual = bce_here || bce_fwd || (phase & 64) != 0;      // (bit 6: phase 2 of a two-phase backward behind such a forward)
   phase &= 3;
   const bool det = item_det(w);                   // item / positional table gradients by sorted segmented sums (no replicas, no float atomics)
   auto logits_scatter = [&](void* s) {      // d log_feats + item rows of pos / neg (+ logits and BCE seed on the deferred path)   (sasrec/model.py:72-76)
@@ -941,6 +947,9 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.x = x; a.gamma = P + lo.dec(i, D_LNW); a.beta = P + lo.dec(i, D_LNB); a.Win = sinw; a.bin = P + lo.dec(i, D_SINB);
         a.dO = s1; a.o = o1; a.lse = lse1; a.mask = reinterpret_cast<const uint32_t*>(base + w.d_mask1); a.dres = gy;
         a.gx = gx; a.acc = i > 0 ? 1 : 0; a.dWin = gsinw; a.dbin = gsinb; a.dgamma = Gq + lo.dec(i, D_LNW); a.dbeta = Gq + lo.dec(i, D_LNB);
+        if (seeds_virtual && i > 0) {      // reconstruction pair (enc_in[nl - i], dec_x[i]): d / d dec_x[i] = -2 lambda (a - b) / n = coef * (x - a)
+          a.acc = 0; a.seed_other = ws + w.enc_x + (nl - i) * Td; a.seed_coef = ws + w.norms + 8 + (nl - i);
+        }
         a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride; a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack; a.saved_bf16 = lean;
         a.part = PART(i, PS_D_SIN); a.part_stride = (size_t)w.part_stride;
         a.vpart = VPART(i, 2);
@@ -1063,6 +1072,9 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.x = x; a.gamma = P + lo.enc(i, E_LN1W); a.beta = P + lo.enc(i, E_LN1B); a.Win = inw; a.bin = P + lo.enc(i, E_INB);
         a.dO = s1; a.o = o; a.lse = lse; a.mask = reinterpret_cast<const uint32_t*>(base + w.e_mask); a.dres = s5;
         a.gx = gx; a.acc = 1; a.dWin = ginw; a.dbin = ginb; a.dgamma = Gq + lo.enc(i, E_LN1W); a.dbeta = Gq + lo.enc(i, E_LN1B);
+        if (seeds_virtual) {               // reconstruction pair (enc_in[i], dec_x[nl - i]): d / d enc_in[i] = coef * (x - b)
+          a.acc = 0; a.seed_other = ws + w.dec_x + (nl - i) * Td; a.seed_coef = ws + w.norms + 8 + i;
+        }
         a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride; a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack; a.saved_bf16 = lean;
         a.part = PART(i, PS_E_IN); a.part_stride = (size_t)w.part_stride;
         a.vpart = VPART(i, 4);

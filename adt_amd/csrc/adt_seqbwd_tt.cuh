@@ -555,8 +555,10 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   auto gx_request = [&](int s) {
     const int tile = TA(s);
     const int l = tile * 16 + c;
-    gxo[s] = tt_load(a.gx + (size_t)(b * L + l) * 64, a.acc && tile >= 0 && l < L, g);
+    const float* const src = a.seed_other ? a.seed_other : a.gx;
+    gxo[s] = tt_load(src + (size_t)(b * L + l) * 64, (a.acc || a.seed_other) && tile >= 0 && l < L, g);
   };
+  const float seed_coef = a.seed_other ? *a.seed_coef : 0.f;
   gx_request(0);
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -591,7 +593,12 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     }
     if (valid) {
       float* dst = a.gx + (size_t)row * 64;
-      tt_add(dx, gxo[s]);                               // zeros unless a.acc
+      if (a.seed_other) {                               // the reconstruction seed of this input row: coef * (x - the other stack's row)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) dx.v[nt] += seed_coef * (xk[s].v[nt] - gxo[s].v[nt]);
+      } else {
+        tt_add(dx, gxo[s]);                             // zeros unless a.acc
+      }
       tt_store(dst, dx, true, g);
     }
     if (s == 0) SB_STAMP(15);

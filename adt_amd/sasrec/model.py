@@ -220,11 +220,14 @@ class SASRecADT(torch.nn.Module):
 
     def run_backward(self, seq, dec, pos, neg, B, training, b_offset=0, phase=0, prezeroed=False, defer_fold=False, bce=False):
         """prezeroed: run_step_begin / run_step_begin_ring of THIS step already zeroed the parameter-gradient replicas (bit 2 of `phase`).
-        defer_fold (phase 0 only): the last replica fold is left to run_fold_clip_adam, which must follow (bit 3)."""
+        defer_fold (phase 0 only): the last replica fold is left to run_fold_clip_adam, which must follow (bit 3).
+        bce: what run_forward_loss of this step returned (pass it to EVERY phase: bits 4 / 5 in phases 0 and 1, bit 6 in phase 2 -- that forward
+        leaves the reconstruction seeds of the block inputs to the backward kernels)."""
         _lib.check(self.lib.adt_sasrec_backward(ctypes.byref(self.cfg), _ptr(self.flat), _ptr(self.flat_grad), _ptr(self.workspace(B)),
                                                 _ptr(seq), _ptr(dec), _ptr(pos), _ptr(neg), B, int(training), _ptr(self._seed),
                                                 b_offset, phase | (4 if prezeroed else 0) | (8 if defer_fold and phase == 0 else 0) |
-                                                ((32 if bce == "fwd" else 16) if bce and phase in (0, 1) else 0), self._stream()),
+                                                ((32 if bce == "fwd" else 16) if bce and phase in (0, 1) else 0) | (64 if bce and phase == 2 else 0),
+                                                self._stream()),
                    "sasrec_backward")
 
     def run_fold_clip_adam(self, B, m, v, wd, clip, lr, b1, b2, eps, scal):

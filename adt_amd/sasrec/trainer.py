@@ -126,7 +126,7 @@ class FusedTrainer:
             # (item/pos tables at flat offset 0) -- that bucket is reduced after phase 2, so nothing is lost.
             m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=1, prezeroed=True, bce=bce)
             self._buckets.tail_ready()
-            m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=2, prezeroed=True)      # the gradient buffer's table rows are still zero
+            m.run_backward(seq, dec, pos, neg, B, True, b_offset, phase=2, prezeroed=True, bce=bce)      # the gradient buffer's table rows are still zero
             self._buckets.finish()
         ops.clip_adam_pre(m.flat, m.flat_grad, self.m, self.v, (m.item_num + 1) * m.hidden_units, self.wd, self.clip, self.lr,
                           self.betas[0], self.betas[1], self.eps, self.scal)

@@ -434,7 +434,9 @@ int adt_sasrec_forward_loss_prefetch(const adt_sasrec_cfg* cfg, const float* par
  * chain kernels (joined before the call returns its last launch; ADT_SIDE_STREAM=0 keeps everything on `stream`).  + 8 (with phase 0 only):
  * the last fold of the gradient replicas into `grads` is left to adt_sasrec_fold_clip_adam, which must follow.  + 16: the step's forward was
  * adt_sasrec_forward_loss on the deferred path (adt_sasrec_bce_deferred): logits, BCE seed and BCE loss terms are formed here.  + 32 (instead
- * of + 16, with + 4, phase 0 or 1): that forward was called with training bit 2 and launched the kernel itself: only its join is left. */
+ * of + 16, with + 4, phase 0 or 1): that forward was called with training bit 2 and launched the kernel itself: only its join is left.
+ * + 64 (phase 2 of a two-phase backward behind such a forward; implied by + 16 / + 32): the reconstruction seeds of the block inputs were not
+ * materialised by the forward -- the attention-block backward forms each from its own input rows and the other stack's. */
 int adt_sasrec_backward(const adt_sasrec_cfg* cfg, const float* params, float* grads, float* ws,
                         const int32_t* seq, const int32_t* dec, const int32_t* pos, const int32_t* neg, int B,
                         int training, const uint32_t* seed, uint32_t b_offset, int phase, void* stream);
