@@ -513,6 +513,7 @@ ADT_DEVICE_INLINE void mse_body(const MseArgs& a, int bid, int nblk, float* sbuf
   const float inv = 1.0f / a.norms[1];
   const float coef = 2.0f * a.lambda * inv;
   if (a.coef_out && bid == 0 && threadIdx.x == 0) *a.coef_out = coef;
+  if (!a.GA && !a.GB) return;      // neither seed is materialised: the consumer of the pair also adds its loss term (SeqBwdArgs::seed_loss)
   float acc = 0.f;
   for (size_t i = ((size_t)bid * 256 + threadIdx.x) * 4; i < a.n; i += (size_t)nblk * 1024) {
     const float4 x = *reinterpret_cast<const float4*>(a.A + i);

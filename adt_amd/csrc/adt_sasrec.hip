@@ -496,7 +496,7 @@ int forward_loss_lean(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, co
   // rows and the other stack's rows (SeqBwdArgs::seed_other) -- 39 MB of stores here and as many loads there less per step.
   for (int i = 0; i < nl; ++i) {
     A[i] = ws + w.enc_x + i * Td; Bm[i] = ws + w.dec_x + (nl - i) * Td;
-    GA[i] = nullptr; GB[i] = i == 0 ? ws + w.g_dec_x + (nl - i) * Td : nullptr;
+    GA[i] = nullptr; GB[i] = i == 0 ? ws + w.g_dec_x + (nl - i) * Td : nullptr;      // (i >= 1: not even read here -- the encoder block's backward adds the loss term)
     lm[i] = loss + 64 * (2 + i);
     rc[i] = ws + i * w.e_stride + w.e_rec; dr[i] = ws + w.g_rec + i * rec; ln[i] = loss + 64 * (2 + nl + i);
   }
@@ -1074,6 +1074,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         a.gx = gx; a.acc = 1; a.dWin = ginw; a.dbin = ginb; a.dgamma = Gq + lo.enc(i, E_LN1W); a.dbeta = Gq + lo.enc(i, E_LN1B);
         if (seeds_virtual) {               // reconstruction pair (enc_in[i], dec_x[nl - i]): d / d enc_in[i] = coef * (x - b)
           a.acc = 0; a.seed_other = ws + w.dec_x + (nl - i) * Td; a.seed_coef = ws + w.norms + 8 + i;
+          if (i > 0) { a.seed_loss = ws + w.loss + 64 * (2 + i); a.seed_norms = ws + w.norms; }      // pair i >= 1 is not touched by the loss pass at all
         }
         a.nrep = NREPP; a.rep_stride = (size_t)w.prep_stride; a.wp_base = P + lo.posw(); a.wp_img = ws + w.wpack; a.saved_bf16 = lean;
         a.part = PART(i, PS_E_IN); a.part_stride = (size_t)w.part_stride;

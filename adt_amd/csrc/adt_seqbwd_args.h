@@ -17,10 +17,11 @@ struct SeqBwdArgs {
   float dres_scale;                   // decoder only: the residual gradient is dres * dres_scale (0 means 1; the supernet's mixing weight)
   const float* dres;                  // encoder: gradient wrt LN(x) from the residual path ; decoder: gradient wrt the layer output (masked here)
   float* gx; int acc;                 // gradient wrt x (acc: add to what is there)
-  const float* seed_other; const float* seed_coef;
+  const float* seed_other; const float* seed_coef; float* seed_loss; const float* seed_norms;
                                       // non-null: the reconstruction term's seed of this layer input is formed here instead of read from gx:
                                       // gx = dx + *seed_coef * (x - seed_other)  (sasrec/main.py:155-158: 2 lambda1 (a - b) / n, a = this block's
-                                      // input, b = the other stack's tensor of the pair; *seed_coef is written by k_loss_seeds; acc must be 0)
+                                      // input, b = the other stack's tensor of the pair; *seed_coef is written by k_loss_seeds; acc must be 0).
+                                      // seed_loss != nullptr: this launch also adds the pair's loss term sum (a - b)^2 / seed_norms[1] to its 64 sub-slots
   float* dWin; float* dbin; float* dgamma; float* dbeta;     // accumulators (global float atomics)
   float* part; size_t part_stride;    // non-null: private partials of dWin (3 x 4096 floats at part + workgroup * part_stride) instead of atomics
   int nrep; size_t rep_stride;        // parameter-gradient replicas (adt_bwdchain_args.h): workgroup b adds into replica b % nrep

@@ -559,6 +559,7 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
     gxo[s] = tt_load(src + (size_t)(b * L + l) * 64, (a.acc || a.seed_other) && tile >= 0 && l < L, g);
   };
   const float seed_coef = a.seed_other ? *a.seed_coef : 0.f;
+  float seed_sq = 0.f;                             // this lane's share of sum (x - other)^2 over the workgroup's tokens
   gx_request(0);
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -595,7 +596,11 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
       float* dst = a.gx + (size_t)row * 64;
       if (a.seed_other) {                               // the reconstruction seed of this input row: coef * (x - the other stack's row)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) dx.v[nt] += seed_coef * (xk[s].v[nt] - gxo[s].v[nt]);
+        for (int nt = 0; nt < 4; ++nt) {
+          const f32x4 df = xk[s].v[nt] - gxo[s].v[nt];
+          dx.v[nt] += seed_coef * df;
+          seed_sq += df[0] * df[0] + df[1] * df[1] + df[2] * df[2] + df[3] * df[3];
+        }
       } else {
         tt_add(dx, gxo[s]);                             // zeros unless a.acc
       }
@@ -606,6 +611,10 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
   // LayerNorm gamma / beta gradients: per-lane partials over this wave's tokens -> this wave's sums in its own LDS row (the keep-bit area is
   // dead behind the attention passes) -> joined in wave order behind the barrier: no LDS float atomics, whose order is the waves' arrival order
   float* sWave = reinterpret_cast<float*>(sM) + w * 128;
+  if (a.seed_loss) {                               // (workgroup-uniform) per-wave sums behind the LayerNorm sums' rows, joined below
+    const float ws_ = wave_sum(seed_sq);
+    if (lane == 0) reinterpret_cast<float*>(sM)[NW * 128 + w] = ws_;
+  }
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -621,6 +630,12 @@ __global__ __launch_bounds__(SB_NW * 64) void k_seqtt_attn_pre_bwd(SeqBwdArgs a)
 #pragma unroll
       for (int k = 0; k < NW; ++k) sum += reinterpret_cast<const float*>(sM)[k * 128 + t];
       sRed[t] = sum;
+    }
+    if (a.seed_loss && t == 320) {
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) sum += reinterpret_cast<const float*>(sM)[NW * 128 + k];
+      atomicAdd(a.seed_loss + (blockIdx.x & 63), sum / a.seed_norms[1]);
     }
     if (a.vpart) {
       if (t < 320) a.vpart[(size_t)blockIdx.x * 512 + t] = sRed[t];
