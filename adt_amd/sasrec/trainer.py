@@ -46,7 +46,8 @@ class FusedTrainer:
         self._dec_off = model.offsets[4 + 14 * nl]
         self._buckets = GradBuckets(model.flat_grad, self._dec_off, process_group)
         self._dp_phases = 2 if os.environ.get("ADT_DP_PHASES", "1") == "2" else 1
-        self._bce_side = os.environ.get("ADT_BCE_SIDE", "1") != "0"
+        # (with the sorted table gradients, ADT_ITEM_SORT, the side stream carries the id sort: the logits kernel stays on the caller's stream there)
+        self._bce_side = os.environ.get("ADT_BCE_SIDE", "1") != "0" and os.environ.get("ADT_ITEM_SORT", "0") == "0"
 
     # ------------------------------------------------------------------------------------------
     NSLOTS = 4          # pinned id ring: the producer may run up to three batches ahead of the step the GPU is executing
