@@ -553,6 +553,16 @@ int adt_loss_seeds(const float* pos_logits, const float* neg_logits, const int32
   return adt_loss_seeds_prefetch(pos_logits, neg_logits, pos, T, norms, dpos, dneg, loss_bce, nmse, A, Bm, n, lambdas, GA, accumulate_a, GB, loss_mse, nnll,
                                  rec, n_rows, H, lambda2, drec, loss_nll, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, stream);
 }
+// The logits / BCE / item-row pass of the deferred path (adt_logits_bce_scatter) as the first workgroups of the NEXT adt_loss_seeds_prefetch launch of
+// this host thread (one launch, no second stream: adt_sasrec.hip, forward_loss_lean).
+static thread_local LogitsBceArgs g_lb_job;
+static thread_local bool g_lb_set = false;
+void adt_loss_seeds_attach_logits(const float* F, const float* E, const int32_t* pos, const int32_t* neg, const float* norms, int T, float* pos_logits,
+                                  float* neg_logits, float* dpos, float* dneg, float* loss_bce, float* dF, float* rep, int nrep, int64_t rep_stride) {
+  g_lb_job = LogitsBceArgs{F, E, pos, neg, norms, T, pos_logits, neg_logits, dpos, dneg, loss_bce, dF, rep, nrep, (size_t)rep_stride};
+  g_lb_set = true;
+}
+
 int adt_loss_seeds_prefetch(const float* pos_logits, const float* neg_logits, const int32_t* pos, int T, const float* norms, float* dpos, float* dneg,
                             float* loss_bce, int nmse, const float* const* A, const float* const* Bm, int64_t n, const float* lambdas, float* const* GA,
                             int accumulate_a, float* const* GB, float* const* loss_mse, int nnll, const float* const* rec, int n_rows, int H, float lambda2,
@@ -570,10 +580,11 @@ int adt_loss_seeds_prefetch(const float* pos_logits, const float* neg_logits, co
     a.mse[i] = MseArgs{A[i], Bm[i], (size_t)n, lambdas[i], norms, GA[i], accumulate_a, GB[i], loss_mse[i], (!GA[i] || !GB[i]) ? const_cast<float*>(norms) + 8 + i : nullptr};
   for (int i = 0; i < nnll; ++i) a.nll[i] = NllArgs{rec[i], n_rows, H, lambda2, norms, drec[i], loss_nll[i]};
   a.nmse = nmse; a.nnll = nnll;
+  if (g_lb_set) { a.lb = g_lb_job; a.gl = grid_for(a.lb.T, 4 * 16, 1024); g_lb_set = false; }
   a.gb = pos_logits ? grid_for(T, 256, 256) : 0;      // no logits: the BCE seed is formed elsewhere (adt_logits_bce_scatter)
   a.gm = nmse ? grid_for((size_t)n / 4, 256, 512) : 1;
   a.gn = nnll ? grid_for((size_t)n_rows * H * H, 256, 512) : 1;
-  hipLaunchKernelGGL(k_loss_seeds, dim3(a.gb + nmse * a.gm + nnll * a.gn + a.gp), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_loss_seeds, dim3(a.gl + a.gb + nmse * a.gm + nnll * a.gn + a.gp), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("loss_seeds");
 }
 

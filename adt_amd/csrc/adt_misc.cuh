@@ -341,9 +341,9 @@ struct LogitsBceArgs {
   float* pos_logits; float* neg_logits; float* dpos; float* dneg; float* loss;      // loss: 2 x 64 sub-slots (pos term, neg term)
   float* dF; float* rep; int nrep; size_t rep_stride;
 };
-__global__ __launch_bounds__(256) void k_logits_bce_scatter(LogitsBceArgs a) {
+ADT_DEVICE_INLINE void logits_bce_body(const LogitsBceArgs& a, const int bid, const int nblk) {
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int wave = bid * 4 + (threadIdx.x >> 6), nwaves = nblk * 4;
   float* dE = a.rep ? a.rep + (a.nrep > 1 ? (size_t)(wave % a.nrep) * a.rep_stride : 0) : nullptr;
   const float inv = 1.0f / a.norms[0];
   float lp = 0.f, ln = 0.f;
@@ -352,15 +352,24 @@ __global__ __launch_bounds__(256) void k_logits_bce_scatter(LogitsBceArgs a) {
   // against 23 for the same pass without them.)
   const int R = (a.T + nwaves - 1) / nwaves, r0 = wave * R, r1 = min(a.T, r0 + R);
   float keep_sp = 0.f, keep_sn = 0.f, keep_gp = 0.f, keep_gn = 0.f;
-  constexpr int U = 2;                          // rows in flight per wave: ids, then the three rows of each, then the arithmetic
+  // EIGHT rows in flight per wave, their ids from one coalesced load per 64 rows (lane = row) + v_readlane: with two rows and an id load per
+  // iteration a wave's ~13 rows were 7 iterations of two dependent round trips each -- the kernel is latency, not bandwidth (20 us alone,
+  // 33-46 beside anything else).
+  constexpr int U = 8;
+  int ipv = 0, inv_ids = 0;
   for (int row0 = r0; row0 < r1; row0 += U) {
+    if (((row0 - r0) & 63) == 0) {              // wave-uniform: the ids of the next (up to) 64 rows
+      const int rr = row0 + lane;
+      ipv = rr < r1 ? a.pos[rr] : 0;
+      inv_ids = rr < r1 ? a.neg[rr] : 0;
+    }
     int ip[U], in[U];
     float p[U], q[U], f[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int row = row0 + u;
-      ip[u] = row < r1 ? a.pos[row] : 0;
-      in[u] = row < r1 ? a.neg[row] : 0;
+      const int k = (row0 + u - r0) & 63;      // (U divides 64: a batch never straddles two id loads)
+      ip[u] = __builtin_amdgcn_readlane(ipv, k);
+      in[u] = __builtin_amdgcn_readlane(inv_ids, k);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -403,10 +412,11 @@ __global__ __launch_bounds__(256) void k_logits_bce_scatter(LogitsBceArgs a) {
   if (lane == 0) { sl[threadIdx.x >> 6] = lp; sl[4 + (threadIdx.x >> 6)] = ln; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(a.loss + (blockIdx.x & 63), (sl[0] + sl[1] + sl[2] + sl[3]) * inv);
-    atomicAdd(a.loss + 64 + (blockIdx.x & 63), (sl[4] + sl[5] + sl[6] + sl[7]) * inv);
+    atomicAdd(a.loss + (bid & 63), (sl[0] + sl[1] + sl[2] + sl[3]) * inv);
+    atomicAdd(a.loss + 64 + (bid & 63), (sl[4] + sl[5] + sl[6] + sl[7]) * inv);
   }
 }
+__global__ __launch_bounds__(256) void k_logits_bce_scatter(LogitsBceArgs a) { logits_bce_body(a, blockIdx.x, gridDim.x); }
 
 // Embedding backward, d = 64, one pass over dX (k_posemb_bwd + k_item_scatter read it twice): a wave owns position l and a slice of the
 // batch; per row it adds dX * sqrt(d) * keep/(1-p) to the item replica row and keeps the positional sum in a register (one atomic per
@@ -616,11 +626,14 @@ ADT_DEVICE_INLINE void ring_prefetch_body(const RingPrefetchArgs& a, int bid, in
 struct LossSeedsArgs {
   BceArgs bce; MseArgs mse[4]; NllArgs nll[4];
   int nmse, nnll, gb, gm, gn, gp;
+  LogitsBceArgs lb; int gl;      // the first gl workgroups: the logits / BCE / item-row pass of the deferred path (k_logits_bce_scatter's body)
   RingPrefetchArgs pf;
 };
 __global__ __launch_bounds__(256) void k_loss_seeds(LossSeedsArgs a) {
   __shared__ float sbuf[4];
   int b = blockIdx.x;
+  if (b < a.gl) { logits_bce_body(a.lb, b, a.gl); return; }      // the longest job first
+  b -= a.gl;
   if (b < a.gb) { bce_body(a.bce, b, a.gb, sbuf); return; }
   b -= a.gb;
   if (b < a.nmse * a.gm) { const int k = b / a.gm; mse_body(a.mse[k], b - k * a.gm, a.gm, sbuf); return; }

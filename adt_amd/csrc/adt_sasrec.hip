@@ -470,6 +470,12 @@ bool bce_deferred(const adt_sasrec_cfg* c) {
   const int d = c->hidden, hd = d / c->num_heads;
   return on && d == 64 && c->num_layers <= 4 && adt_seq_lean(c->prec, c->maxlen, d, hd) != 0;
 }
+// ADT_BCE_MERGED=0: the forward's logits / BCE kernel (training bit 2) goes to the side stream instead of into the loss launch
+bool bce_merged() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("ADT_BCE_MERGED"); on = (e && atoi(e) == 0) ? 0 : 1; }
+  return on != 0;
+}
 struct RingRef { const int32_t* ring; int64_t slot_ints; int nslots; uint32_t* state; uint32_t* consumed; int32_t* staging; };
 // bce_side (training bit 2 of adt_sasrec_forward_loss*): the logits + BCE + item-row scatter kernel of the deferred path is launched HERE, on
 // the library's side stream beside the streaming loss pass (both are memory passes; under the backward's first chain kernels it stretched the
@@ -500,13 +506,17 @@ int forward_loss_lean(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, co
     lm[i] = loss + 64 * (2 + i);
     rc[i] = ws + i * w.e_stride + w.e_rec; dr[i] = ws + w.g_rec + i * rec; ln[i] = loss + 64 * (2 + nl + i);
   }
-  SideStream* const sd = (bce_side && (side_sites() & 1)) ? side_stream((hipStream_t)st) : nullptr;
-  if (bce_side) CK(side_mark(sd, 0, st));
+  const bool merged = bce_side && bce_merged();
+  if (merged)      // ... as the first workgroups of the loss launch itself: no second stream, no fork / join
+    adt_loss_seeds_attach_logits(ws + w.f, P + lo.item(), pos, neg, ws + w.norms, T, ws + w.posl, ws + w.negl, ws + w.g_pos, ws + w.g_neg, ws + w.loss,
+                                 ws + w.g_f, item_det(w) ? nullptr : ws + w.rep, NREP, w.rep_stride);
+  SideStream* const sd = (bce_side && !merged && (side_sites() & 1)) ? side_stream((hipStream_t)st) : nullptr;
+  if (bce_side && !merged) CK(side_mark(sd, 0, st));
   // (+ the next step's id batch, if its producer has published it: the PCIe read runs under this streaming pass)
   CK(adt_loss_seeds_prefetch(nullptr, nullptr, nullptr, 0, ws + w.norms, nullptr, nullptr, loss, nl, A, Bm, w.T * w.d, lambdas1, GA, 0, GB, lm,
                              H > 1 ? nl : 0, rc, T, H, lambdas2[nl - 1], dr, ln, rr.ring, rr.slot_ints, rr.nslots, 4 * (int64_t)w.T + 4, rr.state,
                              rr.consumed, rr.staging, st));
-  if (bce_side) {
+  if (bce_side && !merged) {
     void* s2 = nullptr;
     CK(side_enter(sd, 0, st, &s2));
     CK(adt_logits_bce_scatter(ws + w.f, P + lo.item(), pos, neg, ws + w.norms, T, ws + w.posl, ws + w.negl, ws + w.g_pos, ws + w.g_neg, ws + w.loss,
@@ -904,7 +914,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       }
       if (logits_side == 2) { CK(side_join(sd, 0, st)); logits_side = 0; }      // d log_feats is complete from here on
       if (logits_side == 3) {
-        SideStream* const sl = (side_sites() & 1) ? side_stream((hipStream_t)st) : nullptr;
+        SideStream* const sl = ((side_sites() & 1) && !bce_merged()) ? side_stream((hipStream_t)st) : nullptr;
         if (sl && hipStreamWaitEvent((hipStream_t)st, sl->join_ev[0], 0) != hipSuccess) return adt_set_error("backward: logits join");
         logits_side = 0;
       }
