@@ -56,6 +56,7 @@ SIGNATURES = {
     "adt_logits_fwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     "adt_logits_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P]),
     "adt_item_scatter": (_I, [_P, _P, _I, _P, _I, _I, _F, _F, _P, _U, _U, _P, _I, _L, _P]),
+    "adt_embed_bwd3": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _U, _U, _U, _P, _P, _I, _L, _P]),
     "adt_replica_reduce": (_I, [_P, _P, _L, _I, _L, _P]),
     "adt_posemb_bwd": (_I, [_P, _P, _I, _I, _I, _F, _P, _U, _U, _P, _P]),
     "adt_logits_bwd_df": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _I, _P]),

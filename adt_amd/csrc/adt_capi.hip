@@ -285,9 +285,29 @@ int adt_logits_bwd_scatter(const float* F, int ldf, const float* E, const int32_
 
 int adt_logits_bce_scatter(const float* F, const float* E, const int32_t* pos, const int32_t* neg, const float* norms, int T, float* pos_logits,
                            float* neg_logits, float* dpos, float* dneg, float* loss_bce, float* dF, float* rep, int nrep, int64_t rep_stride, void* stream) {
-  LogitsBceArgs a{F, E, pos, neg, norms, T, pos_logits, neg_logits, dpos, dneg, loss_bce, dF, rep, nrep, (size_t)rep_stride};
+  return adt_logits_bce_scatter_ex(F, E, pos, neg, norms, T, pos_logits, neg_logits, dpos, dneg, loss_bce, dF, rep, nrep, rep_stride, 0, stream);
+}
+// neg_only: the item rows of the positive ids are left to adt_embed_bwd3 of the same step
+int adt_logits_bce_scatter_ex(const float* F, const float* E, const int32_t* pos, const int32_t* neg, const float* norms, int T, float* pos_logits,
+                              float* neg_logits, float* dpos, float* dneg, float* loss_bce, float* dF, float* rep, int nrep, int64_t rep_stride,
+                              int neg_only, void* stream) {
+  LogitsBceArgs a{F, E, pos, neg, norms, T, pos_logits, neg_logits, dpos, dneg, loss_bce, dF, rep, nrep, (size_t)rep_stride, neg_only};
   hipLaunchKernelGGL(k_logits_bce_scatter, dim3(grid_for(T, 4 * 16, 1024)), dim3(256), 0, (hipStream_t)stream, a);      // ~16 rows per wave
   return check_launch("logits_bce_scatter");
+}
+
+/* The encoder embedding gradient, the decoder embedding gradient and the positive-logit rows into the item-table replicas in one pass (d = 64,
+ * T a multiple of L): one atomic row-add per token where the three ids are the shifts of one item list that the reference's sampler produces
+ * (seq[b, l] == dec[b, l + 1] == pos[b, l - 1]); any other ids are added on their own.  dP += the positional sums of both embeddings. */
+int adt_embed_bwd3(const int32_t* seq, const int32_t* dec, const int32_t* pos, const float* dXs, const float* dXd, const float* F, const float* dpos,
+                   int T, int L, float p, const uint32_t* seed, uint32_t site_seq, uint32_t site_dec, uint32_t row_offset, float* dP, float* rep,
+                   int nrep, int64_t rep_stride, void* stream) {
+  if (L < 1 || T % L) return adt_set_error("embed_bwd3: T %d is not a multiple of L %d", T, L);
+  const int B = T / L, ns = B < 32 ? B : 32;
+  EmbedBwd3Args a{seq, dec, pos, dXs, dXd, F, dpos, T, L, 8.0f, adt_make_drop(p, seed, site_seq), adt_make_drop(p, seed, site_dec), row_offset, dP, rep, nrep,
+                  (size_t)rep_stride, ns};
+  hipLaunchKernelGGL(k_embed_bwd3, dim3((L * ns + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("embed_bwd3");
 }
 
 int adt_embed_bwd_rep(const int32_t* ids, const float* dX, int T, int L, int d, float p, const uint32_t* seed, uint32_t site, uint32_t row_offset,
@@ -558,8 +578,9 @@ int adt_loss_seeds(const float* pos_logits, const float* neg_logits, const int32
 static thread_local LogitsBceArgs g_lb_job;
 static thread_local bool g_lb_set = false;
 void adt_loss_seeds_attach_logits(const float* F, const float* E, const int32_t* pos, const int32_t* neg, const float* norms, int T, float* pos_logits,
-                                  float* neg_logits, float* dpos, float* dneg, float* loss_bce, float* dF, float* rep, int nrep, int64_t rep_stride) {
-  g_lb_job = LogitsBceArgs{F, E, pos, neg, norms, T, pos_logits, neg_logits, dpos, dneg, loss_bce, dF, rep, nrep, (size_t)rep_stride};
+                                  float* neg_logits, float* dpos, float* dneg, float* loss_bce, float* dF, float* rep, int nrep, int64_t rep_stride,
+                                  int neg_only) {
+  g_lb_job = LogitsBceArgs{F, E, pos, neg, norms, T, pos_logits, neg_logits, dpos, dneg, loss_bce, dF, rep, nrep, (size_t)rep_stride, neg_only};
   g_lb_set = true;
 }
 

@@ -72,7 +72,11 @@ int adt_step_begin_ring_launch(uint32_t* seed, uint32_t inc, float* norms_dst, f
                                void* pack_img, const int* pack_offs, int npack, void* stream);
 // adt_loss_seeds + the prefetch of the next step's id batch into `staging` as extra workgroups of the same launch (adt_misc.cuh: ring_prefetch_body)
 void adt_loss_seeds_attach_logits(const float* F, const float* E, const int32_t* pos, const int32_t* neg, const float* norms, int T, float* pos_logits,
-                                  float* neg_logits, float* dpos, float* dneg, float* loss_bce, float* dF, float* rep, int nrep, int64_t rep_stride);
+                                  float* neg_logits, float* dpos, float* dneg, float* loss_bce, float* dF, float* rep, int nrep, int64_t rep_stride,
+                                  int neg_only);
+int adt_logits_bce_scatter_ex(const float* F, const float* E, const int32_t* pos, const int32_t* neg, const float* norms, int T, float* pos_logits,
+                              float* neg_logits, float* dpos, float* dneg, float* loss_bce, float* dF, float* rep, int nrep, int64_t rep_stride,
+                              int neg_only, void* stream);
 int adt_loss_seeds_prefetch(const float* pos_logits, const float* neg_logits, const int32_t* pos, int T, const float* norms, float* dpos, float* dneg,
                             float* loss_bce, int nmse, const float* const* A, const float* const* Bm, int64_t n, const float* lambdas, float* const* GA,
                             int accumulate_a, float* const* GB, float* const* loss_mse, int nnll, const float* const* rec, int n_rows, int H, float lambda2,

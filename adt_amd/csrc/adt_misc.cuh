@@ -340,6 +340,7 @@ struct LogitsBceArgs {
   const float* F; const float* E; const int* pos; const int* neg; const float* norms; int T;
   float* pos_logits; float* neg_logits; float* dpos; float* dneg; float* loss;      // loss: 2 x 64 sub-slots (pos term, neg term)
   float* dF; float* rep; int nrep; size_t rep_stride;
+  int neg_only;              // the item rows of the NEGATIVE ids only: the positive ones are added by k_embed_bwd3 with the embedding rows they share
 };
 ADT_DEVICE_INLINE void logits_bce_body(const LogitsBceArgs& a, const int bid, const int nblk) {
   const int lane = threadIdx.x & 63;
@@ -402,7 +403,7 @@ ADT_DEVICE_INLINE void logits_bce_body(const LogitsBceArgs& a, const int bid, co
       }
       a.dF[(size_t)row * 64 + lane] = gp * p[u] + gn * q[u];
       if (a.rep == nullptr) continue;           // the item rows are summed elsewhere (adt_itemgrad.cuh: sorted segments)
-      if (ip[u] != 0 && gp != 0.f) atomicAdd(dE + (size_t)ip[u] * 64 + lane, f[u] * gp);
+      if (!a.neg_only && ip[u] != 0 && gp != 0.f) atomicAdd(dE + (size_t)ip[u] * 64 + lane, f[u] * gp);
       if (in[u] != 0 && gn != 0.f) atomicAdd(dE + (size_t)in[u] * 64 + lane, f[u] * gn);
     }
   }
@@ -456,6 +457,88 @@ __global__ __launch_bounds__(256) void k_embed_bwd64(EmbedBwdArgs a) {
     }
   }
   atomicAdd(a.dP + (size_t)l * 64 + lane, acc);
+}
+
+// The three scatters into the item table whose ids are SHIFTS of one item list, in one pass (d = 64).  The reference's sampler builds
+// seq = items[:-1], pos = items[1:] and the decoder input dec[:, 1:] = seq[:, :-1] (sasrec/utils.py:288-307), so for almost every token
+//   row seq[b, l] receives (A) the encoder embedding gradient of (b, l), (B) the decoder embedding gradient of (b, l + 1) and
+//   (C) the positive-logit row coef_pos[b, l - 1] * log_feats[b, l - 1].
+// Float atomics run at one chip-wide byte rate (~1.3 TB/s: MI355X_MICROARCH.md, Global float atomics) and the four scatters of a step were
+// 52 MB of them; here the wave that owns the anchor token (b, l) adds A + B + C with ONE atomic row-add when the ids agree -- checked per
+// token, so arbitrary ids stay correct: a B or C whose id does not match its anchor is an "orphan" and is added on its own by the wave of
+// its own (b, l).  Every contribution is added exactly once: B(b, l') joins anchor (b, l' - 1) iff l' >= 1 and dec[b, l'] == seq[b, l' - 1],
+// else it is the orphan of (b, l'); C(b, l') joins anchor (b, l' + 1) iff l' + 1 < L and pos[b, l'] == seq[b, l' + 1], else orphan of (b, l').
+// Positional table: the wave keeps the sums of position l (A and orphan B) and l + 1 (joined B) in registers, one atomic per lane each.
+// (sasrec/model.py:34-41, :53-59, :72-76 reversed.)
+static __device__ __attribute__((aligned(256))) const float eb_zero_row[64] = {};
+struct EmbedBwd3Args {
+  const int* seq; const int* dec; const int* pos;
+  const float* dXs; const float* dXd; const float* F; const float* gp;      // d / d (encoder / decoder embedding output), log_feats, d / d pos_logits
+  int T, L; float scale; DropCfg drop_s, drop_d; uint32_t row_offset;
+  float* dP; float* rep; int nrep; size_t rep_stride; int nslices;
+};
+__global__ __launch_bounds__(256) void k_embed_bwd3(EmbedBwd3Args a) {
+  typedef const float __attribute__((address_space(1))) * gf;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= a.L * a.nslices) return;
+  const uint32_t key_s = drop_key(a.drop_s), key_d = drop_key(a.drop_d);
+  const int l = wave % a.L, s = wave / a.L, B = a.T / a.L, L = a.L;
+  const int bper = (B + a.nslices - 1) / a.nslices, b0 = s * bper, b1 = min(B, b0 + bper);
+  float* dE = a.rep + (a.nrep > 1 ? (size_t)(wave % a.nrep) * a.rep_stride : 0);
+  float acc0 = 0.f, acc1 = 0.f;                 // positional sums of positions l and l + 1
+  const bool has_prev = l > 0, has_next = l + 1 < L;
+  constexpr int U = 2;                          // anchors in flight: seven ids, then up to five rows each
+  for (int b = b0; b < b1; b += U) {
+    int s0[U], sp[U], sn[U], d0[U], dn[U], p0[U], pp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool on = b + u < b1;
+      const int row = (b + u) * L + l;
+      s0[u] = on ? a.seq[row] : 0;
+      sp[u] = on && has_prev ? a.seq[row - 1] : 0;
+      sn[u] = on && has_next ? a.seq[row + 1] : 0;
+      d0[u] = on ? a.dec[row] : 0;
+      dn[u] = on && has_next ? a.dec[row + 1] : 0;
+      p0[u] = on ? a.pos[row] : 0;
+      pp[u] = on && has_prev ? a.pos[row - 1] : 0;
+    }
+    bool fA[U], fBm[U], fBo[U], fCm[U], fCo[U];
+    float ga[U], gbn[U], gb0[U], fprev[U], f0[U], cprev[U], c0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {               // every load unconditional (address select): all in flight together
+      const size_t row = (size_t)((b + u) * L + l);
+      fA[u] = s0[u] != 0;
+      fBm[u] = dn[u] != 0 && dn[u] == s0[u];
+      fBo[u] = d0[u] != 0 && (!has_prev || d0[u] != sp[u]);
+      fCm[u] = has_prev && pp[u] != 0 && pp[u] == s0[u];
+      fCo[u] = p0[u] != 0 && (!has_next || p0[u] != sn[u]);
+      ga[u] = *((fA[u] ? (gf)(a.dXs + row * 64) : (gf)eb_zero_row) + lane);
+      gbn[u] = *((fBm[u] ? (gf)(a.dXd + (row + 1) * 64) : (gf)eb_zero_row) + lane);
+      gb0[u] = *((fBo[u] ? (gf)(a.dXd + row * 64) : (gf)eb_zero_row) + lane);
+      fprev[u] = *((fCm[u] ? (gf)(a.F + (row - 1) * 64) : (gf)eb_zero_row) + lane);
+      f0[u] = *((fCo[u] ? (gf)(a.F + row * 64) : (gf)eb_zero_row) + lane);
+      cprev[u] = *(fCm[u] ? (gf)(a.gp + row - 1) : (gf)eb_zero_row);
+      c0[u] = *(fCo[u] ? (gf)(a.gp + row) : (gf)eb_zero_row);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t row = (uint32_t)((b + u) * L + l) + a.row_offset;
+      float va = ga[u], vbn = gbn[u], vb0 = gb0[u];
+      if (a.drop_s.thr) {
+        va = adt_keep(key_s, row * 64u + (uint32_t)lane, a.drop_s.thr) ? va * a.drop_s.scale : 0.f;
+        vbn = adt_keep(key_d, (row + 1u) * 64u + (uint32_t)lane, a.drop_d.thr) ? vbn * a.drop_d.scale : 0.f;
+        vb0 = adt_keep(key_d, row * 64u + (uint32_t)lane, a.drop_d.thr) ? vb0 * a.drop_d.scale : 0.f;
+      }
+      acc0 += va + vb0;
+      acc1 += vbn;
+      if (fA[u]) atomicAdd(dE + (size_t)s0[u] * 64 + lane, (va + vbn) * a.scale + fprev[u] * cprev[u]);
+      if (fBo[u]) atomicAdd(dE + (size_t)d0[u] * 64 + lane, vb0 * a.scale);
+      if (fCo[u] && c0[u] != 0.f) atomicAdd(dE + (size_t)p0[u] * 64 + lane, f0[u] * c0[u]);
+    }
+  }
+  atomicAdd(a.dP + (size_t)l * 64 + lane, acc0);
+  if (has_next) atomicAdd(a.dP + (size_t)(l + 1) * 64 + lane, acc1);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -470,6 +470,13 @@ bool bce_deferred(const adt_sasrec_cfg* c) {
   const int d = c->hidden, hd = d / c->num_heads;
   return on && d == 64 && c->num_layers <= 4 && adt_seq_lean(c->prec, c->maxlen, d, hd) != 0;
 }
+// ADT_EMBED3=0: the two embedding gradients and the positive-logit rows keep their own scatters (default: one pass, adt_embed_bwd3 -- deferred
+// path only, without the sorted form)
+bool embed3_on(const WS& w) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("ADT_EMBED3"); on = (e && atoi(e) == 0) ? 0 : 1; }
+  return on != 0 && !item_det(w) && w.d == 64;
+}
 // ADT_BCE_MERGED=0: the forward's logits / BCE kernel (training bit 2) goes to the side stream instead of into the loss launch
 bool bce_merged() {
   static int on = -1;
@@ -509,7 +516,7 @@ int forward_loss_lean(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, co
   const bool merged = bce_side && bce_merged();
   if (merged)      // ... as the first workgroups of the loss launch itself: no second stream, no fork / join
     adt_loss_seeds_attach_logits(ws + w.f, P + lo.item(), pos, neg, ws + w.norms, T, ws + w.posl, ws + w.negl, ws + w.g_pos, ws + w.g_neg, ws + w.loss,
-                                 ws + w.g_f, item_det(w) ? nullptr : ws + w.rep, NREP, w.rep_stride);
+                                 ws + w.g_f, item_det(w) ? nullptr : ws + w.rep, NREP, w.rep_stride, embed3_on(w) ? 1 : 0);
   SideStream* const sd = (bce_side && !merged && (side_sites() & 1)) ? side_stream((hipStream_t)st) : nullptr;
   if (bce_side && !merged) CK(side_mark(sd, 0, st));
   // (+ the next step's id batch, if its producer has published it: the PCIe read runs under this streaming pass)
@@ -519,8 +526,8 @@ int forward_loss_lean(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, co
   if (bce_side && !merged) {
     void* s2 = nullptr;
     CK(side_enter(sd, 0, st, &s2));
-    CK(adt_logits_bce_scatter(ws + w.f, P + lo.item(), pos, neg, ws + w.norms, T, ws + w.posl, ws + w.negl, ws + w.g_pos, ws + w.g_neg, ws + w.loss,
-                              ws + w.g_f, item_det(w) ? nullptr : ws + w.rep, NREP, w.rep_stride, s2));
+    CK(adt_logits_bce_scatter_ex(ws + w.f, P + lo.item(), pos, neg, ws + w.norms, T, ws + w.posl, ws + w.negl, ws + w.g_pos, ws + w.g_neg, ws + w.loss,
+                                 ws + w.g_f, item_det(w) ? nullptr : ws + w.rep, NREP, w.rep_stride, embed3_on(w) ? 1 : 0, s2));
     if (sd && hipEventRecord(sd->join_ev[0], sd->s) != hipSuccess) return adt_set_error("forward_loss: logits event");
   }
   return 0;
@@ -814,12 +821,14 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
   if (bce_fwd && (bce_here || (phase & 4) == 0 || (phase & 3) == 2)) return adt_set_error("backward: phase bit 5 goes with bit 2, without bit 4, in phase 0 or 1");
   // the forward of the deferred path (forward_loss_lean) does not materialise the reconstruction seeds that k_seqtt_attn_pre_bwd can form itself
   const bool seeds_virtual = bce_here || bce_fwd || (phase & 64) != 0;      // (bit 6: phase 2 of a two-phase backward behind such a forward)
+  // ... and on that path the encoder / decoder embedding gradients and the positive-logit rows share ONE scatter at the end (adt_embed_bwd3)
+  const bool embed3 = seeds_virtual && embed3_on(w);
   phase &= 3;
   const bool det = item_det(w);                   // item / positional table gradients by sorted segmented sums (no replicas, no float atomics)
   auto logits_scatter = [&](void* s) {      // d log_feats + item rows of pos / neg (+ logits and BCE seed on the deferred path)   (sasrec/model.py:72-76)
     if (bce_here)
-      return adt_logits_bce_scatter(f, P + lo.item(), pos, neg, ws + w.norms, T, ws + w.posl, ws + w.negl, ws + w.g_pos, ws + w.g_neg, ws + w.loss,
-                                    gf, det ? nullptr : ws + w.rep, NREP, w.rep_stride, s);
+      return adt_logits_bce_scatter_ex(f, P + lo.item(), pos, neg, ws + w.norms, T, ws + w.posl, ws + w.negl, ws + w.g_pos, ws + w.g_neg, ws + w.loss,
+                                       gf, det ? nullptr : ws + w.rep, NREP, w.rep_stride, embed3 ? 1 : 0, s);
     if (det) return adt_logits_bwd_df(P + lo.item(), pos, neg, ws + w.g_pos, ws + w.g_neg, T, d, gf, d, s);
     return adt_logits_bwd_scatter(f, d, P + lo.item(), pos, neg, ws + w.g_pos, ws + w.g_neg, T, d, gf, d, ws + w.rep, NREP, w.rep_stride, s);
   };
@@ -991,18 +1000,20 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
     // one-phase backward they run on the side stream under it (joined in front of the last fold); in the two-phase form the sum runs
     // beside the embedding gradient.  k_dwpart_reduce adds with atomics and k_replica_reduce2 read-modify-writes the same range of G:
     // the fold always comes behind the join.
-    if (phase == 0 && sd && (side_sites() & 2)) {
+    // (embed3: the decoder embedding's rows go out with the encoder's at the very end -- with the sums left to the optimizer's fold there is then
+    // nothing for the side stream here, and no fork)
+    if (phase == 0 && sd && (side_sites() & 2) && !(embed3 && (late_parts || !parts))) {
       CK(side_mark(sd, 1, st));
       dec_side = 1;                      // enqueued behind the first kernel of the encoder phase
     } else if (phase == 0) {
-      if (!det) CK(adt_embed_bwd_rep(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
+      if (!det && !embed3) CK(adt_embed_bwd_rep(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
     } else if (det) {      // two-phase form: the decoder blocks' partial sums and the fold of the decoder range (nothing of the tables yet)
       if (parts) CK(reduce_partials(c, lo, w, G, ws, false, true, st));
       CK(adt_replica_reduce(G + dec_begin, Gq + dec_begin, lo.total - dec_begin, NREPP, w.prep_stride, st));
     } else {
       void* s2 = nullptr;
       CK(side_mark(sd, 1, st));
-      CK(adt_embed_bwd_rep(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
+      if (!embed3) CK(adt_embed_bwd_rep(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
       CK(side_enter(sd, 1, st, &s2));
       if (parts) CK(reduce_partials(c, lo, w, G, ws, false, true, s2));
       CK(side_join(sd, 1, st));
@@ -1027,7 +1038,7 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
       if (dec_side != 1) return 0;
       void* s2 = nullptr;
       CK(side_enter(sd, 1, st, &s2));
-      if (!det) CK(adt_embed_bwd_rep(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, s2));
+      if (!det && !embed3) CK(adt_embed_bwd_rep(dec, ws + w.g_dec_x, T, L, d, p, seed, SITE_EMB_DEC, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, s2));
       if (parts && !late_parts) { CK(reduce_partials(c, lo, w, G, ws, false, true, s2)); dec_parts_done = true; }
       dec_side = 2;
       return 0;
@@ -1132,6 +1143,9 @@ int adt_sasrec_backward(const adt_sasrec_cfg* c, const float* P, float* G, float
         const float* const dx2[2] = {ws + w.g_enc_x, ws + w.g_dec_x};
         CK(adt_item_segsum_posemb(iwork, 4, T, c->item_num + 1, 0xFu, site4, p, seed, sqrtf((float)d), G + lo.item(), prep_zeroed ? 0 : 1,
                                   ids2, dx2, site4, 2, (int)w.B, L, ro, G + lo.posw(), st));
+      } else if (embed3) {      // encoder + decoder embedding rows + the positive-logit rows: one atomic row-add per token where their ids line up
+        CK(adt_embed_bwd3(seq, dec, pos, ws + w.g_enc_x, ws + w.g_dec_x, f, ws + w.g_pos, T, L, p, seed, SITE_EMB_SEQ, SITE_EMB_DEC, ro, G + lo.posw(),
+                          ws + w.rep, NREP, w.rep_stride, st));
       } else {
         CK(adt_embed_bwd_rep(seq, ws + w.g_enc_x, T, L, d, p, seed, SITE_EMB_SEQ, ro, G + lo.posw(), ws + w.rep, NREP, w.rep_stride, st));
       }

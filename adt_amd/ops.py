@@ -52,6 +52,13 @@ def embed_bwd(ids, dX, L, p, seed, site, dE, dP, row_offset=0):
                                          _p(dE), _p(dP), _stream()), "embed_bwd")
 
 
+def embed_bwd3(seq, dec, pos, dXs, dXd, F, dpos, L, p, seed, site_seq, site_dec, dE_rep, dP, nrep=1, rep_stride=0, row_offset=0):
+    """Encoder + decoder embedding gradients and the positive-logit rows into the item-table replicas in one pass (adt_embed_bwd3, d = 64)."""
+    T = dXs.shape[0]
+    _lib.check(_lib.load().adt_embed_bwd3(_p(_i32(seq)), _p(_i32(dec)), _p(_i32(pos)), _p(_f32(dXs)), _p(_f32(dXd)), _p(_f32(F)), _p(_f32(dpos)), T, L,
+                                          float(p), _p(seed), site_seq, site_dec, row_offset, _p(dP), _p(dE_rep), nrep, rep_stride, _stream()), "embed_bwd3")
+
+
 def layernorm_fwd(X, gamma, beta, eps):
     T, d = X.shape
     Y = torch.empty(T, d, device=X.device, dtype=torch.float32)

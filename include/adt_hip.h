@@ -96,6 +96,13 @@ int adt_item_scatter(const int32_t* ids, const float* G, int ldg, const float* r
                      const uint32_t* seed, uint32_t site, uint32_t row_offset, float* rep, int nrep, int64_t rep_stride,
                      void* stream);
 int adt_replica_reduce(float* dE, const float* rep, int64_t n, int nrep, int64_t rep_stride, void* stream);
+/* The encoder embedding gradient, the decoder embedding gradient and the positive-logit rows (dpos[t] * F[t]) into the item-table replicas in one
+ * pass (d = 64, T a multiple of L) -- sasrec/model.py:34-41, :53-59, :72-76 reversed.  The reference's sampler (sasrec/utils.py:288-307) makes
+ * seq[b, l] == dec[b, l + 1] == pos[b, l - 1] for almost every token: those three rows go out as ONE atomic row-add; ids that do not line up
+ * are added on their own (any ids are correct).  dP += the positional sums of both embeddings (scale sqrt(d) on the item rows only). */
+int adt_embed_bwd3(const int32_t* seq, const int32_t* dec, const int32_t* pos, const float* dXs, const float* dXd, const float* F, const float* dpos,
+                   int T, int L, float p, const uint32_t* seed, uint32_t site_seq, uint32_t site_dec, uint32_t row_offset, float* dP, float* rep,
+                   int nrep, int64_t rep_stride, void* stream);
 /* position-table half of adt_embed_bwd alone: dP[l] += sum_b dX[b, l] * dropmask * (ids != 0) */
 int adt_posemb_bwd(const int32_t* ids, const float* dX, int T, int L, int d, float p, const uint32_t* seed,
                    uint32_t site, uint32_t row_offset, float* dP, void* stream);

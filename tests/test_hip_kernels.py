@@ -82,6 +82,50 @@ def test_embed_fwd_bwd(ops, p):
     check(dP_t, dP, 1e-5, "embed dP")
 
 
+@pytest.mark.parametrize("layout", ["sampler", "random", "mixed"])
+@pytest.mark.parametrize("p", [0.0, 0.25])      # (rates are quantised to 1 / 256: 0.25 is exact)
+def test_embed_bwd3_one_pass_item_scatter(ops, layout, p):
+    """adt_embed_bwd3: encoder + decoder embedding gradients + positive-logit rows into the item table in one pass.  With the reference sampler's
+    layout (seq = items[:-1], pos = items[1:], dec[:, 1:] = seq[:, :-1]: sasrec/utils.py:288-307) the three rows of a token share ONE atomic
+    row-add; with random ids every contribution is an 'orphan' added on its own; 'mixed' breaks the shifts in a third of the places.  All three
+    must equal the three separate scatters (sasrec/model.py:34-41, :53-59, :72-76 reversed), positional sums included."""
+    r = np.random.RandomState(7)
+    B, L, d, V = 6, 44, 64, 50
+    if layout == "random":
+        seq, dec, pos = (ids_with_padding(r, B, L, V) for _ in range(3))
+    else:
+        seq = np.zeros((B, L), np.int64); dec = np.zeros((B, L), np.int64); pos = np.zeros((B, L), np.int64)
+        for b in range(B):
+            n = r.randint(3, L + 1)
+            items = r.randint(1, V + 1, size=n + 1)
+            seq[b, L - n:] = items[:-1]
+            pos[b, L - n:] = items[1:]
+            dec[b, 1:] = seq[b, :-1]
+        if layout == "mixed":
+            for a in (seq, dec, pos):
+                m = r.rand(B, L) < 0.33
+                a[m] = r.randint(0, V + 1, size=int(m.sum()))
+    seed, boff = 77, 2
+    gs, gd, F = (r.randn(B, L, d).astype(np.float32) for _ in range(3))
+    gp = (r.randn(B, L) * (pos != 0)).astype(np.float32)
+    dE = np.zeros((V + 1, d), np.float32)
+    dP = np.zeros((L, d), np.float32)
+    for ids, g, site in ((seq, gs, so.SITE_EMB_SEQ), (dec, gd, so.SITE_EMB_DEC)):
+        _, (keep, m) = so.embed(ids, np.zeros((V + 1, d), np.float32), np.zeros((L, d), np.float32), p, seed, site, boff)
+        gm = g * m
+        if keep is not None:
+            gm = gm * keep / (1 - p)
+        np.add.at(dE, ids, gm * np.float32(math.sqrt(d)))
+        dP += gm.sum(0)
+    np.add.at(dE, pos, F * gp[..., None] * (pos != 0)[..., None])
+    dE[0] = 0.0
+    dE_t, dP_t = torch.zeros(V + 1, d, device=dev()), torch.zeros(L, d, device=dev())
+    ops.embed_bwd3(T_(seq.reshape(-1), torch.int32), T_(dec.reshape(-1), torch.int32), T_(pos.reshape(-1), torch.int32), T_(gs.reshape(-1, d)), T_(gd.reshape(-1, d)), T_(F.reshape(-1, d)),
+                   T_(gp.reshape(-1)), L, p, seed_t(seed), so.SITE_EMB_SEQ, so.SITE_EMB_DEC, dE_t, dP_t, 1, 0, boff * L)
+    check(dE_t, dE, 2e-5, "embed_bwd3 dE")
+    check(dP_t, dP, 2e-5, "embed_bwd3 dP")
+
+
 @pytest.mark.parametrize("d", [64, 256])
 def test_layernorm_fwd_bwd(ops, d):
     r = np.random.RandomState(1)
