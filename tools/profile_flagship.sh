@@ -1,4 +1,4 @@
-# Round-4 profile of the bench step on the GPU box: kernel stats + one-step timelines, HBM traffic of the dominant kernels and of the whole step
+# Round-4 profile of the bench step on the GPU box: kernel stats + one-step timelines (resident and host-fed leg), HBM traffic of the dominant kernels and of the whole step
 # (separate FETCH_SIZE / WRITE_SIZE passes), SQ / MFMA counters of the flagship and the fused logits + CE, small-batch probe.
 # The program sits directly behind `--` (no env / bash -c hop).  Outputs under gpurun_out/r04p/ ; copy the summaries into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && O=gpurun_out/r04p && mkdir -p $O
