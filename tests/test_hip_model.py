@@ -484,6 +484,27 @@ def test_lean_parity_with_one_workgroup_per_sequence():
     assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, tail
 
 
+@pytest.mark.parametrize("switch", ["ADT_EMBED3=0", "ADT_BCE_MERGED=0", "ADT_BCE_SIDE=0", "ADT_LNL_FUSED=0", "ADT_ATTN_SPLIT=0", "ADT_FWD_FUSED=0",
+                                    "ADT_FOLD_PARTS=0", "ADT_SIDE_STREAM=0"])
+def test_ab_switches_keep_parity(switch):
+    """The process-wide A/B switches of the flagship step select older forms of a stage -- separate scatters, the logits
+    kernel on the side stream / in the backward, the last LayerNorm's own kernel, one workgroup per sequence in the attention-block backward,
+    the unfused loss assembly, replica folds, no side stream.  Each must still match the oracle and the reference golden: one child process per
+    switch (they are read once per process) runs the dropout parity case, the fused-trainer golden and the determinism case."""
+    import subprocess
+    import sys
+    here = os.path.abspath(__file__)
+    cases = ["test_lean_step_with_dropout_vs_oracle", "test_fused_trainer_three_steps_vs_reference_golden_h4",
+             "test_lean_step_is_deterministic_and_ignores_workspace_garbage"]
+    k, v = switch.split("=")
+    if k == "ADT_FOLD_PARTS":      # float atomics for the bias / LayerNorm sums again: parity holds, bit-equality across runs does not
+        cases = cases[:2]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"] + ["%s::%s" % (here, c) for c in cases],
+                       cwd=os.path.dirname(os.path.dirname(here)), env=dict(os.environ, **{k: v}), capture_output=True, text=True, timeout=850)
+    tail = r.stdout[-3000:] + "\n" + r.stderr[-2000:]
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, tail
+
+
 def test_side_stream_matches_single_stream(tmp_path):
     """The backward puts its scatter / fold kernels on a side stream under the chain kernels (adt_sasrec.hip: side_stream; in the captured
     step they are parallel branches of the HIP graph).  Two processes run the same three steps at the flagship shape's L = 200 (eager
