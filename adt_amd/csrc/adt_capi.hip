@@ -296,6 +296,12 @@ int adt_logits_bce_scatter_ex(const float* F, const float* E, const int32_t* pos
   return check_launch("logits_bce_scatter");
 }
 
+// adt_loss_seeds_split_prefetch(): the NEXT adt_loss_seeds_prefetch of this host thread copies only the first half of the ring slot and leaves the
+// second half (+ the staged mark) to the next adt_embed_bwd3 launch of this thread (same step, later in the stream).
+static thread_local RingPrefetchArgs g_pf_job;
+static thread_local bool g_pf_set = false, g_pf_split = false;
+void adt_loss_seeds_split_prefetch() { g_pf_split = true; g_pf_set = false; }
+
 /* The encoder embedding gradient, the decoder embedding gradient and the positive-logit rows into the item-table replicas in one pass (d = 64,
  * T a multiple of L): one atomic row-add per token where the three ids are the shifts of one item list that the reference's sampler produces
  * (seq[b, l] == dec[b, l + 1] == pos[b, l - 1]); any other ids are added on their own.  dP += the positional sums of both embeddings. */
@@ -306,7 +312,12 @@ int adt_embed_bwd3(const int32_t* seq, const int32_t* dec, const int32_t* pos, c
   const int B = T / L, ns = B < 32 ? B : 32;
   EmbedBwd3Args a{seq, dec, pos, dXs, dXd, F, dpos, T, L, 8.0f, adt_make_drop(p, seed, site_seq), adt_make_drop(p, seed, site_dec), row_offset, dP, rep, nrep,
                   (size_t)rep_stride, ns};
-  hipLaunchKernelGGL(k_embed_bwd3, dim3((L * ns + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  if (g_pf_set) {      // the second half of this step's ring prefetch (adt_loss_seeds_split_prefetch)
+    g_pf_set = false;
+    hipLaunchKernelGGL(k_embed_bwd3_prefetch, dim3((L * ns + 3) / 4 + 16), dim3(256), 0, (hipStream_t)stream, a, g_pf_job, 16);
+  } else {
+    hipLaunchKernelGGL(k_embed_bwd3, dim3((L * ns + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  }
   return check_launch("embed_bwd3");
 }
 
@@ -592,8 +603,11 @@ int adt_loss_seeds_prefetch(const float* pos_logits, const float* neg_logits, co
   if (nmse > 4 || nnll > 4 || n % 4) return adt_set_error("loss_seeds: at most 4 + 4 terms, n %% 4");
   LossSeedsArgs a{};
   if (ring && staging && state) {
-    a.pf = RingPrefetchArgs{ring, (size_t)slot_ints, nslots, (size_t)n_ints, state, consumed, staging};
+    a.pf = RingPrefetchArgs{ring, (size_t)slot_ints, nslots, (size_t)n_ints, state, consumed, staging, 0, g_pf_split ? 2 : 0};
     a.gp = 32;      // one round of 8 x 16-byte loads per thread covers the flagship batch (819 KB): a PCIe read wants everything in flight at once
+    if (g_pf_split) {      // ... its second half rides on the next adt_embed_bwd3 launch of this host thread
+      g_pf_job = a.pf; g_pf_job.part = 1; g_pf_set = true; g_pf_split = false;
+    }
   }
   a.bce = BceArgs{pos_logits, neg_logits, pos, T, norms, dpos, dneg, loss_bce};
   // (a seed that is not materialised -- GA[i] or GB[i] == nullptr -- leaves its coefficient at norms[8 + i] for its consumer)

@@ -71,6 +71,7 @@ int adt_step_begin_ring_launch(uint32_t* seed, uint32_t inc, float* norms_dst, f
                                uint32_t* consumed, const int32_t* staging, const uint32_t* produced, float* Z, int64_t nz, const float* pack_base,
                                void* pack_img, const int* pack_offs, int npack, void* stream);
 // adt_loss_seeds + the prefetch of the next step's id batch into `staging` as extra workgroups of the same launch (adt_misc.cuh: ring_prefetch_body)
+void adt_loss_seeds_split_prefetch();
 void adt_loss_seeds_attach_logits(const float* F, const float* E, const int32_t* pos, const int32_t* neg, const float* norms, int T, float* pos_logits,
                                   float* neg_logits, float* dpos, float* dneg, float* loss_bce, float* dF, float* rep, int nrep, int64_t rep_stride,
                                   int neg_only);

@@ -513,6 +513,9 @@ int forward_loss_lean(const adt_sasrec_cfg* c, const Layout& lo, const WS& w, co
     lm[i] = loss + 64 * (2 + i);
     rc[i] = ws + i * w.e_stride + w.e_rec; dr[i] = ws + w.g_rec + i * rec; ln[i] = loss + 64 * (2 + nl + i);
   }
+  // host-fed step: the next batch's ring slot is copied to the staging buffer in two halves, one inside this launch, one inside the embedding
+  // scatter at the end of the backward (which then marks it staged) -- 819 KB over PCIe do not fit behind either launch alone
+  if (rr.ring && rr.staging && rr.state && bce_side && embed3_on(w)) adt_loss_seeds_split_prefetch();
   const bool merged = bce_side && bce_merged();
   if (merged)      // ... as the first workgroups of the loss launch itself: no second stream, no fork / join
     adt_loss_seeds_attach_logits(ws + w.f, P + lo.item(), pos, neg, ws + w.norms, T, ws + w.posl, ws + w.negl, ws + w.g_pos, ws + w.g_neg, ws + w.loss,
