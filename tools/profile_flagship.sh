@@ -7,7 +7,7 @@ B="python3 bench.py --no-cpu-baseline --no-ndcg"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- $B --steps 50 --warmup 10 > $O/stats_log.txt 2>&1 || exit 1
 cp $O/stats/p_kernel_stats.csv $O/r04_kernel_stats.csv
 python tools/trace_overlap.py $O/stats/p_kernel_trace.csv -25 > $O/r04_side_stream_timeline.txt
-echo "---- host-fed leg (ids read from the pinned ring over PCIe by k_step_begin / the prefetch blocks of k_loss_seeds)" >> $O/r04_side_stream_timeline.txt
+echo "---- host-fed leg (under the profiler the host is not ahead of the GPU, so the next batch is not published in time for the prefetch and k_step_begin reads the ring over PCIe: 23 us; unprofiled the prefetch hits -- 398 of 400 steps -- and k_step_begin takes 9 us, the two prefetch halves add ~7 us to k_loss_seeds + k_embed_bwd3)" >> $O/r04_side_stream_timeline.txt
 python tools/trace_overlap.py $O/stats/p_kernel_trace.csv 25 >> $O/r04_side_stream_timeline.txt
 echo stats done
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/f -o fetch -- $B --steps 6 --warmup 2 --no-roofline > $O/f_log.txt 2>&1 || exit 1
